@@ -1,0 +1,173 @@
+/*
+ * kmcp_gpu.h — C ABI of libkmcpgpu.so: the MI355X-native replacement of the `kmcp search` hot path.
+ *
+ * The reference (shenwei356/kmcp v0.9.5, pure Go) has no FFI seam; the seam is a pair of Go channel
+ * protocols inside package cmd.  Each entry point below names the reference code it
+ * replaces (paths relative to kmcp/cmd/).  The cgo binding a maintainer would add is shim/kmcp_gpu.go
+ * (see INTEGRATION.md).
+ *
+ * Conventions: every function returns 0 on success or a negative KMCPG_E* code; the message is
+ * available from kmcpg_last_error() (thread-local).  No exception or abort crosses the ABI.  Input
+ * buffers are borrowed for the duration of the call only; buffers returned inside kmcpg_result are
+ * owned by the library and released by kmcpg_result_free().  A kmcpg_db may be used from several OS
+ * threads; calls on one handle are serialised internally.
+ */
+#ifndef KMCP_GPU_H
+#define KMCP_GPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KMCPG_OK 0
+#define KMCPG_EINVAL (-1)   /* bad argument */
+#define KMCPG_EIO (-2)      /* file missing / unreadable */
+#define KMCPG_EFORMAT (-3)  /* invalid or incompatible .uniki / __db.yml (serialization.go:41-57) */
+#define KMCPG_EDEVICE (-4)  /* HIP error, no GPU */
+#define KMCPG_ENOMEM (-5)
+#define KMCPG_EUNSUPPORTED (-6)
+
+typedef struct kmcpg_db kmcpg_db;
+
+/* How the database is placed on the GPU(s).  One process drives one GPU (one rank); the index's
+ * independent .uniki blocks are partitioned over `shard_count` ranks by bytes. */
+typedef struct {
+  int32_t device;      /* HIP device ordinal of this process */
+  int32_t shard_rank;  /* 0..shard_count-1 */
+  int32_t shard_count; /* >=1 */
+  int32_t reserved;
+} kmcpg_opts;
+
+/* What `search` needs to know about the database: UnikIndexDBInfo (util-db-info.go:46-79) + Header
+ * (index/serialization.go:66-82). */
+typedef struct {
+  int32_t k;
+  int32_t canonical;
+  int32_t num_hashes;
+  int32_t scaled;
+  uint32_t scale;
+  int32_t minimizer;
+  uint32_t minimizer_w;
+  int32_t syncmer;
+  uint32_t syncmer_s;
+  double fpr;             /* DB-wide false-positive rate of one Bloom filter (`fpr` in __db.yml) */
+  int32_t n_blocks;       /* all .uniki files of the DB */
+  int32_t n_blocks_local; /* blocks resident on this rank's GPU */
+  uint64_t n_cols;        /* reference chunks (columns) over all blocks */
+  uint64_t matrix_bytes;       /* on-disk bit-matrix bytes over all blocks */
+  uint64_t matrix_bytes_local; /* on-disk bit-matrix bytes of the local blocks */
+  uint64_t row_bytes_sum_local; /* sum over local blocks of NumRowBytes: algorithmic bytes per (k-mer, hash) */
+} kmcpg_info;
+
+/* SearchOptions (util-db-search.go:162-189); defaults are those of search.go:1052-1102. */
+typedef struct {
+  int32_t min_qlen;        /* -m/--min-query-len 30 */
+  int32_t min_matched;     /* -c/--min-kmers 10 */
+  double min_qcov;         /* -t/--min-query-cov 0.55 */
+  double min_tcov;         /* -T/--min-target-cov 0 */
+  double max_fpr;          /* -f/--max-fpr 0.01 */
+  int32_t dedup_threshold; /* -u/--kmer-dedup-threshold 256 */
+  int32_t try_se;          /* --try-se */
+  int32_t sort_by;         /* -s: 0 qcov, 1 tcov, 2 jacc */
+  int32_t do_not_sort;     /* -S */
+  int32_t top_n_scores;    /* -n/--keep-top-scores */
+  int32_t fpr_buf_size;    /* 249 single-end / 499 paired-end (search.go:250-255); 0 = pick */
+} kmcpg_params;
+
+/* One (read, reference chunk) pair that passed the integer thresholds on the GPU:
+ * count >= max(min_matched, smallest c with float64(c) > n*min_qcov)   (util-db-search.go:7468-7470). */
+typedef struct {
+  uint32_t read;  /* index of the read in the batch */
+  uint32_t col;   /* global column: columns numbered over the blocks in __db.yml `files` order */
+  uint32_t count; /* matched k-mers (mKmers) */
+} kmcpg_hit;
+
+/* Match (util-db-search.go:83-93) without the strings; names come from kmcpg_col_info(). */
+typedef struct {
+  uint32_t col;
+  uint32_t target_idx; /* chunkIdx | chunks<<16 (index.go:1096) */
+  uint64_t gsize;
+  int32_t mkmers;
+  int32_t reserved;
+  double fpr, qcov, tcov, jacc;
+} kmcpg_match;
+
+/* QueryResult (util-db-search.go:60-74) for a batch, CSR over reads. */
+typedef struct {
+  uint32_t n_reads;
+  int32_t k;
+  int32_t* qlen;         /* [n_reads] QueryLen (read1+read2 for paired-end; the searched mate after --try-se) */
+  int32_t* qkmers;       /* [n_reads] NumKmers (0 when the query was not searched) */
+  uint64_t* match_offs;  /* [n_reads+1] */
+  kmcpg_match* matches;  /* [match_offs[n_reads]] sorted as handleQuerySingleDB does (:273-282) */
+  void* owner;           /* internal */
+} kmcpg_result;
+
+/* -- lifecycle: replaces NewUnikIndexDB / NewUnikIndex (util-db-search.go:648-743, 1196-1280) and
+ *    UnikIndexDB.Close (:1119-1150).  db_dir is the directory holding __db.yml (e.g. <db>/R001). */
+int kmcpg_open(const char* db_dir, const kmcpg_opts* opts, kmcpg_db** out);
+int kmcpg_close(kmcpg_db* db);
+const char* kmcpg_last_error(void);
+int kmcpg_db_info(const kmcpg_db* db, kmcpg_info* info);
+/* Header.Names/GSizes/Indices/Sizes of one column (serialization.go:73-79) */
+int kmcpg_col_info(const kmcpg_db* db, uint32_t col, const char** name, uint32_t* target_idx, uint64_t* gsize,
+                   uint64_t* size);
+
+/* -- the whole per-query pipeline for a batch of queries: replaces UnikIndexDB.handleQuery
+ *    (util-db-search.go:763-1025) and the sorting/top-N of handleQuerySingleDB (:260-345).
+ *    seqs/offs: read i is seqs[offs[i]..offs[i+1]) (ASCII, as fastx delivers it);
+ *    seqs2/offs2: mates for paired-end input or NULL. */
+int kmcpg_search_batch(kmcpg_db* db, const uint8_t* seqs, const uint64_t* offs, const uint8_t* seqs2,
+                       const uint64_t* offs2, uint32_t n_reads, const kmcpg_params* params, kmcpg_result* out);
+void kmcpg_result_free(kmcpg_result* r);
+
+/* -- the GPU half only (k-mer generation + COBS query on the local blocks), device-resident in and
+ *    out: generateKmers (util-db-search.go:1037-1107) + dedup (:874-908) + the UnikIndex workers
+ *    (:6611-7742, integer thresholds only).  All pointers are DEVICE pointers; `stream` is a
+ *    hipStream_t (NULL = default stream).  d_counters[0] receives the number of hits produced (which
+ *    may exceed hit_cap: then only hit_cap were stored and the caller retries with a larger buffer).
+ *    d_qkmers[i] receives NumKmers of read i (0 if not searched), d_qlen[i] its QueryLen. */
+int kmcpg_query_device(kmcpg_db* db, const uint8_t* d_seqs, const uint64_t* d_offs, const uint8_t* d_seqs2,
+                       const uint64_t* d_offs2, uint32_t n_reads, uint64_t total_bases, uint32_t max_read_len,
+                       const kmcpg_params* params, kmcpg_hit* d_hits, uint64_t hit_cap, uint64_t* d_counters,
+                       int32_t* d_qkmers, int32_t* d_qlen, void* stream);
+
+/* -- the host half: thresholds that need float64/FPR (util-db-search.go:7471-7489), Match values,
+ *    sorting, --keep-top-scores.  `hits` may be the concatenation of the hit lists of all shards
+ *    (any order).  Every rank knows every column's metadata, so this can run on the gathering rank. */
+int kmcpg_finalize(const kmcpg_db* db, const kmcpg_hit* hits, uint64_t n_hits, const int32_t* qkmers,
+                   const int32_t* qlen, uint32_t n_reads, const kmcpg_params* params, kmcpg_result* out);
+
+/* -- benchmarking / full-size parity support (no counterpart in the reference) ------------------ */
+typedef struct {
+  int32_t k;            /* 21 */
+  int32_t num_hashes;   /* 1 */
+  double fpr;           /* 0.3: the fullest column has bit density 1-exp(-1/ratio) = fpr */
+  uint32_t n_blocks;    /* e.g. 32 */
+  uint32_t cols_per_block; /* e.g. 14976 */
+  uint64_t num_sigs;    /* rows per block, e.g. 970000 */
+  uint64_t kmers_per_col; /* Sizes[] of every column, e.g. 346000 */
+  uint64_t seed;
+} kmcpg_synth_spec;
+/* Builds a synthetic database directly in HBM: every bit i.i.d. Bernoulli(density) from a
+ * counter-based generator keyed by (seed, block, row, word).  Column names are "syn<global col>". */
+int kmcpg_open_synthetic(const kmcpg_synth_spec* spec, const kmcpg_opts* opts, kmcpg_db** out);
+/* ORs the Bloom bits of the given k-mer hashes into column `col` (global id) if it is local. */
+int kmcpg_plant(kmcpg_db* db, uint32_t col, const uint64_t* hashes, uint64_t n);
+/* Copies rows (on-disk width NumRowBytes each) of a local block back to the host. */
+int kmcpg_read_rows(kmcpg_db* db, uint32_t block, const uint64_t* row_idx, uint64_t n_rows, uint8_t* out);
+/* Geometry of block b (global index): NumSigs, columns, NumRowBytes, device row stride, is-local. */
+int kmcpg_block_info(const kmcpg_db* db, uint32_t block, uint64_t* num_sigs, uint32_t* n_cols, uint32_t* row_bytes,
+                     uint32_t* dev_stride, int32_t* is_local, uint32_t* col_base);
+/* k-mer generation only (K1): returns hashes of read i at d_hashes[d_koff[i] .. +d_nk[i]). Debug/tests. */
+int kmcpg_kmers_device(kmcpg_db* db, const uint8_t* d_seqs, const uint64_t* d_offs, uint32_t n_reads,
+                       uint64_t total_bases, uint32_t max_read_len, const kmcpg_params* params,
+                       uint64_t* d_hashes, uint64_t hashes_cap, uint64_t* d_koff, int32_t* d_nk, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

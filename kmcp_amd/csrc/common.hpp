@@ -1,0 +1,76 @@
+// common.hpp — structures shared by the host engine and the HIP kernels of libkmcpgpu.so.
+#pragma once
+#include <stdint.h>
+
+#include "../../include/kmcp_gpu.h"
+
+namespace kmcpg {
+
+// Device-side description of one resident .uniki block (index/serialization.go:66-82 Header,
+// re-laid-out: rows padded to `stride` bytes, one all-zero row appended at index num_sigs).
+struct BlockDev {
+  const uint8_t* rows;  // device pointer, (num_sigs + 1) * stride bytes
+  uint64_t num_sigs;    // Header.NumSigs: modulus of the row address (util-db-search.go:6811)
+  uint64_t magic_hi;    // M = floor((2^128-1)/num_sigs)+1, exact 64-bit fastmod (replaces fastdiv, :6611)
+  uint64_t magic_lo;
+  uint32_t stride;      // bytes per row in HBM (multiple of 16)
+  uint32_t row_bytes;   // Header.NumRowBytes = (ncols+7)/8
+  uint32_t ncols;
+  uint32_t col_base;    // global column id of column 0
+};
+
+// One unit of COBS work per read: (local block, tile of LPR*16 bytes of the row).
+struct Slot {
+  uint32_t block;  // index into the BlockDev array
+  uint32_t tile;
+};
+
+struct K1Args {
+  const uint8_t* seqs;
+  const uint64_t* offs;
+  const uint8_t* seqs2;  // mates or nullptr
+  const uint64_t* offs2;
+  uint32_t n_reads;
+  int32_t k;
+  int32_t min_qlen;
+  int32_t scaled;
+  uint64_t max_hash;
+  int32_t mode;          // 0 plain (+scaled), 1 minimizer, 2 syncmer
+  uint32_t w_or_s;       // minimizer-w or syncmer-s
+  uint64_t* hashes;      // read i writes at hashes[offs[i] + offs2[i] ...]
+  uint64_t* scratch;     // same size as hashes (s-mer hashes / dedup output)
+  int32_t* nk_raw;       // k-mers emitted for read i (both mates)
+  int32_t* nk1;          // k-mers emitted for mate 1 (for --try-se)
+  int32_t* qlen;
+};
+
+struct DedupArgs {
+  const uint64_t* offs;
+  const uint64_t* offs2;
+  uint32_t n_reads;
+  int32_t dedup_threshold;
+  int32_t min_matched;
+  uint64_t* hashes;
+  uint64_t* scratch;
+  const int32_t* nk_raw;
+  int32_t* nk_search;    // NumKmers after dedup, 0 if the read is not searched
+};
+
+struct K2Args {
+  const BlockDev* blocks;
+  const Slot* slots;
+  uint32_t nslots;
+  uint32_t n_reads;
+  const uint64_t* hashes;
+  const uint64_t* offs;
+  const uint64_t* offs2;
+  const int32_t* nk;     // nk_search
+  double min_qcov;
+  int32_t min_matched;
+  int32_t num_hashes;
+  kmcpg_hit* hits;
+  uint64_t hit_cap;
+  unsigned long long* counter;
+};
+
+}  // namespace kmcpg

@@ -1,0 +1,853 @@
+// engine.cpp — host side of libkmcpgpu.so: database residency in HBM, the batched query pipeline and
+// the float64 post-processing, behind the C ABI of include/kmcp_gpu.h.
+//
+// Reference counterparts (kmcp/cmd/): NewUnikIndexDB / NewUnikIndex (util-db-search.go:648-743,
+// 1196-1280), handleQuery (:763-1025), threshold+Match (:7415-7733), handleQuerySingleDB (:260-345).
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "common.hpp"
+#include "dbformat.hpp"
+#include "fpr.hpp"
+#include "kernels.hpp"
+
+using namespace kmcpg;
+
+// ------------------------------------------------------------------------------------------------
+// errors
+// ------------------------------------------------------------------------------------------------
+static thread_local std::string g_err;
+
+static int fail(int code, const char* fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return code;
+}
+
+#define HIPCHK(expr)                                                                               \
+  do {                                                                                             \
+    hipError_t e_ = (expr);                                                                        \
+    if (e_ != hipSuccess) return fail(KMCPG_EDEVICE, "%s: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+  } while (0)
+
+extern "C" const char* kmcpg_last_error(void) { return g_err.c_str(); }
+
+// ------------------------------------------------------------------------------------------------
+// database object
+// ------------------------------------------------------------------------------------------------
+namespace {
+
+struct BlockMeta {
+  std::string path;
+  UnikiHeader h;
+  uint32_t col_base = 0;
+  bool local = false;
+  int local_idx = -1;
+  uint32_t stride = 0;
+  uint8_t* d_rows = nullptr;
+};
+
+struct SlotClass {
+  int lpr = 0;
+  std::vector<Slot> slots;
+  Slot* d_slots = nullptr;
+};
+
+template <typename T>
+struct DevBuf {
+  T* p = nullptr;
+  size_t cap = 0;
+  int ensure(size_t n) {
+    if (n <= cap) return 0;
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+    size_t want = n + n / 8 + 64;
+    if (hipMalloc((void**)&p, want * sizeof(T)) != hipSuccess) return -1;
+    cap = want;
+    return 0;
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+  }
+};
+
+}  // namespace
+
+struct kmcpg_db {
+  kmcpg_opts opts{};
+  kmcpg_info info{};
+  std::vector<BlockMeta> blocks;
+  std::vector<int> local;  // global indices of resident blocks, in BlockDev order
+  std::vector<BlockDev> h_blockdev;
+  BlockDev* d_blockdev = nullptr;
+  std::vector<SlotClass> classes;
+  std::vector<uint32_t> col_block;  // global column -> block index
+  std::unique_ptr<QueryFpr> fpr;
+  std::mutex mu;      // guards the device workspace of one GPU-half call
+  std::mutex api_mu;  // serialises kmcpg_search_batch callers (they share the staging buffers)
+  // workspace of kmcpg_query_device
+  DevBuf<uint64_t> w_hashes, w_scratch;
+  DevBuf<int32_t> w_nk_raw, w_nk1;
+  // workspace of kmcpg_search_batch
+  DevBuf<uint8_t> s_seqs, s_seqs2;
+  DevBuf<uint64_t> s_offs, s_offs2, s_counter;
+  DevBuf<kmcpg_hit> s_hits;
+  DevBuf<int32_t> s_qk, s_ql;
+  bool synthetic = false;
+};
+
+namespace {
+
+uint32_t device_stride(uint32_t row_bytes) {
+  // rows are padded so a row never straddles more memory lines than it must: powers of two up to 64 B,
+  // multiples of 64 B above (1872 -> 1920).  The disk format is untouched (serialization.go:288-300).
+  if (row_bytes <= 16) return 16;
+  if (row_bytes <= 32) return 32;
+  if (row_bytes <= 64) return 64;
+  return (row_bytes + 63) / 64 * 64;
+}
+
+int lpr_for_stride(uint32_t stride) { return stride <= 64 ? 4 : (stride <= 256 ? 16 : 64); }
+
+void magic_for(uint64_t d, uint64_t* hi, uint64_t* lo) {
+  unsigned __int128 m = (~(unsigned __int128)0) / d + 1;  // wraps to 0 for d == 1: then x % 1 == 0 falls out
+  *hi = (uint64_t)(m >> 64);
+  *lo = (uint64_t)m;
+}
+
+// blocks are independent: greedy partition by bytes, largest first
+void assign_shards(kmcpg_db* db) {
+  const int S = db->opts.shard_count;
+  std::vector<int> order(db->blocks.size());
+  for (size_t i = 0; i < order.size(); i++) order[i] = (int)i;
+  auto bytes = [&](int i) { return db->blocks[i].h.num_sigs * (uint64_t)db->blocks[i].h.row_bytes; };
+  std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return bytes(a) > bytes(b); });
+  std::vector<uint64_t> load((size_t)S, 0);
+  for (int i : order) {
+    int best = 0;
+    for (int s = 1; s < S; s++)
+      if (load[s] < load[best]) best = s;
+    load[best] += bytes(i);
+    db->blocks[i].local = best == db->opts.shard_rank;
+  }
+}
+
+int finish_open(kmcpg_db* db) {
+  // BlockDev table + slot classes
+  db->local.clear();
+  db->h_blockdev.clear();
+  db->classes.clear();
+  db->info.n_blocks_local = 0;
+  db->info.matrix_bytes_local = 0;
+  db->info.row_bytes_sum_local = 0;
+  for (size_t i = 0; i < db->blocks.size(); i++) {
+    BlockMeta& b = db->blocks[i];
+    if (!b.local) continue;
+    b.local_idx = (int)db->local.size();
+    db->local.push_back((int)i);
+    BlockDev bd{};
+    bd.rows = b.d_rows;
+    bd.num_sigs = b.h.num_sigs;
+    magic_for(b.h.num_sigs, &bd.magic_hi, &bd.magic_lo);
+    bd.stride = b.stride;
+    bd.row_bytes = b.h.row_bytes;
+    bd.ncols = (uint32_t)b.h.names.size();
+    bd.col_base = b.col_base;
+    db->h_blockdev.push_back(bd);
+    db->info.n_blocks_local++;
+    db->info.matrix_bytes_local += b.h.num_sigs * (uint64_t)b.h.row_bytes;
+    db->info.row_bytes_sum_local += b.h.row_bytes;
+    const int lpr = lpr_for_stride(b.stride);
+    SlotClass* cls = nullptr;
+    for (auto& c : db->classes)
+      if (c.lpr == lpr) cls = &c;
+    if (!cls) {
+      db->classes.push_back(SlotClass{});
+      cls = &db->classes.back();
+      cls->lpr = lpr;
+    }
+    const uint32_t tile_bytes = (uint32_t)lpr * 16u;
+    const uint32_t tiles = (b.stride + tile_bytes - 1) / tile_bytes;
+    for (uint32_t t = 0; t < tiles; t++) cls->slots.push_back(Slot{(uint32_t)b.local_idx, t});
+  }
+  if (!db->h_blockdev.empty()) {
+    HIPCHK(hipMalloc((void**)&db->d_blockdev, db->h_blockdev.size() * sizeof(BlockDev)));
+    HIPCHK(hipMemcpy(db->d_blockdev, db->h_blockdev.data(), db->h_blockdev.size() * sizeof(BlockDev), hipMemcpyHostToDevice));
+  }
+  for (auto& c : db->classes) {
+    HIPCHK(hipMalloc((void**)&c.d_slots, c.slots.size() * sizeof(Slot)));
+    HIPCHK(hipMemcpy(c.d_slots, c.slots.data(), c.slots.size() * sizeof(Slot), hipMemcpyHostToDevice));
+  }
+  db->col_block.clear();
+  for (size_t i = 0; i < db->blocks.size(); i++)
+    for (size_t c = 0; c < db->blocks[i].h.names.size(); c++) db->col_block.push_back((uint32_t)i);
+  db->fpr.reset(new QueryFpr(db->info.fpr));
+  return 0;
+}
+
+// upload one block: file rows -> temp device buffer (chunked) -> padded HBM rows
+int upload_block(BlockMeta& b) {
+  const uint64_t ns = b.h.num_sigs;
+  const uint32_t rb = b.h.row_bytes;
+  if (ns + 1 > 0xffffffffULL) return fail(KMCPG_EUNSUPPORTED, "%s: NumSigs %llu exceeds 2^32-2 rows", b.path.c_str(), (unsigned long long)ns);
+  b.stride = device_stride(rb);
+  const uint64_t bytes = (ns + 1) * (uint64_t)b.stride;
+  HIPCHK(hipMalloc((void**)&b.d_rows, bytes));
+  HIPCHK(hipMemset(b.d_rows + ns * b.stride, 0, b.stride));  // the all-zero row
+  FILE* f = fopen(b.path.c_str(), "rb");
+  if (!f) return fail(KMCPG_EIO, "kmcp index file missing: %s", b.path.c_str());
+  fseeko(f, (off_t)b.h.offset0, SEEK_SET);
+  const uint64_t chunk_rows = std::max<uint64_t>(1, (256ull << 20) / rb);
+  std::vector<uint8_t> host(std::min(chunk_rows, ns) * rb);
+  uint8_t* d_tmp = nullptr;
+  HIPCHK(hipMalloc((void**)&d_tmp, host.size() ? host.size() : 1));
+  for (uint64_t r0 = 0; r0 < ns; r0 += chunk_rows) {
+    const uint64_t nr = std::min(chunk_rows, ns - r0);
+    if (fread(host.data(), 1, nr * rb, f) != nr * rb) {
+      fclose(f);
+      (void)hipFree(d_tmp);
+      return fail(KMCPG_EFORMAT, "kmcp: truncated index file: %s", b.path.c_str());
+    }
+    HIPCHK(hipMemcpy(d_tmp, host.data(), nr * rb, hipMemcpyHostToDevice));
+    launch_repack(d_tmp, b.d_rows + r0 * b.stride, nr, rb, b.stride, nullptr);
+    HIPCHK(hipDeviceSynchronize());
+  }
+  fclose(f);
+  HIPCHK(hipFree(d_tmp));
+  return 0;
+}
+
+int check_opts(const kmcpg_opts* o, kmcpg_opts* out) {
+  kmcpg_opts d{};
+  d.device = 0;
+  d.shard_rank = 0;
+  d.shard_count = 1;
+  if (o) d = *o;
+  if (d.shard_count < 1 || d.shard_rank < 0 || d.shard_rank >= d.shard_count) return fail(KMCPG_EINVAL, "bad shard_rank/shard_count");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+    return fail(KMCPG_EDEVICE, "no HIP device available: libkmcpgpu has no CPU fallback");
+  if (d.device < 0 || d.device >= ndev) return fail(KMCPG_EINVAL, "device %d out of range (%d devices)", d.device, ndev);
+  *out = d;
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int kmcpg_open(const char* db_dir, const kmcpg_opts* opts, kmcpg_db** out) {
+  if (!db_dir || !out) return fail(KMCPG_EINVAL, "null argument");
+  *out = nullptr;
+  std::unique_ptr<kmcpg_db> db(new kmcpg_db());
+  int rc = check_opts(opts, &db->opts);
+  if (rc) return rc;
+  HIPCHK(hipSetDevice(db->opts.device));
+  const std::string dir(db_dir);
+  DbYml y;
+  std::string e = read_db_yml(dir + "/__db.yml", &y);
+  if (!e.empty()) return fail(e.find("open") != std::string::npos ? KMCPG_EIO : KMCPG_EFORMAT, "%s", e.c_str());
+  int k = y.ks.empty() ? y.k : *std::max_element(y.ks.begin(), y.ks.end());
+  kmcpg_info& I = db->info;
+  I.k = k;
+  I.canonical = y.canonical;
+  I.num_hashes = y.num_hashes;
+  I.scaled = y.scaled;
+  I.scale = y.scale;
+  I.minimizer = y.minimizer;
+  I.minimizer_w = y.minimizer_w;
+  I.syncmer = y.syncmer;
+  I.syncmer_s = y.syncmer_s;
+  I.fpr = y.fpr;
+  uint32_t base = 0;
+  for (const auto& fn : y.files) {
+    BlockMeta b;
+    b.path = dir + "/" + fn;
+    e = read_uniki_header(b.path, &b.h);
+    if (!e.empty()) return fail(e.find("missing") != std::string::npos ? KMCPG_EIO : KMCPG_EFORMAT, "%s", e.c_str());
+    // compatibility checks of NewUnikIndexDB (:689-695) and Header.Compatible (serialization.go:90-99)
+    if (b.h.k != k || b.h.canonical != (bool)y.canonical || b.h.num_hashes != y.num_hashes || (y.uniki_version >= 0 && y.uniki_version != b.h.version))
+      return fail(KMCPG_EFORMAT, "index files not compatible");
+    b.col_base = base;
+    base += (uint32_t)b.h.names.size();
+    I.matrix_bytes += b.h.num_sigs * (uint64_t)b.h.row_bytes;
+    db->blocks.push_back(std::move(b));
+  }
+  I.n_blocks = (int32_t)db->blocks.size();
+  I.n_cols = base;
+  if (I.num_hashes < 1 || I.num_hashes > 4) return fail(KMCPG_EUNSUPPORTED, "hashes=%d (kmcp index allows 1..4)", I.num_hashes);
+  assign_shards(db.get());
+  for (auto& b : db->blocks)
+    if (b.local) {
+      rc = upload_block(b);
+      if (rc) return rc;
+    }
+  rc = finish_open(db.get());
+  if (rc) return rc;
+  *out = db.release();
+  return 0;
+}
+
+extern "C" int kmcpg_open_synthetic(const kmcpg_synth_spec* s, const kmcpg_opts* opts, kmcpg_db** out) {
+  if (!s || !out) return fail(KMCPG_EINVAL, "null argument");
+  *out = nullptr;
+  if (s->n_blocks == 0 || s->cols_per_block == 0 || s->num_sigs == 0 || s->num_hashes < 1 || s->num_hashes > 4)
+    return fail(KMCPG_EINVAL, "bad synthetic spec");
+  std::unique_ptr<kmcpg_db> db(new kmcpg_db());
+  int rc = check_opts(opts, &db->opts);
+  if (rc) return rc;
+  HIPCHK(hipSetDevice(db->opts.device));
+  db->synthetic = true;
+  kmcpg_info& I = db->info;
+  I.k = s->k;
+  I.canonical = 1;
+  I.num_hashes = s->num_hashes;
+  I.scale = 1;
+  I.fpr = s->fpr;
+  uint32_t base = 0;
+  char name[64];
+  for (uint32_t i = 0; i < s->n_blocks; i++) {
+    BlockMeta b;
+    snprintf(name, sizeof name, "<synthetic block %u>", i);
+    b.path = name;
+    b.h.version = 4;
+    b.h.k = s->k;
+    b.h.canonical = true;
+    b.h.compact = true;
+    b.h.num_hashes = s->num_hashes;
+    b.h.num_sigs = s->num_sigs;
+    b.h.row_bytes = (s->cols_per_block + 7) / 8;
+    for (uint32_t c = 0; c < s->cols_per_block; c++) {
+      snprintf(name, sizeof name, "syn%u", base + c);
+      b.h.names.push_back(name);
+      b.h.gsizes.push_back(4000000);
+      b.h.indices.push_back((c % 10) | (10u << 16));
+      b.h.sizes.push_back(s->kmers_per_col);
+    }
+    b.col_base = base;
+    base += s->cols_per_block;
+    I.matrix_bytes += b.h.num_sigs * (uint64_t)b.h.row_bytes;
+    db->blocks.push_back(std::move(b));
+  }
+  I.n_blocks = (int32_t)db->blocks.size();
+  I.n_cols = base;
+  assign_shards(db.get());
+  // density of one Bloom filter holding kmers_per_col of num_sigs slots with h hashes, at 8-bit resolution
+  const double dens = 1.0 - exp(-(double)s->num_hashes * (double)s->kmers_per_col / (double)s->num_sigs);
+  uint32_t p8 = (uint32_t)llround(dens * 256.0);
+  if (p8 > 255) p8 = 255;
+  for (size_t i = 0; i < db->blocks.size(); i++) {
+    BlockMeta& b = db->blocks[i];
+    if (!b.local) continue;
+    if (b.h.num_sigs + 1 > 0xffffffffULL) return fail(KMCPG_EUNSUPPORTED, "NumSigs too large");
+    b.stride = device_stride(b.h.row_bytes);
+    HIPCHK(hipMalloc((void**)&b.d_rows, (b.h.num_sigs + 1) * (uint64_t)b.stride));
+    HIPCHK(hipMemset(b.d_rows + b.h.num_sigs * b.stride, 0, b.stride));
+    launch_synth_fill(b.d_rows, b.h.num_sigs, b.stride, (uint32_t)b.h.names.size(), s->seed * 0x9e3779b97f4a7c15ULL + i * 0x632be59bd9b4e019ULL + 1, p8,
+                      nullptr);
+  }
+  HIPCHK(hipDeviceSynchronize());
+  rc = finish_open(db.get());
+  if (rc) return rc;
+  *out = db.release();
+  return 0;
+}
+
+extern "C" int kmcpg_close(kmcpg_db* db) {
+  if (!db) return 0;
+  (void)hipSetDevice(db->opts.device);
+  for (auto& b : db->blocks)
+    if (b.d_rows) (void)hipFree(b.d_rows);
+  if (db->d_blockdev) (void)hipFree(db->d_blockdev);
+  for (auto& c : db->classes)
+    if (c.d_slots) (void)hipFree(c.d_slots);
+  db->w_hashes.release();
+  db->w_scratch.release();
+  db->w_nk_raw.release();
+  db->w_nk1.release();
+  db->s_seqs.release();
+  db->s_seqs2.release();
+  db->s_offs.release();
+  db->s_offs2.release();
+  db->s_counter.release();
+  db->s_hits.release();
+  db->s_qk.release();
+  db->s_ql.release();
+  delete db;
+  return 0;
+}
+
+extern "C" int kmcpg_db_info(const kmcpg_db* db, kmcpg_info* info) {
+  if (!db || !info) return fail(KMCPG_EINVAL, "null argument");
+  *info = db->info;
+  return 0;
+}
+
+extern "C" int kmcpg_col_info(const kmcpg_db* db, uint32_t col, const char** name, uint32_t* target_idx, uint64_t* gsize, uint64_t* size) {
+  if (!db) return fail(KMCPG_EINVAL, "null argument");
+  if (col >= db->col_block.size()) return fail(KMCPG_EINVAL, "column %u out of range", col);
+  const BlockMeta& b = db->blocks[db->col_block[col]];
+  const uint32_t c = col - b.col_base;
+  if (name) *name = b.h.names[c].c_str();
+  if (target_idx) *target_idx = b.h.indices[c];
+  if (gsize) *gsize = b.h.gsizes[c];
+  if (size) *size = b.h.sizes[c];
+  return 0;
+}
+
+extern "C" int kmcpg_block_info(const kmcpg_db* db, uint32_t block, uint64_t* num_sigs, uint32_t* n_cols, uint32_t* row_bytes, uint32_t* dev_stride,
+                                int32_t* is_local, uint32_t* col_base) {
+  if (!db || block >= db->blocks.size()) return fail(KMCPG_EINVAL, "bad block");
+  const BlockMeta& b = db->blocks[block];
+  if (num_sigs) *num_sigs = b.h.num_sigs;
+  if (n_cols) *n_cols = (uint32_t)b.h.names.size();
+  if (row_bytes) *row_bytes = b.h.row_bytes;
+  if (dev_stride) *dev_stride = b.stride;
+  if (is_local) *is_local = b.local ? 1 : 0;
+  if (col_base) *col_base = b.col_base;
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// GPU half
+// ------------------------------------------------------------------------------------------------
+namespace {
+
+kmcpg_params default_params() {
+  kmcpg_params p{};
+  p.min_qlen = 30;
+  p.min_matched = 10;
+  p.min_qcov = 0.55;
+  p.min_tcov = 0;
+  p.max_fpr = 0.01;
+  p.dedup_threshold = 256;
+  return p;
+}
+
+uint64_t max_hash_for(uint32_t scale) {
+  // uint64(float64(^uint64(0)) / float64(scale))  (util-db-search.go:1040-1043)
+  const double d = 18446744073709551616.0 / (double)scale;
+  if (d >= 18446744073709551616.0) return ~0ULL;
+  return (uint64_t)d;
+}
+
+// K1 (+K1d): hashes of read i end up at d_hashes[offs[i] + offs2[i] ...], NumKmers in d_nk_search
+int run_kmers(kmcpg_db* db, const uint8_t* d_seqs, const uint64_t* d_offs, const uint8_t* d_seqs2, const uint64_t* d_offs2, uint32_t n_reads,
+              uint32_t max_read_len, const kmcpg_params& p, uint64_t* d_hashes, uint64_t* d_scratch, int32_t* d_nk_raw, int32_t* d_nk1,
+              int32_t* d_nk_search, int32_t* d_qlen, hipStream_t st, uint64_t* max_n_out) {
+  const kmcpg_info& I = db->info;
+  if (I.minimizer || I.syncmer) return fail(KMCPG_EUNSUPPORTED, "minimizer/syncmer databases are not supported by the GPU k-mer kernel yet");
+  if (!I.canonical) return fail(KMCPG_EUNSUPPORTED, "non-canonical index");
+  K1Args a{};
+  a.seqs = d_seqs;
+  a.offs = d_offs;
+  a.seqs2 = d_seqs2;
+  a.offs2 = d_offs2;
+  a.n_reads = n_reads;
+  a.k = I.k;
+  a.min_qlen = p.min_qlen;
+  a.scaled = I.scaled;
+  a.max_hash = I.scaled ? max_hash_for(I.scale) : ~0ULL;
+  a.mode = 0;
+  a.hashes = d_hashes;
+  a.scratch = d_scratch;
+  a.nk_raw = d_nk_raw;
+  a.nk1 = d_nk1;
+  a.qlen = d_qlen;
+  launch_k1(a, st);
+  uint64_t ub = max_read_len >= (uint32_t)I.k ? (uint64_t)(max_read_len - I.k + 1) : 0;
+  if (d_seqs2) ub *= 2;
+  *max_n_out = ub;
+  if (ub > (uint64_t)p.dedup_threshold) {
+    DedupArgs d{};
+    d.offs = d_offs;
+    d.offs2 = d_offs2;
+    d.n_reads = n_reads;
+    d.dedup_threshold = p.dedup_threshold;
+    d.min_matched = p.min_matched;
+    d.hashes = d_hashes;
+    d.scratch = d_scratch;
+    d.nk_raw = d_nk_raw;
+    d.nk_search = d_nk_search;
+    launch_dedup(d, st);
+  } else {
+    launch_nk_simple(d_nk_raw, d_nk_search, n_reads, p.min_matched, st);
+  }
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int kmcpg_kmers_device(kmcpg_db* db, const uint8_t* d_seqs, const uint64_t* d_offs, uint32_t n_reads, uint64_t total_bases,
+                                  uint32_t max_read_len, const kmcpg_params* params, uint64_t* d_hashes, uint64_t hashes_cap, uint64_t* d_koff,
+                                  int32_t* d_nk, void* stream) {
+  if (!db || !d_seqs || !d_offs || !d_hashes || !d_nk) return fail(KMCPG_EINVAL, "null argument");
+  if (hashes_cap < total_bases) return fail(KMCPG_EINVAL, "hashes_cap must be >= total_bases");
+  std::lock_guard<std::mutex> g(db->mu);
+  HIPCHK(hipSetDevice(db->opts.device));
+  const kmcpg_params p = params ? *params : default_params();
+  hipStream_t st = (hipStream_t)stream;
+  if (db->w_scratch.ensure(total_bases + 1) || db->w_nk_raw.ensure(n_reads + 1) || db->w_nk1.ensure(n_reads + 1)) return fail(KMCPG_ENOMEM, "hipMalloc failed");
+  DevBuf<int32_t> ql;
+  if (ql.ensure(n_reads + 1)) return fail(KMCPG_ENOMEM, "hipMalloc failed");
+  uint64_t maxn = 0;
+  int rc = run_kmers(db, d_seqs, d_offs, nullptr, nullptr, n_reads, max_read_len, p, d_hashes, db->w_scratch.p, db->w_nk_raw.p, db->w_nk1.p, d_nk, ql.p, st,
+                     &maxn);
+  if (rc == 0 && d_koff) HIPCHK(hipMemcpyAsync(d_koff, d_offs, (size_t)n_reads * sizeof(uint64_t), hipMemcpyDeviceToDevice, st));
+  hipError_t e = hipStreamSynchronize(st);
+  ql.release();
+  if (rc) return rc;
+  if (e != hipSuccess) return fail(KMCPG_EDEVICE, "k-mer kernel failed: %s", hipGetErrorString(e));
+  return 0;
+}
+
+extern "C" int kmcpg_query_device(kmcpg_db* db, const uint8_t* d_seqs, const uint64_t* d_offs, const uint8_t* d_seqs2, const uint64_t* d_offs2,
+                                  uint32_t n_reads, uint64_t total_bases, uint32_t max_read_len, const kmcpg_params* params, kmcpg_hit* d_hits,
+                                  uint64_t hit_cap, uint64_t* d_counters, int32_t* d_qkmers, int32_t* d_qlen, void* stream) {
+  if (!db || !d_seqs || !d_offs || !d_counters || !d_qkmers || !d_qlen || (!d_hits && hit_cap)) return fail(KMCPG_EINVAL, "null argument");
+  if ((d_seqs2 == nullptr) != (d_offs2 == nullptr)) return fail(KMCPG_EINVAL, "seqs2 and offs2 must be given together");
+  std::lock_guard<std::mutex> g(db->mu);
+  HIPCHK(hipSetDevice(db->opts.device));
+  const kmcpg_params p = params ? *params : default_params();
+  if (p.min_matched < 1) return fail(KMCPG_EINVAL, "min_matched must be >= 1");  // getFlagPositiveInt (search.go:165)
+  hipStream_t st = (hipStream_t)stream;
+  if (db->w_hashes.ensure(total_bases + 1) || db->w_nk_raw.ensure(n_reads + 1) || db->w_nk1.ensure(n_reads + 1)) return fail(KMCPG_ENOMEM, "hipMalloc failed");
+  uint64_t ub = max_read_len >= (uint32_t)db->info.k ? (uint64_t)(max_read_len - db->info.k + 1) : 0;
+  if (d_seqs2) ub *= 2;
+  if (ub > (uint64_t)p.dedup_threshold && db->w_scratch.ensure(total_bases + 1)) return fail(KMCPG_ENOMEM, "hipMalloc failed");
+  uint64_t maxn = 0;
+  int rc = run_kmers(db, d_seqs, d_offs, d_seqs2, d_offs2, n_reads, max_read_len, p, db->w_hashes.p, db->w_scratch.p, db->w_nk_raw.p, db->w_nk1.p, d_qkmers,
+                     d_qlen, st, &maxn);
+  if (rc) return rc;
+  HIPCHK(hipMemsetAsync(d_counters, 0, sizeof(uint64_t), st));
+  const int npl = maxn <= 255 ? 8 : (maxn <= 65535 ? 16 : (maxn <= 16777215 ? 24 : 0));
+  if (!npl) return fail(KMCPG_EUNSUPPORTED, "queries with more than 16777215 k-mers are not supported");
+  for (const auto& c : db->classes) {
+    K2Args a{};
+    a.blocks = db->d_blockdev;
+    a.slots = c.d_slots;
+    a.nslots = (uint32_t)c.slots.size();
+    a.n_reads = n_reads;
+    a.hashes = db->w_hashes.p;
+    a.offs = d_offs;
+    a.offs2 = d_offs2;
+    a.nk = d_qkmers;
+    a.min_qcov = p.min_qcov;
+    a.min_matched = p.min_matched;
+    a.num_hashes = db->info.num_hashes;
+    a.hits = d_hits;
+    a.hit_cap = hit_cap;
+    a.counter = (unsigned long long*)d_counters;
+    if (launch_k2(a, c.lpr, npl, st) != 0) return fail(KMCPG_EINVAL, "batch too large for one launch: split it");
+  }
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// host half: thresholds that need float64, Match values, sorting (util-db-search.go:7471-7489, :260-345)
+// ------------------------------------------------------------------------------------------------
+namespace {
+
+struct ResultOwner {
+  std::vector<int32_t> qlen, qkmers;
+  std::vector<uint64_t> offs;
+  std::vector<kmcpg_match> matches;
+};
+
+bool match_less(const kmcpg_match& x, const kmcpg_match& y, int sort_by) {
+  double s1, s2, t1, t2;
+  switch (sort_by) {  // Matches.Less / SortByTCov.Less / SortByJacc.Less (:105-145)
+    case 1: s1 = x.tcov; s2 = y.tcov; t1 = x.mkmers; t2 = y.mkmers; break;
+    case 2: s1 = x.jacc; s2 = y.jacc; t1 = x.mkmers; t2 = y.mkmers; break;
+    default: s1 = x.qcov; s2 = y.qcov; t1 = x.tcov; t2 = y.tcov; break;
+  }
+  if (s1 != s2) return s1 > s2;
+  if (t1 != t2) return t1 > t2;
+  return x.col < y.col;  // deterministic tie-break; the reference's order among exact ties is arbitrary
+}
+
+}  // namespace
+
+extern "C" int kmcpg_finalize(const kmcpg_db* db, const kmcpg_hit* hits, uint64_t n_hits, const int32_t* qkmers, const int32_t* qlen, uint32_t n_reads,
+                              const kmcpg_params* params, kmcpg_result* out) {
+  if (!db || !out || (!hits && n_hits) || !qkmers || !qlen) return fail(KMCPG_EINVAL, "null argument");
+  const kmcpg_params p = params ? *params : default_params();
+  std::unique_ptr<ResultOwner> o(new ResultOwner());
+  o->qlen.assign(qlen, qlen + n_reads);
+  o->qkmers.assign(qkmers, qkmers + n_reads);
+  // bucket hits by read (counting sort), then order each bucket by column
+  std::vector<uint64_t> start((size_t)n_reads + 1, 0);
+  for (uint64_t i = 0; i < n_hits; i++) {
+    if (hits[i].read >= n_reads) return fail(KMCPG_EINVAL, "hit %llu names read %u of %u", (unsigned long long)i, hits[i].read, n_reads);
+    start[hits[i].read + 1]++;
+  }
+  for (uint32_t r = 0; r < n_reads; r++) start[r + 1] += start[r];
+  std::vector<kmcpg_hit> sorted(n_hits);
+  {
+    std::vector<uint64_t> cur(start.begin(), start.end() - 1);
+    for (uint64_t i = 0; i < n_hits; i++) sorted[cur[hits[i].read]++] = hits[i];
+  }
+  o->offs.assign((size_t)n_reads + 1, 0);
+  o->matches.reserve(n_hits);
+  QueryFpr* F = db->fpr.get();
+  for (uint32_t r = 0; r < n_reads; r++) {
+    const size_t first = o->matches.size();
+    const int n = qkmers[r];
+    const double nh = (double)n;
+    const double thr = nh * p.min_qcov;
+    for (uint64_t i = start[r]; i < start[r + 1]; i++) {
+      const kmcpg_hit& h = sorted[i];
+      if (h.col >= db->col_block.size()) return fail(KMCPG_EINVAL, "hit names column %u of %zu", h.col, db->col_block.size());
+      const int count = (int)h.count;
+      if (count < p.min_matched) continue;
+      const double c = (double)count;
+      if (!(c > thr)) continue;
+      const BlockMeta& b = db->blocks[db->col_block[h.col]];
+      const uint32_t ci = h.col - b.col_base;
+      const double nt = (double)b.h.sizes[ci];
+      const double T = c / nt;
+      if (!(T >= p.min_tcov)) continue;
+      const double fpr = F->get(n, count);
+      if (!(fpr <= p.max_fpr)) continue;
+      kmcpg_match m{};
+      m.col = h.col;
+      m.target_idx = b.h.indices[ci];
+      m.gsize = b.h.gsizes[ci];
+      m.mkmers = count;
+      m.fpr = fpr;
+      m.qcov = c / nh;
+      m.tcov = T;
+      m.jacc = c / (nh + nt - c);
+      o->matches.push_back(m);
+    }
+    size_t cnt = o->matches.size() - first;
+    if (cnt > 1 && !p.do_not_sort) {
+      const int sb = p.sort_by;
+      std::sort(o->matches.begin() + (ptrdiff_t)first, o->matches.end(), [sb](const kmcpg_match& x, const kmcpg_match& y) { return match_less(x, y, sb); });
+    } else if (cnt > 1) {
+      std::sort(o->matches.begin() + (ptrdiff_t)first, o->matches.end(), [](const kmcpg_match& x, const kmcpg_match& y) { return x.col < y.col; });
+    }
+    if (cnt > 0 && p.top_n_scores > 0 && !p.do_not_sort) {  // --keep-top-scores (:285-311), including its [:i+1]
+      int nn = 0;
+      size_t i = 0;
+      double pscore = 1024;
+      for (; i < cnt; i++) {
+        const kmcpg_match& m = o->matches[first + i];
+        const double score = p.sort_by == 1 ? m.tcov : (p.sort_by == 2 ? m.jacc : m.qcov);
+        if (score < pscore) {
+          nn++;
+          if (nn > p.top_n_scores) break;
+          pscore = score;
+        }
+      }
+      if (i >= cnt) i = cnt - 1;
+      o->matches.resize(first + i + 1);
+    }
+    o->offs[r + 1] = o->matches.size();
+  }
+  out->n_reads = n_reads;
+  out->k = db->info.k;
+  out->qlen = o->qlen.data();
+  out->qkmers = o->qkmers.data();
+  out->match_offs = o->offs.data();
+  out->matches = o->matches.data();
+  out->owner = o.release();
+  return 0;
+}
+
+extern "C" void kmcpg_result_free(kmcpg_result* r) {
+  if (!r || !r->owner) return;
+  delete (ResultOwner*)r->owner;
+  memset(r, 0, sizeof *r);
+}
+
+// ------------------------------------------------------------------------------------------------
+// whole pipeline on host buffers
+// ------------------------------------------------------------------------------------------------
+namespace {
+
+struct RawBatch {
+  std::vector<kmcpg_hit> hits;
+  std::vector<int32_t> qk, ql;
+};
+
+int run_raw(kmcpg_db* db, const uint8_t* seqs, const uint64_t* offs, const uint8_t* seqs2, const uint64_t* offs2, uint32_t n, const kmcpg_params& p,
+            RawBatch* rb) {
+  rb->hits.clear();
+  rb->qk.assign(n, 0);
+  rb->ql.assign(n, 0);
+  if (n == 0) return 0;
+  const uint64_t tb1 = offs[n] - offs[0], tb2 = seqs2 ? offs2[n] - offs2[0] : 0;
+  if (offs[0] != 0 || (seqs2 && offs2[0] != 0)) return fail(KMCPG_EINVAL, "offs[0] must be 0");
+  uint32_t maxlen = 0;
+  for (uint32_t i = 0; i < n; i++) {
+    uint64_t l = offs[i + 1] - offs[i];
+    if (seqs2) l = std::max<uint64_t>(l, offs2[i + 1] - offs2[i]);
+    if (l > 0x7fffffffULL) return fail(KMCPG_EUNSUPPORTED, "query longer than 2^31-1 bases");
+    maxlen = std::max<uint32_t>(maxlen, (uint32_t)l);
+  }
+  {
+    std::lock_guard<std::mutex> g(db->mu);
+    HIPCHK(hipSetDevice(db->opts.device));
+    if (db->s_seqs.ensure(tb1 + 16) || db->s_offs.ensure(n + 1) || db->s_counter.ensure(2) || db->s_qk.ensure(n) || db->s_ql.ensure(n))
+      return fail(KMCPG_ENOMEM, "hipMalloc failed");
+    if (seqs2 && (db->s_seqs2.ensure(tb2 + 16) || db->s_offs2.ensure(n + 1))) return fail(KMCPG_ENOMEM, "hipMalloc failed");
+    HIPCHK(hipMemcpy(db->s_seqs.p, seqs, tb1, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(db->s_offs.p, offs, (size_t)(n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice));
+    if (seqs2) {
+      HIPCHK(hipMemcpy(db->s_seqs2.p, seqs2, tb2, hipMemcpyHostToDevice));
+      HIPCHK(hipMemcpy(db->s_offs2.p, offs2, (size_t)(n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice));
+    }
+  }
+  uint64_t cap = std::max<uint64_t>(db->s_hits.cap, (uint64_t)n * 8 + 1024);
+  for (int attempt = 0; attempt < 3; attempt++) {
+    {
+      std::lock_guard<std::mutex> g(db->mu);
+      if (db->s_hits.ensure(cap)) return fail(KMCPG_ENOMEM, "hipMalloc failed");
+    }
+    int rc = kmcpg_query_device(db, db->s_seqs.p, db->s_offs.p, seqs2 ? db->s_seqs2.p : nullptr, seqs2 ? db->s_offs2.p : nullptr, n, tb1 + tb2, maxlen, &p,
+                                db->s_hits.p, db->s_hits.cap, db->s_counter.p, db->s_qk.p, db->s_ql.p, nullptr);
+    if (rc) return rc;
+    uint64_t cnt = 0;
+    HIPCHK(hipMemcpy(&cnt, db->s_counter.p, sizeof cnt, hipMemcpyDeviceToHost));  // synchronises the default stream
+    if (cnt <= db->s_hits.cap) {
+      rb->hits.resize(cnt);
+      if (cnt) HIPCHK(hipMemcpy(rb->hits.data(), db->s_hits.p, cnt * sizeof(kmcpg_hit), hipMemcpyDeviceToHost));
+      HIPCHK(hipMemcpy(rb->qk.data(), db->s_qk.p, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost));
+      HIPCHK(hipMemcpy(rb->ql.data(), db->s_ql.p, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost));
+      return 0;
+    }
+    cap = cnt + cnt / 4;  // buffer was too small: rerun with room for every hit
+  }
+  return fail(KMCPG_ENOMEM, "hit buffer overflow");
+}
+
+}  // namespace
+
+extern "C" int kmcpg_search_batch(kmcpg_db* db, const uint8_t* seqs, const uint64_t* offs, const uint8_t* seqs2, const uint64_t* offs2, uint32_t n_reads,
+                                  const kmcpg_params* params, kmcpg_result* out) {
+  if (!db || !out || (n_reads && (!seqs || !offs))) return fail(KMCPG_EINVAL, "null argument");
+  if ((seqs2 == nullptr) != (offs2 == nullptr)) return fail(KMCPG_EINVAL, "seqs2 and offs2 must be given together");
+  if (db->opts.shard_count != 1) return fail(KMCPG_EINVAL, "kmcpg_search_batch needs the whole database on one GPU; use kmcpg_query_device + kmcpg_finalize per shard");
+  kmcpg_params p = params ? *params : default_params();
+  memset(out, 0, sizeof *out);
+  std::lock_guard<std::mutex> api_guard(db->api_mu);
+  RawBatch rb;
+  int rc = run_raw(db, seqs, offs, seqs2, offs2, n_reads, p, &rb);
+  if (rc) return rc;
+  rc = kmcpg_finalize(db, rb.hits.data(), rb.hits.size(), rb.qk.data(), rb.ql.data(), n_reads, &p, out);
+  if (rc) return rc;
+  if (!(p.try_se && seqs2)) return 0;
+
+  // --try-se (:831-850, :1001-1014): paired-end queries without a match are searched again with read 1, then read 2.
+  // The retries skip the length gate (it is applied once, before k-mer generation) and reuse the mates' own k-mers.
+  ResultOwner* o = (ResultOwner*)out->owner;
+  for (int mate = 0; mate < 2; mate++) {
+    std::vector<uint32_t> todo;
+    for (uint32_t r = 0; r < n_reads; r++)
+      if (o->offs[r + 1] == o->offs[r] && o->qkmers[r] > 0) todo.push_back(r);  // searched (>= MinMatched k-mers) but nothing found
+    if (todo.empty()) break;
+    const uint8_t* S = mate == 0 ? seqs : seqs2;
+    const uint64_t* O = mate == 0 ? offs : offs2;
+    std::vector<uint8_t> sub;
+    std::vector<uint64_t> so(1, 0);
+    for (uint32_t r : todo) {
+      sub.insert(sub.end(), S + O[r], S + O[r + 1]);
+      so.push_back(sub.size());
+    }
+    kmcpg_params q = p;
+    q.min_qlen = 0;
+    q.try_se = 0;
+    RawBatch rb2;
+    rc = run_raw(db, sub.data(), so.data(), nullptr, nullptr, (uint32_t)todo.size(), q, &rb2);
+    if (rc) return rc;
+    kmcpg_result r2;
+    rc = kmcpg_finalize(db, rb2.hits.data(), rb2.hits.size(), rb2.qk.data(), rb2.ql.data(), (uint32_t)todo.size(), &q, &r2);
+    if (rc) return rc;
+    // splice the retried queries back in
+    std::vector<uint64_t> noffs((size_t)n_reads + 1, 0);
+    std::vector<kmcpg_match> nm;
+    size_t t = 0;
+    std::vector<char> stop(n_reads, 0);
+    for (uint32_t r = 0; r < n_reads; r++) {
+      if (t < todo.size() && todo[t] == r) {
+        o->qlen[r] = r2.qlen[t];
+        if (r2.qkmers[t] > 0) o->qkmers[r] = r2.qkmers[t];
+        else stop[r] = 1;  // fewer than MinMatched k-mers in this mate: the reference returns here (:854-869)
+        nm.insert(nm.end(), r2.matches + r2.match_offs[t], r2.matches + r2.match_offs[t + 1]);
+        t++;
+      } else {
+        nm.insert(nm.end(), o->matches.begin() + (ptrdiff_t)o->offs[r], o->matches.begin() + (ptrdiff_t)o->offs[r + 1]);
+      }
+      noffs[r + 1] = nm.size();
+    }
+    kmcpg_result_free(&r2);
+    o->matches.swap(nm);
+    o->offs.swap(noffs);
+    if (mate == 0)
+      for (uint32_t r = 0; r < n_reads; r++)
+        if (stop[r]) o->qkmers[r] = -o->qkmers[r] - 1;  // park: not retried with read 2
+    out->matches = o->matches.data();
+    out->match_offs = o->offs.data();
+  }
+  for (uint32_t r = 0; r < n_reads; r++)
+    if (o->qkmers[r] < 0) o->qkmers[r] = -(o->qkmers[r] + 1);
+  out->qlen = o->qlen.data();
+  out->qkmers = o->qkmers.data();
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// bench / parity support
+// ------------------------------------------------------------------------------------------------
+extern "C" int kmcpg_plant(kmcpg_db* db, uint32_t col, const uint64_t* hashes, uint64_t n) {
+  if (!db || (!hashes && n)) return fail(KMCPG_EINVAL, "null argument");
+  if (col >= db->col_block.size()) return fail(KMCPG_EINVAL, "column out of range");
+  const BlockMeta& b = db->blocks[db->col_block[col]];
+  if (!b.local || n == 0) return 0;
+  std::lock_guard<std::mutex> g(db->mu);
+  HIPCHK(hipSetDevice(db->opts.device));
+  uint64_t* d = nullptr;
+  HIPCHK(hipMalloc((void**)&d, n * sizeof(uint64_t)));
+  HIPCHK(hipMemcpy(d, hashes, n * sizeof(uint64_t), hipMemcpyHostToDevice));
+  launch_plant(db->h_blockdev[(size_t)b.local_idx], col - b.col_base, db->info.num_hashes, d, n, nullptr);
+  HIPCHK(hipDeviceSynchronize());
+  HIPCHK(hipFree(d));
+  return 0;
+}
+
+extern "C" int kmcpg_read_rows(kmcpg_db* db, uint32_t block, const uint64_t* row_idx, uint64_t n_rows, uint8_t* out) {
+  if (!db || block >= db->blocks.size() || (!row_idx && n_rows) || (!out && n_rows)) return fail(KMCPG_EINVAL, "bad argument");
+  const BlockMeta& b = db->blocks[block];
+  if (!b.local) return fail(KMCPG_EINVAL, "block %u is not resident on this rank", block);
+  for (uint64_t i = 0; i < n_rows; i++)
+    if (row_idx[i] >= b.h.num_sigs) return fail(KMCPG_EINVAL, "row out of range");
+  if (n_rows == 0) return 0;
+  std::lock_guard<std::mutex> g(db->mu);
+  HIPCHK(hipSetDevice(db->opts.device));
+  uint64_t* d_idx = nullptr;
+  uint8_t* d_out = nullptr;
+  HIPCHK(hipMalloc((void**)&d_idx, n_rows * sizeof(uint64_t)));
+  HIPCHK(hipMalloc((void**)&d_out, n_rows * b.h.row_bytes));
+  HIPCHK(hipMemcpy(d_idx, row_idx, n_rows * sizeof(uint64_t), hipMemcpyHostToDevice));
+  launch_gather_rows(b.d_rows, b.stride, b.h.row_bytes, d_idx, n_rows, d_out, nullptr);
+  HIPCHK(hipMemcpy(out, d_out, n_rows * b.h.row_bytes, hipMemcpyDeviceToHost));
+  HIPCHK(hipFree(d_idx));
+  HIPCHK(hipFree(d_out));
+  return 0;
+}

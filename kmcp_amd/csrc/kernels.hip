@@ -1,0 +1,544 @@
+// kernels.hip — hand-written CDNA4 (gfx950) kernels of the kmcp search hot path.
+//
+//   K1  k1_kmers      ntHash canonical k-mer hashes of batched reads (+ FracMinHash filter)
+//                     replaces bio/sketches HashIterator.NextHash behind generateKmers
+//                     (kmcp/cmd/util-db-search.go:1037-1107)
+//   K1d k_dedup       per-read sort + unique when #k-mers > -u (util-db-search.go:874-908)
+//   K2  k2_cobs       the COBS query: row = hash % NumSigs, gather rows, AND the h rows, per-column
+//                     match counts, integer threshold, hit emission (util-db-search.go:6611-7742)
+//
+// The path is bitwise/integer and HBM-bound; there is no MFMA here by design.  wave = 64 lanes.
+#include <hip/hip_runtime.h>
+
+#include "common.hpp"
+#include "kernels.hpp"
+
+namespace kmcpg {
+
+// ------------------------------------------------------------------------------------------------
+// small helpers
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t rol1(uint64_t v) { return (v << 1) | (v >> 63); }
+
+// ntHash v1 seed table entry for byte b (rows 0..7 are N,T,N,G,A,A,N,C so that the complement of
+// base x is tab[x & 7]); will-rowe/nthash v0.4.0 seedTab.
+__device__ __forceinline__ uint64_t seed_of(int b) {
+  const uint64_t A = 0x3c8bfbb395c60474ULL, C = 0x3193c18562a02b4cULL, G = 0x20323ed082572324ULL,
+                 T = 0x295549f54be24456ULL;
+  switch (b) {
+    case 1: return T;
+    case 3: return G;
+    case 4: case 5: return A;
+    case 7: return C;
+    case 'A': case 'a': return A;
+    case 'C': case 'c': return C;
+    case 'G': case 'g': return G;
+    case 'T': case 't': case 'U': case 'u': return T;
+    default: return 0;
+  }
+}
+
+// exact a % d for any 64-bit a, d (Lemire fastmod with a 128-bit magic): replaces fastdiv.Uint64.Mod
+// (util-db-search.go:6611,6811).
+__device__ __forceinline__ uint64_t fastmod_u64(uint64_t a, uint64_t d, uint64_t mh, uint64_t ml) {
+  uint64_t lo = ml * a;
+  uint64_t hi = __umul64hi(ml, a) + mh * a;
+  uint64_t p_hi = __umul64hi(lo, d);
+  uint64_t q_lo = hi * d;
+  uint64_t q_hi = __umul64hi(hi, d);
+  uint64_t sum = q_lo + p_hi;
+  return q_hi + (sum < q_lo ? 1ULL : 0ULL);
+}
+
+__device__ __forceinline__ void wave_lds_fence() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// ------------------------------------------------------------------------------------------------
+// K1: k-mer generation.  One wave per read; lane i hashes the k-mer at position base+i by the closed
+// form fh = XOR_j rol(seed[b_j], k-1-j), rh = XOR_j rol(seed[comp b_j], j); kept hashes are compacted
+// in order with a wave ballot.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int hash_mate(const uint8_t* __restrict__ s, int len, int k, const uint64_t* tab, bool scaled,
+                                         uint64_t max_hash, uint64_t* __restrict__ out, int cnt, int lane) {
+  const int npos = len - k + 1;
+  if (npos <= 0) return cnt;  // ErrShortSeq => no k-mers (util-db-search.go:1060-1062)
+  for (int base = 0; base < npos; base += 64) {
+    const int i = base + lane;
+    const bool v = i < npos;
+    uint64_t h = 0;
+    if (v) {
+      uint64_t f = 0, r = 0;
+      for (int j = 0; j < k; j++) {
+        f = rol1(f) ^ tab[s[i + j]];
+        r = rol1(r) ^ tab[s[i + k - 1 - j] & 7];
+      }
+      h = f < r ? f : r;
+    }
+    const bool keep = v && h != 0 && (!scaled || h <= max_hash);  // :1097-1103
+    const uint64_t m = __ballot(keep);
+    if (keep) out[cnt + __popcll(m & ((1ULL << lane) - 1ULL))] = h;
+    cnt += __popcll(m);
+  }
+  return cnt;
+}
+
+__global__ void __launch_bounds__(256) k1_kmers(const K1Args a) {
+  __shared__ uint64_t tab[256];
+  tab[threadIdx.x] = seed_of(threadIdx.x);
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const uint32_t wave = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const uint32_t nwaves = gridDim.x * 4;
+  for (uint32_t r = wave; r < a.n_reads; r += nwaves) {
+    const uint64_t o1 = a.offs[r];
+    const int len1 = (int)(a.offs[r + 1] - o1);
+    uint64_t o2 = 0;
+    int len2 = 0;
+    const bool pe = a.offs2 != nullptr;
+    if (pe) {
+      o2 = a.offs2[r];
+      len2 = (int)(a.offs2[r + 1] - o2);
+    }
+    uint64_t* out = a.hashes + o1 + o2;
+    // skip short query: handleQuery :778-786
+    const bool skip = len1 < a.min_qlen && !(pe && len2 >= a.min_qlen);
+    int cnt = 0, cnt1 = 0;
+    if (!skip) {
+      cnt = hash_mate(a.seqs + o1, len1, a.k, tab, a.scaled != 0, a.max_hash, out, 0, lane);
+      cnt1 = cnt;
+      if (pe) cnt = hash_mate(a.seqs2 + o2, len2, a.k, tab, a.scaled != 0, a.max_hash, out, cnt, lane);
+    }
+    if (lane == 0) {
+      a.nk_raw[r] = cnt;
+      a.nk1[r] = cnt1;
+      a.qlen[r] = len1 + len2;
+    }
+  }
+}
+
+// NumKmers when no read of the batch can exceed the dedup threshold.
+__global__ void k_nk_simple(const int32_t* nk_raw, int32_t* nk_search, uint32_t n, int32_t min_matched) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) {
+    int v = nk_raw[i];
+    nk_search[i] = v >= min_matched ? v : 0;  // :854-869: too few k-mers => not searched
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K1d: sort + in-place unique (handleQuery :874-908).  One workgroup per read.  Bitonic network in
+// its all-ascending form, so indices >= n act as +inf without being stored.
+// ------------------------------------------------------------------------------------------------
+template <typename P>
+__device__ __forceinline__ void bitonic_sort(P a, int n, int tid, int nthreads) {
+  int np2 = 1;
+  while (np2 < n) np2 <<= 1;
+  for (int size = 2; size <= np2; size <<= 1) {
+    // flip: i = blk + t, j = blk + size-1-t
+    for (int p = tid; p < np2 / 2; p += nthreads) {
+      int blk = (p / (size / 2)) * size, t = p % (size / 2);
+      int i = blk + t, j = blk + size - 1 - t;
+      if (j < n) {
+        uint64_t x = a[i], y = a[j];
+        if (x > y) { a[i] = y; a[j] = x; }
+      }
+    }
+    __syncthreads();
+    for (int stride = size / 4; stride >= 1; stride >>= 1) {
+      for (int p = tid; p < np2 / 2; p += nthreads) {
+        int i = (p / stride) * stride * 2 + (p % stride), j = i + stride;
+        if (j < n) {
+          uint64_t x = a[i], y = a[j];
+          if (x > y) { a[i] = y; a[j] = x; }
+        }
+      }
+      __syncthreads();
+    }
+  }
+}
+
+constexpr int DEDUP_LDS = 4096;
+
+__global__ void __launch_bounds__(256) k_dedup(const DedupArgs a) {
+  __shared__ uint64_t s[DEDUP_LDS];
+  __shared__ int scan[256];
+  const uint32_t r = blockIdx.x;
+  const int tid = threadIdx.x;
+  const int n = a.nk_raw[r];
+  if (n <= a.dedup_threshold) {
+    if (tid == 0) a.nk_search[r] = n >= a.min_matched ? n : 0;
+    return;
+  }
+  const uint64_t koff = a.offs[r] + (a.offs2 ? a.offs2[r] : 0);
+  uint64_t* g = a.hashes + koff;
+  uint64_t* tmp = a.scratch + koff;
+  const bool in_lds = n <= DEDUP_LDS;
+  if (in_lds) {
+    for (int i = tid; i < n; i += 256) s[i] = g[i];
+    __syncthreads();
+    bitonic_sort(s, n, tid, 256);
+  } else {
+    bitonic_sort(g, n, tid, 256);
+    __threadfence_block();
+  }
+  const uint64_t* src = in_lds ? s : g;
+  // unique: contiguous chunk per thread, block scan of the per-chunk counts
+  const int chunk = (n + 255) / 256;
+  const int b = tid * chunk, e = min(n, b + chunk);
+  int c = 0;
+  for (int i = b; i < e; i++) c += (i == 0 || src[i] != src[i - 1]) ? 1 : 0;
+  scan[tid] = c;
+  __syncthreads();
+  for (int off = 1; off < 256; off <<= 1) {
+    int v = tid >= off ? scan[tid - off] : 0;
+    __syncthreads();
+    scan[tid] += v;
+    __syncthreads();
+  }
+  int pos = scan[tid] - c;
+  const int total = scan[255];
+  uint64_t* dst = in_lds ? g : tmp;
+  for (int i = b; i < e; i++)
+    if (i == 0 || src[i] != src[i - 1]) dst[pos++] = src[i];
+  if (!in_lds) {
+    __syncthreads();
+    for (int i = tid; i < total; i += 256) g[i] = tmp[i];
+  }
+  // MinMatched is tested on the raw count (:854), NumKmers is the unique count (:910)
+  if (tid == 0) a.nk_search[r] = n >= a.min_matched ? total : 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// K2: the COBS query.
+//
+// Work unit = (read, slot) with slot = (resident block, tile of LPR*16 bytes of its rows).  LPR lanes
+// serve one unit, so a wave carries G = 64/LPR units: LPR = 64 for wide rows (GTDB-scale, 1872 B),
+// 16 or 4 for narrow rows (a 312-column block has 39-byte rows).  Each lane owns 16 bytes = 128
+// columns of its unit's rows and keeps their match counts as NPL bit-sliced planes (vertical
+// counters): 8 rows are reduced with a carry-save adder tree (7 CSAs) and the carry word rippled into
+// the upper planes, ~4 VALU ops per loaded dword, which keeps the kernel HBM-bound.
+// Row indices of a chunk of CH k-mers are computed cooperatively (one exact fastmod per (k-mer,
+// block)) into a per-wave LDS table; k-mers past the end of a read map to the all-zero row appended to
+// each block, so the inner loop has no tail code.
+// ------------------------------------------------------------------------------------------------
+#define CSA(h, l, a_, b_, c_)              \
+  {                                        \
+    uint32_t u_ = (a_) ^ (b_);             \
+    h = ((a_) & (b_)) | (u_ & (c_));       \
+    l = u_ ^ (c_);                         \
+  }
+
+template <int NPL>
+__device__ __forceinline__ void csa8(uint32_t (&pl)[NPL], uint32_t x0, uint32_t x1, uint32_t x2, uint32_t x3, uint32_t x4,
+                                     uint32_t x5, uint32_t x6, uint32_t x7) {
+  uint32_t ta, tb, fa, fb, e;
+  CSA(ta, pl[0], pl[0], x0, x1);
+  CSA(tb, pl[0], pl[0], x2, x3);
+  CSA(fa, pl[1], pl[1], ta, tb);
+  CSA(ta, pl[0], pl[0], x4, x5);
+  CSA(tb, pl[0], pl[0], x6, x7);
+  CSA(fb, pl[1], pl[1], ta, tb);
+  CSA(e, pl[2], pl[2], fa, fb);
+#pragma unroll
+  for (int p = 3; p < NPL; p++) {
+    uint32_t t = pl[p] & e;
+    pl[p] ^= e;
+    e = t;
+  }
+}
+
+template <int LPR, int NPL, bool MULTI>
+__global__ void __launch_bounds__(256) k2_cobs(const K2Args a) {
+  constexpr int G = 64 / LPR;
+  constexpr int PAIRS = MULTI ? 256 : 1024;
+  constexpr int CH = (PAIRS / G) > 64 ? 64 : (PAIRS / G);
+  constexpr int NHMAX = MULTI ? 4 : 1;
+  static_assert(CH % 8 == 0, "chunk must be a multiple of the CSA group");
+  __shared__ uint32_t s_rows[4][NHMAX][G * CH];
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int g = lane / LPR, li = lane % LPR;
+  const uint64_t total_units = (uint64_t)a.n_reads * a.nslots;
+  const uint64_t u = ((uint64_t)blockIdx.x * 4 + wave) * G + g;
+  const bool valid = u < total_units;
+  uint32_t r = 0, sidx = 0;
+  if (valid) {
+    r = (uint32_t)(u / a.nslots);
+    sidx = (uint32_t)(u % a.nslots);
+  }
+  const Slot slot = a.slots[sidx];
+  const BlockDev* __restrict__ bd = a.blocks + slot.block;
+  const int n = valid ? a.nk[r] : 0;
+  int nmax = n;
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) nmax = max(nmax, __shfl_xor(nmax, off));
+  if (nmax == 0) return;
+
+  const uint32_t stride = bd->stride;
+  const uint32_t boff = (slot.tile * LPR + li) * 16u;
+  const bool active = n > 0 && boff < stride;
+  const uint8_t* __restrict__ base = bd->rows + boff;
+  const uint64_t koff = a.offs[r] + (a.offs2 ? a.offs2[r] : 0);
+  const int nh = MULTI ? a.num_hashes : 1;
+
+  uint32_t pl[4][NPL];
+#pragma unroll
+  for (int d = 0; d < 4; d++)
+#pragma unroll
+    for (int p = 0; p < NPL; p++) pl[d][p] = 0;
+
+  for (int c0 = 0; c0 < nmax; c0 += CH) {
+    // ---- row indices of this chunk: loc = h % NumSigs (:6811), multi-hash h_i = uint32(a + b*i) (util-hash.go:125-142)
+    for (int p = lane; p < G * CH; p += 64) {
+      const int q = p / CH, j = p % CH;
+      const int srcl = q * LPR;
+      const int nq = __shfl(n, srcl);
+      const uint64_t koq = __shfl((unsigned long long)koff, srcl);
+      const uint32_t bi = __shfl(slot.block, srcl);
+      const BlockDev* __restrict__ bq = a.blocks + bi;
+      const uint64_t ns = bq->num_sigs;
+      const int kidx = c0 + j;
+      if (kidx < nq) {
+        const uint64_t h = a.hashes[koq + kidx];
+        if (!MULTI) {
+          s_rows[wave][0][p] = (uint32_t)fastmod_u64(h, ns, bq->magic_hi, bq->magic_lo);
+        } else {
+          const uint32_t ha = (uint32_t)(h >> 32), hb = (uint32_t)h;
+          for (int i = 0; i < nh; i++)
+            s_rows[wave][i][p] = (uint32_t)fastmod_u64((uint64_t)(uint32_t)(ha + hb * (uint32_t)i), ns, bq->magic_hi, bq->magic_lo);
+        }
+      } else {
+        for (int i = 0; i < nh; i++) s_rows[wave][i][p] = (uint32_t)ns;  // the appended all-zero row
+      }
+    }
+    wave_lds_fence();
+
+    const int cnt = min(CH, nmax - c0);
+    for (int j = 0; j < cnt; j += 8) {
+      uint4 x[8];
+#pragma unroll
+      for (int i = 0; i < 8; i++) {
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (active) {
+          const uint32_t row = s_rows[wave][0][g * CH + j + i];
+          v = *reinterpret_cast<const uint4*>(base + (uint64_t)row * stride);
+          if (MULTI) {
+            for (int hh = 1; hh < nh; hh++) {  // AND of the h rows (pand.AndUnsafe, :6639-6646)
+              const uint32_t row2 = s_rows[wave][hh][g * CH + j + i];
+              const uint4 w = *reinterpret_cast<const uint4*>(base + (uint64_t)row2 * stride);
+              v.x &= w.x; v.y &= w.y; v.z &= w.z; v.w &= w.w;
+            }
+          }
+        }
+        x[i] = v;
+      }
+      csa8<NPL>(pl[0], x[0].x, x[1].x, x[2].x, x[3].x, x[4].x, x[5].x, x[6].x, x[7].x);
+      csa8<NPL>(pl[1], x[0].y, x[1].y, x[2].y, x[3].y, x[4].y, x[5].y, x[6].y, x[7].y);
+      csa8<NPL>(pl[2], x[0].z, x[1].z, x[2].z, x[3].z, x[4].z, x[5].z, x[6].z, x[7].z);
+      csa8<NPL>(pl[3], x[0].w, x[1].w, x[2].w, x[3].w, x[4].w, x[5].w, x[6].w, x[7].w);
+    }
+    wave_lds_fence();
+  }
+
+  if (!active) return;
+  // ---- integer threshold (:7468-7470): count >= minMatched && float64(count) > nHashes*queryCov
+  const double thr = __dmul_rn((double)n, a.min_qcov);
+  uint32_t cmin = (uint32_t)thr + 1u;  // smallest integer c with (double)c > thr  (thr >= 0)
+  if (cmin < (uint32_t)a.min_matched) cmin = (uint32_t)a.min_matched;
+  if (NPL < 32 && (cmin >> NPL) != 0) return;  // unreachable count
+#pragma unroll
+  for (int d = 0; d < 4; d++) {
+    uint32_t ge = 0xffffffffu;  // bit-sliced (count >= cmin), LSB to MSB
+#pragma unroll
+    for (int p = 0; p < NPL; p++) ge = ((cmin >> p) & 1u) ? (ge & pl[d][p]) : (ge | pl[d][p]);
+    while (ge) {
+      const int q = __ffs(ge) - 1;
+      ge &= ge - 1;
+      uint32_t count = 0;
+#pragma unroll
+      for (int p = 0; p < NPL; p++) count |= ((pl[d][p] >> q) & 1u) << p;
+      // byte (q>>3) of this dword, bit (q&7): bit 7 = first column of the byte (index.go:1157)
+      const uint32_t col = (boff + (uint32_t)d * 4u + (uint32_t)(q >> 3)) * 8u + (7u - (uint32_t)(q & 7));
+      if (col < bd->ncols) {
+        const unsigned long long idx = atomicAdd(a.counter, 1ULL);
+        if (idx < a.hit_cap) {
+          kmcpg_hit hit;
+          hit.read = r;
+          hit.col = bd->col_base + col;
+          hit.count = count;
+          a.hits[idx] = hit;
+        }
+      }
+    }
+  }
+}
+
+template <int LPR, int NPL>
+static void launch_k2_t(const K2Args& a, bool multi, hipStream_t st) {
+  constexpr int G = 64 / LPR;
+  const uint64_t units = (uint64_t)a.n_reads * a.nslots;
+  const uint64_t waves = (units + G - 1) / G;
+  const uint64_t blocks = (waves + 3) / 4;
+  if (blocks == 0) return;
+  if (multi)
+    hipLaunchKernelGGL((k2_cobs<LPR, NPL, true>), dim3((unsigned)blocks), dim3(256), 0, st, a);
+  else
+    hipLaunchKernelGGL((k2_cobs<LPR, NPL, false>), dim3((unsigned)blocks), dim3(256), 0, st, a);
+}
+
+template <int LPR>
+static int launch_k2_l(const K2Args& a, int npl, bool multi, hipStream_t st) {
+  switch (npl) {
+    case 8: launch_k2_t<LPR, 8>(a, multi, st); return 0;
+    case 16: launch_k2_t<LPR, 16>(a, multi, st); return 0;
+    case 24: launch_k2_t<LPR, 24>(a, multi, st); return 0;
+    default: return -1;
+  }
+}
+
+int launch_k2(const K2Args& a, int lpr, int npl, hipStream_t st) {
+  const bool multi = a.num_hashes > 1;
+  if ((uint64_t)a.n_reads * a.nslots / (256 / lpr) > 0x7fffffffULL) return -2;
+  switch (lpr) {
+    case 4: return launch_k2_l<4>(a, npl, multi, st);
+    case 16: return launch_k2_l<16>(a, npl, multi, st);
+    case 64: return launch_k2_l<64>(a, npl, multi, st);
+    default: return -1;
+  }
+}
+
+void launch_k1(const K1Args& a, hipStream_t st) {
+  if (a.n_reads == 0) return;
+  unsigned blocks = (a.n_reads + 3) / 4;
+  if (blocks > 32768) blocks = 32768;
+  hipLaunchKernelGGL(k1_kmers, dim3(blocks), dim3(256), 0, st, a);
+}
+
+void launch_nk_simple(const int32_t* nk_raw, int32_t* nk_search, uint32_t n, int32_t min_matched, hipStream_t st) {
+  if (n == 0) return;
+  hipLaunchKernelGGL(k_nk_simple, dim3((n + 255) / 256), dim3(256), 0, st, nk_raw, nk_search, n, min_matched);
+}
+
+void launch_dedup(const DedupArgs& a, hipStream_t st) {
+  if (a.n_reads == 0) return;
+  hipLaunchKernelGGL(k_dedup, dim3(a.n_reads), dim3(256), 0, st, a);
+}
+
+// ------------------------------------------------------------------------------------------------
+// layout: on-disk rows (NumRowBytes, unpadded — serialization.go:140,379) -> HBM rows (stride)
+// ------------------------------------------------------------------------------------------------
+__global__ void k_repack(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, uint64_t n_rows, uint32_t row_bytes,
+                         uint32_t stride) {
+  const uint32_t wpr = stride / 4;  // dwords per dst row
+  const uint64_t total = n_rows * wpr;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (uint64_t)gridDim.x * blockDim.x) {
+    const uint64_t row = i / wpr;
+    const uint32_t b0 = (uint32_t)(i % wpr) * 4;
+    uint32_t v = 0;
+    const uint8_t* s = src + row * row_bytes;
+#pragma unroll
+    for (int t = 0; t < 4; t++)
+      if (b0 + t < row_bytes) v |= (uint32_t)s[b0 + t] << (8 * t);
+    reinterpret_cast<uint32_t*>(dst + row * stride)[b0 / 4] = v;
+  }
+}
+
+void launch_repack(const uint8_t* src, uint8_t* dst, uint64_t n_rows, uint32_t row_bytes, uint32_t stride, hipStream_t st) {
+  if (n_rows == 0) return;
+  uint64_t total = n_rows * (stride / 4);
+  unsigned blocks = (unsigned)((total + 255) / 256 > 65536 ? 65536 : (total + 255) / 256);
+  hipLaunchKernelGGL(k_repack, dim3(blocks), dim3(256), 0, st, src, dst, n_rows, row_bytes, stride);
+}
+
+__global__ void k_gather_rows(const uint8_t* __restrict__ rows, uint32_t stride, uint32_t row_bytes, const uint64_t* __restrict__ idx,
+                              uint64_t n, uint8_t* __restrict__ out) {
+  const uint64_t total = n * row_bytes;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (uint64_t)gridDim.x * blockDim.x) {
+    const uint64_t r = i / row_bytes;
+    const uint32_t b = (uint32_t)(i % row_bytes);
+    out[i] = rows[idx[r] * stride + b];
+  }
+}
+
+void launch_gather_rows(const uint8_t* rows, uint32_t stride, uint32_t row_bytes, const uint64_t* idx, uint64_t n, uint8_t* out,
+                        hipStream_t st) {
+  if (n == 0) return;
+  uint64_t total = n * row_bytes;
+  unsigned blocks = (unsigned)((total + 255) / 256 > 65536 ? 65536 : (total + 255) / 256);
+  hipLaunchKernelGGL(k_gather_rows, dim3(blocks), dim3(256), 0, st, rows, stride, row_bytes, idx, n, out);
+}
+
+// ------------------------------------------------------------------------------------------------
+// synthetic index (bench / full-size parity only): i.i.d. Bernoulli bits from a counter-based generator
+// ------------------------------------------------------------------------------------------------
+__host__ __device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
+  x += 0x9e3779b97f4a7c15ULL;
+  x = (x ^ (x >> 30)) * 0xbf58476d1ce4e5b9ULL;
+  x = (x ^ (x >> 27)) * 0x94d049bb133111ebULL;
+  return x ^ (x >> 31);
+}
+
+// 64 Bernoulli(p8/256) bits for counter c
+__device__ __forceinline__ uint64_t bernoulli64(uint64_t key, uint64_t c, uint32_t p8) {
+  uint64_t acc = 0;
+#pragma unroll
+  for (int i = 0; i < 8; i++) {  // LSB of p8 first
+    const uint64_t rnd = splitmix64(key ^ (c * 8 + i) * 0xd6e8feb86659fd93ULL);
+    acc = ((p8 >> i) & 1u) ? (acc | rnd) : (acc & rnd);
+  }
+  return acc;
+}
+
+__global__ void k_synth_fill(uint8_t* __restrict__ rows, uint64_t n_rows, uint32_t stride, uint32_t ncols, uint64_t key, uint32_t p8) {
+  const uint32_t qpr = stride / 8;  // qwords per row
+  const uint64_t total = n_rows * qpr;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (uint64_t)gridDim.x * blockDim.x) {
+    const uint64_t row = i / qpr;
+    const uint32_t qw = (uint32_t)(i % qpr);
+    uint64_t v = bernoulli64(key, i, p8);
+    // zero the bits of columns >= ncols (padding columns never match: :7466 scans them but count is 0)
+    const uint32_t col0 = qw * 64;
+    if (col0 >= ncols) v = 0;
+    else if (col0 + 64 > ncols) {
+      uint64_t m = 0;
+      for (uint32_t c = col0; c < ncols; c++) {
+        const uint32_t byte = (c - col0) >> 3, bit = 7 - ((c - col0) & 7);
+        m |= 1ULL << (byte * 8 + bit);
+      }
+      v &= m;
+    }
+    reinterpret_cast<uint64_t*>(rows + row * stride)[qw] = v;
+  }
+}
+
+void launch_synth_fill(uint8_t* rows, uint64_t n_rows, uint32_t stride, uint32_t ncols, uint64_t key, uint32_t p8, hipStream_t st) {
+  uint64_t total = n_rows * (stride / 8);
+  unsigned blocks = (unsigned)((total + 255) / 256 > 262144 ? 262144 : (total + 255) / 256);
+  hipLaunchKernelGGL(k_synth_fill, dim3(blocks), dim3(256), 0, st, rows, n_rows, stride, ncols, key, p8);
+}
+
+// sigs[h % NumSigs] |= 1 << (7 - col%8)  (index.go:1157) for a list of hashes
+__global__ void k_plant(BlockDev bd, uint32_t col, int num_hashes, const uint64_t* __restrict__ hashes, uint64_t n) {
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+    const uint64_t h = hashes[i];
+    const uint32_t ha = (uint32_t)(h >> 32), hb = (uint32_t)h;
+    for (int t = 0; t < num_hashes; t++) {
+      const uint64_t hv = num_hashes == 1 ? h : (uint64_t)(uint32_t)(ha + hb * (uint32_t)t);
+      const uint64_t row = fastmod_u64(hv, bd.num_sigs, bd.magic_hi, bd.magic_lo);
+      const uint64_t byte = row * bd.stride + (col >> 3);
+      uint32_t* w = reinterpret_cast<uint32_t*>(const_cast<uint8_t*>(bd.rows) + (byte & ~3ULL));
+      atomicOr(w, (uint32_t)(1u << (7 - (col & 7))) << (8 * (byte & 3)));
+    }
+  }
+}
+
+void launch_plant(const BlockDev& bd, uint32_t col, int num_hashes, const uint64_t* hashes, uint64_t n, hipStream_t st) {
+  if (n == 0) return;
+  unsigned blocks = (unsigned)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256);
+  hipLaunchKernelGGL(k_plant, dim3(blocks), dim3(256), 0, st, bd, col, num_hashes, hashes, n);
+}
+
+}  // namespace kmcpg

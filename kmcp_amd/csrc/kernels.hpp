@@ -1,0 +1,20 @@
+// kernels.hpp — host-callable launchers of the HIP kernels in kernels.hip.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "common.hpp"
+
+namespace kmcpg {
+
+void launch_k1(const K1Args& a, hipStream_t st);
+void launch_nk_simple(const int32_t* nk_raw, int32_t* nk_search, uint32_t n, int32_t min_matched, hipStream_t st);
+void launch_dedup(const DedupArgs& a, hipStream_t st);
+// lpr in {4,16,64}: lanes per row tile; npl in {8,16,24}: counter planes.  <0 on bad arguments.
+int launch_k2(const K2Args& a, int lpr, int npl, hipStream_t st);
+void launch_repack(const uint8_t* src, uint8_t* dst, uint64_t n_rows, uint32_t row_bytes, uint32_t stride, hipStream_t st);
+void launch_gather_rows(const uint8_t* rows, uint32_t stride, uint32_t row_bytes, const uint64_t* idx, uint64_t n, uint8_t* out,
+                        hipStream_t st);
+void launch_synth_fill(uint8_t* rows, uint64_t n_rows, uint32_t stride, uint32_t ncols, uint64_t key, uint32_t p8, hipStream_t st);
+void launch_plant(const BlockDev& bd, uint32_t col, int num_hashes, const uint64_t* hashes, uint64_t n, hipStream_t st);
+
+}  // namespace kmcpg

@@ -1,0 +1,258 @@
+"""ctypes binding of libkmcpgpu.so (include/kmcp_gpu.h).
+
+Plumbing only: the product is the shared library.  There is no CPU fallback — if the library is missing
+or no GPU is present, every compute entry point raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libkmcpgpu.so")
+
+EXPORTS = [
+    "kmcpg_open", "kmcpg_close", "kmcpg_last_error", "kmcpg_db_info", "kmcpg_col_info", "kmcpg_search_batch",
+    "kmcpg_result_free", "kmcpg_query_device", "kmcpg_finalize", "kmcpg_open_synthetic", "kmcpg_plant",
+    "kmcpg_read_rows", "kmcpg_block_info", "kmcpg_kmers_device",
+]
+
+
+class KmcpGpuError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"libkmcpgpu error {code}: {msg}")
+        self.code = code
+
+
+class Opts(C.Structure):
+    _fields_ = [("device", C.c_int32), ("shard_rank", C.c_int32), ("shard_count", C.c_int32), ("reserved", C.c_int32)]
+
+
+class Info(C.Structure):
+    _fields_ = [("k", C.c_int32), ("canonical", C.c_int32), ("num_hashes", C.c_int32), ("scaled", C.c_int32),
+                ("scale", C.c_uint32), ("minimizer", C.c_int32), ("minimizer_w", C.c_uint32), ("syncmer", C.c_int32),
+                ("syncmer_s", C.c_uint32), ("fpr", C.c_double), ("n_blocks", C.c_int32), ("n_blocks_local", C.c_int32),
+                ("n_cols", C.c_uint64), ("matrix_bytes", C.c_uint64), ("matrix_bytes_local", C.c_uint64),
+                ("row_bytes_sum_local", C.c_uint64)]
+
+
+class Params(C.Structure):
+    _fields_ = [("min_qlen", C.c_int32), ("min_matched", C.c_int32), ("min_qcov", C.c_double), ("min_tcov", C.c_double),
+                ("max_fpr", C.c_double), ("dedup_threshold", C.c_int32), ("try_se", C.c_int32), ("sort_by", C.c_int32),
+                ("do_not_sort", C.c_int32), ("top_n_scores", C.c_int32), ("fpr_buf_size", C.c_int32)]
+
+
+class Hit(C.Structure):
+    _fields_ = [("read", C.c_uint32), ("col", C.c_uint32), ("count", C.c_uint32)]
+
+
+class Match(C.Structure):
+    _fields_ = [("col", C.c_uint32), ("target_idx", C.c_uint32), ("gsize", C.c_uint64), ("mkmers", C.c_int32),
+                ("reserved", C.c_int32), ("fpr", C.c_double), ("qcov", C.c_double), ("tcov", C.c_double), ("jacc", C.c_double)]
+
+
+class Result(C.Structure):
+    _fields_ = [("n_reads", C.c_uint32), ("k", C.c_int32), ("qlen", C.POINTER(C.c_int32)), ("qkmers", C.POINTER(C.c_int32)),
+                ("match_offs", C.POINTER(C.c_uint64)), ("matches", C.POINTER(Match)), ("owner", C.c_void_p)]
+
+
+class SynthSpec(C.Structure):
+    _fields_ = [("k", C.c_int32), ("num_hashes", C.c_int32), ("fpr", C.c_double), ("n_blocks", C.c_uint32),
+                ("cols_per_block", C.c_uint32), ("num_sigs", C.c_uint64), ("kmers_per_col", C.c_uint64), ("seed", C.c_uint64)]
+
+
+HIT_DTYPE = np.dtype([("read", np.uint32), ("col", np.uint32), ("count", np.uint32)])
+MATCH_DTYPE = np.dtype([("col", np.uint32), ("target_idx", np.uint32), ("gsize", np.uint64), ("mkmers", np.int32),
+                        ("reserved", np.int32), ("fpr", np.float64), ("qcov", np.float64), ("tcov", np.float64),
+                        ("jacc", np.float64)])
+assert HIT_DTYPE.itemsize == C.sizeof(Hit) and MATCH_DTYPE.itemsize == C.sizeof(Match)
+
+
+def default_params(**kw):
+    """Defaults of `kmcp search` (kmcp/cmd/search.go:1052-1102)."""
+    p = Params(min_qlen=30, min_matched=10, min_qcov=0.55, min_tcov=0.0, max_fpr=0.01, dedup_threshold=256, try_se=0,
+               sort_by=0, do_not_sort=0, top_n_scores=0, fpr_buf_size=0)
+    for k, v in kw.items():
+        if not hasattr(p, k):
+            raise AttributeError(k)
+        setattr(p, k, v)
+    return p
+
+
+_lib = None
+
+
+def load():
+    """Load libkmcpgpu.so; raises if it has not been built (there is no fallback path)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "(hipcc --offload-arch=gfx950). kmcp_amd has no CPU fallback.")
+    L = C.CDLL(LIB_PATH)
+    vp, u64p, i32p = C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_int32)
+    L.kmcpg_last_error.restype = C.c_char_p
+    L.kmcpg_open.argtypes = [C.c_char_p, C.POINTER(Opts), C.POINTER(vp)]
+    L.kmcpg_open_synthetic.argtypes = [C.POINTER(SynthSpec), C.POINTER(Opts), C.POINTER(vp)]
+    L.kmcpg_close.argtypes = [vp]
+    L.kmcpg_db_info.argtypes = [vp, C.POINTER(Info)]
+    L.kmcpg_col_info.argtypes = [vp, C.c_uint32, C.POINTER(C.c_char_p), C.POINTER(C.c_uint32), u64p, u64p]
+    L.kmcpg_block_info.argtypes = [vp, C.c_uint32, u64p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32),
+                                   C.POINTER(C.c_uint32), i32p, C.POINTER(C.c_uint32)]
+    L.kmcpg_search_batch.argtypes = [vp, vp, vp, vp, vp, C.c_uint32, C.POINTER(Params), C.POINTER(Result)]
+    L.kmcpg_result_free.argtypes = [C.POINTER(Result)]
+    L.kmcpg_result_free.restype = None
+    L.kmcpg_query_device.argtypes = [vp, vp, vp, vp, vp, C.c_uint32, C.c_uint64, C.c_uint32, C.POINTER(Params), vp,
+                                     C.c_uint64, vp, vp, vp, vp]
+    L.kmcpg_finalize.argtypes = [vp, vp, C.c_uint64, vp, vp, C.c_uint32, C.POINTER(Params), C.POINTER(Result)]
+    L.kmcpg_plant.argtypes = [vp, C.c_uint32, vp, C.c_uint64]
+    L.kmcpg_read_rows.argtypes = [vp, C.c_uint32, vp, C.c_uint64, vp]
+    L.kmcpg_kmers_device.argtypes = [vp, vp, vp, C.c_uint32, C.c_uint64, C.c_uint32, C.POINTER(Params), vp, C.c_uint64,
+                                     vp, vp, vp]
+    _lib = L
+    return L
+
+
+def _check(rc):
+    if rc != 0:
+        raise KmcpGpuError(rc, load().kmcpg_last_error().decode(errors="replace"))
+
+
+def pack_reads(reads):
+    """list of bytes -> (uint8 array, uint64 offsets[n+1])."""
+    offs = np.zeros(len(reads) + 1, dtype=np.uint64)
+    if reads:
+        offs[1:] = np.cumsum([len(r) for r in reads], dtype=np.uint64)
+    seqs = np.frombuffer(b"".join(reads), dtype=np.uint8).copy() if reads else np.zeros(0, dtype=np.uint8)
+    return seqs, offs
+
+
+class BatchResult:
+    """QueryResult for a batch (numpy copies of kmcpg_result)."""
+
+    def __init__(self, qlen, qkmers, offs, matches, k):
+        self.qlen, self.qkmers, self.offs, self.matches, self.k = qlen, qkmers, offs, matches, k
+
+    def __len__(self):
+        return len(self.qlen)
+
+    def read(self, i):
+        return self.matches[int(self.offs[i]):int(self.offs[i + 1])]
+
+
+def _copy_result(r):
+    n = r.n_reads
+    qlen = np.ctypeslib.as_array(r.qlen, shape=(n,)).copy() if n else np.zeros(0, np.int32)
+    qk = np.ctypeslib.as_array(r.qkmers, shape=(n,)).copy() if n else np.zeros(0, np.int32)
+    offs = np.ctypeslib.as_array(r.match_offs, shape=(n + 1,)).copy()
+    m = int(offs[-1])
+    if m:
+        buf = C.string_at(r.matches, m * C.sizeof(Match))
+        matches = np.frombuffer(buf, dtype=MATCH_DTYPE).copy()
+    else:
+        matches = np.zeros(0, dtype=MATCH_DTYPE)
+    out = BatchResult(qlen, qk, offs, matches, r.k)
+    load().kmcpg_result_free(C.byref(r))
+    return out
+
+
+class Database:
+    """A kmcp database resident in the HBM of one GPU (or one shard of it)."""
+
+    def __init__(self, handle):
+        self._h = handle
+        info = Info()
+        _check(load().kmcpg_db_info(self._h, C.byref(info)))
+        self.info = info
+        self._names = {}
+
+    @classmethod
+    def open(cls, db_dir, device=0, shard_rank=0, shard_count=1):
+        h = C.c_void_p()
+        o = Opts(device, shard_rank, shard_count, 0)
+        _check(load().kmcpg_open(os.fsencode(db_dir), C.byref(o), C.byref(h)))
+        return cls(h)
+
+    @classmethod
+    def open_synthetic(cls, spec: SynthSpec, device=0, shard_rank=0, shard_count=1):
+        h = C.c_void_p()
+        o = Opts(device, shard_rank, shard_count, 0)
+        _check(load().kmcpg_open_synthetic(C.byref(spec), C.byref(o), C.byref(h)))
+        return cls(h)
+
+    def close(self):
+        if self._h:
+            load().kmcpg_close(self._h)
+            self._h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def col_info(self, col):
+        if col not in self._names:
+            name, ti, gs, sz = C.c_char_p(), C.c_uint32(), C.c_uint64(), C.c_uint64()
+            _check(load().kmcpg_col_info(self._h, col, C.byref(name), C.byref(ti), C.byref(gs), C.byref(sz)))
+            self._names[col] = (name.value.decode(), ti.value, gs.value, sz.value)
+        return self._names[col]
+
+    def block_info(self, b):
+        ns, nc, rb, st, loc, cb = C.c_uint64(), C.c_uint32(), C.c_uint32(), C.c_uint32(), C.c_int32(), C.c_uint32()
+        _check(load().kmcpg_block_info(self._h, b, C.byref(ns), C.byref(nc), C.byref(rb), C.byref(st), C.byref(loc), C.byref(cb)))
+        return dict(num_sigs=ns.value, n_cols=nc.value, row_bytes=rb.value, stride=st.value, local=bool(loc.value), col_base=cb.value)
+
+    # ---- whole pipeline, host buffers -------------------------------------------------------------
+    def search(self, reads, reads2=None, params=None):
+        seqs, offs = pack_reads(reads)
+        s2 = o2 = None
+        if reads2 is not None:
+            s2, o2 = pack_reads(reads2)
+        return self.search_packed(seqs, offs, s2, o2, params)
+
+    def search_packed(self, seqs, offs, seqs2=None, offs2=None, params=None):
+        p = params or default_params()
+        r = Result()
+        n = len(offs) - 1
+        _check(load().kmcpg_search_batch(self._h, seqs.ctypes.data, offs.ctypes.data,
+                                         seqs2.ctypes.data if seqs2 is not None else None,
+                                         offs2.ctypes.data if offs2 is not None else None, n, C.byref(p), C.byref(r)))
+        return _copy_result(r)
+
+    # ---- GPU half on device pointers (torch tensors' data_ptr()) ----------------------------------
+    def query_device(self, d_seqs, d_offs, n_reads, total_bases, max_read_len, d_hits, hit_cap, d_counters, d_qkmers,
+                     d_qlen, params=None, d_seqs2=None, d_offs2=None, stream=None):
+        p = params or default_params()
+        _check(load().kmcpg_query_device(self._h, d_seqs, d_offs, d_seqs2, d_offs2, n_reads, total_bases, max_read_len,
+                                         C.byref(p), d_hits, hit_cap, d_counters, d_qkmers, d_qlen, stream))
+
+    def kmers_device(self, d_seqs, d_offs, n_reads, total_bases, max_read_len, d_hashes, hashes_cap, d_koff, d_nk,
+                     params=None, stream=None):
+        p = params or default_params()
+        _check(load().kmcpg_kmers_device(self._h, d_seqs, d_offs, n_reads, total_bases, max_read_len, C.byref(p),
+                                         d_hashes, hashes_cap, d_koff, d_nk, stream))
+
+    def finalize(self, hits, qkmers, qlen, params=None):
+        """hits: structured array HIT_DTYPE (any order, may be the concatenation of all shards)."""
+        p = params or default_params()
+        hits = np.ascontiguousarray(hits, dtype=HIT_DTYPE)
+        qkmers = np.ascontiguousarray(qkmers, dtype=np.int32)
+        qlen = np.ascontiguousarray(qlen, dtype=np.int32)
+        r = Result()
+        _check(load().kmcpg_finalize(self._h, hits.ctypes.data, len(hits), qkmers.ctypes.data, qlen.ctypes.data,
+                                     len(qkmers), C.byref(p), C.byref(r)))
+        return _copy_result(r)
+
+    # ---- bench / parity support -----------------------------------------------------------------------
+    def plant(self, col, hashes):
+        hashes = np.ascontiguousarray(hashes, dtype=np.uint64)
+        _check(load().kmcpg_plant(self._h, col, hashes.ctypes.data, len(hashes)))
+
+    def read_rows(self, block, row_idx):
+        row_idx = np.ascontiguousarray(row_idx, dtype=np.uint64)
+        rb = self.block_info(block)["row_bytes"]
+        out = np.zeros((len(row_idx), rb), dtype=np.uint8)
+        _check(load().kmcpg_read_rows(self._h, block, row_idx.ctypes.data, len(row_idx), out.ctypes.data))
+        return out

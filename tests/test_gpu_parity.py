@@ -1,0 +1,171 @@
+"""GPU parity: libkmcpgpu (HIP, through the C ABI) vs the CPU oracle on identical seeded inputs.
+
+Bit-exact per-read (qLen, qKmers, {(target column, mKmers, qCov, tCov, jacc)}); FPR with tolerance.
+"""
+import numpy as np
+import pytest
+
+from tests import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def G():
+    from kmcp_amd import Database, default_params, lib
+    lib.load()
+    return dict(Database=Database, default_params=default_params, lib=lib)
+
+
+def _run(G, O, db_dir, reads, reads2=None, oracle_kw=None, gpu_kw=None):
+    odb = O.OracleDB(db_dir)
+    try:
+        with G["Database"].open(db_dir, device=0) as db:
+            res = db.search(reads, reads2, params=G["default_params"](**(gpu_kw or {})))
+        n = synth.assert_parity(odb, res, reads, reads2, O.default_params(**(oracle_kw or {})))
+    finally:
+        odb.close()
+    return n, res
+
+
+def test_narrow_rows_single_hash(G, oracle_lib, tmp_path):
+    """config-1 shape scaled down: many small blocks with 3-byte rows (LPR=4 kernel), 150-bp reads, k=21."""
+    O = oracle_lib
+    genomes = synth.random_genomes(24, 20000, seed=1)
+    db_dir = synth.make_db(tmp_path, genomes, k=21, n_chunks=4, overlap=150, threads=4)  # 96 columns, sBlock 24
+    reads = synth.sample_reads(genomes, 1500, 150, sub_rate=0.01, seed=2, frac_random=0.1)
+    n, res = _run(G, O, db_dir, reads)
+    assert n > 1000
+    assert (res.qkmers == 130).sum() > 1000
+
+
+def test_medium_rows_lpr16(G, oracle_lib, tmp_path):
+    """One block of 1000 columns: 125-byte rows -> 128-byte stride (LPR=16 kernel)."""
+    O = oracle_lib
+    genomes = synth.random_genomes(1000, 1500, seed=3)
+    db_dir = synth.make_db(tmp_path, genomes, k=21, block_size=1000)
+    reads = synth.sample_reads(genomes, 800, 150, sub_rate=0.02, seed=4, frac_random=0.2)
+    n, _ = _run(G, O, db_dir, reads)
+    assert n > 400
+
+
+def test_wide_rows_two_tiles(G, oracle_lib, tmp_path):
+    """One block of 9000 columns: 1125-byte rows -> two 1-KiB tiles per row (LPR=64 kernel), plus a ragged
+    second block of 37 columns."""
+    O = oracle_lib
+    genomes = synth.random_genomes(9037, 600, seed=5)
+    db_dir = synth.make_db(tmp_path, genomes, k=21, block_size=9000)
+    reads = synth.sample_reads(genomes, 600, 150, sub_rate=0.01, seed=6, frac_random=0.1)
+    n, _ = _run(G, O, db_dir, reads)
+    assert n > 300
+
+
+def test_multi_hash_scaled(G, oracle_lib, tmp_path):
+    """FracMinHash database with 3 hash functions (the demo-searching shape): AND of 3 rows, dedup path."""
+    O = oracle_lib
+    genomes = synth.random_genomes(12, 200000, seed=7)
+    db_dir = synth.make_db(tmp_path, genomes, k=31, num_hashes=3, fpr=0.01, scale=20, threads=2)
+    # queries = mutated genomes, each ~10 k sketch hashes -> sort+unique on the GPU, 16-plane counters
+    rng = np.random.default_rng(8)
+    queries = []
+    for g in genomes[:6]:
+        a = np.frombuffer(g, dtype=np.uint8).copy()
+        m = rng.random(len(a)) < 0.002
+        a[m] = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, int(m.sum()))]
+        queries.append(a.tobytes())
+    kw = dict(min_qcov=0.4, sort_by=2)
+    n, res = _run(G, O, db_dir, queries, oracle_kw=kw, gpu_kw=kw)
+    assert n >= 6
+    assert (res.qkmers > 256).all()
+
+
+def test_paired_end_dedup_and_try_se(G, oracle_lib, tmp_path):
+    """Paired-end 2x150: 260 k-mers > -u 256 so every query goes through sort+unique; --try-se retries."""
+    O = oracle_lib
+    genomes = synth.random_genomes(16, 30000, seed=9)
+    db_dir = synth.make_db(tmp_path, genomes, k=21, n_chunks=2, overlap=150, threads=2)
+    r1 = synth.sample_reads(genomes, 400, 150, sub_rate=0.01, seed=10, frac_random=0.0)
+    # mates: half from the same genome population, half random so that only one mate matches
+    r2 = synth.sample_reads(genomes, 400, 150, sub_rate=0.01, seed=11, frac_random=0.5)
+    for try_se in (0, 1):
+        kw = dict(try_se=try_se)
+        okw = dict(try_se=try_se, fpr_buf_size=499)
+        n, res = _run(G, O, db_dir, r1, r2, oracle_kw=okw, gpu_kw=kw)
+        assert n > 100
+
+
+def test_edge_cases(G, oracle_lib, tmp_path):
+    """Empty, shorter than k, shorter than -m, exactly k, N-rich, lower-case, IUPAC, and too-few-k-mers reads."""
+    O = oracle_lib
+    genomes = synth.random_genomes(10, 5000, seed=12)
+    db_dir = synth.make_db(tmp_path, genomes, k=21, threads=2)
+    g0 = genomes[0]
+    reads = [
+        b"",                         # empty
+        g0[:10],                     # shorter than k and than -m
+        g0[:21],                     # one k-mer, shorter than -m 30
+        g0[:30],                     # == -m: 10 k-mers == -c
+        g0[:29],                     # < -m
+        g0[100:250],                 # exact
+        g0[100:250].lower(),         # lower case hashes like upper case
+        g0[100:170] + b"N" + g0[171:250],  # one N: 21 k-mers contain it
+        b"N" * 150,                  # all N: every hash is 0 and dropped
+        g0[300:380] + b"RYKM" + g0[384:450],  # IUPAC codes (rc seed quirk)
+        g0[500:540],                 # 20 k-mers
+        genomes[3][1000:1150],
+    ]
+    reads += synth.sample_reads(genomes, 200, 150, sub_rate=0.03, seed=13, frac_random=0.2, n_rate=0.01)
+    n, res = _run(G, O, db_dir, reads)
+    assert n > 50
+    assert int(res.qkmers[0]) == 0 and int(res.qkmers[8]) == 0
+
+
+def test_thresholds_and_sorting(G, oracle_lib, tmp_path):
+    """Non-default -t/-T/-c/-f, --sort-by tcov/jacc, --keep-top-scores."""
+    O = oracle_lib
+    genomes = synth.random_genomes(20, 8000, seed=14)
+    # related genomes so a read matches several targets with different scores
+    rng = np.random.default_rng(15)
+    rel = []
+    for g in genomes[:5]:
+        for rate in (0.0, 0.01, 0.02, 0.04):
+            a = np.frombuffer(g, dtype=np.uint8).copy()
+            m = rng.random(len(a)) < rate
+            a[m] = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, int(m.sum()))]
+            rel.append(a.tobytes())
+    db_dir = synth.make_db(tmp_path, rel + genomes[5:], k=21, threads=2)
+    reads = synth.sample_reads(rel, 300, 150, sub_rate=0.005, seed=16, frac_random=0.1)
+    for kw in (dict(min_qcov=0.4, min_tcov=0.001, min_matched=5, max_fpr=0.05), dict(sort_by=1), dict(sort_by=2, top_n_scores=1),
+               dict(top_n_scores=2), dict(min_qcov=0.9)):
+        n, _ = _run(G, O, db_dir, reads, oracle_kw=kw, gpu_kw=kw)
+        assert n > 0
+
+
+def test_kmer_kernel_matches_oracle(G, oracle_lib, tmp_path):
+    """K1 alone: device hashes (plain and FracMinHash) equal the oracle's generateKmers in order."""
+    import torch
+    O = oracle_lib
+    genomes = synth.random_genomes(4, 3000, seed=17)
+    for scale in (1, 8):
+        d = tmp_path / f"s{scale}"
+        db_dir = synth.make_db(d, genomes, k=21, threads=2, scale=scale)
+        reads = synth.sample_reads(genomes, 100, 150, seed=18, n_rate=0.02) + [genomes[0][:1000], b"ACGT"]
+        seqs, offs = G["lib"].pack_reads(reads)
+        with G["Database"].open(db_dir, device=0) as db:
+            dev = torch.device("cuda:0")
+            t_seqs = torch.from_numpy(seqs).to(dev)
+            t_offs = torch.from_numpy(offs.view(np.int64)).to(dev)
+            t_h = torch.zeros(len(seqs) + 8, dtype=torch.int64, device=dev)
+            t_nk = torch.zeros(len(reads), dtype=torch.int32, device=dev)
+            p = G["default_params"](min_qlen=0, min_matched=1, dedup_threshold=1 << 30)
+            db.kmers_device(t_seqs.data_ptr(), t_offs.data_ptr(), len(reads), len(seqs), max(len(r) for r in reads),
+                            t_h.data_ptr(), t_h.numel(), None, t_nk.data_ptr(), params=p)
+            torch.cuda.synchronize()
+            h = t_h.cpu().numpy().view(np.uint64)
+            nk = t_nk.cpu().numpy()
+        cfg = O.sketch_cfg(k=21, scale=scale)
+        for i, r in enumerate(reads):
+            want = O.generate_kmers(r, cfg)
+            got = h[int(offs[i]):int(offs[i]) + int(nk[i])]
+            assert len(want) == nk[i]
+            assert np.array_equal(got, want), i
