@@ -90,6 +90,13 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise ImportError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                           "(hipcc --offload-arch=gfx950). kmcp_amd has no CPU fallback.")
+    # PyTorch-ROCm bundles its own HIP/HSA runtime under the soname libamdhip64.so.7.  Two HIP runtimes in
+    # one process cannot both own the GPU, so torch's copy must be mapped first; libkmcpgpu.so's NEEDED entry
+    # then binds to it.  (Stand-alone C/C++/Go hosts simply get /opt/rocm's runtime.)
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(LIB_PATH)
     vp, u64p, i32p = C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_int32)
     L.kmcpg_last_error.restype = C.c_char_p
