@@ -1,0 +1,279 @@
+#!/usr/bin/env python3
+"""bench.py — reads/s searched (150 bp, k=21) against a GTDB-scale COBS index on MI355X.
+
+One "step" = one pass of the hot path (K1 ntHash k-mer generation + K2 COBS query + hit hand-over) over
+one batch of synthetic 150-bp reads that is already resident in HBM.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload gtdb|config1] [--batch-reads B]
+
+N>1 is launched by the driver as `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`:
+one rank per GPU; the index's independent blocks are partitioned over the ranks (libkmcpgpu shards by
+bytes), every rank searches the whole batch against its blocks and the per-read hit lists are gathered on
+rank 0 over RCCL.  Total work is fixed as N grows => "scaling": "strong".
+
+The synthetic index is generated directly in HBM: 32 blocks x 14 976 columns
+(NumRowBytes 1 872) x 968 700 rows = 58.03 GB, bits i.i.d. Bernoulli(0.30) like a Bloom filter at fpr 0.3;
+90 % of the reads are 1 %-mutated, randomly reverse-complemented copies of 150-bp fragments whose k-mers
+were planted into a random column, 10 % are uniform random.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6290 GB/s measured copy ceiling
+
+WORKLOADS = {
+    # GTDB r202 k=21 x10 chunks: 58.03 GB in 32 blocks (docs/database-time-and-mem-v2021.12.md:20-36)
+    "gtdb": dict(k=21, num_hashes=1, fpr=0.3, n_blocks=32, cols_per_block=14976, num_sigs=968700, kmers_per_col=345510,
+                 batch_reads=131072, name="gtdb-scale synthetic: 32 blocks x 14976 cols x 968700 sigs (58.03 GB), 150bp k=21"),
+    # 10 k chunks, `kmcp index -j 32`: 32 blocks x 312 columns (39-byte rows) + 1 x 16 (BASELINE.json configs[1])
+    "config1": dict(k=21, num_hashes=1, fpr=0.3, n_blocks=32, cols_per_block=312, num_sigs=1121470, kmers_per_col=400000,
+                    batch_reads=1048576, name="10k-chunk synthetic: 32 blocks x 312 cols x 1121470 sigs (1.4 GB), 150bp k=21"),
+}
+READ_LEN = 150
+
+
+def make_batch(dev, n_reads, n_cols, seed):
+    """(fragments to plant, their target columns, the reads actually searched), all uint8/int32 on device."""
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    acgt = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=dev)
+    code = torch.randint(0, 4, (n_reads, READ_LEN), generator=g, device=dev)
+    cols = torch.randint(0, n_cols, (n_reads,), generator=g, device=dev).to(torch.int32)
+    is_random = torch.rand(n_reads, generator=g, device=dev) < 0.10
+    cols[is_random] = -1  # 0xFFFFFFFF: not planted
+    # the read: 1 % substitutions, then half of them reverse-complemented
+    sub = torch.rand(n_reads, READ_LEN, generator=g, device=dev) < 0.01
+    rcode = torch.where(sub, torch.randint(0, 4, (n_reads, READ_LEN), generator=g, device=dev), code)
+    rc = torch.rand(n_reads, generator=g, device=dev) < 0.5
+    rcode = torch.where(rc[:, None], 3 - rcode.flip(1), rcode)  # A<->T, C<->G under the ACGT code
+    frag = acgt[code].contiguous().view(-1)
+    reads = acgt[rcode].contiguous().view(-1)
+    offs = (torch.arange(n_reads + 1, device=dev, dtype=torch.int64) * READ_LEN).contiguous()
+    return frag, cols.contiguous(), reads, offs
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="gtdb", choices=sorted(WORKLOADS))
+    ap.add_argument("--batch-reads", type=int, default=0)
+    ap.add_argument("--cpu-sample-reads", type=int, default=0, help="0 = size the CPU sample to ~15 s")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 "
+                             "--master-port P bench.py --gpus N ...")
+        args.gpus = world
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from kmcp_amd import Database, default_params, lib
+
+    wl = dict(WORKLOADS[args.workload])
+    B = args.batch_reads or wl["batch_reads"]
+    spec = lib.SynthSpec(k=wl["k"], num_hashes=wl["num_hashes"], fpr=wl["fpr"], n_blocks=wl["n_blocks"],
+                         cols_per_block=wl["cols_per_block"], num_sigs=wl["num_sigs"], kmers_per_col=wl["kmers_per_col"], seed=42)
+    free_b, _ = torch.cuda.mem_get_info(dev)
+    need = wl["n_blocks"] * wl["num_sigs"] * ((wl["cols_per_block"] + 7) // 8 + 64) / world
+    if need > 0.9 * free_b:
+        raise SystemExit(f"workload needs {need/1e9:.1f} GB of HBM on this rank, {free_b/1e9:.1f} GB free")
+    t0 = time.time()
+    db = Database.open_synthetic(spec, device=local_rank, shard_rank=rank, shard_count=world)
+    torch.cuda.synchronize()
+    info = db.info
+    n_cols = int(info.n_cols)
+    params = default_params()  # kmcp search defaults: -t 0.55 -c 10 -m 30 -f 0.01 -u 256
+    db.set_profiling(True)
+
+    # ---- batches resident in HBM; distinct data per step (cycled if K+W is large)
+    n_batches = min(args.steps + args.warmup, 4)
+    batches = []
+    for i in range(n_batches):
+        frag, cols, reads, offs = make_batch(dev, B, n_cols, seed=1000 + i)
+        db.plant_reads_device(frag.data_ptr(), offs.data_ptr(), B, B * READ_LEN, READ_LEN, cols.data_ptr())
+        batches.append((reads, offs, cols))
+        del frag
+    torch.cuda.synchronize()
+    setup_s = time.time() - t0
+
+    cap = 4 * B + 4096
+    d_hits = torch.empty((cap, 3), dtype=torch.int32, device=dev)
+    d_cnt = torch.zeros(2, dtype=torch.int64, device=dev)
+    d_qk = torch.zeros(B, dtype=torch.int32, device=dev)
+    d_ql = torch.zeros(B, dtype=torch.int32, device=dev)
+    h_hits = torch.empty((cap * world, 3), dtype=torch.int32).pin_memory()
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    if world > 1:
+        d_cnt_all = torch.zeros(world, dtype=torch.int64, device=dev)
+        gather_list = [torch.empty_like(d_hits) for _ in range(world)] if rank == 0 else None
+
+    def step(i):
+        """K1+K2 on this rank's blocks, hit lists to rank 0 (RCCL), hit tuples to host memory. Returns #hits on rank 0."""
+        reads, offs, _ = batches[i % n_batches]
+        db.query_device(reads.data_ptr(), offs.data_ptr(), B, B * READ_LEN, READ_LEN, d_hits.data_ptr(), cap, d_cnt.data_ptr(),
+                        d_qk.data_ptr(), d_ql.data_ptr(), params=params, stream=stream)
+        if world == 1:
+            n = int(d_cnt[0].item())
+            assert n <= cap, "hit buffer overflow"
+            h_hits[:n].copy_(d_hits[:n], non_blocking=True)
+            torch.cuda.current_stream(dev).synchronize()
+            return n
+        dist.all_gather_into_tensor(d_cnt_all, d_cnt[:1])
+        dist.gather(d_hits, gather_list, dst=0)
+        if rank != 0:
+            torch.cuda.current_stream(dev).synchronize()
+            return 0
+        counts = d_cnt_all.cpu().tolist()
+        pos = 0
+        for rk, c in enumerate(counts):
+            assert c <= cap, "hit buffer overflow"
+            h_hits[pos:pos + c].copy_(gather_list[rk][:c], non_blocking=True)
+            pos += c
+        torch.cuda.current_stream(dev).synchronize()
+        return pos
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    barrier()
+    k2_ms, k1_ms, n_hits_total = [], [], 0
+    t_start = time.perf_counter()
+    for i in range(args.steps):
+        n_hits_total += step(args.warmup + i)
+        a, b = db.last_timing()
+        k1_ms.append(a)
+        k2_ms.append(b)
+    barrier()
+    elapsed = time.perf_counter() - t_start
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # ---- roofline of the dominant kernel (k2_cobs) on this rank: algorithmic bytes per launch:
+    #      sum over reads of kept k-mers x sum over local blocks of numHashes x NumRowBytes, + qLen, + 12 B per hit
+    last = (args.warmup + args.steps - 1) % n_batches
+    qk = d_qk.cpu().numpy().astype(np.int64)
+    kmers_per_launch = int(qk.sum())
+    alg_bytes = kmers_per_launch * int(info.row_bytes_sum_local) * int(info.num_hashes) + B * READ_LEN + 12 * (n_hits_total // max(1, args.steps))
+    k2_avg_ms = float(np.mean(k2_ms))
+    achieved = alg_bytes / (k2_avg_ms * 1e-3) / 1e9
+    traffic = None
+    tfile = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tfile):
+        try:
+            tj = json.load(open(tfile))
+            key = f"{args.workload}:{B}:{world}"
+            if key in tj:
+                traffic = tj[key]["hbm_bytes_per_launch"]
+        except Exception:
+            traffic = None
+
+    out = {
+        "metric": "reads/sec searched (150bp, k=21) vs GTDB-scale index",
+        "value": B * args.steps / elapsed,
+        "unit": "reads/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "strong",
+        "vs_baseline": None,
+        "dtype": "u32 bitwise (bit-sliced counters), u64 hashes",
+        "data": "synthetic",
+        "config": {"workload": wl["name"], "batch_reads": B, "read_len": READ_LEN, "k": wl["k"], "num_hashes": wl["num_hashes"],
+                   "index_bytes": int(info.matrix_bytes), "index_bytes_this_rank": int(info.matrix_bytes_local),
+                   "blocks": int(info.n_blocks), "columns": n_cols, "parallelism": f"block-shard x{world}",
+                   "search_flags": "-t 0.55 -c 10 -m 30 -f 0.01 -u 256"},
+        "roofline": {"bound": "hbm", "kernel": "k2_cobs<64,8,false>" if args.workload == "gtdb" else "k2_cobs<4,8,false>",
+                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                     "traffic": traffic, "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": k2_avg_ms,
+                     "kmers_kernel_ms": float(np.mean(k1_ms))},
+        "hits_per_step": n_hits_total / max(1, args.steps),
+        "setup_s": setup_s,
+    }
+
+    # ---- sanity on the last batch (rank 0): planted reads must come back with their column
+    if rank == 0:
+        n_last = step(last)
+        hh = h_hits[:n_last].numpy().astype(np.int64)
+        cols_last = batches[last][2].cpu().numpy().astype(np.int64)
+        got = set(zip(hh[:, 0].tolist(), hh[:, 1].tolist()))
+        planted = np.nonzero(cols_last >= 0)[0]
+        rec = sum((int(r), int(cols_last[r])) in got for r in planted[:20000]) / max(1, min(len(planted), 20000))
+        out["planted_recall"] = rec
+
+    # ---- CPU baseline: the oracle (C restatement of the reference algorithm), timed on this box's host cores on a bounded
+    #      sample: the first S blocks copied back from HBM and the first R reads of the last batch.
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import oracle as O
+        S = 1 if args.workload == "gtdb" else wl["n_blocks"]
+        blocks = []
+        for b in range(S):
+            bi = db.block_info(b)
+            rows = np.empty((bi["num_sigs"], bi["row_bytes"]), dtype=np.uint8)
+            chunk = 65536
+            for r0 in range(0, bi["num_sigs"], chunk):
+                idx = np.arange(r0, min(bi["num_sigs"], r0 + chunk), dtype=np.uint64)
+                rows[r0:r0 + len(idx)] = db.read_rows(b, idx)
+            blocks.append((bi["num_sigs"], bi["n_cols"], bi["col_base"], rows))
+        odb = O.OracleDB.from_memory(O.sketch_cfg(k=wl["k"]), wl["num_hashes"], wl["fpr"], blocks, wl["kmers_per_col"])
+        threads = os.cpu_count() or 1
+        reads_h = batches[last][0].cpu().numpy()
+        offs_h = batches[last][1].cpu().numpy().astype(np.uint64)
+        R = args.cpu_sample_reads or 256
+        tcpu = 0.0
+        while True:  # grow the sample until it is ~10-30 s of CPU work
+            t1 = time.perf_counter()
+            oqk, ohits = odb.search_batch(reads_h[:R * READ_LEN], offs_h[:R + 1], O.default_params(), threads=threads)
+            tcpu = time.perf_counter() - t1
+            if args.cpu_sample_reads or tcpu >= 8.0 or R >= B:
+                break
+            R = min(B, int(R * max(2.0, 12.0 / max(tcpu, 1e-3))))
+        # same-run parity on the sample: GPU hits of these reads restricted to the sampled blocks == oracle hits
+        hi_col = blocks[-1][2] + blocks[-1][1]
+        g = hh[(hh[:, 0] < R) & (hh[:, 1] < hi_col)]
+        g = g[np.lexsort((g[:, 1], g[:, 0]))]
+        parity = bool(np.array_equal(g, ohits.astype(np.int64))) and bool(np.array_equal(oqk[:R], qk[:R]))
+        frac_blocks = S / wl["n_blocks"]
+        out["cpu_baseline"] = {"value": R / tcpu * frac_blocks, "unit": "reads/s", "cores": threads, "kind": "port",
+                               "sample": f"{R} reads x {S} of {wl['n_blocks']} blocks in {tcpu:.2f} s on {threads} threads "
+                                         f"(oracle ko_search_batch, index rows copied back from HBM); value scaled by {frac_blocks:.4f} "
+                                         "to the whole index", "parity_on_sample": parity, "sample_hits": int(len(ohits))}
+        odb.close()
+        assert parity, "GPU hits differ from the CPU oracle on the sample"
+
+    if rank == 0:
+        print(json.dumps(out))
+    db.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -157,6 +157,14 @@ typedef struct {
 int kmcpg_open_synthetic(const kmcpg_synth_spec* spec, const kmcpg_opts* opts, kmcpg_db** out);
 /* ORs the Bloom bits of the given k-mer hashes into column `col` (global id) if it is local. */
 int kmcpg_plant(kmcpg_db* db, uint32_t col, const uint64_t* hashes, uint64_t n);
+/* Device-resident variant for whole batches: ORs the Bloom bits of every k-mer of read i (hashed exactly as a
+ * query would be) into global column d_cols[i]; 0xFFFFFFFF = do not plant; non-local columns are skipped. */
+int kmcpg_plant_reads_device(kmcpg_db* db, const uint8_t* d_seqs, const uint64_t* d_offs, uint32_t n_reads,
+                             uint64_t total_bases, uint32_t max_read_len, const uint32_t* d_cols, void* stream);
+/* HIP-event timing of the kernels inside kmcpg_query_device (events on the caller's stream).
+ * kmcpg_last_timing waits for the last call to finish; times are milliseconds. */
+int kmcpg_set_profiling(kmcpg_db* db, int enable);
+int kmcpg_last_timing(kmcpg_db* db, float* kmers_ms, float* cobs_ms);
 /* Copies rows (on-disk width NumRowBytes each) of a local block back to the host. */
 int kmcpg_read_rows(kmcpg_db* db, uint32_t block, const uint64_t* row_idx, uint64_t n_rows, uint8_t* out);
 /* Geometry of block b (global index): NumSigs, columns, NumRowBytes, device row stride, is-local. */

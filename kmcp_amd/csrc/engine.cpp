@@ -110,6 +110,10 @@ struct kmcpg_db {
   DevBuf<kmcpg_hit> s_hits;
   DevBuf<int32_t> s_qk, s_ql;
   bool synthetic = false;
+  // optional HIP-event timing of the last kmcpg_query_device call
+  bool profiling = false;
+  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  bool ev_valid = false;
 };
 
 namespace {
@@ -387,6 +391,8 @@ extern "C" int kmcpg_close(kmcpg_db* db) {
   db->s_hits.release();
   db->s_qk.release();
   db->s_ql.release();
+  for (auto& ev : db->ev)
+    if (ev) (void)hipEventDestroy(ev);
   delete db;
   return 0;
 }
@@ -530,10 +536,16 @@ extern "C" int kmcpg_query_device(kmcpg_db* db, const uint8_t* d_seqs, const uin
   if (d_seqs2) ub *= 2;
   if (ub > (uint64_t)p.dedup_threshold && db->w_scratch.ensure(total_bases + 1)) return fail(KMCPG_ENOMEM, "hipMalloc failed");
   uint64_t maxn = 0;
+  if (db->profiling) {
+    for (auto& ev : db->ev)
+      if (!ev) HIPCHK(hipEventCreate(&ev));
+    HIPCHK(hipEventRecord(db->ev[0], st));
+  }
   int rc = run_kmers(db, d_seqs, d_offs, d_seqs2, d_offs2, n_reads, max_read_len, p, db->w_hashes.p, db->w_scratch.p, db->w_nk_raw.p, db->w_nk1.p, d_qkmers,
                      d_qlen, st, &maxn);
   if (rc) return rc;
   HIPCHK(hipMemsetAsync(d_counters, 0, sizeof(uint64_t), st));
+  if (db->profiling) HIPCHK(hipEventRecord(db->ev[1], st));
   const int npl = maxn <= 255 ? 8 : (maxn <= 65535 ? 16 : (maxn <= 16777215 ? 24 : 0));
   if (!npl) return fail(KMCPG_EUNSUPPORTED, "queries with more than 16777215 k-mers are not supported");
   for (const auto& c : db->classes) {
@@ -554,7 +566,58 @@ extern "C" int kmcpg_query_device(kmcpg_db* db, const uint8_t* d_seqs, const uin
     a.counter = (unsigned long long*)d_counters;
     if (launch_k2(a, c.lpr, npl, st) != 0) return fail(KMCPG_EINVAL, "batch too large for one launch: split it");
   }
+  if (db->profiling) {
+    HIPCHK(hipEventRecord(db->ev[2], st));
+    db->ev_valid = true;
+  }
   HIPCHK(hipGetLastError());
+  return 0;
+}
+
+extern "C" int kmcpg_set_profiling(kmcpg_db* db, int enable) {
+  if (!db) return fail(KMCPG_EINVAL, "null argument");
+  std::lock_guard<std::mutex> g(db->mu);
+  db->profiling = enable != 0;
+  db->ev_valid = false;
+  return 0;
+}
+
+extern "C" int kmcpg_last_timing(kmcpg_db* db, float* kmers_ms, float* cobs_ms) {
+  if (!db) return fail(KMCPG_EINVAL, "null argument");
+  std::lock_guard<std::mutex> g(db->mu);
+  if (!db->profiling || !db->ev_valid) return fail(KMCPG_EINVAL, "no profiled kmcpg_query_device call yet");
+  HIPCHK(hipSetDevice(db->opts.device));
+  HIPCHK(hipEventSynchronize(db->ev[2]));
+  float a = 0, b = 0;
+  HIPCHK(hipEventElapsedTime(&a, db->ev[0], db->ev[1]));
+  HIPCHK(hipEventElapsedTime(&b, db->ev[1], db->ev[2]));
+  if (kmers_ms) *kmers_ms = a;
+  if (cobs_ms) *cobs_ms = b;
+  return 0;
+}
+
+extern "C" int kmcpg_plant_reads_device(kmcpg_db* db, const uint8_t* d_seqs, const uint64_t* d_offs, uint32_t n_reads, uint64_t total_bases,
+                                        uint32_t max_read_len, const uint32_t* d_cols, void* stream) {
+  if (!db || !d_seqs || !d_offs || !d_cols) return fail(KMCPG_EINVAL, "null argument");
+  std::lock_guard<std::mutex> g(db->mu);
+  HIPCHK(hipSetDevice(db->opts.device));
+  hipStream_t st = (hipStream_t)stream;
+  if (db->w_hashes.ensure(total_bases + 1) || db->w_nk_raw.ensure(n_reads + 1) || db->w_nk1.ensure(n_reads + 1)) return fail(KMCPG_ENOMEM, "hipMalloc failed");
+  DevBuf<int32_t> tmp;
+  if (tmp.ensure(2 * (size_t)n_reads + 2)) return fail(KMCPG_ENOMEM, "hipMalloc failed");
+  kmcpg_params p = default_params();
+  p.min_qlen = 0;
+  p.min_matched = 1;
+  p.dedup_threshold = 0x7fffffff;  // plant every k-mer occurrence (idempotent)
+  uint64_t maxn = 0;
+  int rc = run_kmers(db, d_seqs, d_offs, nullptr, nullptr, n_reads, max_read_len, p, db->w_hashes.p, db->w_scratch.p, db->w_nk_raw.p, db->w_nk1.p, tmp.p,
+                     tmp.p + n_reads + 1, st, &maxn);
+  if (rc == 0)
+    launch_plant_reads(db->d_blockdev, (uint32_t)db->h_blockdev.size(), db->info.num_hashes, db->w_hashes.p, d_offs, db->w_nk_raw.p, d_cols, n_reads, st);
+  hipError_t e = hipStreamSynchronize(st);
+  tmp.release();
+  if (rc) return rc;
+  if (e != hipSuccess) return fail(KMCPG_EDEVICE, "plant kernel failed: %s", hipGetErrorString(e));
   return 0;
 }
 

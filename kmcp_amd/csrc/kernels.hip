@@ -541,4 +541,43 @@ void launch_plant(const BlockDev& bd, uint32_t col, int num_hashes, const uint64
   hipLaunchKernelGGL(k_plant, dim3(blocks), dim3(256), 0, st, bd, col, num_hashes, hashes, n);
 }
 
+// plant every k-mer of read r into global column cols[r] (bench / full-size parity only)
+__global__ void __launch_bounds__(256) k_plant_reads(const BlockDev* __restrict__ blocks, uint32_t nblocks, int num_hashes,
+                                                     const uint64_t* __restrict__ hashes, const uint64_t* __restrict__ offs,
+                                                     const int32_t* __restrict__ nk, const uint32_t* __restrict__ cols, uint32_t n_reads) {
+  const int lane = threadIdx.x & 63;
+  const uint32_t wave = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const uint32_t nwaves = gridDim.x * 4;
+  for (uint32_t r = wave; r < n_reads; r += nwaves) {
+    const uint32_t cg = cols[r];
+    if (cg == 0xffffffffu) continue;
+    uint32_t bi = nblocks;
+    for (uint32_t b = 0; b < nblocks; b++)
+      if (cg >= blocks[b].col_base && cg < blocks[b].col_base + blocks[b].ncols) bi = b;
+    if (bi == nblocks) continue;  // column lives on another shard
+    const BlockDev bd = blocks[bi];
+    const uint32_t col = cg - bd.col_base;
+    const int n = nk[r];
+    for (int j = lane; j < n; j += 64) {
+      const uint64_t h = hashes[offs[r] + j];
+      const uint32_t ha = (uint32_t)(h >> 32), hb = (uint32_t)h;
+      for (int t = 0; t < num_hashes; t++) {
+        const uint64_t hv = num_hashes == 1 ? h : (uint64_t)(uint32_t)(ha + hb * (uint32_t)t);
+        const uint64_t row = fastmod_u64(hv, bd.num_sigs, bd.magic_hi, bd.magic_lo);
+        const uint64_t byte = row * bd.stride + (col >> 3);
+        uint32_t* w = reinterpret_cast<uint32_t*>(const_cast<uint8_t*>(bd.rows) + (byte & ~3ULL));
+        atomicOr(w, (uint32_t)(1u << (7 - (col & 7))) << (8 * (byte & 3)));
+      }
+    }
+  }
+}
+
+void launch_plant_reads(const BlockDev* blocks, uint32_t nblocks, int num_hashes, const uint64_t* hashes, const uint64_t* offs,
+                        const int32_t* nk, const uint32_t* cols, uint32_t n_reads, hipStream_t st) {
+  if (n_reads == 0 || nblocks == 0) return;
+  unsigned nb = (n_reads + 3) / 4;
+  if (nb > 32768) nb = 32768;
+  hipLaunchKernelGGL(k_plant_reads, dim3(nb), dim3(256), 0, st, blocks, nblocks, num_hashes, hashes, offs, nk, cols, n_reads);
+}
+
 }  // namespace kmcpg

@@ -17,4 +17,7 @@ void launch_gather_rows(const uint8_t* rows, uint32_t stride, uint32_t row_bytes
 void launch_synth_fill(uint8_t* rows, uint64_t n_rows, uint32_t stride, uint32_t ncols, uint64_t key, uint32_t p8, hipStream_t st);
 void launch_plant(const BlockDev& bd, uint32_t col, int num_hashes, const uint64_t* hashes, uint64_t n, hipStream_t st);
 
+void launch_plant_reads(const BlockDev* blocks, uint32_t nblocks, int num_hashes, const uint64_t* hashes, const uint64_t* offs,
+                        const int32_t* nk, const uint32_t* cols, uint32_t n_reads, hipStream_t st);
+
 }  // namespace kmcpg

@@ -14,7 +14,8 @@ LIB_PATH = os.path.join(_HERE, "libkmcpgpu.so")
 EXPORTS = [
     "kmcpg_open", "kmcpg_close", "kmcpg_last_error", "kmcpg_db_info", "kmcpg_col_info", "kmcpg_search_batch",
     "kmcpg_result_free", "kmcpg_query_device", "kmcpg_finalize", "kmcpg_open_synthetic", "kmcpg_plant",
-    "kmcpg_read_rows", "kmcpg_block_info", "kmcpg_kmers_device",
+    "kmcpg_read_rows", "kmcpg_block_info", "kmcpg_kmers_device", "kmcpg_plant_reads_device", "kmcpg_set_profiling",
+    "kmcpg_last_timing",
 ]
 
 
@@ -117,6 +118,9 @@ def load():
     L.kmcpg_read_rows.argtypes = [vp, C.c_uint32, vp, C.c_uint64, vp]
     L.kmcpg_kmers_device.argtypes = [vp, vp, vp, C.c_uint32, C.c_uint64, C.c_uint32, C.POINTER(Params), vp, C.c_uint64,
                                      vp, vp, vp]
+    L.kmcpg_plant_reads_device.argtypes = [vp, vp, vp, C.c_uint32, C.c_uint64, C.c_uint32, vp, vp]
+    L.kmcpg_set_profiling.argtypes = [vp, C.c_int]
+    L.kmcpg_last_timing.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]
     _lib = L
     return L
 
@@ -256,6 +260,18 @@ class Database:
     def plant(self, col, hashes):
         hashes = np.ascontiguousarray(hashes, dtype=np.uint64)
         _check(load().kmcpg_plant(self._h, col, hashes.ctypes.data, len(hashes)))
+
+    def plant_reads_device(self, d_seqs, d_offs, n_reads, total_bases, max_read_len, d_cols, stream=None):
+        _check(load().kmcpg_plant_reads_device(self._h, d_seqs, d_offs, n_reads, total_bases, max_read_len, d_cols, stream))
+
+    def set_profiling(self, on=True):
+        _check(load().kmcpg_set_profiling(self._h, int(on)))
+
+    def last_timing(self):
+        """(k-mer kernels ms, COBS kernel ms) of the last query_device call."""
+        a, b = C.c_float(), C.c_float()
+        _check(load().kmcpg_last_timing(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
 
     def read_rows(self, block, row_idx):
         row_idx = np.ascontiguousarray(row_idx, dtype=np.uint64)

@@ -331,6 +331,7 @@ typedef struct {
   size_t file_len;
   size_t offset0;     /* byte offset of row 0 (util-db-search.go:1207) */
   uint32_t col_base;  /* global column number of column 0 */
+  int borrowed;       /* rows not owned (ko_db_create_mem) */
 } ko_block;
 
 struct ko_db {
@@ -592,12 +593,42 @@ ko_db* ko_db_open(const char* db_dir) {
   return db;
 }
 
+ko_db* ko_db_create_mem(const ko_sketch_cfg* cfg, int num_hashes, double fpr, int nblocks, const uint64_t* num_sigs,
+                        const uint32_t* ncols, const uint32_t* col_base, const uint8_t* const* rows, uint64_t size_all) {
+  if (!g_seed_ready) seed_init();
+  ko_db* db = (ko_db*)calloc(1, sizeof *db);
+  db->cfg = *cfg;
+  db->num_hashes = num_hashes;
+  db->fpr = fpr;
+  db->nblocks = nblocks;
+  db->blocks = (ko_block*)calloc((size_t)nblocks, sizeof(ko_block));
+  for (int i = 0; i < nblocks; i++) {
+    ko_block* b = &db->blocks[i];
+    b->k = cfg->k; b->canonical = cfg->canonical; b->compact = 1; b->num_hashes = num_hashes;
+    b->num_sigs = num_sigs[i]; b->ncols = ncols[i]; b->row_bytes = (ncols[i] + 7) / 8;
+    b->names = (char**)calloc(ncols[i], sizeof(char*));
+    b->gsizes = (uint64_t*)calloc(ncols[i], 8);
+    b->indices = (uint32_t*)calloc(ncols[i], 4);
+    b->sizes = (uint64_t*)calloc(ncols[i], 8);
+    for (uint32_t c = 0; c < ncols[i]; c++) {
+      char nm[32];
+      snprintf(nm, sizeof nm, "syn%u", col_base[i] + c);
+      b->names[c] = strdup(nm);
+      b->gsizes[c] = 4000000; b->indices[c] = (c % 10) | (10u << 16); b->sizes[c] = size_all;
+    }
+    b->file = (uint8_t*)rows[i]; b->offset0 = 0; b->borrowed = 1; b->col_base = col_base[i];
+    if ((uint64_t)col_base[i] + ncols[i] > db->ncols_total) db->ncols_total = (uint64_t)col_base[i] + ncols[i];
+  }
+  return db;
+}
+
 void ko_db_close(ko_db* db) {
   if (!db) return;
   for (int i = 0; i < db->nblocks; i++) {
     ko_block* b = &db->blocks[i];
     if (b->names) for (uint32_t c = 0; c < b->ncols; c++) free(b->names[c]);
-    free(b->names); free(b->gsizes); free(b->indices); free(b->sizes); free(b->file);
+    free(b->names); free(b->gsizes); free(b->indices); free(b->sizes);
+    if (!b->borrowed) free(b->file);
   }
   free(db->blocks);
   free(db);
@@ -806,6 +837,14 @@ int ko_format_match(char* buf, size_t cap, const char* qid, const ko_result* r, 
  * instead of the 64-row byte transposition of :6821-6972 (a faster CPU formulation of the same
  * positional popcount, so the reported baseline errs on the fast side).
  * ============================================================================================== */
+typedef uint16_t v8u16 __attribute__((vector_size(16)));
+static v8u16 g_lut[256];
+static int g_lut_ready = 0;
+static void lut_init(void) {
+  for (int v = 0; v < 256; v++)
+    for (int j = 0; j < 8; j++) g_lut[v][j] = (uint16_t)((v >> (7 - j)) & 1); /* bit 7 = first column of the byte */
+  g_lut_ready = 1;
+}
 static void block_counts_fast(const ko_block* b, const uint64_t* kmers, size_t n, uint16_t* cnt /* row_bytes*8 */, uint8_t* acc) {
   const uint8_t* sigs = b->file + b->offset0;
   uint32_t rb = b->row_bytes;
@@ -824,18 +863,15 @@ static void block_counts_fast(const ko_block* b, const uint64_t* kmers, size_t n
       }
       row = acc;
     }
-    for (uint32_t j = 0; j < rb; j++) {
-      uint8_t v = row[j];
-      uint16_t* c = cnt + 8 * (size_t)j;
-      c[0] += (v >> 7) & 1; c[1] += (v >> 6) & 1; c[2] += (v >> 5) & 1; c[3] += (v >> 4) & 1;
-      c[4] += (v >> 3) & 1; c[5] += (v >> 2) & 1; c[6] += (v >> 1) & 1; c[7] += v & 1;
-    }
+    v8u16* cv = (v8u16*)cnt;
+    for (uint32_t j = 0; j < rb; j++) cv[j] += g_lut[row[j]];
   }
 }
 
 int64_t ko_search_batch(ko_db* db, const uint8_t* seqs, const uint64_t* offs, uint32_t n_reads, const ko_search_params* p,
                         int threads, int32_t* qkmers, uint32_t* hits_out, int64_t hits_cap) {
   if (!g_seed_ready) seed_init();
+  if (!g_lut_ready) lut_init();
   uint32_t max_rb = 0;
   for (int b = 0; b < db->nblocks; b++) if (db->blocks[b].row_bytes > max_rb) max_rb = db->blocks[b].row_bytes;
   int64_t nh = 0;
@@ -845,7 +881,7 @@ int64_t ko_search_batch(ko_db* db, const uint8_t* seqs, const uint64_t* offs, ui
 #endif
 #pragma omp parallel
   {
-    uint16_t* cnt = (uint16_t*)malloc((size_t)max_rb * 8 * sizeof(uint16_t));
+    uint16_t* cnt = (uint16_t*)aligned_alloc(64, ((size_t)max_rb * 8 * sizeof(uint16_t) + 63) / 64 * 64);
     uint8_t* acc = (uint8_t*)malloc(max_rb ? max_rb : 1);
     uint64_t* kmers = NULL;
     size_t kcap = 0;

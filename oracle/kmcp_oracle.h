@@ -120,6 +120,10 @@ int ko_build_db(const char* out_dir, const ko_sketch_cfg* cfg, int num_hashes, d
 /* ---- database + search ------------------------------------------------------------------------- */
 ko_db* ko_db_open(const char* db_dir); /* db_dir is the R001-style dir holding __db.yml */
 void ko_db_close(ko_db* db);
+/* in-memory database over caller-owned row-major bit matrices (bench: a sample of the blocks of a synthetic
+ * GTDB-scale index copied back from HBM).  Column c of block b is named "syn<col_base[b]+c>", Sizes = size_all. */
+ko_db* ko_db_create_mem(const ko_sketch_cfg* cfg, int num_hashes, double fpr, int nblocks, const uint64_t* num_sigs,
+                        const uint32_t* ncols, const uint32_t* col_base, const uint8_t* const* rows, uint64_t size_all);
 const char* ko_last_error(void);
 int ko_db_info(const ko_db* db, ko_sketch_cfg* cfg, int* num_hashes, double* fpr, int* nblocks,
                uint64_t* ncols_total);

@@ -102,6 +102,9 @@ def lib():
     L.ko_db_open.restype = C.c_void_p
     L.ko_db_open.argtypes = [C.c_char_p]
     L.ko_db_close.argtypes = [C.c_void_p]
+    L.ko_db_create_mem.restype = C.c_void_p
+    L.ko_db_create_mem.argtypes = [C.POINTER(SketchCfg), C.c_int, C.c_double, C.c_int, u64p, C.POINTER(C.c_uint32),
+                                   C.POINTER(C.c_uint32), C.POINTER(C.c_void_p), C.c_uint64]
     L.ko_db_info.argtypes = [C.c_void_p, C.POINTER(SketchCfg), C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_int), u64p]
     L.ko_db_block_info.argtypes = [C.c_void_p, C.c_int, u64p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
     L.ko_db_block_rows.restype = C.c_void_p
@@ -159,14 +162,28 @@ def build_db(out_dir, cfg, columns, num_hashes=1, fpr=0.3, threads=32, block_siz
 
 
 class OracleDB:
-    def __init__(self, db_dir):
-        self.h = lib().ko_db_open(db_dir.encode())
+    def __init__(self, db_dir=None, _handle=None, _keep=None):
+        self._keep = _keep
+        self.h = _handle if _handle is not None else lib().ko_db_open(db_dir.encode())
         if not self.h:
             raise RuntimeError(lib().ko_last_error().decode())
         cfg = SketchCfg()
         nh, fpr, nb, nc = C.c_int(), C.c_double(), C.c_int(), C.c_uint64()
         lib().ko_db_info(self.h, C.byref(cfg), C.byref(nh), C.byref(fpr), C.byref(nb), C.byref(nc))
         self.cfg, self.num_hashes, self.fpr, self.nblocks, self.ncols = cfg, nh.value, fpr.value, nb.value, nc.value
+
+    @classmethod
+    def from_memory(cls, cfg, num_hashes, fpr, blocks, size_all):
+        """blocks: list of (num_sigs, ncols, col_base, rows uint8[num_sigs, row_bytes])."""
+        n = len(blocks)
+        ns = np.array([b[0] for b in blocks], dtype=np.uint64)
+        nc = np.array([b[1] for b in blocks], dtype=np.uint32)
+        cb = np.array([b[2] for b in blocks], dtype=np.uint32)
+        mats = [np.ascontiguousarray(b[3], dtype=np.uint8) for b in blocks]
+        ptrs = (C.c_void_p * n)(*[m.ctypes.data for m in mats])
+        h = lib().ko_db_create_mem(C.byref(cfg), num_hashes, fpr, n, _u64p(ns), nc.ctypes.data_as(C.POINTER(C.c_uint32)),
+                                   cb.ctypes.data_as(C.POINTER(C.c_uint32)), ptrs, size_all)
+        return cls(_handle=h, _keep=mats)
 
     def close(self):
         if self.h:
