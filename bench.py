@@ -42,6 +42,24 @@ WORKLOADS = {
 READ_LEN = 150
 
 
+def effective_cpus():
+    """Host cores this process may actually use: affinity mask capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(p))))
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, q // p))
+        except Exception:
+            pass
+    return n
+
+
 def make_batch(dev, n_reads, n_cols, seed):
     """(fragments to plant, their target columns, the reads actually searched), all uint8/int32 on device."""
     g = torch.Generator(device=dev)
@@ -243,7 +261,7 @@ def main():
                 rows[r0:r0 + len(idx)] = db.read_rows(b, idx)
             blocks.append((bi["num_sigs"], bi["n_cols"], bi["col_base"], rows))
         odb = O.OracleDB.from_memory(O.sketch_cfg(k=wl["k"]), wl["num_hashes"], wl["fpr"], blocks, wl["kmers_per_col"])
-        threads = os.cpu_count() or 1
+        threads = effective_cpus()
         reads_h = batches[last][0].cpu().numpy()
         offs_h = batches[last][1].cpu().numpy().astype(np.uint64)
         R = args.cpu_sample_reads or 256
