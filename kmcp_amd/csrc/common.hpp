@@ -38,7 +38,8 @@ struct K1Args {
   int32_t mode;          // 0 plain (+scaled), 1 minimizer, 2 syncmer
   uint32_t w_or_s;       // minimizer-w or syncmer-s
   uint64_t* hashes;      // read i writes at hashes[offs[i] + offs2[i] ...]
-  uint64_t* scratch;     // same size as hashes (s-mer hashes / dedup output)
+  uint64_t* scratch;     // same size as hashes: k-mer hashes of window sketches / dedup output
+  uint64_t* scratch2;    // same size: s-mer hashes (syncmer mode)
   int32_t* nk_raw;       // k-mers emitted for read i (both mates)
   int32_t* nk1;          // k-mers emitted for mate 1 (for --try-se)
   int32_t* qlen;

@@ -453,10 +453,9 @@ uint64_t max_hash_for(uint32_t scale) {
 
 // K1 (+K1d): hashes of read i end up at d_hashes[offs[i] + offs2[i] ...], NumKmers in d_nk_search
 int run_kmers(kmcpg_db* db, const uint8_t* d_seqs, const uint64_t* d_offs, const uint8_t* d_seqs2, const uint64_t* d_offs2, uint32_t n_reads,
-              uint32_t max_read_len, const kmcpg_params& p, uint64_t* d_hashes, uint64_t* d_scratch, int32_t* d_nk_raw, int32_t* d_nk1,
+              uint32_t max_read_len, const kmcpg_params& p, uint64_t* d_hashes, uint64_t* d_scratch, uint64_t scratch_half, int32_t* d_nk_raw, int32_t* d_nk1,
               int32_t* d_nk_search, int32_t* d_qlen, hipStream_t st, uint64_t* max_n_out) {
   const kmcpg_info& I = db->info;
-  if (I.minimizer || I.syncmer) return fail(KMCPG_EUNSUPPORTED, "minimizer/syncmer databases are not supported by the GPU k-mer kernel yet");
   if (!I.canonical) return fail(KMCPG_EUNSUPPORTED, "non-canonical index");
   K1Args a{};
   a.seqs = d_seqs;
@@ -468,9 +467,11 @@ int run_kmers(kmcpg_db* db, const uint8_t* d_seqs, const uint64_t* d_offs, const
   a.min_qlen = p.min_qlen;
   a.scaled = I.scaled;
   a.max_hash = I.scaled ? max_hash_for(I.scale) : ~0ULL;
-  a.mode = 0;
+  a.mode = I.syncmer ? 2 : (I.minimizer ? 1 : 0);  // syncmer > minimizer > plain (:1052-1058)
+  a.w_or_s = I.syncmer ? I.syncmer_s : I.minimizer_w;
   a.hashes = d_hashes;
   a.scratch = d_scratch;
+  a.scratch2 = d_scratch ? d_scratch + scratch_half : nullptr;
   a.nk_raw = d_nk_raw;
   a.nk1 = d_nk1;
   a.qlen = d_qlen;
@@ -507,12 +508,12 @@ extern "C" int kmcpg_kmers_device(kmcpg_db* db, const uint8_t* d_seqs, const uin
   HIPCHK(hipSetDevice(db->opts.device));
   const kmcpg_params p = params ? *params : default_params();
   hipStream_t st = (hipStream_t)stream;
-  if (db->w_scratch.ensure(total_bases + 1) || db->w_nk_raw.ensure(n_reads + 1) || db->w_nk1.ensure(n_reads + 1)) return fail(KMCPG_ENOMEM, "hipMalloc failed");
+  if (db->w_scratch.ensure(2 * total_bases + 2) || db->w_nk_raw.ensure(n_reads + 1) || db->w_nk1.ensure(n_reads + 1)) return fail(KMCPG_ENOMEM, "hipMalloc failed");
   DevBuf<int32_t> ql;
   if (ql.ensure(n_reads + 1)) return fail(KMCPG_ENOMEM, "hipMalloc failed");
   uint64_t maxn = 0;
-  int rc = run_kmers(db, d_seqs, d_offs, nullptr, nullptr, n_reads, max_read_len, p, d_hashes, db->w_scratch.p, db->w_nk_raw.p, db->w_nk1.p, d_nk, ql.p, st,
-                     &maxn);
+  int rc = run_kmers(db, d_seqs, d_offs, nullptr, nullptr, n_reads, max_read_len, p, d_hashes, db->w_scratch.p, total_bases + 1, db->w_nk_raw.p, db->w_nk1.p,
+                     d_nk, ql.p, st, &maxn);
   if (rc == 0 && d_koff) HIPCHK(hipMemcpyAsync(d_koff, d_offs, (size_t)n_reads * sizeof(uint64_t), hipMemcpyDeviceToDevice, st));
   hipError_t e = hipStreamSynchronize(st);
   ql.release();
@@ -534,15 +535,16 @@ extern "C" int kmcpg_query_device(kmcpg_db* db, const uint8_t* d_seqs, const uin
   if (db->w_hashes.ensure(total_bases + 1) || db->w_nk_raw.ensure(n_reads + 1) || db->w_nk1.ensure(n_reads + 1)) return fail(KMCPG_ENOMEM, "hipMalloc failed");
   uint64_t ub = max_read_len >= (uint32_t)db->info.k ? (uint64_t)(max_read_len - db->info.k + 1) : 0;
   if (d_seqs2) ub *= 2;
-  if (ub > (uint64_t)p.dedup_threshold && db->w_scratch.ensure(total_bases + 1)) return fail(KMCPG_ENOMEM, "hipMalloc failed");
+  const bool window_sketch = db->info.syncmer || db->info.minimizer;
+  if ((ub > (uint64_t)p.dedup_threshold || window_sketch) && db->w_scratch.ensure(2 * total_bases + 2)) return fail(KMCPG_ENOMEM, "hipMalloc failed");
   uint64_t maxn = 0;
   if (db->profiling) {
     for (auto& ev : db->ev)
       if (!ev) HIPCHK(hipEventCreate(&ev));
     HIPCHK(hipEventRecord(db->ev[0], st));
   }
-  int rc = run_kmers(db, d_seqs, d_offs, d_seqs2, d_offs2, n_reads, max_read_len, p, db->w_hashes.p, db->w_scratch.p, db->w_nk_raw.p, db->w_nk1.p, d_qkmers,
-                     d_qlen, st, &maxn);
+  int rc = run_kmers(db, d_seqs, d_offs, d_seqs2, d_offs2, n_reads, max_read_len, p, db->w_hashes.p, db->w_scratch.p, total_bases + 1, db->w_nk_raw.p,
+                     db->w_nk1.p, d_qkmers, d_qlen, st, &maxn);
   if (rc) return rc;
   HIPCHK(hipMemsetAsync(d_counters, 0, sizeof(uint64_t), st));
   if (db->profiling) HIPCHK(hipEventRecord(db->ev[1], st));
@@ -610,8 +612,9 @@ extern "C" int kmcpg_plant_reads_device(kmcpg_db* db, const uint8_t* d_seqs, con
   p.min_matched = 1;
   p.dedup_threshold = 0x7fffffff;  // plant every k-mer occurrence (idempotent)
   uint64_t maxn = 0;
-  int rc = run_kmers(db, d_seqs, d_offs, nullptr, nullptr, n_reads, max_read_len, p, db->w_hashes.p, db->w_scratch.p, db->w_nk_raw.p, db->w_nk1.p, tmp.p,
-                     tmp.p + n_reads + 1, st, &maxn);
+  if ((db->info.syncmer || db->info.minimizer) && db->w_scratch.ensure(2 * total_bases + 2)) return fail(KMCPG_ENOMEM, "hipMalloc failed");
+  int rc = run_kmers(db, d_seqs, d_offs, nullptr, nullptr, n_reads, max_read_len, p, db->w_hashes.p, db->w_scratch.p, total_bases + 1, db->w_nk_raw.p,
+                     db->w_nk1.p, tmp.p, tmp.p + n_reads + 1, st, &maxn);
   if (rc == 0)
     launch_plant_reads(db->d_blockdev, (uint32_t)db->h_blockdev.size(), db->info.num_hashes, db->w_hashes.p, d_offs, db->w_nk_raw.p, d_cols, n_reads, st);
   hipError_t e = hipStreamSynchronize(st);

@@ -85,6 +85,97 @@ __device__ __forceinline__ int hash_mate(const uint8_t* __restrict__ s, int len,
   return cnt;
 }
 
+// all canonical kk-mer hashes of s, uncompacted (input of the window sketches)
+__device__ __forceinline__ void hash_positions(const uint8_t* __restrict__ s, int len, int kk, const uint64_t* tab, uint64_t* __restrict__ out,
+                                               int lane) {
+  const int npos = len - kk + 1;
+  for (int i = lane; i < npos; i += 64) {
+    uint64_t f = 0, r = 0;
+    for (int j = 0; j < kk; j++) {
+      f = rol1(f) ^ tab[s[i + j]];
+      r = rol1(r) ^ tab[s[i + kk - 1 - j] & 7];
+    }
+    out[i] = f < r ? f : r;
+  }
+}
+
+__device__ __forceinline__ int argmin_left(const uint64_t* __restrict__ h, int b, int n) {
+  int m = b;
+  uint64_t mv = h[b];
+  for (int i = b + 1; i < b + n; i++) {
+    const uint64_t v = h[i];
+    if (v < mv) {  // strict: the leftmost of equal values wins
+      mv = v;
+      m = i;
+    }
+  }
+  return m;
+}
+
+// Closed Syncmer as bio/sketches emits it (NextSyncmer, call site util-db-search.go:1053,1068; semantics pinned by
+// demo-searching/README.md:61-68): window of 2k-s-1 bases = 2(k-s) s-mers, m = leftmost minimal canonical s-mer;
+// emit the k-mer starting at m if m-w0 < k-s, else the k-mer ending at m+s.  One emission per window.
+__device__ __forceinline__ int syncmer_mate(const uint8_t* __restrict__ s, int len, int k, int sm, const uint64_t* tab, bool scaled,
+                                            uint64_t max_hash, uint64_t* hk, uint64_t* hs, uint64_t* __restrict__ out, int cnt, int lane) {
+  const int L = 2 * k - sm - 1;
+  if (sm < 1 || sm > k || len < L || len < k) return cnt;  // ErrShortSeq
+  hash_positions(s, len, k, tab, hk, lane);
+  hash_positions(s, len, sm, tab, hs, lane);
+  __threadfence_block();
+  const int wsz = 2 * (k - sm);
+  const int nw = wsz > 0 ? len - L + 1 : len - k + 1;  // s == k: every k-mer is its own window
+  for (int base = 0; base < nw; base += 64) {
+    const int w0 = base + lane;
+    const bool v = w0 < nw;
+    uint64_t h = 0;
+    if (v) {
+      int pos = w0;
+      if (wsz > 0) {
+        const int m = argmin_left(hs, w0, wsz);
+        pos = (m - w0 < k - sm) ? m : m + sm - k;
+      }
+      h = hk[pos];
+    }
+    const bool keep = v && h != 0 && (!scaled || h <= max_hash);
+    const uint64_t mk = __ballot(keep);
+    if (keep) out[cnt + __popcll(mk & ((1ULL << lane) - 1ULL))] = h;
+    cnt += __popcll(mk);
+  }
+  return cnt;
+}
+
+// Minimizer sketch (NextMinimizer, call site util-db-search.go:1055,1081): leftmost minimum of every window of w
+// k-mers, emitted when its position changes.  (Parity unpinned: the reference holds no golden for this mode.)
+__device__ __forceinline__ int minimizer_mate(const uint8_t* __restrict__ s, int len, int k, int w, const uint64_t* tab, bool scaled,
+                                              uint64_t max_hash, uint64_t* hk, uint64_t* __restrict__ out, int cnt, int lane) {
+  if (w < 1 || len < k + w - 1) return cnt;  // ErrShortSeq
+  hash_positions(s, len, k, tab, hk, lane);
+  __threadfence_block();
+  const int nw = len - k + 1 - w + 1;
+  for (int base = 0; base < nw; base += 64) {
+    const int w0 = base + lane;
+    const bool v = w0 < nw;
+    int m = -1, pm = -2;
+    if (v) {
+      m = argmin_left(hk, w0, w);
+      pm = w0 > 0 ? argmin_left(hk, w0 - 1, w) : -2;
+    }
+    const uint64_t h = (v && m != pm) ? hk[m] : 0;
+    const bool keep = v && m != pm && h != 0 && (!scaled || h <= max_hash);
+    const uint64_t mk = __ballot(keep);
+    if (keep) out[cnt + __popcll(mk & ((1ULL << lane) - 1ULL))] = h;
+    cnt += __popcll(mk);
+  }
+  return cnt;
+}
+
+__device__ __forceinline__ int sketch_mate(const K1Args& a, const uint8_t* s, int len, const uint64_t* tab, uint64_t* tmp_k, uint64_t* tmp_s,
+                                           uint64_t* out, int cnt, int lane) {
+  if (a.mode == 2) return syncmer_mate(s, len, a.k, (int)a.w_or_s, tab, a.scaled != 0, a.max_hash, tmp_k, tmp_s, out, cnt, lane);
+  if (a.mode == 1) return minimizer_mate(s, len, a.k, (int)a.w_or_s, tab, a.scaled != 0, a.max_hash, tmp_k, out, cnt, lane);
+  return hash_mate(s, len, a.k, tab, a.scaled != 0, a.max_hash, out, cnt, lane);
+}
+
 __global__ void __launch_bounds__(256) k1_kmers(const K1Args a) {
   __shared__ uint64_t tab[256];
   tab[threadIdx.x] = seed_of(threadIdx.x);
@@ -107,9 +198,14 @@ __global__ void __launch_bounds__(256) k1_kmers(const K1Args a) {
     const bool skip = len1 < a.min_qlen && !(pe && len2 >= a.min_qlen);
     int cnt = 0, cnt1 = 0;
     if (!skip) {
-      cnt = hash_mate(a.seqs + o1, len1, a.k, tab, a.scaled != 0, a.max_hash, out, 0, lane);
+      uint64_t* tk = a.scratch ? a.scratch + o1 + o2 : nullptr;   // k-mer hashes of the mate being sketched
+      uint64_t* ts = a.scratch2 ? a.scratch2 + o1 + o2 : nullptr;  // its s-mer hashes (syncmer mode)
+      cnt = sketch_mate(a, a.seqs + o1, len1, tab, tk, ts, out, 0, lane);
       cnt1 = cnt;
-      if (pe) cnt = hash_mate(a.seqs2 + o2, len2, a.k, tab, a.scaled != 0, a.max_hash, out, cnt, lane);
+      if (pe) {
+        __threadfence_block();
+        cnt = sketch_mate(a, a.seqs2 + o2, len2, tab, tk, ts, out, cnt, lane);
+      }
     }
     if (lane == 0) {
       a.nk_raw[r] = cnt;

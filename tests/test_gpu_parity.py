@@ -169,3 +169,48 @@ def test_kmer_kernel_matches_oracle(G, oracle_lib, tmp_path):
             got = h[int(offs[i]):int(offs[i]) + int(nk[i])]
             assert len(want) == nk[i]
             assert np.array_equal(got, want), i
+
+
+def test_syncmer_and_minimizer_databases(G, oracle_lib, tmp_path):
+    """Closed-Syncmer (k=21 s=11: BASELINE config 4 shape) and Minimizer (w=10) databases: short reads (no dedup: the
+    emission multiplicity matters) and 5-kb reads (sort+unique, 16-plane counters)."""
+    O = oracle_lib
+    genomes = synth.random_genomes(12, 40000, seed=30)
+    for name, kw in (("syn", dict(syncmer_s=11)), ("min", dict(minimizer_w=10)), ("synscaled", dict(syncmer_s=9, scale=4))):
+        db_dir = synth.make_db(tmp_path / name, genomes, k=21, n_chunks=2, overlap=150, threads=2, **kw)
+        short = synth.sample_reads(genomes, 300, 150, sub_rate=0.01, seed=31, frac_random=0.1, n_rate=0.003)
+        short += [genomes[0][:29], genomes[0][:30], genomes[0][:31], genomes[0][:40], b""]
+        long_ = synth.sample_reads(genomes, 40, 5000, sub_rate=0.005, seed=32, frac_random=0.1)
+        for reads in (short, long_):
+            n, _ = _run(G, O, db_dir, reads)
+            assert n > 20
+
+
+def test_sketch_kernels_match_oracle_in_order(G, oracle_lib, tmp_path):
+    """K1 in syncmer / minimizer mode emits exactly the oracle's list (values, order, multiplicity)."""
+    import torch
+    O = oracle_lib
+    genomes = synth.random_genomes(3, 4000, seed=33)
+    for kw in (dict(syncmer_s=11), dict(syncmer_s=21), dict(syncmer_s=1), dict(minimizer_w=1), dict(minimizer_w=7), dict(minimizer_w=50)):
+        d = tmp_path / ("k" + "_".join(f"{a}{b}" for a, b in kw.items()))
+        db_dir = synth.make_db(d, genomes, k=21, threads=2, **kw)
+        reads = synth.sample_reads(genomes, 60, 150, seed=34, n_rate=0.02) + [genomes[0][:1500], genomes[1][:69], genomes[1][:70], genomes[1][:71], b"ACGT"]
+        seqs, offs = G["lib"].pack_reads(reads)
+        with G["Database"].open(db_dir, device=0) as db:
+            dev = torch.device("cuda:0")
+            t_seqs = torch.from_numpy(seqs).to(dev)
+            t_offs = torch.from_numpy(offs.view(np.int64)).to(dev)
+            t_h = torch.zeros(len(seqs) + 8, dtype=torch.int64, device=dev)
+            t_nk = torch.zeros(len(reads), dtype=torch.int32, device=dev)
+            p = G["default_params"](min_qlen=0, min_matched=1, dedup_threshold=1 << 30)
+            db.kmers_device(t_seqs.data_ptr(), t_offs.data_ptr(), len(reads), len(seqs), max(len(r) for r in reads),
+                            t_h.data_ptr(), t_h.numel(), None, t_nk.data_ptr(), params=p)
+            torch.cuda.synchronize()
+            h = t_h.cpu().numpy().view(np.uint64)
+            nk = t_nk.cpu().numpy()
+        cfg = O.sketch_cfg(k=21, **kw)
+        for i, r in enumerate(reads):
+            want = O.generate_kmers(r, cfg)
+            got = h[int(offs[i]):int(offs[i]) + int(nk[i])]
+            assert len(want) == nk[i], (kw, i, len(want), nk[i])
+            assert np.array_equal(got, want), (kw, i)
