@@ -1,0 +1,680 @@
+// kmcp-search — `kmcp search` on MI355X: same flags, same 15-column TSV, same trailer (kmcp/cmd/search.go),
+// with the per-query work done by libkmcpgpu.so (include/kmcp_gpu.h) instead of the Go search engine.
+//
+// Mirrors: flags search.go:1031-1107 + root.go:62-82; input handling :793-1000 (single-end, -1/-2 paired-end,
+// -g whole file incl. the k-1 N's appended after records 2..m, :899-914); output :436-438 (header), :448-588
+// (rows), :1022-1025 (trailer); fatal errors as checkError (util-cli.go:35-40: message + exit status 255).
+// Three threads: reader (FASTA/Q, gz via zlib) -> GPU batches -> ordered writer.
+#include <errno.h>
+#include <math.h>
+#include <stdarg.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <zlib.h>
+
+#include <algorithm>
+#include <chrono>
+#include <condition_variable>
+#include <deque>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <unordered_map>
+#include <vector>
+
+#include <dirent.h>
+#include <sys/stat.h>
+
+#include "../include/kmcp_gpu.h"
+
+static const char* VERSION = "0.9.5-mi355x";
+static bool g_quiet = false;
+static FILE* g_log = nullptr;
+
+static void logf(const char* level, const char* fmt, va_list ap) {
+  char buf[2048];
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  time_t t = time(nullptr);
+  struct tm tmv;
+  localtime_r(&t, &tmv);
+  char ts[32];
+  strftime(ts, sizeof ts, "%H:%M:%S.000", &tmv);
+  fprintf(stderr, "%s [%s] %s\n", ts, level, buf);
+  if (g_log) fprintf(g_log, "%s [%s] %s\n", ts, level, buf);
+}
+static void info(const char* fmt, ...) {
+  if (g_quiet && !g_log) return;
+  va_list ap;
+  va_start(ap, fmt);
+  logf("INFO", fmt, ap);
+  va_end(ap);
+}
+static void warn(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  logf("WARN", fmt, ap);
+  va_end(ap);
+}
+[[noreturn]] static void die(const char* fmt, ...) {  // checkError: log + os.Exit(-1)
+  va_list ap;
+  va_start(ap, fmt);
+  logf("ERRO", fmt, ap);
+  va_end(ap);
+  exit(255);
+}
+
+// ------------------------------------------------------------------------------------------------
+// options
+// ------------------------------------------------------------------------------------------------
+struct Options {
+  std::string db_dir, out_file = "-", read1, read2, query_id, sort_by = "qcov", infile_list, log_file;
+  std::vector<std::string> name_maps, files;
+  int min_qlen = 30, min_kmers = 10, dedup = 256, top_scores = 0, threads = 0, device = 0, batch = 131072;
+  double min_qcov = 0.55, min_tcov = 0, max_fpr = 0.01;
+  bool load_whole = false, low_mem = false, whole_file = false, use_filename = false, keep_unmatched = false, no_header = false,
+       do_not_sort = false, default_name_map = false, try_se = false, quiet = false;
+};
+
+static void usage() {
+  fputs(
+      "kmcp-search: search sequences against a kmcp database on an AMD MI355X GPU\n\n"
+      "Usage:\n  kmcp-search [-w] -d <kmcp db> [-t <min-query-cov>] [read1.fq.gz] [read2.fq.gz] [unpaired.fq.gz] [-o read.tsv.gz]\n\n"
+      "Flags (identical to `kmcp search`, kmcp/cmd/search.go:1031-1107):\n"
+      "  -d, --db-dir string            database directory created by \"kmcp index\"\n"
+      "  -1, --read1 / -2, --read2      paired-end files;   --try-se   retry unmatched pairs with read1, then read2\n"
+      "  -o, --out-file string          out file, \".gz\" supported (default \"-\")\n"
+      "  -t, --min-query-cov float      (default 0.55)      -T, --min-target-cov float (default 0)\n"
+      "  -c, --min-kmers int            (default 10)        -m, --min-query-len int    (default 30)\n"
+      "  -f, --max-fpr float            (default 0.01)      -u, --kmer-dedup-threshold int (default 256)\n"
+      "  -s, --sort-by qcov|tcov|jacc   -S, --do-not-sort   -n, --keep-top-scores int  -K, --keep-unmatched  -H, --no-header-row\n"
+      "  -g, --query-whole-file         -G, --use-filename  --query-id string\n"
+      "  -N, --name-map file(s)         -D, --default-name-map\n"
+      "  -w, --load-whole-db / --low-mem  accepted for compatibility (the index is always resident in HBM)\n"
+      "  -j, --threads int  -i, --infile-list file  -q, --quiet  --log file\n"
+      "GPU flags: --gpu int (device, default 0)  --gpu-batch int (queries per GPU call, default 131072)\n",
+      stderr);
+}
+
+static double to_f(const std::string& flag, const std::string& v) {
+  char* e = nullptr;
+  double d = strtod(v.c_str(), &e);
+  if (!e || *e || v.empty()) die("invalid argument \"%s\" for \"%s\" flag", v.c_str(), flag.c_str());
+  return d;
+}
+static int to_i(const std::string& flag, const std::string& v) {
+  char* e = nullptr;
+  long d = strtol(v.c_str(), &e, 10);
+  if (!e || *e || v.empty()) die("invalid argument \"%s\" for \"%s\" flag", v.c_str(), flag.c_str());
+  return (int)d;
+}
+
+static Options parse_args(int argc, char** argv) {
+  Options o;
+  struct Spec { const char* lng; char sht; int kind; };  // kind 0 bool, 1 value
+  static const Spec specs[] = {
+      {"db-dir", 'd', 1}, {"out-file", 'o', 1}, {"read1", '1', 1}, {"read2", '2', 1}, {"try-se", 0, 0}, {"load-whole-db", 'w', 0},
+      {"low-mem", 0, 0}, {"kmer-dedup-threshold", 'u', 1}, {"query-whole-file", 'g', 0}, {"use-filename", 'G', 0}, {"query-id", 0, 1},
+      {"min-kmers", 'c', 1}, {"min-query-len", 'm', 1}, {"min-query-cov", 't', 1}, {"min-target-cov", 'T', 1}, {"max-fpr", 'f', 1},
+      {"name-map", 'N', 1}, {"default-name-map", 'D', 0}, {"keep-unmatched", 'K', 0}, {"keep-top-scores", 'n', 1}, {"no-header-row", 'H', 0},
+      {"sort-by", 's', 1}, {"do-not-sort", 'S', 0}, {"threads", 'j', 1}, {"quiet", 'q', 0}, {"infile-list", 'i', 1}, {"log", 0, 1},
+      {"gpu", 0, 1}, {"gpu-batch", 0, 1}, {"help", 'h', 0}, {"version", 'V', 0}};
+  auto apply = [&](const std::string& name, const std::string& v) {
+    if (name == "db-dir") o.db_dir = v;
+    else if (name == "out-file") o.out_file = v;
+    else if (name == "read1") o.read1 = v;
+    else if (name == "read2") o.read2 = v;
+    else if (name == "try-se") o.try_se = true;
+    else if (name == "load-whole-db") o.load_whole = true;
+    else if (name == "low-mem") o.low_mem = true;
+    else if (name == "kmer-dedup-threshold") o.dedup = to_i(name, v);
+    else if (name == "query-whole-file") o.whole_file = true;
+    else if (name == "use-filename") o.use_filename = true;
+    else if (name == "query-id") o.query_id = v;
+    else if (name == "min-kmers") o.min_kmers = to_i(name, v);
+    else if (name == "min-query-len") o.min_qlen = to_i(name, v);
+    else if (name == "min-query-cov") o.min_qcov = to_f(name, v);
+    else if (name == "min-target-cov") o.min_tcov = to_f(name, v);
+    else if (name == "max-fpr") o.max_fpr = to_f(name, v);
+    else if (name == "name-map") {
+      size_t b = 0;  // StringSlice: comma separated and repeatable
+      while (b <= v.size()) {
+        size_t e = v.find(',', b);
+        if (e == std::string::npos) e = v.size();
+        if (e > b) o.name_maps.push_back(v.substr(b, e - b));
+        b = e + 1;
+      }
+    } else if (name == "default-name-map") o.default_name_map = true;
+    else if (name == "keep-unmatched") o.keep_unmatched = true;
+    else if (name == "keep-top-scores") o.top_scores = to_i(name, v);
+    else if (name == "no-header-row") o.no_header = true;
+    else if (name == "sort-by") o.sort_by = v;
+    else if (name == "do-not-sort") o.do_not_sort = true;
+    else if (name == "threads") o.threads = to_i(name, v);
+    else if (name == "quiet") o.quiet = true;
+    else if (name == "infile-list") o.infile_list = v;
+    else if (name == "log") o.log_file = v;
+    else if (name == "gpu") o.device = to_i(name, v);
+    else if (name == "gpu-batch") o.batch = to_i(name, v);
+    else if (name == "help") { usage(); exit(0); }
+    else if (name == "version") { printf("kmcp-search v%s\n", VERSION); exit(0); }
+  };
+  bool only_pos = false;
+  for (int i = 1; i < argc; i++) {
+    std::string a = argv[i];
+    if (only_pos || a == "-" || a.empty() || a[0] != '-') { o.files.push_back(a); continue; }
+    if (a == "--") { only_pos = true; continue; }
+    if (a[1] == '-') {
+      std::string name = a.substr(2), val;
+      bool has = false;
+      size_t eq = name.find('=');
+      if (eq != std::string::npos) { val = name.substr(eq + 1); name = name.substr(0, eq); has = true; }
+      const Spec* sp = nullptr;
+      for (const auto& s : specs) if (name == s.lng) sp = &s;
+      if (!sp) die("unknown flag: --%s", name.c_str());
+      if (sp->kind == 1 && !has) {
+        if (i + 1 >= argc) die("flag needs an argument: --%s", name.c_str());
+        val = argv[++i];
+      }
+      apply(sp->lng, val);
+    } else {
+      for (size_t p = 1; p < a.size(); p++) {
+        const Spec* sp = nullptr;
+        for (const auto& s : specs) if (s.sht && a[p] == s.sht) sp = &s;
+        if (!sp) die("unknown shorthand flag: '%c' in %s", a[p], a.c_str());
+        if (sp->kind == 0) { apply(sp->lng, ""); continue; }
+        std::string val = a.substr(p + 1);
+        if (!val.empty() && val[0] == '=') val = val.substr(1);
+        if (val.empty()) {
+          if (i + 1 >= argc) die("flag needs an argument: '%c' in %s", a[p], a.c_str());
+          val = argv[++i];
+        }
+        apply(sp->lng, val);
+        break;
+      }
+    }
+  }
+  return o;
+}
+
+// ------------------------------------------------------------------------------------------------
+// FASTA/Q reader (what bio/seqio/fastx delivers to search.go: ID = header up to the first blank, sequence
+// with line breaks removed; gzip transparently)
+// ------------------------------------------------------------------------------------------------
+class FastxReader {
+ public:
+  explicit FastxReader(const std::string& path) {
+    gz_ = (path == "-") ? gzdopen(0, "rb") : gzopen(path.c_str(), "rb");
+    if (!gz_) die("%s: %s", path.c_str(), strerror(errno));
+    gzbuffer(gz_, 1 << 20);
+  }
+  ~FastxReader() { if (gz_) gzclose(gz_); }
+  // returns false at EOF
+  bool next(std::string* id, std::string* seq) {
+    id->clear();
+    seq->clear();
+    std::string line;
+    if (!have_hdr_) {
+      while (getline(&line)) {
+        if (line.empty()) continue;
+        if (line[0] == '>' || line[0] == '@') { hdr_ = line; have_hdr_ = true; break; }
+      }
+      if (!have_hdr_) return false;
+    }
+    const bool fastq = hdr_[0] == '@';
+    size_t e = 1;
+    while (e < hdr_.size() && hdr_[e] != ' ' && hdr_[e] != '\t') e++;
+    *id = hdr_.substr(1, e - 1);
+    have_hdr_ = false;
+    if (!fastq) {
+      while (getline(&line)) {
+        if (!line.empty() && line[0] == '>') { hdr_ = line; have_hdr_ = true; break; }
+        seq->append(line);
+      }
+      return true;
+    }
+    // FASTQ: sequence lines up to '+', then as many quality characters as bases
+    while (getline(&line)) {
+      if (!line.empty() && line[0] == '+') break;
+      seq->append(line);
+    }
+    size_t q = 0;
+    while (q < seq->size() && getline(&line)) q += line.size();
+    return true;
+  }
+
+ private:
+  bool getline(std::string* out) {
+    out->clear();
+    char buf[1 << 16];
+    bool any = false;
+    while (gzgets(gz_, buf, sizeof buf)) {
+      any = true;
+      size_t n = strlen(buf);
+      bool eol = n && buf[n - 1] == '\n';
+      while (n && (buf[n - 1] == '\n' || buf[n - 1] == '\r')) n--;
+      out->append(buf, n);
+      if (eol) break;
+    }
+    return any;
+  }
+  gzFile gz_ = nullptr;
+  std::string hdr_;
+  bool have_hdr_ = false;
+};
+
+// ------------------------------------------------------------------------------------------------
+// pipeline
+// ------------------------------------------------------------------------------------------------
+struct Batch {
+  uint64_t first_idx = 0;
+  std::vector<std::string> ids;
+  std::vector<uint8_t> seqs, seqs2;
+  std::vector<uint64_t> offs{0}, offs2{0};
+  kmcpg_result res{};
+  bool paired = false;
+  size_t size() const { return ids.size(); }
+};
+
+template <typename T>
+class Queue {
+ public:
+  explicit Queue(size_t cap) : cap_(cap) {}
+  void push(T v) {
+    std::unique_lock<std::mutex> l(m_);
+    cv_.wait(l, [&] { return q_.size() < cap_; });
+    q_.push_back(std::move(v));
+    cv_.notify_all();
+  }
+  bool pop(T* v) {
+    std::unique_lock<std::mutex> l(m_);
+    cv_.wait(l, [&] { return !q_.empty() || closed_; });
+    if (q_.empty()) return false;
+    *v = std::move(q_.front());
+    q_.pop_front();
+    cv_.notify_all();
+    return true;
+  }
+  void close() {
+    std::lock_guard<std::mutex> l(m_);
+    closed_ = true;
+    cv_.notify_all();
+  }
+
+ private:
+  std::mutex m_;
+  std::condition_variable cv_;
+  std::deque<T> q_;
+  size_t cap_;
+  bool closed_ = false;
+};
+
+class Out {
+ public:
+  explicit Out(const std::string& path) {
+    gz_ = path.size() > 3 && path.compare(path.size() - 3, 3, ".gz") == 0;
+    if (gz_) {
+      g_ = gzopen(path.c_str(), "wb");
+      if (!g_) die("%s: %s", path.c_str(), strerror(errno));
+      gzbuffer(g_, 1 << 20);
+    } else {
+      f_ = path == "-" ? stdout : fopen(path.c_str(), "wb");
+      if (!f_) die("%s: %s", path.c_str(), strerror(errno));
+    }
+  }
+  void write(const std::string& s) {
+    if (s.empty()) return;
+    if (gz_) gzwrite(g_, s.data(), (unsigned)s.size());
+    else fwrite(s.data(), 1, s.size(), f_);
+  }
+  void close() {
+    if (gz_) gzclose(g_);
+    else if (f_ != stdout) fclose(f_);
+    else fflush(f_);
+  }
+
+ private:
+  bool gz_ = false;
+  gzFile g_ = nullptr;
+  FILE* f_ = nullptr;
+};
+
+static std::unordered_map<std::string, std::string> read_kvs(const std::string& file) {  // cliutil.ReadKVs
+  std::unordered_map<std::string, std::string> m;
+  gzFile g = gzopen(file.c_str(), "rb");
+  if (!g) die("%s: %s", file.c_str(), strerror(errno));
+  char buf[1 << 16];
+  while (gzgets(g, buf, sizeof buf)) {
+    size_t n = strlen(buf);
+    while (n && (buf[n - 1] == '\n' || buf[n - 1] == '\r')) buf[--n] = 0;
+    if (!n || buf[0] == '#') continue;
+    char* tab = strchr(buf, '\t');
+    if (!tab) continue;
+    *tab = 0;
+    m[buf] = tab + 1;
+  }
+  gzclose(g);
+  return m;
+}
+
+static std::string trim_ext(const std::string& path) {  // filepathTrimExtension: basename without (.gz/.xz/..)+ext
+  size_t s = path.find_last_of('/');
+  std::string b = s == std::string::npos ? path : path.substr(s + 1);
+  for (const char* z : {".gz", ".xz", ".zst", ".bz2"}) {
+    size_t l = strlen(z);
+    if (b.size() > l && b.compare(b.size() - l, l, z) == 0) { b.resize(b.size() - l); break; }
+  }
+  size_t d = b.find_last_of('.');
+  if (d != std::string::npos && d > 0) b.resize(d);
+  return b;
+}
+
+int main(int argc, char** argv) {
+  Options o = parse_args(argc, argv);
+  g_quiet = o.quiet;
+  if (!o.log_file.empty()) {
+    g_log = fopen(o.log_file.c_str(), "w");
+    if (!g_log) die("%s: %s", o.log_file.c_str(), strerror(errno));
+  }
+  const bool verbose = !o.quiet;
+  const auto t_start = std::chrono::steady_clock::now();
+  if (o.db_dir.empty()) die("flag -d/--db-dir needed");
+  if (o.min_kmers < 1) die("value of flag --min-kmers should be positive: %d", o.min_kmers);
+  if (o.dedup < 1) die("value of flag --kmer-dedup-threshold should be positive: %d", o.dedup);
+  if (!(o.max_fpr > 0)) die("value of flag --max-fpr should be positive: %f", o.max_fpr);
+  if (o.min_qlen < 0 || o.top_scores < 0) die("value of flag --min-query-len/--keep-top-scores should not be negative");
+  if (o.do_not_sort && o.top_scores > 0) warn("flag -n/--keep-top-scores ignored when -S/--do-not-sort given");
+  int sort_by = 0;
+  if (o.sort_by == "qcov") sort_by = 0;
+  else if (o.sort_by == "tcov") sort_by = 1;
+  else if (o.sort_by == "jacc") sort_by = 2;
+  else die("invalid value for flag -s/--sort-by: %s. Available: qcov/tsov/jacc", o.sort_by.c_str());
+  if (o.min_qcov < 0 || o.min_qcov > 1) die("value of -t/--min-query-cov should be in range [0, 1]");
+  if (o.min_tcov < 0 || o.min_tcov > 1) die("value of -T/-target-cov should be in range [0, 1]");
+  if (verbose) {
+    info("kmcp-search v%s (MI355X build of the kmcp search hot path)", VERSION);
+    info("  https://github.com/shenwei356/kmcp");
+    info("");
+    info("checking input files ...");
+  }
+
+  // ---- input files (search.go:219-290)
+  bool paired = false;
+  std::vector<std::string> files;
+  if (o.read1.empty()) {
+    if (!o.read2.empty()) { warn("only flag -2/--read2 given, it's treated as single-end"); files.push_back(o.read2); }
+  } else if (o.read2.empty()) {
+    warn("only flag -1/--read1 given, it's treated as single-end");
+    files.push_back(o.read1);
+  } else {
+    paired = true;
+    if (verbose) { info("paired end files given: %s, %s", o.read1.c_str(), o.read2.c_str()); info("other input files via positional arguments are ignored"); }
+  }
+  if (o.try_se && !paired) { warn("flag --try-se ignored for single-end input(s)"); o.try_se = false; }
+  if (!paired) {
+    std::vector<std::string> f1 = o.files;
+    if (!o.infile_list.empty()) {
+      gzFile g = gzopen(o.infile_list.c_str(), "rb");
+      if (!g) die("%s: %s", o.infile_list.c_str(), strerror(errno));
+      char buf[1 << 14];
+      while (gzgets(g, buf, sizeof buf)) {
+        size_t n = strlen(buf);
+        while (n && (buf[n - 1] == '\n' || buf[n - 1] == '\r')) buf[--n] = 0;
+        if (n) f1.push_back(buf);
+      }
+      gzclose(g);
+    }
+    if (f1.empty() && files.empty()) f1.push_back("-");
+    for (const auto& f : f1) {
+      if ((!o.read1.empty() || !o.read2.empty()) && f == "-") continue;
+      files.push_back(f);
+    }
+    for (const auto& f : files) {
+      struct stat st;
+      if (f != "-" && stat(f.c_str(), &st) != 0) die("%s: %s", f.c_str(), strerror(errno));
+      if (f != "-" && f == o.out_file) die("out file should not be one of the input file");
+    }
+    if (verbose) {
+      if (files.size() == 1 && files[0] == "-") info("  no files given, reading from stdin");
+      else info("  %zu input file(s) given", files.size());
+    }
+  }
+
+  // ---- database: sub-directories holding __db.yml (search.go:299-324)
+  if (verbose) info("checking the database: %s", o.db_dir.c_str());
+  std::vector<std::string> db_dirs;
+  {
+    DIR* d = opendir(o.db_dir.c_str());
+    if (!d) die("read database error: open %s: %s", o.db_dir.c_str(), strerror(errno));
+    std::vector<std::string> subs;
+    while (struct dirent* e = readdir(d)) {
+      std::string n = e->d_name;
+      if (n == "." || n == "..") continue;
+      subs.push_back(n);
+    }
+    closedir(d);
+    std::sort(subs.begin(), subs.end());
+    for (const auto& n : subs) {
+      struct stat st;
+      std::string p = o.db_dir + "/" + n;
+      if (stat(p.c_str(), &st) != 0 || !S_ISDIR(st.st_mode)) continue;
+      if (stat((p + "/__db.yml").c_str(), &st) == 0) db_dirs.push_back(p);
+    }
+  }
+  if (db_dirs.empty()) die("invalid kmcp database: %s", o.db_dir.c_str());
+  if (db_dirs.size() > 1) die("databases with several repeats (R001, R002, ...) are not supported: `kmcp index` only writes R001");
+
+  std::unordered_map<std::string, std::string> name_map;
+  const bool mapping = !o.name_maps.empty();
+  if (mapping) {
+    if (verbose) info("loading name mapping file ...");
+    for (const auto& f : o.name_maps)
+      for (auto& kv : read_kvs(f)) name_map[kv.first] = kv.second;
+    if (verbose) info("  %zu pairs of name mapping values from %zu file(s) loaded", name_map.size(), o.name_maps.size());
+  }
+  std::unordered_map<std::string, std::string> default_map;
+  if (o.default_name_map) {
+    struct stat st;
+    std::string f = db_dirs[0] + "/__name_mapping.tsv";
+    if (stat(f.c_str(), &st) == 0) default_map = read_kvs(f);
+  }
+
+  if (verbose) info("loading database into GPU memory ...");
+  kmcpg_db* db = nullptr;
+  kmcpg_opts gopts{o.device, 0, 1, 0};
+  if (kmcpg_open(db_dirs[0].c_str(), &gopts, &db) != 0) die("open kmcp db: %s: %s", db_dirs[0].c_str(), kmcpg_last_error());
+  kmcpg_info dbi;
+  kmcpg_db_info(db, &dbi);
+  if (o.min_qcov <= dbi.fpr)  // search.go:405-409
+    die("query coverage threshold (%f) should not be smaller than FPR of single bloom filter of index database (%f)", o.min_qcov, dbi.fpr);
+  if (verbose) {
+    info("database loaded: %s", o.db_dir.c_str());
+    info("");
+    info("-------------------- [main parameters] --------------------");
+    info("  minimum    query length: %d", o.min_qlen);
+    info("  minimum  matched k-mers: %d", o.min_kmers);
+    info("  minimum  query coverage: %f", o.min_qcov);
+    info("  minimum target coverage: %f", o.min_tcov);
+    info("-------------------- [main parameters] --------------------");
+    info("");
+    info("searching ...");
+  }
+  // target names after mapping (util-db-search.go:317-332), resolved once per column
+  std::vector<std::string> target(dbi.n_cols);
+  for (uint32_t c = 0; c < dbi.n_cols; c++) {
+    const char* nm = nullptr;
+    kmcpg_col_info(db, c, &nm, nullptr, nullptr, nullptr);
+    target[c] = nm;
+    if (mapping || o.default_name_map) {
+      auto it = name_map.find(target[c]);
+      if (it != name_map.end()) target[c] = it->second;
+      else if (o.default_name_map) {
+        auto it2 = default_map.find(target[c]);
+        if (it2 != default_map.end()) target[c] = it2->second;
+      }
+    }
+  }
+
+  kmcpg_params params{};
+  params.min_qlen = o.min_qlen;
+  params.min_matched = o.min_kmers;
+  params.min_qcov = o.min_qcov;
+  params.min_tcov = o.min_tcov;
+  params.max_fpr = o.max_fpr;
+  params.dedup_threshold = o.dedup;
+  params.try_se = o.try_se;
+  params.sort_by = sort_by;
+  params.do_not_sort = o.do_not_sort;
+  params.top_n_scores = o.top_scores;
+  params.fpr_buf_size = paired ? 499 : 249;
+
+  const auto t_search = std::chrono::steady_clock::now();
+  Out out(o.out_file);
+  if (!o.no_header) out.write("#query\tqLen\tqKmers\tFPR\thits\ttarget\tchunkIdx\tchunks\ttLen\tkSize\tmKmers\tqCov\ttCov\tjacc\tqueryIdx\n");
+
+  Queue<std::unique_ptr<Batch>> q_in(3), q_out(3);
+  uint64_t total = 0, matched = 0;
+  const size_t max_bases = 64u << 20;  // a batch also closes at 64 Mbases (long queries)
+
+  std::thread reader([&] {
+    uint64_t id = 0;
+    std::unique_ptr<Batch> b(new Batch());
+    b->paired = paired;
+    auto flush = [&] {
+      if (b->size() == 0) return;
+      q_in.push(std::move(b));
+      b.reset(new Batch());
+      b->paired = paired;
+      b->first_idx = id;
+    };
+    auto add = [&](const std::string& qid, const std::string& s1, const std::string* s2) {
+      b->ids.push_back(qid);
+      b->seqs.insert(b->seqs.end(), s1.begin(), s1.end());
+      b->offs.push_back(b->seqs.size());
+      if (s2) {
+        b->seqs2.insert(b->seqs2.end(), s2->begin(), s2->end());
+        b->offs2.push_back(b->seqs2.size());
+      }
+      id++;
+      if (b->size() >= (size_t)o.batch || b->seqs.size() + b->seqs2.size() >= max_bases) flush();
+    };
+    std::string id1, s1, id2, s2;
+    if (paired) {
+      if (verbose) info("reading from paired-end files: %s, %s", o.read1.c_str(), o.read2.c_str());
+      FastxReader r1(o.read1), r2(o.read2);
+      while (r1.next(&id1, &s1) && r2.next(&id2, &s2)) add(id1, s1, &s2);
+      if (id == 0) warn("no valid sequences in files: %s, %s", o.read1.c_str(), o.read2.c_str());
+    } else {
+      const std::string nnn((size_t)std::max(0, dbi.k - 1), 'N');
+      for (const auto& file : files) {
+        if (verbose) info("reading sequence file: %s", file.c_str());
+        FastxReader r(file);
+        if (o.whole_file) {  // search.go:885-935
+          std::string qid, whole;
+          bool first = true;
+          while (r.next(&id1, &s1)) {
+            if (first) {
+              qid = o.use_filename ? trim_ext(file) : (!o.query_id.empty() ? o.query_id : id1);
+              whole = s1;
+              first = false;
+            } else {
+              whole += s1;
+              whole += nnn;
+            }
+          }
+          if (first) { warn("no valid sequences in file: %s", file.c_str()); continue; }
+          add(qid, whole, nullptr);
+          continue;
+        }
+        const uint64_t id0 = id;
+        while (r.next(&id1, &s1)) add(id1, s1, nullptr);
+        if (id0 == id) warn("no valid sequences in file: %s", file.c_str());
+      }
+    }
+    flush();
+    q_in.close();
+  });
+
+  std::thread searcher([&] {
+    std::unique_ptr<Batch> b;
+    while (q_in.pop(&b)) {
+      int rc = kmcpg_search_batch(db, b->seqs.data(), b->offs.data(), b->paired ? b->seqs2.data() : nullptr, b->paired ? b->offs2.data() : nullptr,
+                                  (uint32_t)b->size(), &params, &b->res);
+      if (rc != 0) die("%s", kmcpg_last_error());
+      q_out.push(std::move(b));
+    }
+    q_out.close();
+  });
+
+  // writer: rows exactly as search.go:517-575 / :458-512
+  {
+    std::unique_ptr<Batch> b;
+    std::string buf;
+    char line[4096];
+    while (q_out.pop(&b)) {
+      buf.clear();
+      const kmcpg_result& r = b->res;
+      for (uint32_t i = 0; i < r.n_reads; i++) {
+        total++;
+        const uint64_t qidx = b->first_idx + i;
+        const uint64_t m0 = r.match_offs[i], m1 = r.match_offs[i + 1];
+        if (m0 == m1) {
+          if (o.keep_unmatched) {
+            int n = snprintf(line, sizeof line, "\t%d\t%d\t0\t0\t\t-1\t0\t0\t%d\t0\t0\t0\t0\t%llu\n", r.qlen[i], r.qkmers[i], r.k, (unsigned long long)qidx);
+            buf += b->ids[i];
+            buf.append(line, (size_t)n);
+          }
+          continue;
+        }
+        matched++;
+        for (uint64_t j = m0; j < m1; j++) {
+          const kmcpg_match& m = r.matches[j];
+          int n = snprintf(line, sizeof line, "\t%d\t%d\t%.4e\t%llu\t", r.qlen[i], r.qkmers[i], m.fpr, (unsigned long long)(m1 - m0));
+          buf += b->ids[i];
+          buf.append(line, (size_t)n);
+          buf += target[m.col];
+          n = snprintf(line, sizeof line, "\t%d\t%d\t%llu\t%d\t%d\t%.4f\t%.4f\t%.4f\t%llu\n", (int)(uint16_t)m.target_idx, (int)(m.target_idx >> 16),
+                       (unsigned long long)m.gsize, r.k, m.mkmers, m.qcov, m.tcov, m.jacc, (unsigned long long)qidx);
+          buf.append(line, (size_t)n);
+        }
+      }
+      out.write(buf);
+      kmcpg_result_free(&b->res);
+      if (verbose && !o.quiet) {
+        double min = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_search).count() / 60.0;
+        fprintf(stderr, "processed queries: %llu, speed: %.3f million queries per minute\r", (unsigned long long)total, total / 1e6 / min);
+      }
+    }
+  }
+  reader.join();
+  searcher.join();
+
+  if (verbose) {
+    fprintf(stderr, "\n");
+    double min = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_search).count() / 60.0;
+    info("");
+    info("processed queries: %llu, speed: %.3f million queries per minute", (unsigned long long)total, total / 1e6 / min);
+    info("%.4f%% (%llu/%llu) queries matched", total ? (double)matched / (double)total * 100 : NAN, (unsigned long long)matched, (unsigned long long)total);
+    info("done searching");
+    if (o.out_file != "-") info("search results saved to: %s", o.out_file.c_str());
+  }
+  // trailer read by `kmcp profile` (profile.go:1945-1951)
+  char tr[256];
+  int n = snprintf(tr, sizeof tr, "# input queries: %llu\n# matched queries: %llu\n", (unsigned long long)total, (unsigned long long)matched);
+  std::string trailer(tr, (size_t)n);
+  if (total) n = snprintf(tr, sizeof tr, "# matched percentage: %.4f%%\n", (double)matched / (double)total * 100);
+  else n = snprintf(tr, sizeof tr, "# matched percentage: NaN%%\n");
+  trailer.append(tr, (size_t)n);
+  out.write(trailer);
+  out.close();
+  if (kmcpg_close(db) != 0) die("%s", kmcpg_last_error());
+  if (verbose) {
+    info("");
+    info("elapsed time: %.3fs", std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count());
+    info("");
+  }
+  if (g_log) fclose(g_log);
+  return 0;
+}

@@ -1,0 +1,155 @@
+"""kmcp-search (C++ host above the C ABI) vs the oracle's TSV lines: the 15 columns of kmcp/cmd/search.go:517-575,
+the header (:436-438) and the 3-line trailer (:1022-1025) that `kmcp profile` parses."""
+import ctypes as C
+import gzip
+import os
+import subprocess
+
+import pytest
+
+from tests import synth
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CLI = os.path.join(ROOT, "kmcp_amd", "kmcp-search")
+HEADER = "#query\tqLen\tqKmers\tFPR\thits\ttarget\tchunkIdx\tchunks\ttLen\tkSize\tmKmers\tqCov\ttCov\tjacc\tqueryIdx"
+
+
+def oracle_tsv(O, odb, ids, reads, reads2=None, params=None, keep_unmatched=False, name_map=None):
+    """What `kmcp search` would print (FPR column kept as float for a tolerant compare)."""
+    L = O.lib()
+    p = params or O.default_params()
+    lines, matched = [], 0
+    buf = C.create_string_buffer(4096)
+    for i, r in enumerate(reads):
+        res = O.Result()
+        r2 = reads2[i] if reads2 is not None else None
+        L.ko_search(odb.h, r, len(r), r2, len(r2) if r2 is not None else 0, C.byref(p), C.byref(res))
+        if res.nmatches < 0:
+            if keep_unmatched:
+                lines.append(f"{ids[i]}\t{res.qlen}\t{res.qkmers}\t0\t0\t\t-1\t0\t0\t{res.k}\t0\t0\t0\t0\t{i}")
+        else:
+            matched += 1
+            for j in range(res.nmatches):
+                L.ko_format_match(buf, 4096, ids[i].encode(), C.byref(res), C.byref(res.matches[j]), i)
+                f = buf.value.decode().rstrip("\n").split("\t")
+                if name_map and f[5] in name_map:
+                    f[5] = name_map[f[5]]
+                lines.append("\t".join(f))
+        L.ko_result_free(C.byref(res))
+    n = len(reads)
+    trailer = [f"# input queries: {n}", f"# matched queries: {matched}", "# matched percentage: %.4f%%" % (matched / n * 100)]
+    return lines, trailer
+
+
+def run_cli(args, out_path):
+    r = subprocess.run([CLI] + args + ["-o", out_path, "-q"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    opener = gzip.open if out_path.endswith(".gz") else open
+    with opener(out_path, "rt") as fh:
+        return fh.read().split("\n")
+
+
+def compare(got_lines, want_rows, want_trailer, header=True):
+    assert got_lines[-1] == ""
+    got = got_lines[:-1]
+    if header:
+        assert got[0] == HEADER
+        got = got[1:]
+    assert got[-3:] == want_trailer
+    rows = got[:-3]
+    assert len(rows) == len(want_rows)
+    for g, w in zip(rows, want_rows):
+        gf, wf = g.split("\t"), w.split("\t")
+        assert gf[:3] == wf[:3] and gf[4:] == wf[4:], (g, w)
+        a, b = float(gf[3]), float(wf[3])
+        assert abs(a - b) <= 1e-12 or abs(a - b) <= 1e-4 * abs(b), (g, w)  # printed with 5 significant digits
+
+
+def write_fastq(path, ids, reads, gz=False):
+    opener = gzip.open if gz else open
+    with opener(path, "wt") as fh:
+        for i, r in zip(ids, reads):
+            fh.write(f"@{i} some description\n{r.decode()}\n+\n{'I' * len(r)}\n")
+
+
+def write_fasta(path, recs, width=70):
+    with open(path, "w") as fh:
+        for name, s in recs:
+            fh.write(f">{name} desc\n")
+            s = s.decode()
+            for i in range(0, len(s), width):
+                fh.write(s[i:i + width] + "\n")
+
+
+def test_cli_single_end_gz_and_flags(oracle_lib, tmp_path):
+    O = oracle_lib
+    genomes = synth.random_genomes(20, 12000, seed=40)
+    db_dir = synth.make_db(tmp_path / "db", genomes, k=21, n_chunks=3, overlap=150, threads=4)
+    db_root = os.path.dirname(db_dir)
+    reads = synth.sample_reads(genomes, 700, 150, sub_rate=0.01, seed=41, frac_random=0.15) + [b"ACGT", genomes[0][:29]]
+    ids = [f"read{i}/1" for i in range(len(reads))]
+    fq = str(tmp_path / "reads.fq.gz")
+    write_fastq(fq, ids, reads, gz=True)
+    odb = O.OracleDB(db_dir)
+    # default flags, gz in, gz out, small GPU batches so that several batches are stitched in order
+    want, trailer = oracle_tsv(O, odb, ids, reads)
+    compare(run_cli(["-d", db_root, fq, "--gpu-batch", "100"], str(tmp_path / "o1.tsv.gz")), want, trailer)
+    # -K keeps unmatched rows; -H drops the header; thresholds + sort by jacc + top score
+    p = O.default_params(min_qcov=0.4, min_matched=5, sort_by=2, top_n_scores=1)
+    want, trailer = oracle_tsv(O, odb, ids, reads, params=p, keep_unmatched=True)
+    compare(run_cli(["-d", db_root, fq, "-K", "-H", "-t", "0.4", "-c", "5", "-s", "jacc", "-n", "1"], str(tmp_path / "o2.tsv")), want, trailer,
+            header=False)
+    # name map
+    nm = {f"g{i:05d}": f"Genome number {i}" for i in range(0, 20, 2)}
+    with open(tmp_path / "name.map", "w") as fh:
+        for k, v in nm.items():
+            fh.write(f"{k}\t{v}\n")
+    want, trailer = oracle_tsv(O, odb, ids, reads, name_map=nm)
+    compare(run_cli(["-d", db_root, fq, "-N", str(tmp_path / "name.map")], str(tmp_path / "o3.tsv")), want, trailer)
+    odb.close()
+
+
+def test_cli_paired_end_and_whole_file(oracle_lib, tmp_path):
+    O = oracle_lib
+    genomes = synth.random_genomes(10, 20000, seed=42)
+    db_dir = synth.make_db(tmp_path / "db", genomes, k=21, n_chunks=2, overlap=150, threads=2)
+    db_root = os.path.dirname(db_dir)
+    odb = O.OracleDB(db_dir)
+    r1 = synth.sample_reads(genomes, 300, 150, seed=43, frac_random=0.0)
+    r2 = synth.sample_reads(genomes, 300, 150, seed=44, frac_random=0.5)
+    ids = [f"pair{i}" for i in range(300)]
+    write_fastq(str(tmp_path / "r1.fq"), ids, r1)
+    write_fastq(str(tmp_path / "r2.fq"), ids, r2)
+    p = O.default_params(try_se=1, fpr_buf_size=499)
+    want, trailer = oracle_tsv(O, odb, ids, r1, r2, params=p)
+    compare(run_cli(["-d", db_root, "-1", str(tmp_path / "r1.fq"), "-2", str(tmp_path / "r2.fq"), "--try-se"], str(tmp_path / "pe.tsv")), want, trailer)
+    # -g: records 2..m are each followed by k-1 N's (search.go:899-914); query id = first record / file name
+    recs = [("ctgA", genomes[0][:3000]), ("ctgB", genomes[0][5000:7000]), ("ctgC", genomes[1][100:900])]
+    fa = str(tmp_path / "asm.fasta")
+    write_fasta(fa, recs)
+    whole = recs[0][1] + recs[1][1] + b"N" * 20 + recs[2][1] + b"N" * 20
+    p = O.default_params(min_qcov=0.35)
+    want, trailer = oracle_tsv(O, odb, ["ctgA"], [whole], params=p)
+    compare(run_cli(["-d", db_root, "-g", "-t", "0.35", fa], str(tmp_path / "g.tsv")), want, trailer)
+    want, trailer = oracle_tsv(O, odb, ["asm"], [whole], params=p)
+    compare(run_cli(["-d", db_root, "-g", "-G", "-t", "0.35", fa], str(tmp_path / "g2.tsv")), want, trailer)
+    odb.close()
+
+
+def test_cli_errors(tmp_path, oracle_lib):
+    O = oracle_lib
+    genomes = synth.random_genomes(3, 3000, seed=45)
+    db_dir = synth.make_db(tmp_path / "db", genomes, k=21, threads=2)
+    db_root = os.path.dirname(db_dir)
+    fq = str(tmp_path / "r.fq")
+    write_fastq(fq, ["a"], [genomes[0][:150]])
+    # search refuses min-query-cov <= db fpr (search.go:405-409); exit status of checkError is 255
+    r = subprocess.run([CLI, "-d", db_root, "-t", "0.3", fq], capture_output=True, text=True)
+    assert r.returncode == 255 and "should not be smaller than FPR" in r.stderr
+    r = subprocess.run([CLI, fq], capture_output=True, text=True)
+    assert r.returncode == 255 and "flag -d/--db-dir needed" in r.stderr
+    r = subprocess.run([CLI, "-d", str(tmp_path), fq], capture_output=True, text=True)
+    assert r.returncode == 255 and "invalid kmcp database" in r.stderr
+    _ = O
