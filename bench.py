@@ -106,6 +106,7 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     from kmcp_amd import Database, default_params, lib
+    from kmcp_amd.dist import gather_hits
 
     wl = dict(WORKLOADS[args.workload])
     B = args.batch_reads or wl["batch_reads"]
@@ -141,9 +142,6 @@ def main():
     d_ql = torch.zeros(B, dtype=torch.int32, device=dev)
     h_hits = torch.empty((cap * world, 3), dtype=torch.int32).pin_memory()
     stream = torch.cuda.current_stream(dev).cuda_stream
-    if world > 1:
-        d_cnt_all = torch.zeros(world, dtype=torch.int64, device=dev)
-        gather_list = [torch.empty_like(d_hits) for _ in range(world)] if rank == 0 else None
 
     def step(i):
         """K1+K2 on this rank's blocks, hit lists to rank 0 (RCCL), hit tuples to host memory. Returns #hits on rank 0."""
@@ -156,16 +154,14 @@ def main():
             h_hits[:n].copy_(d_hits[:n], non_blocking=True)
             torch.cuda.current_stream(dev).synchronize()
             return n
-        dist.all_gather_into_tensor(d_cnt_all, d_cnt[:1])
-        dist.gather(d_hits, gather_list, dst=0)
+        parts = gather_hits(d_hits, d_cnt[:1], dst=0)  # RCCL: all_gather(counts) + gather(hit buffers) over xGMI
         if rank != 0:
             torch.cuda.current_stream(dev).synchronize()
             return 0
-        counts = d_cnt_all.cpu().tolist()
         pos = 0
-        for rk, c in enumerate(counts):
-            assert c <= cap, "hit buffer overflow"
-            h_hits[pos:pos + c].copy_(gather_list[rk][:c], non_blocking=True)
+        for part in parts:
+            c = part.shape[0]
+            h_hits[pos:pos + c].copy_(part, non_blocking=True)
             pos += c
         torch.cuda.current_stream(dev).synchronize()
         return pos

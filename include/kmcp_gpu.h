@@ -35,7 +35,8 @@ typedef struct kmcpg_db kmcpg_db;
 /* How the database is placed on the GPU(s).  One process drives one GPU (one rank); the index's
  * independent .uniki blocks are partitioned over `shard_count` ranks by bytes. */
 typedef struct {
-  int32_t device;      /* HIP device ordinal of this process */
+  int32_t device;      /* HIP device ordinal of this process; -1 = metadata only (headers parsed, nothing resident:
+                          kmcpg_db_info/col_info/block_info/finalize work, every GPU entry point fails) */
   int32_t shard_rank;  /* 0..shard_count-1 */
   int32_t shard_count; /* >=1 */
   int32_t reserved;

@@ -43,6 +43,13 @@ static int fail(int code, const char* fmt, ...) {
     if (e_ != hipSuccess) return fail(KMCPG_EDEVICE, "%s: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
   } while (0)
 
+// GPU work on a handle: refused for metadata-only handles (opts.device == -1)
+#define KMCPG_USE_DEVICE(db)                                                                                      \
+  do {                                                                                                            \
+    if ((db)->opts.device < 0) return fail(KMCPG_EDEVICE, "metadata-only handle (device -1): no GPU work possible"); \
+    HIPCHK(hipSetDevice((db)->opts.device));                                                                      \
+  } while (0)
+
 extern "C" const char* kmcpg_last_error(void) { return g_err.c_str(); }
 
 // ------------------------------------------------------------------------------------------------
@@ -190,11 +197,12 @@ int finish_open(kmcpg_db* db) {
     const uint32_t tiles = (b.stride + tile_bytes - 1) / tile_bytes;
     for (uint32_t t = 0; t < tiles; t++) cls->slots.push_back(Slot{(uint32_t)b.local_idx, t});
   }
-  if (!db->h_blockdev.empty()) {
+  if (db->opts.device >= 0 && !db->h_blockdev.empty()) {
     HIPCHK(hipMalloc((void**)&db->d_blockdev, db->h_blockdev.size() * sizeof(BlockDev)));
     HIPCHK(hipMemcpy(db->d_blockdev, db->h_blockdev.data(), db->h_blockdev.size() * sizeof(BlockDev), hipMemcpyHostToDevice));
   }
   for (auto& c : db->classes) {
+    if (db->opts.device < 0) break;
     HIPCHK(hipMalloc((void**)&c.d_slots, c.slots.size() * sizeof(Slot)));
     HIPCHK(hipMemcpy(c.d_slots, c.slots.data(), c.slots.size() * sizeof(Slot), hipMemcpyHostToDevice));
   }
@@ -244,6 +252,10 @@ int check_opts(const kmcpg_opts* o, kmcpg_opts* out) {
   d.shard_count = 1;
   if (o) d = *o;
   if (d.shard_count < 1 || d.shard_rank < 0 || d.shard_rank >= d.shard_count) return fail(KMCPG_EINVAL, "bad shard_rank/shard_count");
+  if (d.device == -1) {  // metadata only: headers parsed, nothing resident, every GPU entry point refuses
+    *out = d;
+    return 0;
+  }
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
     return fail(KMCPG_EDEVICE, "no HIP device available: libkmcpgpu has no CPU fallback");
@@ -260,7 +272,8 @@ extern "C" int kmcpg_open(const char* db_dir, const kmcpg_opts* opts, kmcpg_db**
   std::unique_ptr<kmcpg_db> db(new kmcpg_db());
   int rc = check_opts(opts, &db->opts);
   if (rc) return rc;
-  HIPCHK(hipSetDevice(db->opts.device));
+  const bool meta_only = db->opts.device < 0;
+  if (!meta_only) HIPCHK(hipSetDevice(db->opts.device));
   const std::string dir(db_dir);
   DbYml y;
   std::string e = read_db_yml(dir + "/__db.yml", &y);
@@ -296,9 +309,11 @@ extern "C" int kmcpg_open(const char* db_dir, const kmcpg_opts* opts, kmcpg_db**
   if (I.num_hashes < 1 || I.num_hashes > 4) return fail(KMCPG_EUNSUPPORTED, "hashes=%d (kmcp index allows 1..4)", I.num_hashes);
   assign_shards(db.get());
   for (auto& b : db->blocks)
-    if (b.local) {
+    if (b.local && !meta_only) {
       rc = upload_block(b);
       if (rc) return rc;
+    } else if (b.local) {
+      b.stride = device_stride(b.h.row_bytes);
     }
   rc = finish_open(db.get());
   if (rc) return rc;
@@ -314,7 +329,7 @@ extern "C" int kmcpg_open_synthetic(const kmcpg_synth_spec* s, const kmcpg_opts*
   std::unique_ptr<kmcpg_db> db(new kmcpg_db());
   int rc = check_opts(opts, &db->opts);
   if (rc) return rc;
-  HIPCHK(hipSetDevice(db->opts.device));
+  KMCPG_USE_DEVICE(db);  // a synthetic index only exists in HBM
   db->synthetic = true;
   kmcpg_info& I = db->info;
   I.k = s->k;
@@ -373,7 +388,7 @@ extern "C" int kmcpg_open_synthetic(const kmcpg_synth_spec* s, const kmcpg_opts*
 
 extern "C" int kmcpg_close(kmcpg_db* db) {
   if (!db) return 0;
-  (void)hipSetDevice(db->opts.device);
+  if (db->opts.device >= 0) (void)hipSetDevice(db->opts.device);
   for (auto& b : db->blocks)
     if (b.d_rows) (void)hipFree(b.d_rows);
   if (db->d_blockdev) (void)hipFree(db->d_blockdev);
@@ -505,7 +520,7 @@ extern "C" int kmcpg_kmers_device(kmcpg_db* db, const uint8_t* d_seqs, const uin
   if (!db || !d_seqs || !d_offs || !d_hashes || !d_nk) return fail(KMCPG_EINVAL, "null argument");
   if (hashes_cap < total_bases) return fail(KMCPG_EINVAL, "hashes_cap must be >= total_bases");
   std::lock_guard<std::mutex> g(db->mu);
-  HIPCHK(hipSetDevice(db->opts.device));
+  KMCPG_USE_DEVICE(db);
   const kmcpg_params p = params ? *params : default_params();
   hipStream_t st = (hipStream_t)stream;
   if (db->w_scratch.ensure(2 * total_bases + 2) || db->w_nk_raw.ensure(n_reads + 1) || db->w_nk1.ensure(n_reads + 1)) return fail(KMCPG_ENOMEM, "hipMalloc failed");
@@ -528,7 +543,7 @@ extern "C" int kmcpg_query_device(kmcpg_db* db, const uint8_t* d_seqs, const uin
   if (!db || !d_seqs || !d_offs || !d_counters || !d_qkmers || !d_qlen || (!d_hits && hit_cap)) return fail(KMCPG_EINVAL, "null argument");
   if ((d_seqs2 == nullptr) != (d_offs2 == nullptr)) return fail(KMCPG_EINVAL, "seqs2 and offs2 must be given together");
   std::lock_guard<std::mutex> g(db->mu);
-  HIPCHK(hipSetDevice(db->opts.device));
+  KMCPG_USE_DEVICE(db);
   const kmcpg_params p = params ? *params : default_params();
   if (p.min_matched < 1) return fail(KMCPG_EINVAL, "min_matched must be >= 1");  // getFlagPositiveInt (search.go:165)
   hipStream_t st = (hipStream_t)stream;
@@ -588,7 +603,7 @@ extern "C" int kmcpg_last_timing(kmcpg_db* db, float* kmers_ms, float* cobs_ms) 
   if (!db) return fail(KMCPG_EINVAL, "null argument");
   std::lock_guard<std::mutex> g(db->mu);
   if (!db->profiling || !db->ev_valid) return fail(KMCPG_EINVAL, "no profiled kmcpg_query_device call yet");
-  HIPCHK(hipSetDevice(db->opts.device));
+  KMCPG_USE_DEVICE(db);
   HIPCHK(hipEventSynchronize(db->ev[2]));
   float a = 0, b = 0;
   HIPCHK(hipEventElapsedTime(&a, db->ev[0], db->ev[1]));
@@ -602,7 +617,7 @@ extern "C" int kmcpg_plant_reads_device(kmcpg_db* db, const uint8_t* d_seqs, con
                                         uint32_t max_read_len, const uint32_t* d_cols, void* stream) {
   if (!db || !d_seqs || !d_offs || !d_cols) return fail(KMCPG_EINVAL, "null argument");
   std::lock_guard<std::mutex> g(db->mu);
-  HIPCHK(hipSetDevice(db->opts.device));
+  KMCPG_USE_DEVICE(db);
   hipStream_t st = (hipStream_t)stream;
   if (db->w_hashes.ensure(total_bases + 1) || db->w_nk_raw.ensure(n_reads + 1) || db->w_nk1.ensure(n_reads + 1)) return fail(KMCPG_ENOMEM, "hipMalloc failed");
   DevBuf<int32_t> tmp;
@@ -769,7 +784,7 @@ int run_raw(kmcpg_db* db, const uint8_t* seqs, const uint64_t* offs, const uint8
   }
   {
     std::lock_guard<std::mutex> g(db->mu);
-    HIPCHK(hipSetDevice(db->opts.device));
+    KMCPG_USE_DEVICE(db);
     if (db->s_seqs.ensure(tb1 + 16) || db->s_offs.ensure(n + 1) || db->s_counter.ensure(2) || db->s_qk.ensure(n) || db->s_ql.ensure(n))
       return fail(KMCPG_ENOMEM, "hipMalloc failed");
     if (seqs2 && (db->s_seqs2.ensure(tb2 + 16) || db->s_offs2.ensure(n + 1))) return fail(KMCPG_ENOMEM, "hipMalloc failed");
@@ -887,7 +902,7 @@ extern "C" int kmcpg_plant(kmcpg_db* db, uint32_t col, const uint64_t* hashes, u
   const BlockMeta& b = db->blocks[db->col_block[col]];
   if (!b.local || n == 0) return 0;
   std::lock_guard<std::mutex> g(db->mu);
-  HIPCHK(hipSetDevice(db->opts.device));
+  KMCPG_USE_DEVICE(db);
   uint64_t* d = nullptr;
   HIPCHK(hipMalloc((void**)&d, n * sizeof(uint64_t)));
   HIPCHK(hipMemcpy(d, hashes, n * sizeof(uint64_t), hipMemcpyHostToDevice));
@@ -905,7 +920,7 @@ extern "C" int kmcpg_read_rows(kmcpg_db* db, uint32_t block, const uint64_t* row
     if (row_idx[i] >= b.h.num_sigs) return fail(KMCPG_EINVAL, "row out of range");
   if (n_rows == 0) return 0;
   std::lock_guard<std::mutex> g(db->mu);
-  HIPCHK(hipSetDevice(db->opts.device));
+  KMCPG_USE_DEVICE(db);
   uint64_t* d_idx = nullptr;
   uint8_t* d_out = nullptr;
   HIPCHK(hipMalloc((void**)&d_idx, n_rows * sizeof(uint64_t)));
