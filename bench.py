@@ -34,7 +34,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6290 GB/
 WORKLOADS = {
     # GTDB r202 k=21 x10 chunks: 58.03 GB in 32 blocks (docs/database-time-and-mem-v2021.12.md:20-36)
     "gtdb": dict(k=21, num_hashes=1, fpr=0.3, n_blocks=32, cols_per_block=14976, num_sigs=968700, kmers_per_col=345510,
-                 batch_reads=131072, name="gtdb-scale synthetic: 32 blocks x 14976 cols x 968700 sigs (58.03 GB), 150bp k=21"),
+                 batch_reads=524288, name="gtdb-scale synthetic: 32 blocks x 14976 cols x 968700 sigs (58.03 GB), 150bp k=21"),
     # 10 k chunks, `kmcp index -j 32`: 32 blocks x 312 columns (39-byte rows) + 1 x 16 (BASELINE.json configs[1])
     "config1": dict(k=21, num_hashes=1, fpr=0.3, n_blocks=32, cols_per_block=312, num_sigs=1121470, kmers_per_col=400000,
                     batch_reads=1048576, name="10k-chunk synthetic: 32 blocks x 312 cols x 1121470 sigs (1.4 GB), 150bp k=21"),

@@ -1,0 +1,113 @@
+"""Parity at BASELINE.json's full size (GTDB-scale index: 32 blocks x 14 976 columns x 968 700 rows = 58 GB in HBM)
+through size-independent properties, plus an oracle check on rows read back from HBM:
+
+  * planting: a fragment whose k-mers were planted in column c comes back with (c, count == n): no false negatives;
+  * shard invariance: the union of the hit lists of the two halves of the index == the hit list of the whole index
+    (this is also the multi-GPU merge, exercised here with two handles on one GPU);
+  * oracle on a sample: for a few reads the 130 x 32 rows they touch are copied back and counted by the oracle.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+N_BLOCKS, COLS, NUM_SIGS, KMERS = 32, 14976, 968700, 345510
+B, L = 8192, 150
+
+
+@pytest.fixture(scope="module")
+def setup():
+    import torch
+    from kmcp_amd import Database, default_params, lib
+    free_b, _ = torch.cuda.mem_get_info(0)
+    if free_b < 130e9:
+        pytest.skip("needs 130 GB of free HBM")
+    dev = torch.device("cuda:0")
+    spec = lib.SynthSpec(k=21, num_hashes=1, fpr=0.3, n_blocks=N_BLOCKS, cols_per_block=COLS, num_sigs=NUM_SIGS, kmers_per_col=KMERS, seed=7)
+    whole = Database.open_synthetic(spec, device=0)
+    halves = [Database.open_synthetic(spec, device=0, shard_rank=r, shard_count=2) for r in range(2)]
+    g = torch.Generator(device=dev)
+    g.manual_seed(99)
+    acgt = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=dev)
+    reads = acgt[torch.randint(0, 4, (B, L), generator=g, device=dev)].contiguous().view(-1)
+    cols = torch.randint(0, N_BLOCKS * COLS, (B,), generator=g, device=dev).to(torch.int32)
+    cols[B // 2:] = -1  # second half: random reads, nothing planted
+    offs = (torch.arange(B + 1, device=dev, dtype=torch.int64) * L).contiguous()
+    for db in [whole] + halves:  # the same generator + the same plants => identical bit matrices
+        db.plant_reads_device(reads.data_ptr(), offs.data_ptr(), B, B * L, L, cols.data_ptr())
+    yield dict(torch=torch, dev=dev, whole=whole, halves=halves, reads=reads, offs=offs, cols=cols.cpu().numpy(), params=default_params(), lib=lib)
+    for db in [whole] + halves:
+        db.close()
+
+
+def _query(s, db):
+    torch, dev = s["torch"], s["dev"]
+    cap = 8 * B
+    hits = torch.zeros((cap, 3), dtype=torch.int32, device=dev)
+    cnt = torch.zeros(2, dtype=torch.int64, device=dev)
+    qk = torch.zeros(B, dtype=torch.int32, device=dev)
+    ql = torch.zeros(B, dtype=torch.int32, device=dev)
+    db.query_device(s["reads"].data_ptr(), s["offs"].data_ptr(), B, B * L, L, hits.data_ptr(), cap, cnt.data_ptr(), qk.data_ptr(), ql.data_ptr(),
+                    params=s["params"])
+    torch.cuda.synchronize()
+    n = int(cnt[0].item())
+    assert n <= cap
+    h = hits[:n].cpu().numpy().astype(np.int64)
+    return h[np.lexsort((h[:, 1], h[:, 0]))], qk.cpu().numpy(), ql.cpu().numpy()
+
+
+def test_info_is_gtdb_scale(setup):
+    i = setup["whole"].info
+    assert i.n_blocks == 32 and i.n_cols == 479232 and i.matrix_bytes == 32 * 968700 * 1872 == 58029004800
+    assert i.row_bytes_sum_local == 32 * 1872
+    assert setup["halves"][0].info.n_blocks_local == 16 and setup["halves"][1].info.n_blocks_local == 16
+
+
+def test_planted_fragments_have_no_false_negatives(setup):
+    h, qk, ql = _query(setup, setup["whole"])
+    assert (qk == 130).all() and (ql == 150).all()
+    got = {(int(r), int(c)): int(n) for r, c, n in h}
+    cols = setup["cols"]
+    for r in range(B // 2):
+        assert got.get((r, int(cols[r]))) == 130, r  # every planted k-mer is found: count == n
+    # chance hits: P(Bin(130, 0.3) >= 72) ~ 1e-9 per (read, column) x 3.9e9 pairs => a handful, all barely above 72
+    chance = [n for (r, c), n in got.items() if r >= B // 2 or c != int(cols[r])]
+    assert len(chance) < 60 and all(72 <= n < 85 for n in chance)
+
+
+def test_shard_union_equals_whole(setup):
+    hw, qk, _ = _query(setup, setup["whole"])
+    parts = [_query(setup, db) for db in setup["halves"]]
+    merged = np.concatenate([p[0] for p in parts])
+    merged = merged[np.lexsort((merged[:, 1], merged[:, 0]))]
+    assert np.array_equal(hw, merged)
+    assert len(parts[0][0]) > 0 and len(parts[1][0]) > 0
+    for p in parts:
+        assert np.array_equal(p[1], qk)
+    # finalize over the concatenated shard lists == finalize over the whole index's list
+    lib = setup["lib"]
+    ql = np.full(B, 150, dtype=np.int32)
+    a = setup["whole"].finalize(np.ascontiguousarray(hw.astype(np.uint32)).view(lib.HIT_DTYPE).reshape(-1), qk, ql)
+    b = setup["halves"][1].finalize(np.ascontiguousarray(np.concatenate([p[0] for p in parts])[::-1].astype(np.uint32)).view(lib.HIT_DTYPE).reshape(-1), qk, ql)
+    assert np.array_equal(a.offs, b.offs) and np.array_equal(a.matches, b.matches)
+
+
+def test_oracle_on_rows_read_back(setup, oracle_lib):
+    """Counts of 6 reads recomputed by the oracle from the very rows resident in HBM (130 x 32 rows each)."""
+    O = oracle_lib
+    db = setup["whole"]
+    h, qk, _ = _query(setup, db)
+    reads = setup["reads"].cpu().numpy()
+    cfg = O.sketch_cfg(k=21)
+    for r in (0, 1, 2, B // 2 - 1, B // 2, B - 1):
+        km = O.generate_kmers(reads[r * L:(r + 1) * L].tobytes(), cfg)
+        assert len(km) == qk[r] == 130
+        want = []
+        for b in range(N_BLOCKS):
+            rows = db.read_rows(b, km % np.uint64(NUM_SIGS))          # [130, 1872] bytes
+            bits = np.unpackbits(rows, axis=1)[:, :COLS]               # bit 7 of byte c/8 = column c
+            cnt = bits.sum(axis=0)
+            for c in np.nonzero(cnt >= 72)[0]:                         # float64(c) > 130*0.55 = 71.5
+                want.append((r, b * COLS + int(c), int(cnt[c])))
+        got = [tuple(int(x) for x in row) for row in h[h[:, 0] == r]]
+        assert got == sorted(want), r
