@@ -152,6 +152,10 @@ typedef struct {
   uint64_t num_sigs;    /* rows per block, e.g. 970000 */
   uint64_t kmers_per_col; /* Sizes[] of every column, e.g. 346000 */
   uint64_t seed;
+  uint32_t scale;       /* 0/1 = all k-mers; >1 = FracMinHash database (`scaled: true`, `scale`) */
+  uint32_t syncmer_s;   /* >0 = Closed-Syncmer database */
+  uint32_t minimizer_w; /* >0 = Minimizer database */
+  uint32_t reserved;
 } kmcpg_synth_spec;
 /* Builds a synthetic database directly in HBM: every bit i.i.d. Bernoulli(density) from a
  * counter-based generator keyed by (seed, block, row, word).  Column names are "syn<global col>". */

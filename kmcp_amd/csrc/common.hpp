@@ -51,6 +51,7 @@ struct DedupArgs {
   uint32_t n_reads;
   int32_t dedup_threshold;
   int32_t min_matched;
+  int32_t lo, hi;        // this launch handles queries with lo < n <= hi
   uint64_t* hashes;
   uint64_t* scratch;
   const int32_t* nk_raw;

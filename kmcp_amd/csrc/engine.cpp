@@ -335,7 +335,12 @@ extern "C" int kmcpg_open_synthetic(const kmcpg_synth_spec* s, const kmcpg_opts*
   I.k = s->k;
   I.canonical = 1;
   I.num_hashes = s->num_hashes;
-  I.scale = 1;
+  I.scale = s->scale > 1 ? s->scale : 1;
+  I.scaled = s->scale > 1;
+  I.syncmer = s->syncmer_s > 0;
+  I.syncmer_s = s->syncmer_s;
+  I.minimizer = s->minimizer_w > 0;
+  I.minimizer_w = s->minimizer_w;
   I.fpr = s->fpr;
   uint32_t base = 0;
   char name[64];
@@ -490,7 +495,7 @@ int run_kmers(kmcpg_db* db, const uint8_t* d_seqs, const uint64_t* d_offs, const
   a.nk_raw = d_nk_raw;
   a.nk1 = d_nk1;
   a.qlen = d_qlen;
-  launch_k1(a, st);
+  launch_k1(a, max_read_len, st);
   uint64_t ub = max_read_len >= (uint32_t)I.k ? (uint64_t)(max_read_len - I.k + 1) : 0;
   if (d_seqs2) ub *= 2;
   *max_n_out = ub;
@@ -505,7 +510,7 @@ int run_kmers(kmcpg_db* db, const uint8_t* d_seqs, const uint64_t* d_offs, const
     d.scratch = d_scratch;
     d.nk_raw = d_nk_raw;
     d.nk_search = d_nk_search;
-    launch_dedup(d, st);
+    launch_dedup(d, ub, st);
   } else {
     launch_nk_simple(d_nk_raw, d_nk_search, n_reads, p.min_matched, st);
   }

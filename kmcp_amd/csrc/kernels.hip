@@ -215,6 +215,133 @@ __global__ void __launch_bounds__(256) k1_kmers(const K1Args a) {
   }
 }
 
+// ---- long queries (HiFi reads, -g whole genomes): one 1024-thread workgroup per read -------------------------
+constexpr int K1WG = 1024;
+
+// ordered compaction of one tile of K1WG candidates into out[cnt...]; returns the new (uniform) count
+__device__ __forceinline__ int wg_compact(bool keep, uint64_t h, uint64_t* __restrict__ out, int cnt, int* s_wave, int tid) {
+  const int lane = tid & 63, w = tid >> 6;
+  const uint64_t m = __ballot(keep);
+  if (lane == 0) s_wave[w] = __popcll(m);
+  __syncthreads();
+  int before = 0, total = 0;
+#pragma unroll
+  for (int i = 0; i < K1WG / 64; i++) {
+    const int c = s_wave[i];
+    if (i < w) before += c;
+    total += c;
+  }
+  if (keep) out[cnt + before + __popcll(m & ((1ULL << lane) - 1ULL))] = h;
+  __syncthreads();
+  return cnt + total;
+}
+
+__device__ __forceinline__ uint64_t hash_at(const uint8_t* __restrict__ s, int i, int kk, const uint64_t* tab) {
+  uint64_t f = 0, r = 0;
+  for (int j = 0; j < kk; j++) {
+    f = rol1(f) ^ tab[s[i + j]];
+    r = rol1(r) ^ tab[s[i + kk - 1 - j] & 7];
+  }
+  return f < r ? f : r;
+}
+
+__device__ __forceinline__ int wg_sketch_mate(const K1Args& a, const uint8_t* __restrict__ s, int len, const uint64_t* tab, uint64_t* hk, uint64_t* hs,
+                                              uint64_t* __restrict__ out, int cnt, int* s_wave, int tid) {
+  const int k = a.k;
+  const bool scaled = a.scaled != 0;
+  if (a.mode == 0) {
+    const int npos = len - k + 1;
+    if (npos <= 0) return cnt;
+    for (int base = 0; base < npos; base += K1WG) {
+      const int i = base + tid;
+      const bool v = i < npos;
+      const uint64_t h = v ? hash_at(s, i, k, tab) : 0;
+      cnt = wg_compact(v && h != 0 && (!scaled || h <= a.max_hash), h, out, cnt, s_wave, tid);
+    }
+    return cnt;
+  }
+  if (a.mode == 2) {  // closed syncmer, see syncmer_mate
+    const int sm = (int)a.w_or_s, L = 2 * k - sm - 1;
+    if (sm < 1 || sm > k || len < L || len < k) return cnt;
+    for (int i = tid; i < len - k + 1; i += K1WG) hk[i] = hash_at(s, i, k, tab);
+    for (int i = tid; i < len - sm + 1; i += K1WG) hs[i] = hash_at(s, i, sm, tab);
+    __threadfence_block();
+    __syncthreads();
+    const int wsz = 2 * (k - sm);
+    const int nw = wsz > 0 ? len - L + 1 : len - k + 1;
+    for (int base = 0; base < nw; base += K1WG) {
+      const int w0 = base + tid;
+      const bool v = w0 < nw;
+      uint64_t h = 0;
+      if (v) {
+        int pos = w0;
+        if (wsz > 0) {
+          const int m = argmin_left(hs, w0, wsz);
+          pos = (m - w0 < k - sm) ? m : m + sm - k;
+        }
+        h = hk[pos];
+      }
+      cnt = wg_compact(v && h != 0 && (!scaled || h <= a.max_hash), h, out, cnt, s_wave, tid);
+    }
+    __syncthreads();
+    return cnt;
+  }
+  // minimizer, see minimizer_mate
+  const int w = (int)a.w_or_s;
+  if (w < 1 || len < k + w - 1) return cnt;
+  for (int i = tid; i < len - k + 1; i += K1WG) hk[i] = hash_at(s, i, k, tab);
+  __threadfence_block();
+  __syncthreads();
+  const int nw = len - k + 1 - w + 1;
+  for (int base = 0; base < nw; base += K1WG) {
+    const int w0 = base + tid;
+    const bool v = w0 < nw;
+    int m = -1, pm = -2;
+    if (v) {
+      m = argmin_left(hk, w0, w);
+      pm = w0 > 0 ? argmin_left(hk, w0 - 1, w) : -2;
+    }
+    const uint64_t h = (v && m != pm) ? hk[m] : 0;
+    cnt = wg_compact(v && m != pm && h != 0 && (!scaled || h <= a.max_hash), h, out, cnt, s_wave, tid);
+  }
+  __syncthreads();
+  return cnt;
+}
+
+__global__ void __launch_bounds__(K1WG) k1_kmers_wg(const K1Args a) {
+  __shared__ uint64_t tab[256];
+  __shared__ int s_wave[K1WG / 64];
+  const int tid = threadIdx.x;
+  if (tid < 256) tab[tid] = seed_of(tid);
+  __syncthreads();
+  for (uint32_t r = blockIdx.x; r < a.n_reads; r += gridDim.x) {
+    const uint64_t o1 = a.offs[r];
+    const int len1 = (int)(a.offs[r + 1] - o1);
+    uint64_t o2 = 0;
+    int len2 = 0;
+    const bool pe = a.offs2 != nullptr;
+    if (pe) {
+      o2 = a.offs2[r];
+      len2 = (int)(a.offs2[r + 1] - o2);
+    }
+    uint64_t* out = a.hashes + o1 + o2;
+    const bool skip = len1 < a.min_qlen && !(pe && len2 >= a.min_qlen);
+    int cnt = 0, cnt1 = 0;
+    if (!skip) {
+      uint64_t* tk = a.scratch ? a.scratch + o1 + o2 : nullptr;
+      uint64_t* ts = a.scratch2 ? a.scratch2 + o1 + o2 : nullptr;
+      cnt = wg_sketch_mate(a, a.seqs + o1, len1, tab, tk, ts, out, 0, s_wave, tid);
+      cnt1 = cnt;
+      if (pe) cnt = wg_sketch_mate(a, a.seqs2 + o2, len2, tab, tk, ts, out, cnt, s_wave, tid);
+    }
+    if (tid == 0) {
+      a.nk_raw[r] = cnt;
+      a.nk1[r] = cnt1;
+      a.qlen[r] = len1 + len2;
+    }
+  }
+}
+
 // NumKmers when no read of the batch can exceed the dedup threshold.
 __global__ void k_nk_simple(const int32_t* nk_raw, int32_t* nk_search, uint32_t n, int32_t min_matched) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -256,14 +383,21 @@ __device__ __forceinline__ void bitonic_sort(P a, int n, int tid, int nthreads) 
   }
 }
 
-constexpr int DEDUP_LDS = 4096;
-
-__global__ void __launch_bounds__(256) k_dedup(const DedupArgs a) {
-  __shared__ uint64_t s[DEDUP_LDS];
-  __shared__ int scan[256];
+// Two size classes: n <= 4096 sorts in 32 KB of LDS with 256 threads; larger queries use 1024 threads and 128 KB of
+// LDS (n <= 16384), beyond that the network runs in global memory.
+template <int NT, int CAP>
+__global__ void __launch_bounds__(NT) k_dedup(const DedupArgs a) {
+  __shared__ uint64_t s[CAP];
+  __shared__ int scan[NT];
   const uint32_t r = blockIdx.x;
   const int tid = threadIdx.x;
   const int n = a.nk_raw[r];
+  if (n <= a.lo || n > a.hi) {
+    // not this launch's size class; queries at or below the dedup threshold are settled by the small-class launch
+    if (a.lo == 0 && tid == 0 && n <= a.dedup_threshold) a.nk_search[r] = n >= a.min_matched ? n : 0;
+    if (!(a.lo == 0 && n <= a.dedup_threshold)) return;
+    return;
+  }
   if (n <= a.dedup_threshold) {
     if (tid == 0) a.nk_search[r] = n >= a.min_matched ? n : 0;
     return;
@@ -271,37 +405,37 @@ __global__ void __launch_bounds__(256) k_dedup(const DedupArgs a) {
   const uint64_t koff = a.offs[r] + (a.offs2 ? a.offs2[r] : 0);
   uint64_t* g = a.hashes + koff;
   uint64_t* tmp = a.scratch + koff;
-  const bool in_lds = n <= DEDUP_LDS;
+  const bool in_lds = n <= CAP;
   if (in_lds) {
-    for (int i = tid; i < n; i += 256) s[i] = g[i];
+    for (int i = tid; i < n; i += NT) s[i] = g[i];
     __syncthreads();
-    bitonic_sort(s, n, tid, 256);
+    bitonic_sort(s, n, tid, NT);
   } else {
-    bitonic_sort(g, n, tid, 256);
+    bitonic_sort(g, n, tid, NT);
     __threadfence_block();
   }
   const uint64_t* src = in_lds ? s : g;
   // unique: contiguous chunk per thread, block scan of the per-chunk counts
-  const int chunk = (n + 255) / 256;
-  const int b = tid * chunk, e = min(n, b + chunk);
+  const int chunk = (n + NT - 1) / NT;
+  const int b = min(n, tid * chunk), e = min(n, b + chunk);
   int c = 0;
   for (int i = b; i < e; i++) c += (i == 0 || src[i] != src[i - 1]) ? 1 : 0;
   scan[tid] = c;
   __syncthreads();
-  for (int off = 1; off < 256; off <<= 1) {
+  for (int off = 1; off < NT; off <<= 1) {
     int v = tid >= off ? scan[tid - off] : 0;
     __syncthreads();
     scan[tid] += v;
     __syncthreads();
   }
   int pos = scan[tid] - c;
-  const int total = scan[255];
+  const int total = scan[NT - 1];
   uint64_t* dst = in_lds ? g : tmp;
   for (int i = b; i < e; i++)
     if (i == 0 || src[i] != src[i - 1]) dst[pos++] = src[i];
   if (!in_lds) {
     __syncthreads();
-    for (int i = tid; i < total; i += 256) g[i] = tmp[i];
+    for (int i = tid; i < total; i += NT) g[i] = tmp[i];
   }
   // MinMatched is tested on the raw count (:854), NumKmers is the unique count (:910)
   if (tid == 0) a.nk_search[r] = n >= a.min_matched ? total : 0;
@@ -506,8 +640,13 @@ int launch_k2(const K2Args& a, int lpr, int npl, hipStream_t st) {
   }
 }
 
-void launch_k1(const K1Args& a, hipStream_t st) {
+void launch_k1(const K1Args& a, uint32_t max_read_len, hipStream_t st) {
   if (a.n_reads == 0) return;
+  if (max_read_len > 2048) {  // long queries: a whole workgroup per read
+    unsigned blocks = a.n_reads > 65536 ? 65536 : a.n_reads;
+    hipLaunchKernelGGL(k1_kmers_wg, dim3(blocks), dim3(K1WG), 0, st, a);
+    return;
+  }
   unsigned blocks = (a.n_reads + 3) / 4;
   if (blocks > 32768) blocks = 32768;
   hipLaunchKernelGGL(k1_kmers, dim3(blocks), dim3(256), 0, st, a);
@@ -518,9 +657,16 @@ void launch_nk_simple(const int32_t* nk_raw, int32_t* nk_search, uint32_t n, int
   hipLaunchKernelGGL(k_nk_simple, dim3((n + 255) / 256), dim3(256), 0, st, nk_raw, nk_search, n, min_matched);
 }
 
-void launch_dedup(const DedupArgs& a, hipStream_t st) {
+void launch_dedup(DedupArgs a, uint64_t max_n, hipStream_t st) {
   if (a.n_reads == 0) return;
-  hipLaunchKernelGGL(k_dedup, dim3(a.n_reads), dim3(256), 0, st, a);
+  a.lo = 0;
+  a.hi = max_n > 4096 ? 4096 : 0x7fffffff;
+  hipLaunchKernelGGL((k_dedup<256, 4096>), dim3(a.n_reads), dim3(256), 0, st, a);
+  if (max_n > 4096) {
+    a.lo = 4096;
+    a.hi = 0x7fffffff;
+    hipLaunchKernelGGL((k_dedup<1024, 16384>), dim3(a.n_reads), dim3(1024), 0, st, a);
+  }
 }
 
 // ------------------------------------------------------------------------------------------------

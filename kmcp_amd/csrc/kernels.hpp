@@ -6,9 +6,9 @@
 
 namespace kmcpg {
 
-void launch_k1(const K1Args& a, hipStream_t st);
+void launch_k1(const K1Args& a, uint32_t max_read_len, hipStream_t st);
 void launch_nk_simple(const int32_t* nk_raw, int32_t* nk_search, uint32_t n, int32_t min_matched, hipStream_t st);
-void launch_dedup(const DedupArgs& a, hipStream_t st);
+void launch_dedup(DedupArgs a, uint64_t max_n, hipStream_t st);
 // lpr in {4,16,64}: lanes per row tile; npl in {8,16,24}: counter planes.  <0 on bad arguments.
 int launch_k2(const K2Args& a, int lpr, int npl, hipStream_t st);
 void launch_repack(const uint8_t* src, uint8_t* dst, uint64_t n_rows, uint32_t row_bytes, uint32_t stride, hipStream_t st);

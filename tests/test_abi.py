@@ -32,7 +32,7 @@ def test_struct_layouts_match_header(L):
     assert C.sizeof(L.Match) == 56
     assert C.sizeof(L.Opts) == 16
     assert C.sizeof(L.Params) == 56
-    assert C.sizeof(L.SynthSpec) == 48
+    assert C.sizeof(L.SynthSpec) == 64
 
 
 def test_no_cpu_fallback(L, tmp_path):
