@@ -214,3 +214,50 @@ def test_sketch_kernels_match_oracle_in_order(G, oracle_lib, tmp_path):
             got = h[int(offs[i]):int(offs[i]) + int(nk[i])]
             assert len(want) == nk[i], (kw, i, len(want), nk[i])
             assert np.array_equal(got, want), (kw, i)
+
+
+def test_mixed_block_widths_and_hash_counts(G, oracle_lib, tmp_path):
+    """A database whose blocks fall into all three kernel classes (1125-, 38- and 3-byte rows), with 2 and 4 hash
+    functions, k = 31 / 64 / 65 (rotations wrap past 64 bits)."""
+    import ctypes as C
+    O = oracle_lib
+    for k, nh, fpr in ((31, 2, 0.05), (64, 4, 0.1), (65, 1, 0.3)):
+        genomes = synth.random_genomes(9320, 400, seed=60 + k)
+        cfg = O.sketch_cfg(k=k)
+        cols = synth.make_columns(genomes, cfg)
+        d = tmp_path / f"k{k}"
+        root = d / "R001"
+        root.mkdir(parents=True)
+        # three blocks written directly: 9000, 300 and 20 columns
+        arr = (O.Column * len(cols))()
+        keep = []
+        for i, (name, gsize, ci, nch, h) in enumerate(cols):
+            h = np.ascontiguousarray(h, dtype=np.uint64)
+            keep.append(h)
+            arr[i] = O.Column(name.encode(), gsize, ci, nch, h.ctypes.data_as(C.POINTER(C.c_uint64)), len(h))
+        lo = 0
+        files = []
+        for bi, n in enumerate((9000, 300, 20)):
+            sub = (O.Column * n)(*[arr[lo + j] for j in range(n)])
+            f = f"_block{bi + 1:03d}.uniki"
+            assert O.lib().ko_write_block(str(root / f).encode(), k, 1, nh, fpr, 0, sub, n) == 0
+            files.append(f)
+            lo += n
+        (root / "__db.yml").write_text(
+            f"version: 4\nunikiVersion: 4\nalias: t\nk: {k}\nks:\n- {k}\nhashed: true\ncanonical: true\nscaled: false\nscale: 1\n"
+            f"minimizer: false\nminimizer-w: 0\nsyncmer: false\nsyncmer-s: 0\nhashes: {nh}\nfpr: {fpr}\nfiles:\n" + "".join(f"- {f}\n" for f in files))
+        reads = synth.sample_reads(genomes, 400, 150, sub_rate=0.005, seed=61, frac_random=0.1)
+        kw = dict(min_qcov=max(0.55, fpr + 0.2))
+        n, _ = _run(G, O, str(root), reads, oracle_kw=kw, gpu_kw=kw)
+        assert n > 200
+
+
+def test_very_long_query_24_plane_counters(G, oracle_lib, tmp_path):
+    """A 90-kb query with every k-mer kept (n > 65 535 => 24 counter planes, global-memory sort) and dedup disabled/enabled."""
+    O = oracle_lib
+    genomes = synth.random_genomes(6, 90000, seed=70)
+    db_dir = synth.make_db(tmp_path, genomes, k=21, threads=2)
+    reads = [genomes[0], genomes[1][:70000] + genomes[2][:20000], genomes[3][5:80005]]
+    for kw in (dict(), dict(dedup_threshold=1000000)):
+        n, res = _run(G, O, db_dir, reads, oracle_kw=kw, gpu_kw=kw)
+        assert n >= 3 and int(res.qkmers[0]) > 65535
