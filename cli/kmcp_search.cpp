@@ -72,7 +72,8 @@ static void warn(const char* fmt, ...) {
 struct Options {
   std::string db_dir, out_file = "-", read1, read2, query_id, sort_by = "qcov", infile_list, log_file;
   std::vector<std::string> name_maps, files;
-  int min_qlen = 30, min_kmers = 10, dedup = 256, top_scores = 0, threads = 0, device = 0, batch = 131072;
+  int min_qlen = 30, min_kmers = 10, dedup = 256, top_scores = 0, threads = 0, device = 0, batch = 131072, gpus = 1;
+  std::vector<int32_t> gpu_ids;
   double min_qcov = 0.55, min_tcov = 0, max_fpr = 0.01;
   bool load_whole = false, low_mem = false, whole_file = false, use_filename = false, keep_unmatched = false, no_header = false,
        do_not_sort = false, default_name_map = false, try_se = false, quiet = false;
@@ -94,7 +95,8 @@ static void usage() {
       "  -N, --name-map file(s)         -D, --default-name-map\n"
       "  -w, --load-whole-db / --low-mem  accepted for compatibility (the index is always resident in HBM)\n"
       "  -j, --threads int  -i, --infile-list file  -q, --quiet  --log file\n"
-      "GPU flags: --gpu int (device, default 0)  --gpu-batch int (queries per GPU call, default 131072)\n",
+      "GPU flags: --gpu int (device, default 0)  --gpus int (use devices 0..N-1, index blocks partitioned over them)\n"
+      "           --gpu-ids a,b,c (explicit device list)  --gpu-batch int (queries per GPU call, default 131072)\n",
       stderr);
 }
 
@@ -120,7 +122,7 @@ static Options parse_args(int argc, char** argv) {
       {"min-kmers", 'c', 1}, {"min-query-len", 'm', 1}, {"min-query-cov", 't', 1}, {"min-target-cov", 'T', 1}, {"max-fpr", 'f', 1},
       {"name-map", 'N', 1}, {"default-name-map", 'D', 0}, {"keep-unmatched", 'K', 0}, {"keep-top-scores", 'n', 1}, {"no-header-row", 'H', 0},
       {"sort-by", 's', 1}, {"do-not-sort", 'S', 0}, {"threads", 'j', 1}, {"quiet", 'q', 0}, {"infile-list", 'i', 1}, {"log", 0, 1},
-      {"gpu", 0, 1}, {"gpu-batch", 0, 1}, {"help", 'h', 0}, {"version", 'V', 0}};
+      {"gpu", 0, 1}, {"gpu-batch", 0, 1}, {"gpus", 0, 1}, {"gpu-ids", 0, 1}, {"help", 'h', 0}, {"version", 'V', 0}};
   auto apply = [&](const std::string& name, const std::string& v) {
     if (name == "db-dir") o.db_dir = v;
     else if (name == "out-file") o.out_file = v;
@@ -158,6 +160,16 @@ static Options parse_args(int argc, char** argv) {
     else if (name == "log") o.log_file = v;
     else if (name == "gpu") o.device = to_i(name, v);
     else if (name == "gpu-batch") o.batch = to_i(name, v);
+    else if (name == "gpus") o.gpus = to_i(name, v);
+    else if (name == "gpu-ids") {
+      size_t b = 0;
+      while (b <= v.size()) {
+        size_t e = v.find(',', b);
+        if (e == std::string::npos) e = v.size();
+        if (e > b) o.gpu_ids.push_back(to_i(name, v.substr(b, e - b)));
+        b = e + 1;
+      }
+    }
     else if (name == "help") { usage(); exit(0); }
     else if (name == "version") { printf("kmcp-search v%s\n", VERSION); exit(0); }
   };
@@ -483,8 +495,15 @@ int main(int argc, char** argv) {
 
   if (verbose) info("loading database into GPU memory ...");
   kmcpg_db* db = nullptr;
-  kmcpg_opts gopts{o.device, 0, 1, 0};
-  if (kmcpg_open(db_dirs[0].c_str(), &gopts, &db) != 0) die("open kmcp db: %s: %s", db_dirs[0].c_str(), kmcpg_last_error());
+  if (o.gpu_ids.empty() && o.gpus > 1)
+    for (int i = 0; i < o.gpus; i++) o.gpu_ids.push_back(i);
+  if (!o.gpu_ids.empty()) {  // one process, several GPUs: blocks partitioned over the devices, hits merged on the host
+    if (kmcpg_open_devices(db_dirs[0].c_str(), o.gpu_ids.data(), (int32_t)o.gpu_ids.size(), &db) != 0)
+      die("open kmcp db: %s: %s", db_dirs[0].c_str(), kmcpg_last_error());
+  } else {
+    kmcpg_opts gopts{o.device, 0, 1, 0};
+    if (kmcpg_open(db_dirs[0].c_str(), &gopts, &db) != 0) die("open kmcp db: %s: %s", db_dirs[0].c_str(), kmcpg_last_error());
+  }
   kmcpg_info dbi;
   kmcpg_db_info(db, &dbi);
   if (o.min_qcov <= dbi.fpr)  // search.go:405-409

@@ -110,6 +110,10 @@ typedef struct {
 /* -- lifecycle: replaces NewUnikIndexDB / NewUnikIndex (util-db-search.go:648-743, 1196-1280) and
  *    UnikIndexDB.Close (:1119-1150).  db_dir is the directory holding __db.yml (e.g. <db>/R001). */
 int kmcpg_open(const char* db_dir, const kmcpg_opts* opts, kmcpg_db** out);
+/* One host process, several GPUs (what a cgo host needs): the blocks are partitioned over `devices` (ordinals may repeat),
+ * kmcpg_search_batch fans every batch out to all of them from one host thread per GPU and merges the hit lists on the
+ * host.  kmcpg_query_device is not available on such a handle. */
+int kmcpg_open_devices(const char* db_dir, const int32_t* devices, int32_t n_devices, kmcpg_db** out);
 int kmcpg_close(kmcpg_db* db);
 const char* kmcpg_last_error(void);
 int kmcpg_db_info(const kmcpg_db* db, kmcpg_info* info);

@@ -13,6 +13,7 @@
 #include <memory>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "common.hpp"
@@ -117,6 +118,8 @@ struct kmcpg_db {
   DevBuf<kmcpg_hit> s_hits;
   DevBuf<int32_t> s_qk, s_ql;
   bool synthetic = false;
+  // in-process multi-GPU front handle (kmcpg_open_devices): metadata only itself, one resident shard handle per device
+  std::vector<kmcpg_db*> shards;
   // optional HIP-event timing of the last kmcpg_query_device call
   bool profiling = false;
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -393,6 +396,8 @@ extern "C" int kmcpg_open_synthetic(const kmcpg_synth_spec* s, const kmcpg_opts*
 
 extern "C" int kmcpg_close(kmcpg_db* db) {
   if (!db) return 0;
+  for (kmcpg_db* sh : db->shards) kmcpg_close(sh);
+  db->shards.clear();
   if (db->opts.device >= 0) (void)hipSetDevice(db->opts.device);
   for (auto& b : db->blocks)
     if (b.d_rows) (void)hipFree(b.d_rows);
@@ -823,18 +828,73 @@ int run_raw(kmcpg_db* db, const uint8_t* seqs, const uint64_t* offs, const uint8
   return fail(KMCPG_ENOMEM, "hit buffer overflow");
 }
 
+// all resident shards of a multi-device handle search the batch concurrently (one host thread per GPU); the hit lists are
+// concatenated exactly as the reference concatenates the replies of its per-block workers (:946-964)
+int run_raw_any(kmcpg_db* db, const uint8_t* seqs, const uint64_t* offs, const uint8_t* seqs2, const uint64_t* offs2, uint32_t n, const kmcpg_params& p,
+                RawBatch* rb) {
+  if (db->shards.empty()) return run_raw(db, seqs, offs, seqs2, offs2, n, p, rb);
+  const size_t S = db->shards.size();
+  std::vector<RawBatch> parts(S);
+  std::vector<int> rcs(S, 0);
+  std::vector<std::string> errs(S);
+  std::vector<std::thread> th;
+  for (size_t i = 0; i < S; i++)
+    th.emplace_back([&, i] {
+      rcs[i] = run_raw(db->shards[i], seqs, offs, seqs2, offs2, n, p, &parts[i]);
+      if (rcs[i]) errs[i] = g_err;  // thread-local message of the worker
+    });
+  for (auto& t : th) t.join();
+  for (size_t i = 0; i < S; i++)
+    if (rcs[i]) return fail(rcs[i], "device %d: %s", db->shards[i]->opts.device, errs[i].c_str());
+  rb->qk = parts[0].qk;  // every shard generates the same k-mers
+  rb->ql = parts[0].ql;
+  rb->hits.clear();
+  for (auto& pt : parts) rb->hits.insert(rb->hits.end(), pt.hits.begin(), pt.hits.end());
+  return 0;
+}
+
 }  // namespace
+
+extern "C" int kmcpg_open_devices(const char* db_dir, const int32_t* devices, int32_t n_devices, kmcpg_db** out) {
+  if (!db_dir || !devices || !out || n_devices < 1) return fail(KMCPG_EINVAL, "bad argument");
+  *out = nullptr;
+  kmcpg_opts mo{-1, 0, 1, 0};
+  kmcpg_db* front = nullptr;
+  int rc = kmcpg_open(db_dir, &mo, &front);  // metadata of every block: names, sizes, FPR table
+  if (rc) return rc;
+  front->info.n_blocks_local = 0;
+  front->info.matrix_bytes_local = 0;
+  front->info.row_bytes_sum_local = 0;
+  for (int32_t i = 0; i < n_devices; i++) {
+    kmcpg_opts so{devices[i], i, n_devices, 0};
+    kmcpg_db* sh = nullptr;
+    rc = kmcpg_open(db_dir, &so, &sh);
+    if (rc) {
+      std::string keep = g_err;
+      kmcpg_close(front);
+      g_err = keep;
+      return rc;
+    }
+    front->shards.push_back(sh);
+    front->info.n_blocks_local += sh->info.n_blocks_local;
+    front->info.matrix_bytes_local += sh->info.matrix_bytes_local;
+    front->info.row_bytes_sum_local += sh->info.row_bytes_sum_local;
+  }
+  *out = front;
+  return 0;
+}
 
 extern "C" int kmcpg_search_batch(kmcpg_db* db, const uint8_t* seqs, const uint64_t* offs, const uint8_t* seqs2, const uint64_t* offs2, uint32_t n_reads,
                                   const kmcpg_params* params, kmcpg_result* out) {
   if (!db || !out || (n_reads && (!seqs || !offs))) return fail(KMCPG_EINVAL, "null argument");
   if ((seqs2 == nullptr) != (offs2 == nullptr)) return fail(KMCPG_EINVAL, "seqs2 and offs2 must be given together");
-  if (db->opts.shard_count != 1) return fail(KMCPG_EINVAL, "kmcpg_search_batch needs the whole database on one GPU; use kmcpg_query_device + kmcpg_finalize per shard");
+  if (db->opts.shard_count != 1)
+    return fail(KMCPG_EINVAL, "kmcpg_search_batch needs the whole database: open it on one GPU or with kmcpg_open_devices; use kmcpg_query_device + kmcpg_finalize per shard");
   kmcpg_params p = params ? *params : default_params();
   memset(out, 0, sizeof *out);
   std::lock_guard<std::mutex> api_guard(db->api_mu);
   RawBatch rb;
-  int rc = run_raw(db, seqs, offs, seqs2, offs2, n_reads, p, &rb);
+  int rc = run_raw_any(db, seqs, offs, seqs2, offs2, n_reads, p, &rb);
   if (rc) return rc;
   rc = kmcpg_finalize(db, rb.hits.data(), rb.hits.size(), rb.qk.data(), rb.ql.data(), n_reads, &p, out);
   if (rc) return rc;
@@ -860,7 +920,7 @@ extern "C" int kmcpg_search_batch(kmcpg_db* db, const uint8_t* seqs, const uint6
     q.min_qlen = 0;
     q.try_se = 0;
     RawBatch rb2;
-    rc = run_raw(db, sub.data(), so.data(), nullptr, nullptr, (uint32_t)todo.size(), q, &rb2);
+    rc = run_raw_any(db, sub.data(), so.data(), nullptr, nullptr, (uint32_t)todo.size(), q, &rb2);
     if (rc) return rc;
     kmcpg_result r2;
     rc = kmcpg_finalize(db, rb2.hits.data(), rb2.hits.size(), rb2.qk.data(), rb2.ql.data(), (uint32_t)todo.size(), &q, &r2);

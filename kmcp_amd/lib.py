@@ -15,7 +15,7 @@ EXPORTS = [
     "kmcpg_open", "kmcpg_close", "kmcpg_last_error", "kmcpg_db_info", "kmcpg_col_info", "kmcpg_search_batch",
     "kmcpg_result_free", "kmcpg_query_device", "kmcpg_finalize", "kmcpg_open_synthetic", "kmcpg_plant",
     "kmcpg_read_rows", "kmcpg_block_info", "kmcpg_kmers_device", "kmcpg_plant_reads_device", "kmcpg_set_profiling",
-    "kmcpg_last_timing",
+    "kmcpg_last_timing", "kmcpg_open_devices",
 ]
 
 
@@ -104,6 +104,7 @@ def load():
     L.kmcpg_last_error.restype = C.c_char_p
     L.kmcpg_open.argtypes = [C.c_char_p, C.POINTER(Opts), C.POINTER(vp)]
     L.kmcpg_open_synthetic.argtypes = [C.POINTER(SynthSpec), C.POINTER(Opts), C.POINTER(vp)]
+    L.kmcpg_open_devices.argtypes = [C.c_char_p, C.POINTER(C.c_int32), C.c_int32, C.POINTER(vp)]
     L.kmcpg_close.argtypes = [vp]
     L.kmcpg_db_info.argtypes = [vp, C.POINTER(Info)]
     L.kmcpg_col_info.argtypes = [vp, C.c_uint32, C.POINTER(C.c_char_p), C.POINTER(C.c_uint32), u64p, u64p]
@@ -184,6 +185,14 @@ class Database:
         h = C.c_void_p()
         o = Opts(device, shard_rank, shard_count, 0)
         _check(load().kmcpg_open(os.fsencode(db_dir), C.byref(o), C.byref(h)))
+        return cls(h)
+
+    @classmethod
+    def open_devices(cls, db_dir, devices):
+        """One process, several GPUs: blocks partitioned over `devices`, search() fans out and merges on the host."""
+        h = C.c_void_p()
+        arr = (C.c_int32 * len(devices))(*devices)
+        _check(load().kmcpg_open_devices(os.fsencode(db_dir), arr, len(devices), C.byref(h)))
         return cls(h)
 
     @classmethod

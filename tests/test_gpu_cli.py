@@ -96,6 +96,8 @@ def test_cli_single_end_gz_and_flags(oracle_lib, tmp_path):
     # default flags, gz in, gz out, small GPU batches so that several batches are stitched in order
     want, trailer = oracle_tsv(O, odb, ids, reads)
     compare(run_cli(["-d", db_root, fq, "--gpu-batch", "100"], str(tmp_path / "o1.tsv.gz")), want, trailer)
+    # one process driving several shards (here two on the same GPU)
+    compare(run_cli(["-d", db_root, fq, "--gpu-ids", "0,0"], str(tmp_path / "o1b.tsv")), want, trailer)
     # -K keeps unmatched rows; -H drops the header; thresholds + sort by jacc + top score
     p = O.default_params(min_qcov=0.4, min_matched=5, sort_by=2, top_n_scores=1)
     want, trailer = oracle_tsv(O, odb, ids, reads, params=p, keep_unmatched=True)

@@ -261,3 +261,23 @@ def test_very_long_query_24_plane_counters(G, oracle_lib, tmp_path):
     for kw in (dict(), dict(dedup_threshold=1000000)):
         n, res = _run(G, O, db_dir, reads, oracle_kw=kw, gpu_kw=kw)
         assert n >= 3 and int(res.qkmers[0]) > 65535
+
+
+def test_in_process_multi_device_handle(G, oracle_lib, tmp_path):
+    """kmcpg_open_devices: one process, the blocks partitioned over a device list (here three shards on GPU 0), batches
+    fanned out from one host thread per shard and merged; incl. paired-end --try-se on top of the merged result."""
+    O = oracle_lib
+    genomes = synth.random_genomes(40, 10000, seed=80)
+    db_dir = synth.make_db(tmp_path, genomes, k=21, n_chunks=2, overlap=150, threads=8)  # 80 columns -> 8 blocks
+    r1 = synth.sample_reads(genomes, 500, 150, seed=81, frac_random=0.05)
+    r2 = synth.sample_reads(genomes, 500, 150, seed=82, frac_random=0.5)
+    odb = O.OracleDB(db_dir)
+    try:
+        with G["Database"].open_devices(db_dir, [0, 0, 0]) as db:
+            assert db.info.n_blocks_local == db.info.n_blocks >= 3
+            res = db.search(r1, params=G["default_params"]())
+            assert synth.assert_parity(odb, res, r1) > 300
+            res = db.search(r1, r2, params=G["default_params"](try_se=1))
+            assert synth.assert_parity(odb, res, r1, r2, O.default_params(try_se=1)) > 100
+    finally:
+        odb.close()
