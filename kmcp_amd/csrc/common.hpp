@@ -70,6 +70,7 @@ struct K2Args {
   double min_qcov;
   int32_t min_matched;
   int32_t num_hashes;
+  int32_t nt_loads;      // non-temporal row loads
   kmcpg_hit* hits;
   uint64_t hit_cap;
   unsigned long long* counter;

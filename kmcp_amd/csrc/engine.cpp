@@ -7,6 +7,7 @@
 #include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -588,6 +589,7 @@ extern "C" int kmcpg_query_device(kmcpg_db* db, const uint8_t* d_seqs, const uin
     a.min_qcov = p.min_qcov;
     a.min_matched = p.min_matched;
     a.num_hashes = db->info.num_hashes;
+    a.nt_loads = getenv("KMCPG_NT_LOADS") ? atoi(getenv("KMCPG_NT_LOADS")) : 1;
     a.hits = d_hits;
     a.hit_cap = hit_cap;
     a.counter = (unsigned long long*)d_counters;

@@ -461,6 +461,15 @@ __global__ void __launch_bounds__(NT) k_dedup(const DedupArgs a) {
     l = u_ ^ (c_);                         \
   }
 
+// 16 bytes of a row.  Index rows are read once and never reused: non-temporal loads keep them from displacing the
+// hash/offset lines in L2 (+2 % on the random-gather microbenchmark, profiles/).
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint4 load_row16(const uint8_t* p, int nt) {
+  const u32x4* q = reinterpret_cast<const u32x4*>(p);
+  const u32x4 v = nt ? __builtin_nontemporal_load(q) : *q;
+  return make_uint4(v.x, v.y, v.z, v.w);
+}
+
 template <int NPL>
 __device__ __forceinline__ void csa8(uint32_t (&pl)[NPL], uint32_t x0, uint32_t x1, uint32_t x2, uint32_t x3, uint32_t x4,
                                      uint32_t x5, uint32_t x6, uint32_t x7) {
@@ -554,11 +563,11 @@ __global__ void __launch_bounds__(256) k2_cobs(const K2Args a) {
         uint4 v = make_uint4(0, 0, 0, 0);
         if (active) {
           const uint32_t row = s_rows[wave][0][g * CH + j + i];
-          v = *reinterpret_cast<const uint4*>(base + (uint64_t)row * stride);
+          v = load_row16(base + (uint64_t)row * stride, a.nt_loads);
           if (MULTI) {
             for (int hh = 1; hh < nh; hh++) {  // AND of the h rows (pand.AndUnsafe, :6639-6646)
               const uint32_t row2 = s_rows[wave][hh][g * CH + j + i];
-              const uint4 w = *reinterpret_cast<const uint4*>(base + (uint64_t)row2 * stride);
+              const uint4 w = load_row16(base + (uint64_t)row2 * stride, a.nt_loads);
               v.x &= w.x; v.y &= w.y; v.z &= w.z; v.w &= w.w;
             }
           }
