@@ -99,11 +99,18 @@ def main():
             raise SystemExit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 "
                              "--master-port P bench.py --gpus N ...")
         args.gpus = world
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # KMCP_BENCH_SAME_GPU=1 (debugging on a 1-GPU box): every rank uses GPU 0 and the exchange runs over gloo, because
+    # RCCL refuses two ranks on one device.  Never set by the driver; the measured path is nccl = RCCL over xGMI.
+    same_gpu = os.environ.get("KMCP_BENCH_SAME_GPU") == "1"
+    dev_index = 0 if same_gpu else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        if same_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     from kmcp_amd import Database, default_params, lib
     from kmcp_amd.dist import gather_hits
@@ -117,7 +124,7 @@ def main():
     if need > 0.9 * free_b:
         raise SystemExit(f"workload needs {need/1e9:.1f} GB of HBM on this rank, {free_b/1e9:.1f} GB free")
     t0 = time.time()
-    db = Database.open_synthetic(spec, device=local_rank, shard_rank=rank, shard_count=world)
+    db = Database.open_synthetic(spec, device=dev_index, shard_rank=rank, shard_count=world)
     torch.cuda.synchronize()
     info = db.info
     n_cols = int(info.n_cols)
@@ -184,7 +191,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t_start
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if same_gpu else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -232,9 +239,10 @@ def main():
         "setup_s": setup_s,
     }
 
-    # ---- sanity on the last batch (rank 0): planted reads must come back with their column
+    # ---- sanity on the last batch: planted reads must come back with their column (the step holds collectives: every
+    #      rank takes part, rank 0 evaluates the merged hit list)
+    n_last = step(last)
     if rank == 0:
-        n_last = step(last)
         hh = h_hits[:n_last].numpy().astype(np.int64)
         cols_last = batches[last][2].cpu().numpy().astype(np.int64)
         got = set(zip(hh[:, 0].tolist(), hh[:, 1].tolist()))

@@ -23,6 +23,9 @@ def gather_hits(hits: torch.Tensor, count: torch.Tensor, dst: int = 0, group=Non
     rank = dist.get_rank(group)
     if world == 1:
         return [hits[:int(count.item())]]
+    if dist.get_backend(group) == "gloo" and hits.is_cuda:
+        # debugging aid (several ranks sharing one GPU, where RCCL refuses duplicate devices): stage through the host
+        hits, count = hits.cpu(), count.cpu()
     counts = torch.zeros(world, dtype=torch.int64, device=hits.device)
     dist.all_gather_into_tensor(counts, count.reshape(1).to(torch.int64), group=group)
     bufs = [torch.empty_like(hits) for _ in range(world)] if rank == dst else None
