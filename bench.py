@@ -15,6 +15,9 @@ The synthetic index is generated directly in HBM: 32 b
 (NumRowBytes 1 872) x 968 700 rows = 58.03 GB, bits i.i.d. Bernoulli(0.30) like a Bloom filter at fpr 0.3;
 90 % of the reads are 1 %-mutated, randomly reverse-complemented copies of 150-bp fragments whose k-mers
 were planted into a random column, 10 % are uniform random.
+
+The JSON line reports the GTDB-scale workload (the configuration BASELINE.json's metric is quoted on).  At N=1 the
+same line carries, under "secondary", the numbers of BASELINE.json configs[1] (10 k chunks, 39-byte rows).
 """
 import argparse
 import json
@@ -29,15 +32,17 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6290 GB/s measured copy ceiling
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.2-6.3 TB/s is what copies/gathers reach
 
 WORKLOADS = {
     # GTDB r202 k=21 x10 chunks: 58.03 GB in 32 blocks (docs/database-time-and-mem-v2021.12.md:20-36)
     "gtdb": dict(k=21, num_hashes=1, fpr=0.3, n_blocks=32, cols_per_block=14976, num_sigs=968700, kmers_per_col=345510,
-                 batch_reads=524288, name="gtdb-scale synthetic: 32 blocks x 14976 cols x 968700 sigs (58.03 GB), 150bp k=21"),
-    # 10 k chunks, `kmcp index -j 32`: 32 blocks x 312 columns (39-byte rows) + 1 x 16 (BASELINE.json configs[1])
+                 batch_reads=524288, kernel="k2_cobs<64,8,false>",
+                 name="gtdb-scale synthetic: 32 blocks x 14976 cols x 968700 sigs (58.03 GB), 150bp k=21"),
+    # 10 k chunks, `kmcp index -j 32`: 32 blocks x 312 columns, 39-byte rows (BASELINE.json configs[1])
     "config1": dict(k=21, num_hashes=1, fpr=0.3, n_blocks=32, cols_per_block=312, num_sigs=1121470, kmers_per_col=400000,
-                    batch_reads=1048576, name="10k-chunk synthetic: 32 blocks x 312 cols x 1121470 sigs (1.4 GB), 150bp k=21"),
+                    batch_reads=1048576, kernel="k2_cobs<4,8,false>",
+                    name="10k-chunk synthetic: 32 blocks x 312 cols x 1121470 sigs (1.4 GB), 150bp k=21"),
 }
 READ_LEN = 150
 
@@ -80,43 +85,18 @@ def make_batch(dev, n_reads, n_cols, seed):
     return frag, cols.contiguous(), reads, offs
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="gtdb", choices=sorted(WORKLOADS))
-    ap.add_argument("--batch-reads", type=int, default=0)
-    ap.add_argument("--cpu-sample-reads", type=int, default=0, help="0 = size the CPU sample to ~15 s")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    args = ap.parse_args()
+class Ctx:
+    pass
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 "
-                             "--master-port P bench.py --gpus N ...")
-        args.gpus = world
-    # KMCP_BENCH_SAME_GPU=1 (debugging on a 1-GPU box): every rank uses GPU 0 and the exchange runs over gloo, because
-    # RCCL refuses two ranks on one device.  Never set by the driver; the measured path is nccl = RCCL over xGMI.
-    same_gpu = os.environ.get("KMCP_BENCH_SAME_GPU") == "1"
-    dev_index = 0 if same_gpu else local_rank
-    torch.cuda.set_device(dev_index)
-    dev = torch.device("cuda", dev_index)
-    if world > 1:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        if same_gpu:
-            dist.init_process_group("gloo")
-        else:
-            dist.init_process_group("nccl", device_id=dev)
 
+def run_workload(name, ctx, steps, warmup, batch_reads=0, cpu_baseline=True, cpu_target_s=8.0, cpu_sample_reads=0):
+    """Builds the synthetic index of workload `name` in HBM, times `steps` steps, returns the result dict (rank 0)."""
     from kmcp_amd import Database, default_params, lib
     from kmcp_amd.dist import gather_hits
 
-    wl = dict(WORKLOADS[args.workload])
-    B = args.batch_reads or wl["batch_reads"]
+    world, rank, dev, dev_index = ctx.world, ctx.rank, ctx.dev, ctx.dev_index
+    wl = dict(WORKLOADS[name])
+    B = batch_reads or wl["batch_reads"]
     spec = lib.SynthSpec(k=wl["k"], num_hashes=wl["num_hashes"], fpr=wl["fpr"], n_blocks=wl["n_blocks"],
                          cols_per_block=wl["cols_per_block"], num_sigs=wl["num_sigs"], kmers_per_col=wl["kmers_per_col"], seed=42)
     free_b, _ = torch.cuda.mem_get_info(dev)
@@ -132,7 +112,7 @@ def main():
     db.set_profiling(True)
 
     # ---- batches resident in HBM; distinct data per step (cycled if K+W is large)
-    n_batches = min(args.steps + args.warmup, 4)
+    n_batches = max(1, min(steps + warmup, 4))
     batches = []
     for i in range(n_batches):
         frag, cols, reads, offs = make_batch(dev, B, n_cols, seed=1000 + i)
@@ -151,7 +131,8 @@ def main():
     stream = torch.cuda.current_stream(dev).cuda_stream
 
     def step(i):
-        """K1+K2 on this rank's blocks, hit lists to rank 0 (RCCL), hit tuples to host memory. Returns #hits on rank 0."""
+        """K1+K2 on this rank's blocks, hit lists to rank 0 (RCCL), hit tuples to host memory. Returns #hits on rank 0.
+        Holds collectives: every rank must call it the same number of times."""
         reads, offs, _ = batches[i % n_batches]
         db.query_device(reads.data_ptr(), offs.data_ptr(), B, B * READ_LEN, READ_LEN, d_hits.data_ptr(), cap, d_cnt.data_ptr(),
                         d_qk.data_ptr(), d_ql.data_ptr(), params=params, stream=stream)
@@ -178,29 +159,29 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for i in range(args.warmup):
+    for i in range(warmup):
         step(i)
     barrier()
     k2_ms, k1_ms, n_hits_total = [], [], 0
     t_start = time.perf_counter()
-    for i in range(args.steps):
-        n_hits_total += step(args.warmup + i)
+    for i in range(steps):
+        n_hits_total += step(warmup + i)
         a, b = db.last_timing()
         k1_ms.append(a)
         k2_ms.append(b)
     barrier()
     elapsed = time.perf_counter() - t_start
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if same_gpu else dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if ctx.same_gpu else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
     # ---- roofline of the dominant kernel (k2_cobs) on this rank: algorithmic bytes per launch:
     #      sum over reads of kept k-mers x sum over local blocks of numHashes x NumRowBytes, + qLen, + 12 B per hit
-    last = (args.warmup + args.steps - 1) % n_batches
+    last = (warmup + steps - 1) % n_batches
     qk = d_qk.cpu().numpy().astype(np.int64)
     kmers_per_launch = int(qk.sum())
-    alg_bytes = kmers_per_launch * int(info.row_bytes_sum_local) * int(info.num_hashes) + B * READ_LEN + 12 * (n_hits_total // max(1, args.steps))
+    alg_bytes = kmers_per_launch * int(info.row_bytes_sum_local) * int(info.num_hashes) + B * READ_LEN + 12 * (n_hits_total // max(1, steps))
     k2_avg_ms = float(np.mean(k2_ms))
     achieved = alg_bytes / (k2_avg_ms * 1e-3) / 1e9
     traffic = None
@@ -208,7 +189,7 @@ def main():
     if os.path.exists(tfile):
         try:
             tj = json.load(open(tfile))
-            key = f"{args.workload}:{B}:{world}"
+            key = f"{name}:{B}:{world}"
             if key in tj:
                 traffic = tj[key]["hbm_bytes_per_launch"]
         except Exception:
@@ -216,12 +197,12 @@ def main():
 
     out = {
         "metric": "reads/sec searched (150bp, k=21) vs GTDB-scale index",
-        "value": B * args.steps / elapsed,
+        "value": B * steps / elapsed,
         "unit": "reads/s",
         "n_gpus": world,
-        "steps": args.steps,
-        "warmup": args.warmup,
-        "ms_per_step": elapsed / args.steps * 1e3,
+        "steps": steps,
+        "warmup": warmup,
+        "ms_per_step": elapsed / steps * 1e3,
         "higher_is_better": True,
         "scaling": "strong",
         "vs_baseline": None,
@@ -231,30 +212,29 @@ def main():
                    "index_bytes": int(info.matrix_bytes), "index_bytes_this_rank": int(info.matrix_bytes_local),
                    "blocks": int(info.n_blocks), "columns": n_cols, "parallelism": f"block-shard x{world}",
                    "search_flags": "-t 0.55 -c 10 -m 30 -f 0.01 -u 256"},
-        "roofline": {"bound": "hbm", "kernel": "k2_cobs<64,8,false>" if args.workload == "gtdb" else "k2_cobs<4,8,false>",
-                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": traffic, "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": k2_avg_ms,
-                     "kmers_kernel_ms": float(np.mean(k1_ms))},
-        "hits_per_step": n_hits_total / max(1, args.steps),
+        "roofline": {"bound": "hbm", "kernel": wl["kernel"], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes_per_launch": alg_bytes,
+                     "kernel_ms": k2_avg_ms, "kmers_kernel_ms": float(np.mean(k1_ms))},
+        "hits_per_step": n_hits_total / max(1, steps),
         "setup_s": setup_s,
     }
 
     # ---- sanity on the last batch: planted reads must come back with their column (the step holds collectives: every
     #      rank takes part, rank 0 evaluates the merged hit list)
     n_last = step(last)
+    hh = None
     if rank == 0:
         hh = h_hits[:n_last].numpy().astype(np.int64)
         cols_last = batches[last][2].cpu().numpy().astype(np.int64)
         got = set(zip(hh[:, 0].tolist(), hh[:, 1].tolist()))
         planted = np.nonzero(cols_last >= 0)[0]
-        rec = sum((int(r), int(cols_last[r])) in got for r in planted[:20000]) / max(1, min(len(planted), 20000))
-        out["planted_recall"] = rec
+        out["planted_recall"] = sum((int(r), int(cols_last[r])) in got for r in planted[:20000]) / max(1, min(len(planted), 20000))
 
     # ---- CPU baseline: the oracle (C restatement of the reference algorithm), timed on this box's host cores on a bounded
     #      sample: the first S blocks copied back from HBM and the first R reads of the last batch.
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and cpu_baseline:
         from oracle import oracle as O
-        S = 1 if args.workload == "gtdb" else wl["n_blocks"]
+        S = 1 if name == "gtdb" else wl["n_blocks"]
         blocks = []
         for b in range(S):
             bi = db.block_info(b)
@@ -268,15 +248,15 @@ def main():
         threads = effective_cpus()
         reads_h = batches[last][0].cpu().numpy()
         offs_h = batches[last][1].cpu().numpy().astype(np.uint64)
-        R = args.cpu_sample_reads or 256
+        R = cpu_sample_reads or 256
         tcpu = 0.0
-        while True:  # grow the sample until it is ~10-30 s of CPU work
+        while True:  # grow the sample until it is several seconds of CPU work
             t1 = time.perf_counter()
             oqk, ohits = odb.search_batch(reads_h[:R * READ_LEN], offs_h[:R + 1], O.default_params(), threads=threads)
             tcpu = time.perf_counter() - t1
-            if args.cpu_sample_reads or tcpu >= 8.0 or R >= B:
+            if cpu_sample_reads or tcpu >= cpu_target_s or R >= B:
                 break
-            R = min(B, int(R * max(2.0, 12.0 / max(tcpu, 1e-3))))
+            R = min(B, int(R * max(2.0, 1.5 * cpu_target_s / max(tcpu, 1e-3))))
         # same-run parity on the sample: GPU hits of these reads restricted to the sampled blocks == oracle hits
         hi_col = blocks[-1][2] + blocks[-1][1]
         g = hh[(hh[:, 0] < R) & (hh[:, 1] < hi_col)]
@@ -288,12 +268,58 @@ def main():
                                          f"(oracle ko_search_batch, index rows copied back from HBM); value scaled by {frac_blocks:.4f} "
                                          "to the whole index", "parity_on_sample": parity, "sample_hits": int(len(ohits))}
         odb.close()
+        del blocks
         assert parity, "GPU hits differ from the CPU oracle on the sample"
 
-    if rank == 0:
-        print(json.dumps(out))
     db.close()
-    if world > 1:
+    del d_hits, batches
+    torch.cuda.empty_cache()
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="gtdb", choices=sorted(WORKLOADS))
+    ap.add_argument("--batch-reads", type=int, default=0)
+    ap.add_argument("--cpu-sample-reads", type=int, default=0, help="0 = size the CPU sample to several seconds of CPU work")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the configs[1] numbers that ride along at N=1")
+    args = ap.parse_args()
+
+    ctx = Ctx()
+    ctx.world = int(os.environ.get("WORLD_SIZE", "1"))
+    ctx.rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != ctx.world:
+        if ctx.world == 1 and args.gpus > 1:
+            raise SystemExit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 "
+                             "--master-port P bench.py --gpus N ...")
+        args.gpus = ctx.world
+    # KMCP_BENCH_SAME_GPU=1 (debugging on a 1-GPU box): every rank uses GPU 0 and the exchange runs over gloo, because
+    # RCCL refuses two ranks on one device.  Never set by the driver; the measured path is nccl = RCCL over xGMI.
+    ctx.same_gpu = os.environ.get("KMCP_BENCH_SAME_GPU") == "1"
+    ctx.dev_index = 0 if ctx.same_gpu else local_rank
+    torch.cuda.set_device(ctx.dev_index)
+    ctx.dev = torch.device("cuda", ctx.dev_index)
+    if ctx.world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if ctx.same_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=ctx.dev)
+
+    out = run_workload(args.workload, ctx, args.steps, args.warmup, args.batch_reads, cpu_baseline=not args.no_cpu_baseline,
+                       cpu_sample_reads=args.cpu_sample_reads)
+    if ctx.world == 1 and args.workload == "gtdb" and not args.no_secondary and not args.batch_reads:
+        sec = run_workload("config1", ctx, min(args.steps, 3), 1, cpu_baseline=not args.no_cpu_baseline, cpu_target_s=3.0)
+        out["secondary"] = {"config1": {k: sec[k] for k in ("value", "unit", "ms_per_step", "config", "roofline", "planted_recall", "cpu_baseline")
+                                        if k in sec}}
+    if ctx.rank == 0:
+        print(json.dumps(out))
+    if ctx.world > 1:
         dist.destroy_process_group()
 
 

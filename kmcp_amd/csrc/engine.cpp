@@ -240,14 +240,27 @@ int upload_block(BlockMeta& b) {
       (void)hipFree(d_tmp);
       return fail(KMCPG_EFORMAT, "kmcp: truncated index file: %s", b.path.c_str());
     }
-    HIPCHK(hipMemcpy(d_tmp, host.data(), nr * rb, hipMemcpyHostToDevice));
-    launch_repack(d_tmp, b.d_rows + r0 * b.stride, nr, rb, b.stride, nullptr);
-    HIPCHK(hipDeviceSynchronize());
+    hipError_t he = hipMemcpy(d_tmp, host.data(), nr * rb, hipMemcpyHostToDevice);
+    if (he == hipSuccess) {
+      launch_repack(d_tmp, b.d_rows + r0 * b.stride, nr, rb, b.stride, nullptr);
+      he = hipDeviceSynchronize();
+    }
+    if (he != hipSuccess) {
+      fclose(f);
+      (void)hipFree(d_tmp);
+      return fail(KMCPG_EDEVICE, "uploading %s: %s", b.path.c_str(), hipGetErrorString(he));
+    }
   }
   fclose(f);
   HIPCHK(hipFree(d_tmp));
   return 0;
 }
+
+// releases device memory too when an open fails half-way
+struct DbCloser {
+  void operator()(kmcpg_db* d) const { kmcpg_close(d); }
+};
+typedef std::unique_ptr<kmcpg_db, DbCloser> DbPtr;
 
 int check_opts(const kmcpg_opts* o, kmcpg_opts* out) {
   kmcpg_opts d{};
@@ -273,7 +286,7 @@ int check_opts(const kmcpg_opts* o, kmcpg_opts* out) {
 extern "C" int kmcpg_open(const char* db_dir, const kmcpg_opts* opts, kmcpg_db** out) {
   if (!db_dir || !out) return fail(KMCPG_EINVAL, "null argument");
   *out = nullptr;
-  std::unique_ptr<kmcpg_db> db(new kmcpg_db());
+  DbPtr db(new kmcpg_db());
   int rc = check_opts(opts, &db->opts);
   if (rc) return rc;
   const bool meta_only = db->opts.device < 0;
@@ -330,7 +343,7 @@ extern "C" int kmcpg_open_synthetic(const kmcpg_synth_spec* s, const kmcpg_opts*
   *out = nullptr;
   if (s->n_blocks == 0 || s->cols_per_block == 0 || s->num_sigs == 0 || s->num_hashes < 1 || s->num_hashes > 4)
     return fail(KMCPG_EINVAL, "bad synthetic spec");
-  std::unique_ptr<kmcpg_db> db(new kmcpg_db());
+  DbPtr db(new kmcpg_db());
   int rc = check_opts(opts, &db->opts);
   if (rc) return rc;
   KMCPG_USE_DEVICE(db);  // a synthetic index only exists in HBM

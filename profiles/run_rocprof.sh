@@ -18,8 +18,8 @@ run() {  # name, rocprof args..., -- bench args
   python $R/profiles/extract_rocprof.py $d/${name}_results.db $OUT/${TAG}_${name} >> $OUT/${TAG}_${name}.err 2>&1
   rm -rf $d
 }
-run gtdb_stats --kernel-trace --stats -d $OUT/_prof_gtdb_stats -o gtdb_stats -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline
-run gtdb_pmc --pmc FETCH_SIZE --kernel-trace -d $OUT/_prof_gtdb_pmc -o gtdb_pmc -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline
-run config1_stats --kernel-trace --stats -d $OUT/_prof_config1_stats -o config1_stats -- python $R/bench.py --workload config1 --steps 3 --warmup 1 --no-cpu-baseline
-run config1_pmc --pmc FETCH_SIZE --kernel-trace -d $OUT/_prof_config1_pmc -o config1_pmc -- python $R/bench.py --workload config1 --steps 2 --warmup 1 --no-cpu-baseline
+run gtdb_stats --kernel-trace --stats -d $OUT/_prof_gtdb_stats -o gtdb_stats -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-secondary
+run gtdb_pmc --pmc FETCH_SIZE --kernel-trace -d $OUT/_prof_gtdb_pmc -o gtdb_pmc -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-secondary
+run config1_stats --kernel-trace --stats -d $OUT/_prof_config1_stats -o config1_stats -- python $R/bench.py --workload config1 --steps 3 --warmup 1 --no-cpu-baseline --no-secondary
+run config1_pmc --pmc FETCH_SIZE --kernel-trace -d $OUT/_prof_config1_pmc -o config1_pmc -- python $R/bench.py --workload config1 --steps 2 --warmup 1 --no-cpu-baseline --no-secondary
 ls -la $OUT | head -40
