@@ -28,13 +28,17 @@ def gather_hits(hits: torch.Tensor, count: torch.Tensor, dst: int = 0, group=Non
         hits, count = hits.cpu(), count.cpu()
     counts = torch.zeros(world, dtype=torch.int64, device=hits.device)
     dist.all_gather_into_tensor(counts, count.reshape(1).to(torch.int64), group=group)
-    bufs = [torch.empty_like(hits) for _ in range(world)] if rank == dst else None
-    dist.gather(hits, bufs, dst=dst, group=group)
+    c = counts.cpu().tolist()  # every rank learns every count: the gather below moves only max(c) rows per rank
+    m = max(c)
+    if m > hits.shape[0]:
+        raise OverflowError(f"hit buffer overflow on a rank: {m} > {hits.shape[0]}")
+    if m == 0:
+        return [hits[:0] for _ in range(world)] if rank == dst else None
+    send = hits[:m].contiguous()
+    bufs = [torch.empty_like(send) for _ in range(world)] if rank == dst else None
+    dist.gather(send, bufs, dst=dst, group=group)
     if rank != dst:
         return None
-    c = counts.cpu().tolist()
-    if max(c) > hits.shape[0]:
-        raise OverflowError(f"hit buffer overflow on a rank: {max(c)} > {hits.shape[0]}")
     return [bufs[r][:c[r]] for r in range(world)]
 
 

@@ -57,6 +57,21 @@ func OpenGPUDB(path string, device int) (*GPUDB, error) {
 	return db, nil
 }
 
+// OpenGPUDBDevices is OpenGPUDB over several GPUs of the node: the index blocks are partitioned over `devices` and every
+// SearchBatch call fans out to all of them (one host thread per GPU inside the library).
+func OpenGPUDBDevices(path string, devices []int32) (*GPUDB, error) {
+	cpath := C.CString(path)
+	defer C.free(unsafe.Pointer(cpath))
+	db := &GPUDB{}
+	if err := gpuErr(C.kmcpg_open_devices(cpath, (*C.int32_t)(unsafe.Pointer(&devices[0])), C.int32_t(len(devices)), &db.h)); err != nil {
+		return nil, err
+	}
+	if err := gpuErr(C.kmcpg_db_info(db.h, &db.Info)); err != nil {
+		return nil, err
+	}
+	return db, nil
+}
+
 // Close replaces UnikIndexDB.Close (util-db-search.go:1119-1150).
 func (db *GPUDB) Close() error { return gpuErr(C.kmcpg_close(db.h)) }
 
