@@ -308,12 +308,110 @@ __device__ __forceinline__ int wg_sketch_mate(const K1Args& a, const uint8_t* __
   return cnt;
 }
 
+// LDS-tiled form of wg_sketch_mate: the bases of one tile (1024 positions + halo) and the k-/s-mer hashes the tile's windows
+// need are staged in LDS, so the window scans never go to global memory.  Usable while the halo fits (L = 2k-s-1 <= 512 for
+// syncmers, w < 512 for minimizers); otherwise the scratch-buffer version above is used.
+constexpr int K1H = 512;
+struct K1Lds {
+  uint64_t hk[K1WG + K1H];
+  uint64_t hs[K1WG + K1H];
+  uint8_t bases[K1WG + 2 * K1H];
+};
+
+__device__ __forceinline__ uint64_t hash_lds(const uint8_t* b, int i, int kk, const uint64_t* tab) {
+  uint64_t f = 0, r = 0;
+  for (int j = 0; j < kk; j++) {
+    f = rol1(f) ^ tab[b[i + j]];
+    r = rol1(r) ^ tab[b[i + kk - 1 - j] & 7];
+  }
+  return f < r ? f : r;
+}
+
+__device__ __forceinline__ bool wg_lds_usable(const K1Args& a) {
+  if (a.k > 255) return false;
+  if (a.mode == 2) return 2 * a.k - (int)a.w_or_s - 1 <= K1H && (int)a.w_or_s >= 1 && (int)a.w_or_s <= a.k;
+  if (a.mode == 1) return (int)a.w_or_s >= 1 && (int)a.w_or_s + 1 < K1H;
+  return true;
+}
+
+__device__ __forceinline__ int wg_sketch_mate_lds(const K1Args& a, const uint8_t* __restrict__ s, int len, const uint64_t* tab, K1Lds& L,
+                                                  uint64_t* __restrict__ out, int cnt, int* s_wave, int tid) {
+  const int k = a.k;
+  const bool scaled = a.scaled != 0;
+  const int nk = len - k + 1;  // k-mer positions
+  if (nk <= 0) return cnt;
+  if (a.mode == 0) {
+    for (int p0 = 0; p0 < nk; p0 += K1WG) {
+      const int nb = min(len - p0, K1WG + k - 1);
+      for (int i = tid; i < nb; i += K1WG) L.bases[i] = s[p0 + i];
+      __syncthreads();
+      const bool v = p0 + tid < nk;
+      const uint64_t h = v ? hash_lds(L.bases, tid, k, tab) : 0;
+      cnt = wg_compact(v && h != 0 && (!scaled || h <= a.max_hash), h, out, cnt, s_wave, tid);
+    }
+    return cnt;
+  }
+  if (a.mode == 2) {  // closed syncmer (see syncmer_mate)
+    const int sm = (int)a.w_or_s, Lw = 2 * k - sm - 1;
+    if (len < Lw) return cnt;
+    const int wsz = 2 * (k - sm);
+    const int nw = wsz > 0 ? len - Lw + 1 : nk;
+    const int ns = len - sm + 1;
+    for (int p0 = 0; p0 < nw; p0 += K1WG) {
+      const int nb = min(len - p0, K1WG + Lw);
+      for (int i = tid; i < nb; i += K1WG) L.bases[i] = s[p0 + i];
+      __syncthreads();
+      const int nkt = min(nk - p0, K1WG + (k - sm)), nst = min(ns - p0, K1WG + max(wsz - 1, 0));
+      for (int i = tid; i < nkt; i += K1WG) L.hk[i] = hash_lds(L.bases, i, k, tab);
+      for (int i = tid; i < nst; i += K1WG) L.hs[i] = hash_lds(L.bases, i, sm, tab);
+      __syncthreads();
+      const bool v = p0 + tid < nw;
+      uint64_t h = 0;
+      if (v) {
+        int pos = tid;
+        if (wsz > 0) {
+          const int m = argmin_left(L.hs, tid, wsz);
+          pos = (m - tid < k - sm) ? m : m + sm - k;
+        }
+        h = L.hk[pos];
+      }
+      cnt = wg_compact(v && h != 0 && (!scaled || h <= a.max_hash), h, out, cnt, s_wave, tid);
+    }
+    return cnt;
+  }
+  // minimizer (see minimizer_mate)
+  const int w = (int)a.w_or_s;
+  if (len < k + w - 1) return cnt;
+  const int nw = nk - w + 1;
+  for (int p0 = 0; p0 < nw; p0 += K1WG) {
+    const int b0 = p0 > 0 ? p0 - 1 : 0, off = p0 - b0;  // the window before the tile's first one is needed too
+    const int nb = min(len - b0, K1WG + w + k);
+    for (int i = tid; i < nb; i += K1WG) L.bases[i] = s[b0 + i];
+    __syncthreads();
+    const int nkt = min(nk - b0, K1WG + w);
+    for (int i = tid; i < nkt; i += K1WG) L.hk[i] = hash_lds(L.bases, i, k, tab);
+    __syncthreads();
+    const int w0 = p0 + tid;
+    const bool v = w0 < nw;
+    int m = -1, pm = -2;
+    if (v) {
+      m = argmin_left(L.hk, off + tid, w);
+      pm = w0 > 0 ? argmin_left(L.hk, off + tid - 1, w) : -2;
+    }
+    const uint64_t h = (v && m != pm) ? L.hk[m] : 0;
+    cnt = wg_compact(v && m != pm && h != 0 && (!scaled || h <= a.max_hash), h, out, cnt, s_wave, tid);
+  }
+  return cnt;
+}
+
 __global__ void __launch_bounds__(K1WG) k1_kmers_wg(const K1Args a) {
   __shared__ uint64_t tab[256];
   __shared__ int s_wave[K1WG / 64];
+  __shared__ K1Lds lds;
   const int tid = threadIdx.x;
   if (tid < 256) tab[tid] = seed_of(tid);
   __syncthreads();
+  const bool use_lds = wg_lds_usable(a);
   for (uint32_t r = blockIdx.x; r < a.n_reads; r += gridDim.x) {
     const uint64_t o1 = a.offs[r];
     const int len1 = (int)(a.offs[r + 1] - o1);
@@ -330,9 +428,12 @@ __global__ void __launch_bounds__(K1WG) k1_kmers_wg(const K1Args a) {
     if (!skip) {
       uint64_t* tk = a.scratch ? a.scratch + o1 + o2 : nullptr;
       uint64_t* ts = a.scratch2 ? a.scratch2 + o1 + o2 : nullptr;
-      cnt = wg_sketch_mate(a, a.seqs + o1, len1, tab, tk, ts, out, 0, s_wave, tid);
+      cnt = use_lds ? wg_sketch_mate_lds(a, a.seqs + o1, len1, tab, lds, out, 0, s_wave, tid)
+                    : wg_sketch_mate(a, a.seqs + o1, len1, tab, tk, ts, out, 0, s_wave, tid);
       cnt1 = cnt;
-      if (pe) cnt = wg_sketch_mate(a, a.seqs2 + o2, len2, tab, tk, ts, out, cnt, s_wave, tid);
+      if (pe)
+        cnt = use_lds ? wg_sketch_mate_lds(a, a.seqs2 + o2, len2, tab, lds, out, cnt, s_wave, tid)
+                      : wg_sketch_mate(a, a.seqs2 + o2, len2, tab, tk, ts, out, cnt, s_wave, tid);
     }
     if (tid == 0) {
       a.nk_raw[r] = cnt;
@@ -383,6 +484,30 @@ __device__ __forceinline__ void bitonic_sort(P a, int n, int tid, int nthreads) 
   }
 }
 
+// order-preserving removal of adjacent repeats: src[0..n) -> dst (a different array); returns the new length (uniform)
+template <int NT, typename P>
+__device__ __forceinline__ int block_unique(P src, int n, uint64_t* __restrict__ dst, int* scan, int tid) {
+  const int chunk = (n + NT - 1) / NT;
+  const int b = min(n, tid * chunk), e = min(n, b + chunk);
+  int c = 0;
+  for (int i = b; i < e; i++) c += (i == 0 || src[i] != src[i - 1]) ? 1 : 0;
+  __syncthreads();
+  scan[tid] = c;
+  __syncthreads();
+  for (int off = 1; off < NT; off <<= 1) {
+    int v = tid >= off ? scan[tid - off] : 0;
+    __syncthreads();
+    scan[tid] += v;
+    __syncthreads();
+  }
+  int pos = scan[tid] - c;
+  const int total = scan[NT - 1];
+  for (int i = b; i < e; i++)
+    if (i == 0 || src[i] != src[i - 1]) dst[pos++] = src[i];
+  __syncthreads();
+  return total;
+}
+
 // Two size classes: n <= 4096 sorts in 32 KB of LDS with 256 threads; larger queries use 1024 threads and 128 KB of
 // LDS (n <= 16384), beyond that the network runs in global memory.
 template <int NT, int CAP>
@@ -405,37 +530,33 @@ __global__ void __launch_bounds__(NT) k_dedup(const DedupArgs a) {
   const uint64_t koff = a.offs[r] + (a.offs2 ? a.offs2[r] : 0);
   uint64_t* g = a.hashes + koff;
   uint64_t* tmp = a.scratch + koff;
-  const bool in_lds = n <= CAP;
-  if (in_lds) {
-    for (int i = tid; i < n; i += NT) s[i] = g[i];
-    __syncthreads();
-    bitonic_sort(s, n, tid, NT);
-  } else {
-    bitonic_sort(g, n, tid, NT);
+  int m = n;  // elements still to sort
+  const uint64_t* in = g;
+  if (NT == 1024) {
+    // long queries: window sketches emit the same k-mer for runs of consecutive windows, so a first order-preserving
+    // pass that drops adjacent repeats shrinks the sort several-fold (10 k syncmer emissions of a HiFi read -> ~2 k)
+    m = block_unique<NT>(g, n, tmp, scan, tid);
     __threadfence_block();
+    __syncthreads();
+    in = tmp;
   }
-  const uint64_t* src = in_lds ? s : g;
-  // unique: contiguous chunk per thread, block scan of the per-chunk counts
-  const int chunk = (n + NT - 1) / NT;
-  const int b = min(n, tid * chunk), e = min(n, b + chunk);
-  int c = 0;
-  for (int i = b; i < e; i++) c += (i == 0 || src[i] != src[i - 1]) ? 1 : 0;
-  scan[tid] = c;
-  __syncthreads();
-  for (int off = 1; off < NT; off <<= 1) {
-    int v = tid >= off ? scan[tid - off] : 0;
+  int total;
+  if (m <= CAP) {
+    for (int i = tid; i < m; i += NT) s[i] = in[i];
     __syncthreads();
-    scan[tid] += v;
-    __syncthreads();
-  }
-  int pos = scan[tid] - c;
-  const int total = scan[NT - 1];
-  uint64_t* dst = in_lds ? g : tmp;
-  for (int i = b; i < e; i++)
-    if (i == 0 || src[i] != src[i - 1]) dst[pos++] = src[i];
-  if (!in_lds) {
-    __syncthreads();
-    for (int i = tid; i < total; i += NT) g[i] = tmp[i];
+    bitonic_sort(s, m, tid, NT);
+    total = block_unique<NT>(s, m, g, scan, tid);
+  } else {
+    uint64_t* w = const_cast<uint64_t*>(in);
+    if (in == g) {  // sort a copy so that the result can be compacted back into g
+      for (int i = tid; i < m; i += NT) tmp[i] = g[i];
+      __threadfence_block();
+      __syncthreads();
+      w = tmp;
+    }
+    bitonic_sort(w, m, tid, NT);
+    __threadfence_block();
+    total = block_unique<NT>(w, m, g, scan, tid);
   }
   // MinMatched is tested on the raw count (:854), NumKmers is the unique count (:910)
   if (tid == 0) a.nk_search[r] = n >= a.min_matched ? total : 0;
