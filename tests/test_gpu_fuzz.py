@@ -1,0 +1,63 @@
+"""Randomised parity sweep: database shape, k, hash count, sketch mode and search flags drawn from a seeded generator;
+every draw must give bit-identical per-read results on the GPU and in the oracle."""
+import numpy as np
+import pytest
+
+from tests import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _draw(rng):
+    k = int(rng.choice([11, 15, 21, 25, 31, 32, 33, 47, 63]))
+    mode = rng.choice(["plain", "plain", "scaled", "syncmer", "minimizer"])
+    kw = {}
+    if mode == "scaled":
+        kw["scale"] = int(rng.choice([2, 5, 16]))
+    elif mode == "syncmer":
+        kw["syncmer_s"] = int(rng.integers(max(1, k - 12), k + 1))
+        if rng.random() < 0.5:
+            kw["scale"] = int(rng.choice([2, 4]))
+    elif mode == "minimizer":
+        kw["minimizer_w"] = int(rng.integers(1, 25))
+    nh = int(rng.choice([1, 1, 2, 3, 4]))
+    fpr = float(rng.choice([0.3, 0.1, 0.01])) if nh == 1 else float(rng.choice([0.05, 0.01]))
+    n_genomes = int(rng.choice([5, 40, 300, 1500]))
+    glen = int(rng.choice([600, 2500, 9000])) if n_genomes <= 300 else 500
+    n_chunks = int(rng.choice([1, 1, 3]))
+    threads = int(rng.choice([1, 2, 8, 32]))
+    return k, kw, nh, fpr, n_genomes, glen, n_chunks, threads
+
+
+@pytest.mark.parametrize("seed", list(range(24)))
+def test_random_configuration(oracle_lib, tmp_path, seed):
+    from kmcp_amd import Database, default_params
+    O = oracle_lib
+    rng = np.random.default_rng(1000 + seed)
+    k, kw, nh, fpr, n_genomes, glen, n_chunks, threads = _draw(rng)
+    genomes = synth.random_genomes(n_genomes, glen, seed=2000 + seed)
+    db_dir = synth.make_db(tmp_path, genomes, k=k, n_chunks=n_chunks, overlap=min(150, glen // 8), num_hashes=nh, fpr=fpr, threads=threads, **kw)
+    # ragged reads: 20 .. 400 bases, some N, some shorter than k / than -m
+    reads = []
+    for i in range(250):
+        L = int(rng.integers(20, 400))
+        reads += synth.sample_reads(genomes, 1, min(L, glen - 1), sub_rate=float(rng.choice([0, 0.01, 0.05])), seed=int(rng.integers(1 << 30)),
+                                    frac_random=0.15, n_rate=float(rng.choice([0, 0, 0.01])))
+    reads += [b"", b"A" * 25, genomes[0][:k], genomes[0][:k - 1]]
+    paired = rng.random() < 0.3
+    reads2 = None
+    if paired:
+        reads2 = [synth.sample_reads(genomes, 1, max(1, min(len(r), glen - 1)), seed=int(rng.integers(1 << 30)), frac_random=0.4)[0] if len(r) else b""
+                  for r in reads]
+    t = float(rng.choice([0.55, 0.4, 0.7, 0.9]))
+    t = max(t, fpr + 0.05)
+    flags = dict(min_qcov=t, min_matched=int(rng.choice([1, 3, 10, 30])), min_qlen=int(rng.choice([0, 30, 70])), max_fpr=float(rng.choice([0.01, 0.05, 1e-6])),
+                 min_tcov=float(rng.choice([0, 0, 0.01])), dedup_threshold=int(rng.choice([256, 256, 64, 100000])), sort_by=int(rng.integers(0, 3)),
+                 top_n_scores=int(rng.choice([0, 0, 1, 2])), try_se=int(paired and rng.random() < 0.5))
+    odb = O.OracleDB(db_dir)
+    try:
+        with Database.open(db_dir, device=0) as db:
+            res = db.search(reads, reads2, params=default_params(**flags))
+        synth.assert_parity(odb, res, reads, reads2, O.default_params(**flags))
+    finally:
+        odb.close()
