@@ -71,6 +71,13 @@ struct K2Args {
   int32_t min_matched;
   int32_t num_hashes;
   int32_t nt_loads;      // non-temporal row loads
+  int32_t split_min;     // >0: queries with more k-mers are handled by the SPLIT launch
+  // long-query (SPLIT) form
+  const uint32_t* long_list;  // indices of the long queries
+  uint32_t n_long;
+  uint32_t split_chunks;      // chunks of SPLIT_CHK k-mers per long query (from the largest one)
+  uint32_t* long_counts;      // [n_long][ncols_total] match counts
+  uint32_t ncols_total;
   kmcpg_hit* hits;
   uint64_t hit_cap;
   unsigned long long* counter;

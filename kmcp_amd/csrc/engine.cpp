@@ -113,6 +113,7 @@ struct kmcpg_db {
   // workspace of kmcpg_query_device
   DevBuf<uint64_t> w_hashes, w_scratch;
   DevBuf<int32_t> w_nk_raw, w_nk1;
+  DevBuf<uint32_t> w_long_list, w_long_meta, w_long_counts;  // long-query (split) path
   // workspace of kmcpg_search_batch
   DevBuf<uint8_t> s_seqs, s_seqs2;
   DevBuf<uint64_t> s_offs, s_offs2, s_counter;
@@ -422,6 +423,9 @@ extern "C" int kmcpg_close(kmcpg_db* db) {
   db->w_scratch.release();
   db->w_nk_raw.release();
   db->w_nk1.release();
+  db->w_long_list.release();
+  db->w_long_meta.release();
+  db->w_long_counts.release();
   db->s_seqs.release();
   db->s_seqs2.release();
   db->s_offs.release();
@@ -587,26 +591,60 @@ extern "C" int kmcpg_query_device(kmcpg_db* db, const uint8_t* d_seqs, const uin
   if (rc) return rc;
   HIPCHK(hipMemsetAsync(d_counters, 0, sizeof(uint64_t), st));
   if (db->profiling) HIPCHK(hipEventRecord(db->ev[1], st));
-  const int npl = maxn <= 255 ? 8 : (maxn <= 65535 ? 16 : (maxn <= 16777215 ? 24 : 0));
-  if (!npl) return fail(KMCPG_EUNSUPPORTED, "queries with more than 16777215 k-mers are not supported");
+  // long queries (whole genomes, -g) are split into chunks of k-mers so that they spread over the chip; short ones keep
+  // the one-wave-per-(query, slot) kernel.  Which queries are long is only known on the device: one small D2H read.
+  const char* sm_env = getenv("KMCPG_SPLIT_MIN");
+  const int32_t split_min = sm_env ? atoi(sm_env) : 16384;
+  uint32_t long_meta[2] = {0, 0};
+  if (split_min > 0 && maxn > (uint64_t)split_min) {
+    if (db->w_long_list.ensure(n_reads + 1) || db->w_long_meta.ensure(2)) return fail(KMCPG_ENOMEM, "hipMalloc failed");
+    HIPCHK(hipMemsetAsync(db->w_long_meta.p, 0, 2 * sizeof(uint32_t), st));
+    launch_list_long(d_qkmers, n_reads, split_min, db->w_long_list.p, db->w_long_meta.p, st);
+    HIPCHK(hipMemcpyAsync(long_meta, db->w_long_meta.p, sizeof long_meta, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+  }
+  const uint32_t n_long = long_meta[0];
+  const uint64_t max_short = n_long ? std::min<uint64_t>(maxn, (uint64_t)split_min) : maxn;
+  const int npl = max_short <= 255 ? 8 : (max_short <= 65535 ? 16 : (max_short <= 16777215 ? 24 : 0));
+  if (!npl) return fail(KMCPG_EUNSUPPORTED, "queries with more than 16777215 k-mers need KMCPG_SPLIT_MIN > 0");
+  K2Args a{};
+  a.blocks = db->d_blockdev;
+  a.n_reads = n_reads;
+  a.hashes = db->w_hashes.p;
+  a.offs = d_offs;
+  a.offs2 = d_offs2;
+  a.nk = d_qkmers;
+  a.min_qcov = p.min_qcov;
+  a.min_matched = p.min_matched;
+  a.num_hashes = db->info.num_hashes;
+  a.nt_loads = getenv("KMCPG_NT_LOADS") ? atoi(getenv("KMCPG_NT_LOADS")) : 1;
+  a.split_min = n_long ? split_min : 0;
+  a.hits = d_hits;
+  a.hit_cap = hit_cap;
+  a.counter = (unsigned long long*)d_counters;
   for (const auto& c : db->classes) {
-    K2Args a{};
-    a.blocks = db->d_blockdev;
     a.slots = c.d_slots;
     a.nslots = (uint32_t)c.slots.size();
-    a.n_reads = n_reads;
-    a.hashes = db->w_hashes.p;
-    a.offs = d_offs;
-    a.offs2 = d_offs2;
-    a.nk = d_qkmers;
-    a.min_qcov = p.min_qcov;
-    a.min_matched = p.min_matched;
-    a.num_hashes = db->info.num_hashes;
-    a.nt_loads = getenv("KMCPG_NT_LOADS") ? atoi(getenv("KMCPG_NT_LOADS")) : 1;
-    a.hits = d_hits;
-    a.hit_cap = hit_cap;
-    a.counter = (unsigned long long*)d_counters;
     if (launch_k2(a, c.lpr, npl, st) != 0) return fail(KMCPG_EINVAL, "batch too large for one launch: split it");
+  }
+  if (n_long) {
+    a.ncols_total = (uint32_t)db->info.n_cols;
+    a.split_chunks = (long_meta[1] + (uint32_t)split_chunk_kmers() - 1) / (uint32_t)split_chunk_kmers();
+    // count arrays of at most ~2 GB at a time
+    const uint32_t group = (uint32_t)std::max<uint64_t>(1, (2ull << 30) / ((uint64_t)a.ncols_total * 4));
+    if (db->w_long_counts.ensure((size_t)std::min<uint32_t>(group, n_long) * a.ncols_total)) return fail(KMCPG_ENOMEM, "hipMalloc failed");
+    a.long_counts = db->w_long_counts.p;
+    for (uint32_t g0 = 0; g0 < n_long; g0 += group) {
+      a.long_list = db->w_long_list.p + g0;
+      a.n_long = std::min<uint32_t>(group, n_long - g0);
+      HIPCHK(hipMemsetAsync(a.long_counts, 0, (size_t)a.n_long * a.ncols_total * sizeof(uint32_t), st));
+      for (const auto& c : db->classes) {
+        a.slots = c.d_slots;
+        a.nslots = (uint32_t)c.slots.size();
+        if (launch_k2_split(a, c.lpr, st) != 0) return fail(KMCPG_EINVAL, "batch too large for one launch: split it");
+      }
+      launch_threshold_long(a, st);
+    }
   }
   if (db->profiling) {
     HIPCHK(hipEventRecord(db->ev[2], st));

@@ -610,7 +610,12 @@ __device__ __forceinline__ void csa8(uint32_t (&pl)[NPL], uint32_t x0, uint32_t 
   }
 }
 
-template <int LPR, int NPL, bool MULTI>
+// SPLIT = true is the long-query form: a unit is (long query, slot, chunk of SPLIT_CHK k-mers); its counts are added to a
+// per-query u32 array with atomics and thresholded by k_threshold_long, so a whole genome spreads over the chip instead
+// of one wave per (query, slot).
+constexpr int SPLIT_CHK = 8192;
+
+template <int LPR, int NPL, bool MULTI, bool SPLIT>
 __global__ void __launch_bounds__(256) k2_cobs(const K2Args a) {
   constexpr int G = 64 / LPR;
   constexpr int PAIRS = MULTI ? 256 : 1024;
@@ -621,17 +626,29 @@ __global__ void __launch_bounds__(256) k2_cobs(const K2Args a) {
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int g = lane / LPR, li = lane % LPR;
-  const uint64_t total_units = (uint64_t)a.n_reads * a.nslots;
+  const uint64_t per_read = SPLIT ? (uint64_t)a.nslots * a.split_chunks : (uint64_t)a.nslots;
+  const uint64_t total_units = (SPLIT ? (uint64_t)a.n_long : (uint64_t)a.n_reads) * per_read;
   const uint64_t u = ((uint64_t)blockIdx.x * 4 + wave) * G + g;
   const bool valid = u < total_units;
-  uint32_t r = 0, sidx = 0;
+  uint32_t r = 0, sidx = 0, li_long = 0;
+  int k0 = 0;
   if (valid) {
-    r = (uint32_t)(u / a.nslots);
-    sidx = (uint32_t)(u % a.nslots);
+    if (SPLIT) {
+      li_long = (uint32_t)(u / per_read);
+      const uint32_t rem = (uint32_t)(u % per_read);
+      sidx = rem / a.split_chunks;
+      k0 = (int)(rem % a.split_chunks) * SPLIT_CHK;
+      r = a.long_list[li_long];
+    } else {
+      r = (uint32_t)(u / a.nslots);
+      sidx = (uint32_t)(u % a.nslots);
+    }
   }
   const Slot slot = a.slots[sidx];
   const BlockDev* __restrict__ bd = a.blocks + slot.block;
-  const int n = valid ? a.nk[r] : 0;
+  int n = valid ? a.nk[r] : 0;
+  if (SPLIT) n = max(0, min(n - k0, SPLIT_CHK));
+  else if (a.split_min > 0 && n > a.split_min) n = 0;  // long queries are left to the SPLIT launch
   int nmax = n;
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) nmax = max(nmax, __shfl_xor(nmax, off));
@@ -641,7 +658,7 @@ __global__ void __launch_bounds__(256) k2_cobs(const K2Args a) {
   const uint32_t boff = (slot.tile * LPR + li) * 16u;
   const bool active = n > 0 && boff < stride;
   const uint8_t* __restrict__ base = bd->rows + boff;
-  const uint64_t koff = a.offs[r] + (a.offs2 ? a.offs2[r] : 0);
+  const uint64_t koff = a.offs[r] + (a.offs2 ? a.offs2[r] : 0) + (uint64_t)k0;
   const int nh = MULTI ? a.num_hashes : 1;
 
   uint32_t pl[4][NPL];
@@ -704,6 +721,21 @@ __global__ void __launch_bounds__(256) k2_cobs(const K2Args a) {
   }
 
   if (!active) return;
+  if (SPLIT) {
+    // partial counts of this chunk -> the query's count array (consecutive lanes hit consecutive words)
+    uint32_t* __restrict__ acc = a.long_counts + (uint64_t)li_long * a.ncols_total + bd->col_base;
+#pragma unroll
+    for (int d = 0; d < 4; d++) {
+      for (int q = 0; q < 32; q++) {
+        uint32_t count = 0;
+#pragma unroll
+        for (int p = 0; p < NPL; p++) count |= ((pl[d][p] >> q) & 1u) << p;
+        const uint32_t col = (boff + (uint32_t)d * 4u + (uint32_t)(q >> 3)) * 8u + (7u - (uint32_t)(q & 7));
+        if (count && col < bd->ncols) atomicAdd(acc + col, count);
+      }
+    }
+    return;
+  }
   // ---- integer threshold (:7468-7470): count >= minMatched && float64(count) > nHashes*queryCov
   const double thr = __dmul_rn((double)n, a.min_qcov);
   uint32_t cmin = (uint32_t)thr + 1u;  // smallest integer c with (double)c > thr  (thr >= 0)
@@ -744,9 +776,9 @@ static void launch_k2_t(const K2Args& a, bool multi, hipStream_t st) {
   const uint64_t blocks = (waves + 3) / 4;
   if (blocks == 0) return;
   if (multi)
-    hipLaunchKernelGGL((k2_cobs<LPR, NPL, true>), dim3((unsigned)blocks), dim3(256), 0, st, a);
+    hipLaunchKernelGGL((k2_cobs<LPR, NPL, true, false>), dim3((unsigned)blocks), dim3(256), 0, st, a);
   else
-    hipLaunchKernelGGL((k2_cobs<LPR, NPL, false>), dim3((unsigned)blocks), dim3(256), 0, st, a);
+    hipLaunchKernelGGL((k2_cobs<LPR, NPL, false, false>), dim3((unsigned)blocks), dim3(256), 0, st, a);
 }
 
 template <int LPR>
@@ -768,6 +800,76 @@ int launch_k2(const K2Args& a, int lpr, int npl, hipStream_t st) {
     case 64: return launch_k2_l<64>(a, npl, multi, st);
     default: return -1;
   }
+}
+
+template <int LPR>
+static void launch_k2_split_t(const K2Args& a, bool multi, hipStream_t st) {
+  constexpr int G = 64 / LPR;
+  const uint64_t units = (uint64_t)a.n_long * a.nslots * a.split_chunks;
+  const uint64_t blocks = ((units + G - 1) / G + 3) / 4;
+  if (blocks == 0) return;
+  if (multi)
+    hipLaunchKernelGGL((k2_cobs<LPR, 16, true, true>), dim3((unsigned)blocks), dim3(256), 0, st, a);
+  else
+    hipLaunchKernelGGL((k2_cobs<LPR, 16, false, true>), dim3((unsigned)blocks), dim3(256), 0, st, a);
+}
+
+int split_chunk_kmers() { return SPLIT_CHK; }
+
+int launch_k2_split(const K2Args& a, int lpr, hipStream_t st) {
+  const bool multi = a.num_hashes > 1;
+  if ((uint64_t)a.n_long * a.nslots * a.split_chunks / (256 / lpr) > 0x7fffffffULL) return -2;
+  switch (lpr) {
+    case 4: launch_k2_split_t<4>(a, multi, st); return 0;
+    case 16: launch_k2_split_t<16>(a, multi, st); return 0;
+    case 64: launch_k2_split_t<64>(a, multi, st); return 0;
+    default: return -1;
+  }
+}
+
+// queries with more than split_min k-mers: meta[0] = how many, meta[1] = their largest NumKmers
+__global__ void k_list_long(const int32_t* __restrict__ nk, uint32_t n_reads, int32_t split_min, uint32_t* __restrict__ list, uint32_t* __restrict__ meta) {
+  const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r < n_reads && nk[r] > split_min) {
+    list[atomicAdd(&meta[0], 1u)] = r;
+    atomicMax(&meta[1], (uint32_t)nk[r]);
+  }
+}
+
+void launch_list_long(const int32_t* nk, uint32_t n_reads, int32_t split_min, uint32_t* list, uint32_t* meta, hipStream_t st) {
+  if (n_reads == 0) return;
+  hipLaunchKernelGGL(k_list_long, dim3((n_reads + 255) / 256), dim3(256), 0, st, nk, n_reads, split_min, list, meta);
+}
+
+// threshold over the accumulated counts of the long queries (same integer rule as the k2_cobs epilogue)
+__global__ void k_threshold_long(const K2Args a) {
+  const uint64_t total = (uint64_t)a.n_long * a.ncols_total;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (uint64_t)gridDim.x * blockDim.x) {
+    const uint32_t c = a.long_counts[i];
+    if (c == 0) continue;
+    const uint32_t li = (uint32_t)(i / a.ncols_total), col = (uint32_t)(i % a.ncols_total);
+    const uint32_t r = a.long_list[li];
+    const double thr = __dmul_rn((double)a.nk[r], a.min_qcov);
+    uint32_t cmin = (uint32_t)thr + 1u;
+    if (cmin < (uint32_t)a.min_matched) cmin = (uint32_t)a.min_matched;
+    if (c >= cmin) {
+      const unsigned long long idx = atomicAdd(a.counter, 1ULL);
+      if (idx < a.hit_cap) {
+        kmcpg_hit hit;
+        hit.read = r;
+        hit.col = col;
+        hit.count = c;
+        a.hits[idx] = hit;
+      }
+    }
+  }
+}
+
+void launch_threshold_long(const K2Args& a, hipStream_t st) {
+  const uint64_t total = (uint64_t)a.n_long * a.ncols_total;
+  if (total == 0) return;
+  unsigned blocks = (unsigned)((total + 255) / 256 > 65536 ? 65536 : (total + 255) / 256);
+  hipLaunchKernelGGL(k_threshold_long, dim3(blocks), dim3(256), 0, st, a);
 }
 
 void launch_k1(const K1Args& a, uint32_t max_read_len, hipStream_t st) {

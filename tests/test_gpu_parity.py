@@ -281,3 +281,23 @@ def test_in_process_multi_device_handle(G, oracle_lib, tmp_path):
             assert synth.assert_parity(odb, res, r1, r2, O.default_params(try_se=1)) > 100
     finally:
         odb.close()
+
+
+@pytest.mark.parametrize("split_min", ["50", "3000"])
+def test_long_query_split_path(G, oracle_lib, tmp_path, monkeypatch, split_min):
+    """The chunked long-query form of the COBS kernel (whole genomes): forced onto ordinary reads with KMCPG_SPLIT_MIN so
+    that every kernel class (3-byte, 125-byte, 1125-byte rows; 1 and 3 hashes) and many chunk boundaries are exercised."""
+    O = oracle_lib
+    monkeypatch.setenv("KMCPG_SPLIT_MIN", split_min)
+    # narrow rows + long reads (several chunks of 8192 k-mers when split_min is small)
+    genomes = synth.random_genomes(12, 30000, seed=90)
+    db_dir = synth.make_db(tmp_path / "a", genomes, k=21, n_chunks=2, overlap=150, threads=4)
+    reads = synth.sample_reads(genomes, 200, 150, seed=91) + [genomes[0], genomes[1][:20000], genomes[2][:8192 + 20], genomes[3][:8192 + 21]]
+    n, res = _run(G, O, db_dir, reads, oracle_kw=dict(dedup_threshold=1 << 30), gpu_kw=dict(dedup_threshold=1 << 30))
+    assert n > 150 and int(res.qkmers[200]) == 29980
+    # medium and wide rows in one database, 3 hashes, FracMinHash
+    genomes = synth.random_genomes(9100, 500, seed=92)
+    db_dir = synth.make_db(tmp_path / "b", genomes, k=25, num_hashes=3, fpr=0.05, block_size=9000)
+    reads = synth.sample_reads(genomes, 300, 300, sub_rate=0.01, seed=93)
+    n, _ = _run(G, O, db_dir, reads)
+    assert n > 150

@@ -69,6 +69,16 @@ def main():
         lens = torch.full((n,), 4000000, dtype=torch.int64)
         s, o, t = rand_reads(n, lens, 5)
         out["genome_4Mbp_fracminhash_vs_50k_refs"] = run(db, s, o, n, t, 4000000, default_params(min_qcov=0.4, sort_by=2))
+    # whole-genome query, all k-mers (`-g`), against the GTDB-scale index: the reference's "whole-genome query" benchmark
+    # (benchmarks/searching/README.md:139-163: 12.7-13.7 s hot on 40 threads against an unchunked 55 GB index)
+    free_b, _ = torch.cuda.mem_get_info(dev)
+    if free_b > 80e9:
+        spec = lib.SynthSpec(k=21, num_hashes=1, fpr=0.3, n_blocks=32, cols_per_block=14976, num_sigs=968700, kmers_per_col=345510, seed=4)
+        with Database.open_synthetic(spec) as db:
+            n = 2
+            lens = torch.full((n,), 5000000, dtype=torch.int64)
+            s, o, t = rand_reads(n, lens, 6)
+            out["genome_5Mbp_all_kmers_vs_gtdb_scale"] = run(db, s, o, n, t, 5000000, default_params(min_qcov=0.5, dedup_threshold=256))
     print(json.dumps(out, indent=1))
 
 
