@@ -114,6 +114,8 @@ struct kmcpg_db {
   DevBuf<uint64_t> w_hashes, w_scratch;
   DevBuf<int32_t> w_nk_raw, w_nk1;
   DevBuf<uint32_t> w_long_list, w_long_meta, w_long_counts;  // long-query (split) path
+  DevBuf<uint64_t> w_huge_info;                             // whole-genome queries: (read, n, offset)
+  DevBuf<uint8_t> w_huge_temp;                              // hipCUB temporary storage
   // workspace of kmcpg_search_batch
   DevBuf<uint8_t> s_seqs, s_seqs2;
   DevBuf<uint64_t> s_offs, s_offs2, s_counter;
@@ -426,6 +428,8 @@ extern "C" int kmcpg_close(kmcpg_db* db) {
   db->w_long_list.release();
   db->w_long_meta.release();
   db->w_long_counts.release();
+  db->w_huge_info.release();
+  db->w_huge_temp.release();
   db->s_seqs.release();
   db->s_seqs2.release();
   db->s_offs.release();
@@ -534,6 +538,32 @@ int run_kmers(kmcpg_db* db, const uint8_t* d_seqs, const uint64_t* d_offs, const
     d.nk_raw = d_nk_raw;
     d.nk_search = d_nk_search;
     launch_dedup(d, ub, st);
+    if (ub > HUGE_MIN) {
+      // whole-genome queries: which ones they are is only known on the device -> one small read-back, then a device-wide
+      // sort + unique per such query
+      const int32_t thr = std::max<int32_t>((int32_t)HUGE_MIN, p.dedup_threshold);
+      uint32_t meta[2] = {0, 0};
+      if (db->w_long_list.ensure(n_reads + 1) || db->w_long_meta.ensure(2)) return fail(KMCPG_ENOMEM, "hipMalloc failed");
+      HIPCHK(hipMemsetAsync(db->w_long_meta.p, 0, 2 * sizeof(uint32_t), st));
+      launch_list_long(d_nk_raw, n_reads, thr, db->w_long_list.p, db->w_long_meta.p, st);
+      HIPCHK(hipMemcpyAsync(meta, db->w_long_meta.p, sizeof meta, hipMemcpyDeviceToHost, st));
+      HIPCHK(hipStreamSynchronize(st));
+      if (meta[0]) {
+        const size_t tb = huge_dedup_temp_bytes(meta[1]);
+        if (db->w_huge_info.ensure(3 * (size_t)meta[0] + 1) || db->w_huge_temp.ensure(tb + 64)) return fail(KMCPG_ENOMEM, "hipMalloc failed");
+        launch_gather_huge(db->w_long_list.p, meta[0], d_nk_raw, d_offs, d_offs2, db->w_huge_info.p, st);
+        std::vector<uint64_t> hinfo(3 * (size_t)meta[0]);
+        HIPCHK(hipMemcpyAsync(hinfo.data(), db->w_huge_info.p, hinfo.size() * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        int* d_num = (int*)db->w_huge_temp.p;  // first 64 bytes: the unique count
+        for (uint32_t i = 0; i < meta[0]; i++) {
+          const uint32_t r = (uint32_t)hinfo[3 * i], n = (uint32_t)hinfo[3 * i + 1];
+          const uint64_t koff = hinfo[3 * i + 2];
+          if (huge_dedup(d_hashes + koff, d_scratch + koff, n, d_num, db->w_huge_temp.p + 64, tb, d_nk_search, r, p.min_matched, st) != 0)
+            return fail(KMCPG_EDEVICE, "device-wide sort of a %u-k-mer query failed", n);
+        }
+      }
+    }
   } else {
     launch_nk_simple(d_nk_raw, d_nk_search, n_reads, p.min_matched, st);
   }

@@ -896,7 +896,7 @@ void launch_dedup(DedupArgs a, uint64_t max_n, hipStream_t st) {
   hipLaunchKernelGGL((k_dedup<256, 4096>), dim3(a.n_reads), dim3(256), 0, st, a);
   if (max_n > 4096) {
     a.lo = 4096;
-    a.hi = 0x7fffffff;
+    a.hi = max_n > HUGE_MIN ? (int32_t)HUGE_MIN : 0x7fffffff;  // beyond that: device-wide sort (sort_huge.hip)
     hipLaunchKernelGGL((k_dedup<1024, 16384>), dim3(a.n_reads), dim3(1024), 0, st, a);
   }
 }

@@ -8,7 +8,7 @@ namespace kmcpg {
 
 void launch_k1(const K1Args& a, uint32_t max_read_len, hipStream_t st);
 void launch_nk_simple(const int32_t* nk_raw, int32_t* nk_search, uint32_t n, int32_t min_matched, hipStream_t st);
-void launch_dedup(DedupArgs a, uint64_t max_n, hipStream_t st);
+void launch_dedup(DedupArgs a, uint64_t max_n, hipStream_t st);  // queries above HUGE_MIN are left to huge_dedup
 // lpr in {4,16,64}: lanes per row tile; npl in {8,16,24}: counter planes.  <0 on bad arguments.
 int launch_k2(const K2Args& a, int lpr, int npl, hipStream_t st);
 // long queries: chunked counting into a.long_counts, then one thresholding pass
@@ -24,5 +24,13 @@ void launch_plant(const BlockDev& bd, uint32_t col, int num_hashes, const uint64
 
 void launch_plant_reads(const BlockDev* blocks, uint32_t nblocks, int num_hashes, const uint64_t* hashes, const uint64_t* offs,
                         const int32_t* nk, const uint32_t* cols, uint32_t n_reads, hipStream_t st);
+
+// queries with more than HUGE_MIN k-mers: device-wide sort + unique (sort_huge.hip)
+constexpr uint32_t HUGE_MIN = 65536;
+size_t huge_dedup_temp_bytes(uint32_t max_n);
+void launch_gather_huge(const uint32_t* list, uint32_t n, const int32_t* nk_raw, const uint64_t* offs, const uint64_t* offs2, uint64_t* out,
+                        hipStream_t st);
+int huge_dedup(uint64_t* keys, uint64_t* tmp, uint32_t n, int* d_num, void* d_temp, size_t temp_bytes, int32_t* nk_search, uint32_t r, int min_matched,
+               hipStream_t st);
 
 }  // namespace kmcpg
