@@ -75,7 +75,8 @@ struct K2Args {
   // long-query (SPLIT) form
   const uint32_t* long_list;  // indices of the long queries
   uint32_t n_long;
-  uint32_t split_chunks;      // chunks of SPLIT_CHK k-mers per long query (from the largest one)
+  uint32_t split_chk;         // k-mers per chunk (<= 8192: 16 counter planes)
+  uint32_t split_chunks;      // chunks per long query (from the largest one)
   uint32_t* long_counts;      // [n_long][ncols_total] match counts
   uint32_t ncols_total;
   kmcpg_hit* hits;

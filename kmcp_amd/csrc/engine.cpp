@@ -624,7 +624,7 @@ extern "C" int kmcpg_query_device(kmcpg_db* db, const uint8_t* d_seqs, const uin
   // long queries (whole genomes, -g) are split into chunks of k-mers so that they spread over the chip; short ones keep
   // the one-wave-per-(query, slot) kernel.  Which queries are long is only known on the device: one small D2H read.
   const char* sm_env = getenv("KMCPG_SPLIT_MIN");
-  const int32_t split_min = sm_env ? atoi(sm_env) : 16384;
+  const int32_t split_min = sm_env ? atoi(sm_env) : 2048;
   uint32_t long_meta[2] = {0, 0};
   if (split_min > 0 && maxn > (uint64_t)split_min) {
     if (db->w_long_list.ensure(n_reads + 1) || db->w_long_meta.ensure(2)) return fail(KMCPG_ENOMEM, "hipMalloc failed");
@@ -633,8 +633,16 @@ extern "C" int kmcpg_query_device(kmcpg_db* db, const uint8_t* d_seqs, const uin
     HIPCHK(hipMemcpyAsync(long_meta, db->w_long_meta.p, sizeof long_meta, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
   }
-  const uint32_t n_long = long_meta[0];
-  const uint64_t max_short = n_long ? std::min<uint64_t>(maxn, (uint64_t)split_min) : maxn;
+  uint32_t n_long = long_meta[0];
+  size_t total_slots = 0;
+  for (const auto& c : db->classes) total_slots += c.slots.size();
+  // splitting pays when the long queries alone would leave the chip idle (few (query, slot) pairs) or need more than 16
+  // counter planes; a batch of thousands of 10-kb reads already fills it and keeps the plain kernel (unless forced by env)
+  if (n_long && !sm_env && (uint64_t)n_long * total_slots > 16384 && long_meta[1] <= 65535) n_long = 0;
+  // largest NumKmers the plain kernel will meet: bounded by the read length, and exactly known once the long ones were listed
+  uint64_t max_short = maxn;
+  if (split_min > 0 && maxn > (uint64_t)split_min)
+    max_short = n_long ? (uint64_t)split_min : std::max<uint64_t>(long_meta[1], (uint64_t)split_min);
   const int npl = max_short <= 255 ? 8 : (max_short <= 65535 ? 16 : (max_short <= 16777215 ? 24 : 0));
   if (!npl) return fail(KMCPG_EUNSUPPORTED, "queries with more than 16777215 k-mers need KMCPG_SPLIT_MIN > 0");
   K2Args a{};
@@ -659,7 +667,11 @@ extern "C" int kmcpg_query_device(kmcpg_db* db, const uint8_t* d_seqs, const uin
   }
   if (n_long) {
     a.ncols_total = (uint32_t)db->info.n_cols;
-    a.split_chunks = (long_meta[1] + (uint32_t)split_chunk_kmers() - 1) / (uint32_t)split_chunk_kmers();
+    // ~64 chunks for the largest query, 1024..8192 k-mers each (at most 8192: the chunk's counts fit 16 planes)
+    uint32_t chk = 1024;
+    while (chk < 8192 && (uint64_t)chk * 64 < long_meta[1]) chk <<= 1;
+    a.split_chk = chk;
+    a.split_chunks = (long_meta[1] + chk - 1) / chk;
     // count arrays of at most ~2 GB at a time
     const uint32_t group = (uint32_t)std::max<uint64_t>(1, (2ull << 30) / ((uint64_t)a.ncols_total * 4));
     if (db->w_long_counts.ensure((size_t)std::min<uint32_t>(group, n_long) * a.ncols_total)) return fail(KMCPG_ENOMEM, "hipMalloc failed");

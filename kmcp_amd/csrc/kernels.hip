@@ -610,10 +610,9 @@ __device__ __forceinline__ void csa8(uint32_t (&pl)[NPL], uint32_t x0, uint32_t 
   }
 }
 
-// SPLIT = true is the long-query form: a unit is (long query, slot, chunk of SPLIT_CHK k-mers); its counts are added to a
+// SPLIT = true is the long-query form: a unit is (long query, slot, chunk of a.split_chk <= 8192 k-mers); its counts are added to a
 // per-query u32 array with atomics and thresholded by k_threshold_long, so a whole genome spreads over the chip instead
 // of one wave per (query, slot).
-constexpr int SPLIT_CHK = 8192;
 
 template <int LPR, int NPL, bool MULTI, bool SPLIT>
 __global__ void __launch_bounds__(256) k2_cobs(const K2Args a) {
@@ -637,7 +636,7 @@ __global__ void __launch_bounds__(256) k2_cobs(const K2Args a) {
       li_long = (uint32_t)(u / per_read);
       const uint32_t rem = (uint32_t)(u % per_read);
       sidx = rem / a.split_chunks;
-      k0 = (int)(rem % a.split_chunks) * SPLIT_CHK;
+      k0 = (int)(rem % a.split_chunks) * (int)a.split_chk;
       r = a.long_list[li_long];
     } else {
       r = (uint32_t)(u / a.nslots);
@@ -647,7 +646,7 @@ __global__ void __launch_bounds__(256) k2_cobs(const K2Args a) {
   const Slot slot = a.slots[sidx];
   const BlockDev* __restrict__ bd = a.blocks + slot.block;
   int n = valid ? a.nk[r] : 0;
-  if (SPLIT) n = max(0, min(n - k0, SPLIT_CHK));
+  if (SPLIT) n = max(0, min(n - k0, (int)a.split_chk));
   else if (a.split_min > 0 && n > a.split_min) n = 0;  // long queries are left to the SPLIT launch
   int nmax = n;
 #pragma unroll
@@ -813,8 +812,6 @@ static void launch_k2_split_t(const K2Args& a, bool multi, hipStream_t st) {
   else
     hipLaunchKernelGGL((k2_cobs<LPR, 16, false, true>), dim3((unsigned)blocks), dim3(256), 0, st, a);
 }
-
-int split_chunk_kmers() { return SPLIT_CHK; }
 
 int launch_k2_split(const K2Args& a, int lpr, hipStream_t st) {
   const bool multi = a.num_hashes > 1;

@@ -12,7 +12,6 @@ void launch_dedup(DedupArgs a, uint64_t max_n, hipStream_t st);  // queries abov
 // lpr in {4,16,64}: lanes per row tile; npl in {8,16,24}: counter planes.  <0 on bad arguments.
 int launch_k2(const K2Args& a, int lpr, int npl, hipStream_t st);
 // long queries: chunked counting into a.long_counts, then one thresholding pass
-int split_chunk_kmers();
 int launch_k2_split(const K2Args& a, int lpr, hipStream_t st);
 void launch_list_long(const int32_t* nk, uint32_t n_reads, int32_t split_min, uint32_t* list, uint32_t* meta, hipStream_t st);
 void launch_threshold_long(const K2Args& a, hipStream_t st);
