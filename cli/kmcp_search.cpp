@@ -217,7 +217,7 @@ static Options parse_args(int argc, char** argv) {
 // ------------------------------------------------------------------------------------------------
 class FastxReader {
  public:
-  explicit FastxReader(const std::string& path) {
+  explicit FastxReader(const std::string& path) : buf_(4u << 20) {
     gz_ = (path == "-") ? gzdopen(0, "rb") : gzopen(path.c_str(), "rb");
     if (!gz_) die("%s: %s", path.c_str(), strerror(errno));
     gzbuffer(gz_, 1 << 20);
@@ -227,52 +227,74 @@ class FastxReader {
   bool next(std::string* id, std::string* seq) {
     id->clear();
     seq->clear();
-    std::string line;
+    const char* l;
+    size_t n;
     if (!have_hdr_) {
-      while (getline(&line)) {
-        if (line.empty()) continue;
-        if (line[0] == '>' || line[0] == '@') { hdr_ = line; have_hdr_ = true; break; }
+      while (getline(&l, &n)) {
+        if (n == 0) continue;
+        if (l[0] == '>' || l[0] == '@') { hdr_.assign(l, n); have_hdr_ = true; break; }
       }
       if (!have_hdr_) return false;
     }
     const bool fastq = hdr_[0] == '@';
     size_t e = 1;
     while (e < hdr_.size() && hdr_[e] != ' ' && hdr_[e] != '\t') e++;
-    *id = hdr_.substr(1, e - 1);
+    id->assign(hdr_, 1, e - 1);
     have_hdr_ = false;
     if (!fastq) {
-      while (getline(&line)) {
-        if (!line.empty() && line[0] == '>') { hdr_ = line; have_hdr_ = true; break; }
-        seq->append(line);
+      while (getline(&l, &n)) {
+        if (n && l[0] == '>') { hdr_.assign(l, n); have_hdr_ = true; break; }
+        seq->append(l, n);
       }
       return true;
     }
     // FASTQ: sequence lines up to '+', then as many quality characters as bases
-    while (getline(&line)) {
-      if (!line.empty() && line[0] == '+') break;
-      seq->append(line);
+    while (getline(&l, &n)) {
+      if (n && l[0] == '+') break;
+      seq->append(l, n);
     }
     size_t q = 0;
-    while (q < seq->size() && getline(&line)) q += line.size();
+    while (q < seq->size() && getline(&l, &n)) q += n;
     return true;
   }
 
  private:
-  bool getline(std::string* out) {
-    out->clear();
-    char buf[1 << 16];
-    bool any = false;
-    while (gzgets(gz_, buf, sizeof buf)) {
-      any = true;
-      size_t n = strlen(buf);
-      bool eol = n && buf[n - 1] == '\n';
-      while (n && (buf[n - 1] == '\n' || buf[n - 1] == '\r')) n--;
-      out->append(buf, n);
-      if (eol) break;
+  // next line without its terminator ("\n" or "\r\n"); the pointer is valid until the next call
+  bool getline(const char** out, size_t* n) {
+    for (;;) {
+      const char* nl = pos_ < end_ ? (const char*)memchr(buf_.data() + pos_, '\n', end_ - pos_) : nullptr;
+      if (nl) {
+        size_t len = (size_t)(nl - (buf_.data() + pos_));
+        *out = buf_.data() + pos_;
+        pos_ += len + 1;
+        while (len && (*out)[len - 1] == '\r') len--;
+        *n = len;
+        return true;
+      }
+      if (eof_) {
+        if (pos_ >= end_) return false;
+        size_t len = end_ - pos_;
+        *out = buf_.data() + pos_;
+        pos_ = end_;
+        while (len && (*out)[len - 1] == '\r') len--;
+        *n = len;
+        return true;
+      }
+      // keep the partial line, refill behind it
+      const size_t tail = end_ - pos_;
+      if (tail && pos_) memmove(&buf_[0], buf_.data() + pos_, tail);
+      pos_ = 0;
+      end_ = tail;
+      if (end_ == buf_.size()) buf_.resize(buf_.size() * 2);  // a line longer than the buffer (whole-genome FASTA on one line)
+      const int got = gzread(gz_, &buf_[end_], (unsigned)std::min<size_t>(buf_.size() - end_, 1u << 30));
+      if (got <= 0) eof_ = true;
+      else end_ += (size_t)got;
     }
-    return any;
   }
   gzFile gz_ = nullptr;
+  std::vector<char> buf_;
+  size_t pos_ = 0, end_ = 0;
+  bool eof_ = false;
   std::string hdr_;
   bool have_hdr_ = false;
 };
@@ -323,34 +345,105 @@ class Queue {
   bool closed_ = false;
 };
 
+// one complete gzip member holding `in` (deflate level 6 as compress/gzip's default in the reference's outStream)
+static std::string gzip_member(const std::string& in) {
+  z_stream z;
+  memset(&z, 0, sizeof z);
+  if (deflateInit2(&z, 6, Z_DEFLATED, 15 + 16, 8, Z_DEFAULT_STRATEGY) != Z_OK) die("zlib: deflateInit2 failed");
+  std::string out;
+  out.resize(deflateBound(&z, (uLong)in.size()) + 64);
+  z.next_in = (Bytef*)in.data();
+  z.avail_in = (uInt)in.size();
+  z.next_out = (Bytef*)&out[0];
+  z.avail_out = (uInt)out.size();
+  if (deflate(&z, Z_FINISH) != Z_STREAM_END) die("zlib: deflate failed");
+  out.resize(z.total_out);
+  deflateEnd(&z);
+  return out;
+}
+
 class Out {
  public:
   explicit Out(const std::string& path) {
     gz_ = path.size() > 3 && path.compare(path.size() - 3, 3, ".gz") == 0;
-    if (gz_) {
-      g_ = gzopen(path.c_str(), "wb");
-      if (!g_) die("%s: %s", path.c_str(), strerror(errno));
-      gzbuffer(g_, 1 << 20);
-    } else {
-      f_ = path == "-" ? stdout : fopen(path.c_str(), "wb");
-      if (!f_) die("%s: %s", path.c_str(), strerror(errno));
-    }
+    f_ = path == "-" ? stdout : fopen(path.c_str(), "wb");
+    if (!f_) die("%s: %s", path.c_str(), strerror(errno));
   }
+  bool gz() const { return gz_; }
+  // text: compressed here when the file is .gz
   void write(const std::string& s) {
     if (s.empty()) return;
-    if (gz_) gzwrite(g_, s.data(), (unsigned)s.size());
-    else fwrite(s.data(), 1, s.size(), f_);
+    if (gz_) write_raw(gzip_member(s));
+    else write_raw(s);
+  }
+  // bytes that are already in the file's encoding
+  void write_raw(const std::string& s) {
+    if (!s.empty() && fwrite(s.data(), 1, s.size(), f_) != s.size()) die("write failed: %s", strerror(errno));
   }
   void close() {
-    if (gz_) gzclose(g_);
-    else if (f_ != stdout) fclose(f_);
+    if (f_ != stdout) fclose(f_);
     else fflush(f_);
   }
 
  private:
   bool gz_ = false;
-  gzFile g_ = nullptr;
   FILE* f_ = nullptr;
+};
+
+// ---- TSV rows.  Number formatting must equal Go's strconv (FormatFloat 'f',4 / 'e',4 = correctly rounded decimals, which is
+// what printf gives); the fast paths below produce the same digits and fall back to snprintf whenever a rounding tie is near.
+struct RowFormatter {
+  char tmp[64];
+  std::unordered_map<uint64_t, std::string> fpr_cache;  // the FPR of a match depends on (qKmers, mKmers) only
+
+  static void put_u64(std::string& b, uint64_t v) {
+    char t[24];
+    int n = 0;
+    do { t[n++] = (char)('0' + v % 10); v /= 10; } while (v);
+    while (n) b.push_back(t[--n]);
+  }
+  static void put_i(std::string& b, int64_t v) {
+    if (v < 0) { b.push_back('-'); put_u64(b, (uint64_t)(-v)); } else put_u64(b, (uint64_t)v);
+  }
+  void put_f4(std::string& b, double v) {  // "%.4f"
+    if (v >= 0 && v < 1e9) {
+      const double sc = v * 10000.0;
+      const double fl = floor(sc);
+      const double fr = sc - fl;
+      if (fabs(fr - 0.5) > 1e-6) {  // far from a tie: the scaled value rounds like the exact decimal expansion
+        uint64_t q = (uint64_t)fl + (fr > 0.5 ? 1 : 0);
+        put_u64(b, q / 10000);
+        b.push_back('.');
+        const unsigned f = (unsigned)(q % 10000);
+        b.push_back((char)('0' + f / 1000));
+        b.push_back((char)('0' + f / 100 % 10));
+        b.push_back((char)('0' + f / 10 % 10));
+        b.push_back((char)('0' + f % 10));
+        return;
+      }
+    }
+    b.append(tmp, (size_t)snprintf(tmp, sizeof tmp, "%.4f", v));
+  }
+  const std::string& fpr(int n, int c, double v) {
+    const uint64_t key = ((uint64_t)(uint32_t)n << 32) | (uint32_t)c;
+    auto it = fpr_cache.find(key);
+    if (it != fpr_cache.end()) return it->second;
+    if (fpr_cache.size() > (1u << 20)) fpr_cache.clear();
+    return fpr_cache.emplace(key, std::string(tmp, (size_t)snprintf(tmp, sizeof tmp, "%.4e", v))).first->second;
+  }
+  void row(std::string& b, const std::string& id, int qlen, int qkmers, uint64_t hits, const std::string& target, const kmcpg_match& m, int k,
+           uint64_t qidx) {
+    b += id; b.push_back('\t'); put_i(b, qlen); b.push_back('\t'); put_i(b, qkmers); b.push_back('\t');
+    b += fpr(qkmers, m.mkmers, m.fpr); b.push_back('\t'); put_u64(b, hits); b.push_back('\t');
+    b += target; b.push_back('\t'); put_u64(b, (uint16_t)m.target_idx); b.push_back('\t'); put_u64(b, m.target_idx >> 16); b.push_back('\t');
+    put_u64(b, m.gsize); b.push_back('\t'); put_i(b, k); b.push_back('\t'); put_i(b, m.mkmers); b.push_back('\t');
+    put_f4(b, m.qcov); b.push_back('\t'); put_f4(b, m.tcov); b.push_back('\t'); put_f4(b, m.jacc); b.push_back('\t');
+    put_u64(b, qidx); b.push_back('\n');
+  }
+  void unmatched(std::string& b, const std::string& id, int qlen, int qkmers, int k, uint64_t qidx) {
+    b += id; b.push_back('\t'); put_i(b, qlen); b.push_back('\t'); put_i(b, qkmers);
+    b += "\t0\t0\t\t-1\t0\t0\t"; put_i(b, k); b += "\t0\t0\t0\t0\t"; put_u64(b, qidx); b.push_back('\n');
+  }
 };
 
 static std::unordered_map<std::string, std::string> read_kvs(const std::string& file) {  // cliutil.ReadKVs
@@ -616,51 +709,66 @@ int main(int argc, char** argv) {
     q_in.close();
   });
 
+  double t_gpu = 0, t_fmt = 0, t_read_wait = 0;  // seconds spent inside libkmcpgpu / formatting+writing / waiting for input
   std::thread searcher([&] {
     std::unique_ptr<Batch> b;
-    while (q_in.pop(&b)) {
+    for (;;) {
+      const auto tw = std::chrono::steady_clock::now();
+      if (!q_in.pop(&b)) break;
+      const auto t0 = std::chrono::steady_clock::now();
+      t_read_wait += std::chrono::duration<double>(t0 - tw).count();
       int rc = kmcpg_search_batch(db, b->seqs.data(), b->offs.data(), b->paired ? b->seqs2.data() : nullptr, b->paired ? b->offs2.data() : nullptr,
                                   (uint32_t)b->size(), &params, &b->res);
       if (rc != 0) die("%s", kmcpg_last_error());
+      t_gpu += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
       q_out.push(std::move(b));
     }
     q_out.close();
   });
 
-  // writer: rows exactly as search.go:517-575 / :458-512
+  // writer: rows exactly as search.go:517-575 / :458-512.  A batch is formatted by several threads (contiguous ranges of
+  // queries, concatenated in order); with -o *.gz each range becomes its own gzip member, compressed in the same thread
+  // (a multi-member .gz is what pgzip/gzip readers, `kmcp profile` included, accept).
   {
+    const int nfmt = std::max(1, std::min(o.threads > 0 ? o.threads : 8, 16));
     std::unique_ptr<Batch> b;
-    std::string buf;
-    char line[4096];
     while (q_out.pop(&b)) {
-      buf.clear();
+      const auto tf0 = std::chrono::steady_clock::now();
       const kmcpg_result& r = b->res;
-      for (uint32_t i = 0; i < r.n_reads; i++) {
-        total++;
-        const uint64_t qidx = b->first_idx + i;
-        const uint64_t m0 = r.match_offs[i], m1 = r.match_offs[i + 1];
-        if (m0 == m1) {
-          if (o.keep_unmatched) {
-            int n = snprintf(line, sizeof line, "\t%d\t%d\t0\t0\t\t-1\t0\t0\t%d\t0\t0\t0\t0\t%llu\n", r.qlen[i], r.qkmers[i], r.k, (unsigned long long)qidx);
-            buf += b->ids[i];
-            buf.append(line, (size_t)n);
+      const uint32_t n = r.n_reads;
+      const int parts = (int)std::max<uint32_t>(1, std::min<uint32_t>((uint32_t)nfmt, (n + 4095) / 4096));
+      std::vector<std::string> chunk((size_t)parts);
+      std::vector<uint64_t> part_matched((size_t)parts, 0);
+      auto work = [&](int pi) {
+        RowFormatter F;
+        std::string& buf = chunk[(size_t)pi];
+        const uint32_t lo = (uint32_t)((uint64_t)n * pi / parts), hi = (uint32_t)((uint64_t)n * (pi + 1) / parts);
+        buf.reserve((size_t)(hi - lo) * 96);
+        for (uint32_t i = lo; i < hi; i++) {
+          const uint64_t qidx = b->first_idx + i;
+          const uint64_t m0 = r.match_offs[i], m1 = r.match_offs[i + 1];
+          if (m0 == m1) {
+            if (o.keep_unmatched) F.unmatched(buf, b->ids[i], r.qlen[i], r.qkmers[i], r.k, qidx);
+            continue;
           }
-          continue;
+          part_matched[(size_t)pi]++;
+          for (uint64_t j = m0; j < m1; j++) F.row(buf, b->ids[i], r.qlen[i], r.qkmers[i], m1 - m0, target[r.matches[j].col], r.matches[j], r.k, qidx);
         }
-        matched++;
-        for (uint64_t j = m0; j < m1; j++) {
-          const kmcpg_match& m = r.matches[j];
-          int n = snprintf(line, sizeof line, "\t%d\t%d\t%.4e\t%llu\t", r.qlen[i], r.qkmers[i], m.fpr, (unsigned long long)(m1 - m0));
-          buf += b->ids[i];
-          buf.append(line, (size_t)n);
-          buf += target[m.col];
-          n = snprintf(line, sizeof line, "\t%d\t%d\t%llu\t%d\t%d\t%.4f\t%.4f\t%.4f\t%llu\n", (int)(uint16_t)m.target_idx, (int)(m.target_idx >> 16),
-                       (unsigned long long)m.gsize, r.k, m.mkmers, m.qcov, m.tcov, m.jacc, (unsigned long long)qidx);
-          buf.append(line, (size_t)n);
-        }
+        if (out.gz()) buf = gzip_member(buf);
+      };
+      if (parts == 1) work(0);
+      else {
+        std::vector<std::thread> th;
+        for (int pi = 0; pi < parts; pi++) th.emplace_back(work, pi);
+        for (auto& t : th) t.join();
       }
-      out.write(buf);
+      for (int pi = 0; pi < parts; pi++) {
+        out.write_raw(chunk[(size_t)pi]);
+        matched += part_matched[(size_t)pi];
+      }
+      total += n;
       kmcpg_result_free(&b->res);
+      t_fmt += std::chrono::duration<double>(std::chrono::steady_clock::now() - tf0).count();
       if (verbose && !o.quiet) {
         double min = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_search).count() / 60.0;
         fprintf(stderr, "processed queries: %llu, speed: %.3f million queries per minute\r", (unsigned long long)total, total / 1e6 / min);
@@ -676,7 +784,7 @@ int main(int argc, char** argv) {
     info("");
     info("processed queries: %llu, speed: %.3f million queries per minute", (unsigned long long)total, total / 1e6 / min);
     info("%.4f%% (%llu/%llu) queries matched", total ? (double)matched / (double)total * 100 : NAN, (unsigned long long)matched, (unsigned long long)total);
-    info("done searching");
+    info("done searching (pipeline: %.3f s in the GPU library, %.3f s formatting/writing, %.3f s waiting for the reader)", t_gpu, t_fmt, t_read_wait);
     if (o.out_file != "-") info("search results saved to: %s", o.out_file.c_str());
   }
   // trailer read by `kmcp profile` (profile.go:1945-1951)
