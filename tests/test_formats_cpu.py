@@ -1,0 +1,141 @@
+"""On-disk format handling of libkmcpgpu without a GPU (metadata-only handles, device = -1): what `.uniki` headers and
+`__db.yml` say must come back through kmcpg_db_info / kmcpg_col_info / kmcpg_block_info, and broken databases must be refused
+with the reference's error texts (index/serialization.go:41-57, util-db-info.go:98-129, util-db-search.go:654-695)."""
+import os
+import shutil
+
+import numpy as np
+import pytest
+
+from tests import synth
+
+
+@pytest.fixture(scope="module")
+def small_db(oracle_lib, tmp_path_factory):
+    tmp = tmp_path_factory.mktemp("fmt")
+    genomes = synth.random_genomes(21, 3000, seed=5)
+    names = [f"GCF_{i:09d}.1" for i in range(21)]
+    db_dir = synth.make_db(tmp, genomes, k=31, n_chunks=3, overlap=100, num_hashes=2, fpr=0.05, threads=4, scale=3, names=names)
+    return db_dir, names
+
+
+def test_metadata_matches_oracle_reader(oracle_lib, small_db):
+    from kmcp_amd.lib import Database
+    O = oracle_lib
+    db_dir, names = small_db
+    odb = O.OracleDB(db_dir)
+    with Database.open(db_dir, device=-1) as db:
+        i = db.info
+        assert (i.k, i.canonical, i.num_hashes, i.scaled, i.scale, i.minimizer, i.syncmer) == (31, 1, 2, 1, 3, 0, 0)
+        assert abs(i.fpr - 0.05) < 1e-15 and i.n_blocks == odb.nblocks and i.n_cols == odb.ncols == 63
+        tot = 0
+        for b in range(i.n_blocks):
+            ns, nc, rb = odb.block_info(b)
+            bi = db.block_info(b)
+            assert (bi["num_sigs"], bi["n_cols"], bi["row_bytes"], bi["col_base"]) == (ns, nc, rb, tot)
+            assert bi["stride"] >= rb and bi["stride"] % 16 == 0
+            tot += nc
+        for c in range(63):
+            assert db.col_info(c) == odb.col_info(c)
+        assert {db.col_info(c)[0] for c in range(63)} == set(names)
+        assert i.matrix_bytes == sum(odb.block_info(b)[0] * odb.block_info(b)[2] for b in range(odb.nblocks))
+    odb.close()
+
+
+def _copy(db_dir, tmp_path):
+    d = tmp_path / "R001"
+    shutil.copytree(db_dir, d)
+    return str(d)
+
+
+def _open_fails(path, needle):
+    from kmcp_amd.lib import Database, KmcpGpuError
+    with pytest.raises(KmcpGpuError) as e:
+        Database.open(path, device=-1)
+    assert needle in str(e.value), str(e.value)
+    return e.value.code
+
+
+def test_broken_databases_are_refused(small_db, tmp_path):
+    db_dir, _ = small_db
+    # no __db.yml
+    assert _open_fails(str(tmp_path), "fail to open kmcp database info file") == -2
+    # wrong magic
+    d = _copy(db_dir, tmp_path / "magic")
+    with open(os.path.join(d, "_block001.uniki"), "r+b") as f:
+        f.write(b".kmcpXXX")
+    assert _open_fails(d, "invalid index format") == -3
+    # index version
+    d = _copy(db_dir, tmp_path / "ver")
+    with open(os.path.join(d, "_block001.uniki"), "r+b") as f:
+        f.seek(8)
+        f.write(bytes([3]))
+    _open_fails(d, "version mismatch")
+    # truncated matrix
+    d = _copy(db_dir, tmp_path / "trunc")
+    p = os.path.join(d, "_block002.uniki")
+    os.truncate(p, os.path.getsize(p) - 10)
+    _open_fails(d, "truncated index file")
+    # block listed in __db.yml but missing
+    d = _copy(db_dir, tmp_path / "missing")
+    os.remove(os.path.join(d, "_block001.uniki"))
+    assert _open_fails(d, "kmcp index file missing") == -2
+    # k in __db.yml differs from the blocks' k; database version
+    d = _copy(db_dir, tmp_path / "k")
+    y = open(os.path.join(d, "__db.yml")).read()
+    open(os.path.join(d, "__db.yml"), "w").write(y.replace("k: 31", "k: 21").replace("- 31", "- 21"))
+    _open_fails(d, "index files not compatible")
+    open(os.path.join(d, "__db.yml"), "w").write(y.replace("version: 4\n", "version: 3\n", 1))
+    _open_fails(d, "version mismatch")
+    open(os.path.join(d, "__db.yml"), "w").write(y.split("files:")[0] + "files: []\n")
+    _open_fails(d, "no index files")
+
+
+def test_yaml_variants(small_db, tmp_path):
+    """yaml.v2 output and hand-edited variants (flow lists, quotes, comments) parse the same."""
+    from kmcp_amd.lib import Database
+    db_dir, _ = small_db
+    d = _copy(db_dir, tmp_path / "y")
+    y = open(os.path.join(d, "__db.yml")).read()
+    files = [ln[2:].strip() for ln in y.split("files:")[1].splitlines() if ln.startswith("- ")]
+    head = y.split("ks:")[0]
+    rest = y.split("ks:")[1].split("\n", 2)[2].split("files:")[0]
+    y2 = "# edited by hand\n" + head + "ks: [31]\n" + rest + "files: [" + ", ".join(f'"{f}"' for f in files) + "]\n"
+    open(os.path.join(d, "__db.yml"), "w").write(y2.replace("alias: oracle-db", "alias: 'my db'"))
+    with Database.open(d, device=-1) as db:
+        assert db.info.k == 31 and db.info.n_blocks == len(files) and db.info.scale == 3
+
+
+def test_finalize_on_cpu_matches_oracle(oracle_lib, small_db):
+    """kmcpg_finalize (float64 thresholds, FPR, Match values, sorting) fed with the oracle's raw counts: the host half of the
+    product is exercised without a GPU."""
+    from kmcp_amd.lib import HIT_DTYPE, Database, default_params
+    O = oracle_lib
+    db_dir, _ = small_db
+    odb = O.OracleDB(db_dir)
+    genomes = synth.random_genomes(21, 3000, seed=5)
+    reads = synth.sample_reads(genomes, 120, 400, sub_rate=0.01, seed=6, frac_random=0.1)
+    for flags in (dict(), dict(sort_by=2, top_n_scores=1, min_qcov=0.3), dict(sort_by=1, min_tcov=0.02, max_fpr=1e-4, min_matched=3)):
+        p, op = default_params(**flags), O.default_params(**flags)
+        hits, qk, ql = [], [], []
+        for i, r in enumerate(reads):
+            km = O.generate_kmers(r, odb.cfg)
+            n = len(km) if len(km) >= p.min_matched else 0
+            if n > p.dedup_threshold:
+                km = O.sort_unique(km)
+                n = len(km)
+            qk.append(n)
+            ql.append(len(r))
+            if n == 0:
+                continue
+            tot = 0
+            for b in range(odb.nblocks):
+                cnt = odb.block_counts(b, km)
+                for c in np.nonzero(cnt)[0]:
+                    hits.append((i, tot + int(c), int(cnt[c])))  # every non-zero count: finalize must apply all thresholds itself
+                tot += len(cnt)
+        h = np.array(hits, dtype=np.uint32).view(HIT_DTYPE).reshape(-1) if hits else np.zeros(0, dtype=HIT_DTYPE)
+        with Database.open(db_dir, device=-1) as db:
+            res = db.finalize(h, np.array(qk, dtype=np.int32), np.array(ql, dtype=np.int32), params=p)
+        assert synth.assert_parity(odb, res, reads, None, op) > 30
+    odb.close()
