@@ -184,6 +184,34 @@ int kmcpg_kmers_device(kmcpg_db* db, const uint8_t* d_seqs, const uint64_t* d_of
                        uint64_t total_bases, uint32_t max_read_len, const kmcpg_params* params,
                        uint64_t* d_hashes, uint64_t hashes_cap, uint64_t* d_koff, int32_t* d_nk, void* stream);
 
+/* -- index building on the GPU ("next" row of SURVEY.md §8f): the Bloom-column scatter of `kmcp index`
+ *    (kmcp/cmd/index.go:657-682 block layout, :1023 signature size, :1107-1309 scatter, index/serialization.go:159-300 file,
+ *    util-db-info.go:46-79 __db.yml) from lists of k-mer hashes — what the .unik files of `kmcp compute` hold.  Writes
+ *    <out_dir>/R001/{_blockNNN.uniki, __db.yml, __name_mapping.tsv} byte-compatible with the reference's reader.  Only the
+ *    common block layout is implemented (no column above the -x 10M k-mer threshold). */
+typedef struct {
+  int32_t k;
+  int32_t canonical;
+  int32_t num_hashes;   /* -n */
+  double fpr;           /* -f */
+  int32_t threads;      /* -j: block size = (int(#cols/threads)+7)/8*8 clamped to [8, #cols] when block_size == 0 */
+  int32_t block_size;   /* -b */
+  uint32_t scale;       /* recorded in __db.yml (scaled: scale > 1) */
+  uint32_t minimizer_w;
+  uint32_t syncmer_s;
+  int32_t split_seq, split_size, split_num, split_overlap; /* recorded in __db.yml */
+  const char* alias;
+} kmcpg_build_cfg;
+typedef struct {
+  const char* name;       /* reference name */
+  uint64_t gsize;         /* genome size */
+  uint32_t chunk_idx;     /* index of this chunk */
+  uint32_t chunks;        /* number of chunks of the genome */
+  const uint64_t* hashes; /* host pointer: sorted-unique k-mer hashes of the chunk */
+  uint64_t n_hashes;
+} kmcpg_build_col;
+int kmcpg_build_db(const char* out_dir, const kmcpg_build_cfg* cfg, const kmcpg_build_col* cols, uint32_t n_cols, int32_t device);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,197 @@
+// build.cpp — kmcpg_build_db: `kmcp index` on the GPU from lists of k-mer hashes.
+// Host part: block layout (kmcp/cmd/index.go:657-682), signature size (util-hash.go:46-50), .uniki header
+// (index/serialization.go:159-300), __db.yml (util-db-info.go:46-79), __name_mapping.tsv (index.go:1375-1393).
+// Device part: the Bloom-column scatter (index.go:1107-1309) as one atomicOr per (k-mer, hash).
+#include <errno.h>
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+#include <sys/stat.h>
+
+#include <algorithm>
+#include <string>
+#include <vector>
+
+#include "fpr.hpp"
+#include "kernels.hpp"
+
+using namespace kmcpg;
+
+int kmcpg_fail(int code, const char* fmt, ...);  // engine.cpp
+
+namespace {
+
+void be32(FILE* f, uint32_t v) {
+  uint8_t b[4] = {(uint8_t)(v >> 24), (uint8_t)(v >> 16), (uint8_t)(v >> 8), (uint8_t)v};
+  fwrite(b, 1, 4, f);
+}
+void be64(FILE* f, uint64_t v) {
+  be32(f, (uint32_t)(v >> 32));
+  be32(f, (uint32_t)v);
+}
+
+// CalcSignatureSize (util-hash.go:46-50)
+uint64_t signature_size(uint64_t n, int h, double fpr) {
+  const double ratio = (double)(-h) / log(1.0 - go_pow(fpr, 1.0 / (double)h));
+  return (uint64_t)ceil((double)n * ratio);
+}
+
+int mkdirs(const std::string& d) {
+  std::string cur;
+  for (size_t i = 0; i <= d.size(); i++) {
+    if (i == d.size() || d[i] == '/') {
+      if (!cur.empty() && mkdir(cur.c_str(), 0755) != 0 && errno != EEXIST) return -1;
+    }
+    if (i < d.size()) cur.push_back(d[i]);
+  }
+  return 0;
+}
+
+#define BHIP(expr)                                                                                        \
+  do {                                                                                                    \
+    hipError_t e_ = (expr);                                                                               \
+    if (e_ != hipSuccess) {                                                                               \
+      rc = kmcpg_fail(KMCPG_EDEVICE, "%s: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+      goto done;                                                                                          \
+    }                                                                                                     \
+  } while (0)
+
+int build_block(const std::string& path, const kmcpg_build_cfg& cfg, const std::vector<const kmcpg_build_col*>& cols) {
+  int rc = 0;
+  const uint32_t n = (uint32_t)cols.size();
+  uint64_t max_elems = 0, total = 0;
+  for (auto* c : cols) {
+    max_elems = std::max(max_elems, c->n_hashes);
+    total += c->n_hashes;
+  }
+  const uint64_t num_sigs = signature_size(max_elems, cfg.num_hashes, cfg.fpr);  // index.go:936-946,1023
+  const uint32_t row_bytes = (n + 7) / 8;
+  const uint64_t bytes = num_sigs * (uint64_t)row_bytes;
+  unsigned __int128 m = (~(unsigned __int128)0) / num_sigs + 1;
+  uint8_t* d_sigs = nullptr;
+  uint64_t *d_hashes = nullptr, *d_off = nullptr;
+  std::vector<uint8_t> host;
+  FILE* f = nullptr;
+  const uint64_t chunk_cap = std::max<uint64_t>(max_elems, 64ull << 20);  // hashes per upload
+  std::vector<uint64_t> stage, off;
+  BHIP(hipMalloc((void**)&d_sigs, bytes + 8));
+  BHIP(hipMemset(d_sigs, 0, bytes + 8));
+  BHIP(hipMalloc((void**)&d_hashes, chunk_cap * sizeof(uint64_t)));
+  BHIP(hipMalloc((void**)&d_off, ((size_t)n + 1) * sizeof(uint64_t)));
+  for (uint32_t c0 = 0; c0 < n;) {  // groups of consecutive columns that fit one upload
+    stage.clear();
+    off.assign(1, 0);
+    uint32_t c1 = c0;
+    while (c1 < n && (c1 == c0 || stage.size() + cols[c1]->n_hashes <= chunk_cap)) {
+      stage.insert(stage.end(), cols[c1]->hashes, cols[c1]->hashes + cols[c1]->n_hashes);
+      off.push_back(stage.size());
+      c1++;
+    }
+    if (!stage.empty()) {
+      BHIP(hipMemcpy(d_hashes, stage.data(), stage.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
+      BHIP(hipMemcpy(d_off, off.data(), off.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
+      launch_build_scatter(d_sigs, num_sigs, (uint64_t)(m >> 64), (uint64_t)m, row_bytes, cfg.num_hashes, d_hashes, d_off, c0, c1 - c0, stage.size(), nullptr);
+      BHIP(hipDeviceSynchronize());
+    }
+    c0 = c1;
+  }
+  host.resize(bytes);
+  BHIP(hipMemcpy(host.data(), d_sigs, bytes, hipMemcpyDeviceToHost));
+  f = fopen(path.c_str(), "wb");
+  if (!f) {
+    rc = kmcpg_fail(KMCPG_EIO, "cannot write %s: %s", path.c_str(), strerror(errno));
+    goto done;
+  }
+  {
+    fwrite(".kmcpidx", 1, 8, f);
+    const uint8_t meta[4] = {4, (uint8_t)cfg.k, (uint8_t)((cfg.canonical ? 1 : 0) | 2 /* COMPACT = !faster (index.go:207) */), (uint8_t)cfg.num_hashes};
+    fwrite(meta, 1, 4, f);
+    be64(f, num_sigs);
+    be32(f, n);
+    for (auto* c : cols) {
+      be32(f, (uint32_t)strlen(c->name) + 1);
+      fwrite(c->name, 1, strlen(c->name), f);
+      fputc('\n', f);
+    }
+    be32(f, n);
+    for (auto* c : cols) {
+      be32(f, 1);
+      be64(f, c->gsize);
+    }
+    be32(f, n);
+    for (auto* c : cols) {
+      be32(f, 1);
+      be32(f, c->chunk_idx + (c->chunks << 16));  // index.go:1096
+    }
+    for (auto* c : cols) be64(f, c->n_hashes);
+    if (fwrite(host.data(), 1, bytes, f) != bytes) rc = kmcpg_fail(KMCPG_EIO, "short write on %s", path.c_str());
+  }
+done:
+  if (f) fclose(f);
+  if (d_sigs) (void)hipFree(d_sigs);
+  if (d_hashes) (void)hipFree(d_hashes);
+  if (d_off) (void)hipFree(d_off);
+  (void)total;
+  return rc;
+}
+
+}  // namespace
+
+extern "C" int kmcpg_build_db(const char* out_dir, const kmcpg_build_cfg* cfg, const kmcpg_build_col* cols, uint32_t n_cols, int32_t device) {
+  if (!out_dir || !cfg || !cols || n_cols == 0) return kmcpg_fail(KMCPG_EINVAL, "bad argument");
+  if (cfg->num_hashes < 1 || cfg->num_hashes > 4 || !(cfg->fpr > 0 && cfg->fpr < 1) || cfg->k < 1 || cfg->k > 255)
+    return kmcpg_fail(KMCPG_EINVAL, "bad build configuration");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return kmcpg_fail(KMCPG_EDEVICE, "no HIP device available: libkmcpgpu has no CPU fallback");
+  if (device < 0 || device >= ndev) return kmcpg_fail(KMCPG_EINVAL, "device %d out of range", device);
+  if (hipSetDevice(device) != hipSuccess) return kmcpg_fail(KMCPG_EDEVICE, "hipSetDevice failed");
+  std::vector<const kmcpg_build_col*> order;
+  uint64_t total = 0;
+  for (uint32_t i = 0; i < n_cols; i++) {
+    if (!cols[i].name || (!cols[i].hashes && cols[i].n_hashes)) return kmcpg_fail(KMCPG_EINVAL, "column %u: null name or hashes", i);
+    if (cols[i].n_hashes > 10ull * 1024 * 1024) return kmcpg_fail(KMCPG_EUNSUPPORTED, "big-genome block rules (index.go:813-883) are not implemented");
+    order.push_back(&cols[i]);
+    total += cols[i].n_hashes;
+  }
+  // files sorted by #k-mers ascending (index.go:667); the reference's parallel quicksort is unstable, input order breaks ties here
+  std::stable_sort(order.begin(), order.end(), [](const kmcpg_build_col* a, const kmcpg_build_col* b) { return a->n_hashes < b->n_hashes; });
+  int sblock = cfg->block_size > 0 ? cfg->block_size : ((int)((double)n_cols / (double)std::max(1, cfg->threads)) + 7) / 8 * 8;  // index.go:671-682
+  if (sblock > (int)n_cols) sblock = (int)n_cols;
+  if (sblock < 8) sblock = 8;
+  const std::string dir = std::string(out_dir) + "/R001";
+  if (mkdirs(dir) != 0) return kmcpg_fail(KMCPG_EIO, "cannot create %s: %s", dir.c_str(), strerror(errno));
+  std::vector<std::string> files;
+  for (size_t i = 0; i < order.size();) {
+    std::vector<const kmcpg_build_col*> batch;
+    while ((int)batch.size() < sblock && i < order.size()) {
+      if (order[i]->n_hashes > 0) batch.push_back(order[i]);  // empty inputs are skipped (index.go:803)
+      i++;
+    }
+    if (batch.empty()) break;
+    char name[64];
+    snprintf(name, sizeof name, "_block%03zu.uniki", files.size() + 1);  // index.go:1283-1285
+    int rc = build_block(dir + "/" + name, *cfg, batch);
+    if (rc) return rc;
+    files.push_back(name);
+  }
+  FILE* f = fopen((dir + "/__db.yml").c_str(), "w");
+  if (!f) return kmcpg_fail(KMCPG_EIO, "cannot write %s/__db.yml", dir.c_str());
+  auto b = [](int v) { return v ? "true" : "false"; };
+  fprintf(f, "version: 4\nunikiVersion: 4\nalias: %s\nk: %d\nks:\n- %d\nhashed: true\ncanonical: %s\n", cfg->alias ? cfg->alias : "kmcp-gpu-db", cfg->k, cfg->k,
+          b(cfg->canonical));
+  fprintf(f, "scaled: %s\nscale: %u\nminimizer: %s\nminimizer-w: %u\nsyncmer: %s\nsyncmer-s: %u\n", b(cfg->scale > 1), cfg->scale > 1 ? cfg->scale : 1,
+          b(cfg->minimizer_w > 0), cfg->minimizer_w, b(cfg->syncmer_s > 0), cfg->syncmer_s);
+  fprintf(f, "split-seq: %s\nsplit-size: %d\nsplit-num: %d\nsplit-overlap: %d\ncompact-size: true\n", b(cfg->split_seq), cfg->split_size, cfg->split_num,
+          cfg->split_overlap);
+  fprintf(f, "hashes: %d\nfpr: %.17g\nnumNameGroups: %u\nblocksize: %d\ntotalKmers: %llu\nfiles:\n", cfg->num_hashes, cfg->fpr, n_cols, sblock,
+          (unsigned long long)total);
+  for (const auto& fn : files) fprintf(f, "- %s\n", fn.c_str());
+  fclose(f);
+  f = fopen((dir + "/__name_mapping.tsv").c_str(), "w");
+  if (f) {
+    for (uint32_t i = 0; i < n_cols; i++) fprintf(f, "%s\t%s\n", cols[i].name, cols[i].name);
+    fclose(f);
+  }
+  return 0;
+}

@@ -54,6 +54,17 @@ static int fail(int code, const char* fmt, ...) {
 
 extern "C" const char* kmcpg_last_error(void) { return g_err.c_str(); }
 
+// error sink shared with build.cpp
+int kmcpg_fail(int code, const char* fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return code;
+}
+
 // ------------------------------------------------------------------------------------------------
 // database object
 // ------------------------------------------------------------------------------------------------

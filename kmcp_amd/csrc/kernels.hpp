@@ -24,6 +24,9 @@ void launch_plant(const BlockDev& bd, uint32_t col, int num_hashes, const uint64
 void launch_plant_reads(const BlockDev* blocks, uint32_t nblocks, int num_hashes, const uint64_t* hashes, const uint64_t* offs,
                         const int32_t* nk, const uint32_t* cols, uint32_t n_reads, hipStream_t st);
 
+void launch_build_scatter(uint8_t* sigs, uint64_t num_sigs, uint64_t mh, uint64_t ml, uint32_t row_bytes, int num_hashes, const uint64_t* hashes,
+                          const uint64_t* col_off, uint32_t col0, uint32_t n_cols, uint64_t n, hipStream_t st);
+
 // queries with more than HUGE_MIN k-mers: device-wide sort + unique (sort_huge.hip)
 constexpr uint32_t HUGE_MIN = 65536;
 size_t huge_dedup_temp_bytes(uint32_t max_n);

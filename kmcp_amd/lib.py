@@ -15,7 +15,7 @@ EXPORTS = [
     "kmcpg_open", "kmcpg_close", "kmcpg_last_error", "kmcpg_db_info", "kmcpg_col_info", "kmcpg_search_batch",
     "kmcpg_result_free", "kmcpg_query_device", "kmcpg_finalize", "kmcpg_open_synthetic", "kmcpg_plant",
     "kmcpg_read_rows", "kmcpg_block_info", "kmcpg_kmers_device", "kmcpg_plant_reads_device", "kmcpg_set_profiling",
-    "kmcpg_last_timing", "kmcpg_open_devices",
+    "kmcpg_last_timing", "kmcpg_open_devices", "kmcpg_build_db",
 ]
 
 
@@ -61,6 +61,18 @@ class SynthSpec(C.Structure):
     _fields_ = [("k", C.c_int32), ("num_hashes", C.c_int32), ("fpr", C.c_double), ("n_blocks", C.c_uint32),
                 ("cols_per_block", C.c_uint32), ("num_sigs", C.c_uint64), ("kmers_per_col", C.c_uint64), ("seed", C.c_uint64),
                 ("scale", C.c_uint32), ("syncmer_s", C.c_uint32), ("minimizer_w", C.c_uint32), ("reserved", C.c_uint32)]
+
+
+class BuildCfg(C.Structure):
+    _fields_ = [("k", C.c_int32), ("canonical", C.c_int32), ("num_hashes", C.c_int32), ("fpr", C.c_double), ("threads", C.c_int32),
+                ("block_size", C.c_int32), ("scale", C.c_uint32), ("minimizer_w", C.c_uint32), ("syncmer_s", C.c_uint32),
+                ("split_seq", C.c_int32), ("split_size", C.c_int32), ("split_num", C.c_int32), ("split_overlap", C.c_int32),
+                ("alias", C.c_char_p)]
+
+
+class BuildCol(C.Structure):
+    _fields_ = [("name", C.c_char_p), ("gsize", C.c_uint64), ("chunk_idx", C.c_uint32), ("chunks", C.c_uint32),
+                ("hashes", C.c_void_p), ("n_hashes", C.c_uint64)]
 
 
 HIT_DTYPE = np.dtype([("read", np.uint32), ("col", np.uint32), ("count", np.uint32)])
@@ -123,6 +135,7 @@ def load():
     L.kmcpg_plant_reads_device.argtypes = [vp, vp, vp, C.c_uint32, C.c_uint64, C.c_uint32, vp, vp]
     L.kmcpg_set_profiling.argtypes = [vp, C.c_int]
     L.kmcpg_last_timing.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    L.kmcpg_build_db.argtypes = [C.c_char_p, C.POINTER(BuildCfg), C.POINTER(BuildCol), C.c_uint32, C.c_int32]
     _lib = L
     return L
 
@@ -139,6 +152,21 @@ def pack_reads(reads):
         offs[1:] = np.cumsum([len(r) for r in reads], dtype=np.uint64)
     seqs = np.frombuffer(b"".join(reads), dtype=np.uint8).copy() if reads else np.zeros(0, dtype=np.uint8)
     return seqs, offs
+
+
+def build_db(out_dir, columns, k=21, num_hashes=1, fpr=0.3, threads=32, block_size=0, scale=1, minimizer_w=0, syncmer_s=0, device=0,
+             alias="kmcp-gpu-db"):
+    """`kmcp index` on the GPU.  columns: list of (name, gsize, chunk_idx, chunks, sorted-unique uint64 hashes)."""
+    cfg = BuildCfg(k=k, canonical=1, num_hashes=num_hashes, fpr=fpr, threads=threads, block_size=block_size, scale=scale,
+                   minimizer_w=minimizer_w, syncmer_s=syncmer_s, alias=alias.encode())
+    arr = (BuildCol * len(columns))()
+    keep = []
+    for i, (name, gsize, ci, nch, h) in enumerate(columns):
+        h = np.ascontiguousarray(h, dtype=np.uint64)
+        keep.append(h)
+        arr[i] = BuildCol(name.encode(), gsize, ci, nch, h.ctypes.data, len(h))
+    _check(load().kmcpg_build_db(os.fsencode(out_dir), C.byref(cfg), arr, len(columns), device))
+    return os.path.join(out_dir, "R001")
 
 
 class BatchResult:

@@ -1,0 +1,68 @@
+"""kmcpg_build_db (`kmcp index` on the GPU from k-mer hash lists) vs the oracle's restatement of index.go: the `.uniki` block
+files must be byte-identical (header, row-major Bloom matrix, bit order), `__db.yml` must carry the same values, and a search
+over the GPU-built database must equal the oracle's search over its own."""
+import filecmp
+import os
+
+import pytest
+
+from tests import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _yml(path):
+    out, key = {}, None
+    for line in open(path):
+        line = line.rstrip("\n")
+        if line.startswith("- "):
+            out.setdefault(key, []).append(line[2:])
+        elif ":" in line:
+            key, v = line.split(":", 1)
+            out[key] = v.strip() if v.strip() else []
+    return out
+
+
+@pytest.mark.parametrize("case", [
+    dict(k=21, n=60, glen=4000, chunks=2, nh=1, fpr=0.3, threads=4, kw={}),                       # several 3-byte-row blocks
+    dict(k=31, n=9, glen=60000, chunks=1, nh=3, fpr=0.01, threads=8, kw=dict(scale=10)),           # the demo-searching shape
+    dict(k=21, n=1203, glen=700, chunks=1, nh=2, fpr=0.1, threads=1, kw=dict(syncmer_s=11)),       # one 151-byte-row block, ragged
+    dict(k=25, n=40, glen=3000, chunks=3, nh=4, fpr=0.05, threads=2, kw=dict(minimizer_w=8), block_size=16),
+])
+def test_gpu_built_database_is_byte_identical(oracle_lib, tmp_path, case):
+    from kmcp_amd import Database, default_params, lib
+    O = oracle_lib
+    genomes = synth.random_genomes(case["n"], case["glen"], seed=77)
+    cfg = O.sketch_cfg(k=case["k"], **case["kw"])
+    cols = synth.make_columns(genomes, cfg, n_chunks=case["chunks"], overlap=100)
+    bs = case.get("block_size", 0)
+    ref = O.build_db(str(tmp_path / "oracle"), cfg, cols, num_hashes=case["nh"], fpr=case["fpr"], threads=case["threads"], block_size=bs)
+    got = lib.build_db(str(tmp_path / "gpu"), cols, k=case["k"], num_hashes=case["nh"], fpr=case["fpr"], threads=case["threads"], block_size=bs,
+                       scale=case["kw"].get("scale", 1), minimizer_w=case["kw"].get("minimizer_w", 0), syncmer_s=case["kw"].get("syncmer_s", 0))
+    yr, yg = _yml(os.path.join(ref, "__db.yml")), _yml(os.path.join(got, "__db.yml"))
+    assert yr["files"] == yg["files"] and len(yr["files"]) >= 1
+    for key in ("version", "unikiVersion", "k", "ks", "hashed", "canonical", "scaled", "scale", "minimizer", "minimizer-w", "syncmer", "syncmer-s",
+                "hashes", "numNameGroups", "blocksize", "totalKmers"):
+        assert yr[key] == yg[key], key
+    assert float(yr["fpr"]) == float(yg["fpr"])
+    for f in yr["files"]:
+        assert filecmp.cmp(os.path.join(ref, f), os.path.join(got, f), shallow=False), f
+    # and it searches like the oracle's
+    reads = synth.sample_reads(genomes, 200, min(300, case["glen"] - 1), sub_rate=0.01, seed=78, frac_random=0.1)
+    t = max(0.55, case["fpr"] + 0.1)
+    odb = O.OracleDB(ref)
+    try:
+        with Database.open(got, device=0) as db:
+            res = db.search(reads, params=default_params(min_qcov=t))
+        assert synth.assert_parity(odb, res, reads, None, O.default_params(min_qcov=t)) > 50
+    finally:
+        odb.close()
+
+
+def test_build_refuses_bad_input(tmp_path):
+    import numpy as np
+    from kmcp_amd import lib
+    with pytest.raises(lib.KmcpGpuError):
+        lib.build_db(str(tmp_path / "x"), [("a", 10, 0, 1, np.arange(5, dtype=np.uint64))], num_hashes=7)
+    with pytest.raises(lib.KmcpGpuError):
+        lib.build_db(str(tmp_path / "y"), [("a", 10, 0, 1, np.arange(5, dtype=np.uint64))], fpr=1.5)
