@@ -134,7 +134,10 @@ void kmcpg_result_free(kmcpg_result* r);
  *    (:6611-7742, integer thresholds only).  All pointers are DEVICE pointers; `stream` is a
  *    hipStream_t (NULL = default stream).  d_counters[0] receives the number of hits produced (which
  *    may exceed hit_cap: then only hit_cap were stored and the caller retries with a larger buffer).
- *    d_qkmers[i] receives NumKmers of read i (0 if not searched), d_qlen[i] its QueryLen. */
+ *    d_qkmers[i] receives NumKmers of read i (0 if not searched), d_qlen[i] its QueryLen.
+ *    max_read_len must be >= the longest read (mate) of the batch: it sizes the counters.  The call only enqueues work on
+ *    `stream` for short-read batches; when a query may exceed 2048 k-mers it reads 8 bytes back (which queries are long is
+ *    known only on the device) and therefore synchronises the stream once or twice. */
 int kmcpg_query_device(kmcpg_db* db, const uint8_t* d_seqs, const uint64_t* d_offs, const uint8_t* d_seqs2,
                        const uint64_t* d_offs2, uint32_t n_reads, uint64_t total_bases, uint32_t max_read_len,
                        const kmcpg_params* params, kmcpg_hit* d_hits, uint64_t hit_cap, uint64_t* d_counters,
