@@ -15,6 +15,7 @@
 #include <mutex>
 #include <string>
 #include <thread>
+#include <unordered_map>
 #include <vector>
 
 #include "common.hpp"
@@ -799,64 +800,90 @@ extern "C" int kmcpg_finalize(const kmcpg_db* db, const kmcpg_hit* hits, uint64_
     std::vector<uint64_t> cur(start.begin(), start.end() - 1);
     for (uint64_t i = 0; i < n_hits; i++) sorted[cur[hits[i].read]++] = hits[i];
   }
-  o->offs.assign((size_t)n_reads + 1, 0);
-  o->matches.reserve(n_hits);
+  for (uint64_t i = 0; i < n_hits; i++)
+    if (hits[i].col >= db->col_block.size()) return fail(KMCPG_EINVAL, "hit names column %u of %zu", hits[i].col, db->col_block.size());
+  // FPR rows of the NumKmers values present (a handful for short reads), fetched once so that the workers below never lock
   QueryFpr* F = db->fpr.get();
+  std::unordered_map<int, const std::vector<double>*> fpr_rows;
   for (uint32_t r = 0; r < n_reads; r++) {
-    const size_t first = o->matches.size();
     const int n = qkmers[r];
-    const double nh = (double)n;
-    const double thr = nh * p.min_qcov;
-    for (uint64_t i = start[r]; i < start[r + 1]; i++) {
-      const kmcpg_hit& h = sorted[i];
-      if (h.col >= db->col_block.size()) return fail(KMCPG_EINVAL, "hit names column %u of %zu", h.col, db->col_block.size());
-      const int count = (int)h.count;
-      if (count < p.min_matched) continue;
-      const double c = (double)count;
-      if (!(c > thr)) continue;
-      const BlockMeta& b = db->blocks[db->col_block[h.col]];
-      const uint32_t ci = h.col - b.col_base;
-      const double nt = (double)b.h.sizes[ci];
-      const double T = c / nt;
-      if (!(T >= p.min_tcov)) continue;
-      const double fpr = F->get(n, count);
-      if (!(fpr <= p.max_fpr)) continue;
-      kmcpg_match m{};
-      m.col = h.col;
-      m.target_idx = b.h.indices[ci];
-      m.gsize = b.h.gsizes[ci];
-      m.mkmers = count;
-      m.fpr = fpr;
-      m.qcov = c / nh;
-      m.tcov = T;
-      m.jacc = c / (nh + nt - c);
-      o->matches.push_back(m);
-    }
-    size_t cnt = o->matches.size() - first;
-    if (cnt > 1 && !p.do_not_sort) {
-      const int sb = p.sort_by;
-      std::sort(o->matches.begin() + (ptrdiff_t)first, o->matches.end(), [sb](const kmcpg_match& x, const kmcpg_match& y) { return match_less(x, y, sb); });
-    } else if (cnt > 1) {
-      std::sort(o->matches.begin() + (ptrdiff_t)first, o->matches.end(), [](const kmcpg_match& x, const kmcpg_match& y) { return x.col < y.col; });
-    }
-    if (cnt > 0 && p.top_n_scores > 0 && !p.do_not_sort) {  // --keep-top-scores (:285-311), including its [:i+1]
-      int nn = 0;
-      size_t i = 0;
-      double pscore = 1024;
-      for (; i < cnt; i++) {
-        const kmcpg_match& m = o->matches[first + i];
-        const double score = p.sort_by == 1 ? m.tcov : (p.sort_by == 2 ? m.jacc : m.qcov);
-        if (score < pscore) {
-          nn++;
-          if (nn > p.top_n_scores) break;
-          pscore = score;
-        }
-      }
-      if (i >= cnt) i = cnt - 1;
-      o->matches.resize(first + i + 1);
-    }
-    o->offs[r + 1] = o->matches.size();
+    if (n > 0 && n <= QueryFpr::kCachedMaxN && start[r + 1] > start[r] && !fpr_rows.count(n)) fpr_rows.emplace(n, F->ensure_row(n));
   }
+  // reads are independent: contiguous ranges of reads per worker thread, results concatenated in order
+  const int workers = (int)std::max<uint64_t>(1, std::min<uint64_t>(8, n_hits / 32768));
+  std::vector<std::vector<kmcpg_match>> part((size_t)workers);
+  std::vector<uint64_t> per_read((size_t)n_reads, 0);
+  auto work = [&](int w) {
+    const uint32_t lo = (uint32_t)((uint64_t)n_reads * w / workers), hi = (uint32_t)((uint64_t)n_reads * (w + 1) / workers);
+    std::vector<kmcpg_match>& ms = part[(size_t)w];
+    ms.reserve((size_t)(start[hi] - start[lo]));
+    for (uint32_t r = lo; r < hi; r++) {
+      const size_t first = ms.size();
+      const int n = qkmers[r];
+      const double nh = (double)n;
+      const double thr = nh * p.min_qcov;
+      const std::vector<double>* row = nullptr;
+      if (start[r + 1] > start[r] && n > 0 && n <= QueryFpr::kCachedMaxN) row = fpr_rows.find(n)->second;
+      for (uint64_t i = start[r]; i < start[r + 1]; i++) {
+        const kmcpg_hit& h = sorted[i];
+        const int count = (int)h.count;
+        if (count < p.min_matched) continue;
+        const double c = (double)count;
+        if (!(c > thr)) continue;
+        const BlockMeta& b = db->blocks[db->col_block[h.col]];
+        const uint32_t ci = h.col - b.col_base;
+        const double nt = (double)b.h.sizes[ci];
+        const double T = c / nt;
+        if (!(T >= p.min_tcov)) continue;
+        const double fpr = row ? (*row)[(size_t)std::min(count, n)] : F->get(n, count);
+        if (!(fpr <= p.max_fpr)) continue;
+        kmcpg_match m{};
+        m.col = h.col;
+        m.target_idx = b.h.indices[ci];
+        m.gsize = b.h.gsizes[ci];
+        m.mkmers = count;
+        m.fpr = fpr;
+        m.qcov = c / nh;
+        m.tcov = T;
+        m.jacc = c / (nh + nt - c);
+        ms.push_back(m);
+      }
+      size_t cnt = ms.size() - first;
+      if (cnt > 1 && !p.do_not_sort) {
+        const int sb = p.sort_by;
+        std::sort(ms.begin() + (ptrdiff_t)first, ms.end(), [sb](const kmcpg_match& x, const kmcpg_match& y) { return match_less(x, y, sb); });
+      } else if (cnt > 1) {
+        std::sort(ms.begin() + (ptrdiff_t)first, ms.end(), [](const kmcpg_match& x, const kmcpg_match& y) { return x.col < y.col; });
+      }
+      if (cnt > 0 && p.top_n_scores > 0 && !p.do_not_sort) {  // --keep-top-scores (:285-311), including its [:i+1]
+        int nn = 0;
+        size_t i = 0;
+        double pscore = 1024;
+        for (; i < cnt; i++) {
+          const kmcpg_match& m = ms[first + i];
+          const double score = p.sort_by == 1 ? m.tcov : (p.sort_by == 2 ? m.jacc : m.qcov);
+          if (score < pscore) {
+            nn++;
+            if (nn > p.top_n_scores) break;
+            pscore = score;
+          }
+        }
+        if (i >= cnt) i = cnt - 1;
+        ms.resize(first + i + 1);
+      }
+      per_read[r] = ms.size() - first;
+    }
+  };
+  if (workers == 1) work(0);
+  else {
+    std::vector<std::thread> th;
+    for (int w = 0; w < workers; w++) th.emplace_back(work, w);
+    for (auto& t : th) t.join();
+  }
+  o->offs.assign((size_t)n_reads + 1, 0);
+  for (uint32_t r = 0; r < n_reads; r++) o->offs[r + 1] = o->offs[r] + per_read[r];
+  o->matches.reserve((size_t)o->offs[n_reads]);
+  for (auto& ms : part) o->matches.insert(o->matches.end(), ms.begin(), ms.end());
   out->n_reads = n_reads;
   out->k = db->info.k;
   out->qlen = o->qlen.data();

@@ -108,11 +108,16 @@ const std::vector<double>& QueryFpr::row(int n) {
   return rows_.emplace(n, fpr_row(p_, n, n)).first->second;
 }
 
+const std::vector<double>* QueryFpr::ensure_row(int n) {
+  std::lock_guard<std::mutex> g(mu_);
+  return &row(n);  // unordered_map never moves its mapped values
+}
+
 double QueryFpr::get(int n, int k) {
   if (n <= 0) return 1;
   if (k > n) k = n;
   if (k < 0) return 1;
-  if (n > 4096) return fpr_row(p_, n, k)[(size_t)k];  // long queries: do not keep O(n) rows around
+  if (n > kCachedMaxN) return fpr_row(p_, n, k)[(size_t)k];  // long queries: do not keep O(n) rows around
   std::lock_guard<std::mutex> g(mu_);
   return row(n)[(size_t)k];
 }

@@ -18,6 +18,10 @@ class QueryFpr {
   explicit QueryFpr(double p) : p_(p) {}
   // queryFPR(n, k): 1 - sum_{i<=k} C(n,i) p^i (1-p)^(n-i), clamped at 0
   double get(int n, int k);
+  // rows are cached for n <= kCachedMaxN; ensure_row builds row n (FPR(n, 0..n)) if needed and returns it — the pointer
+  // stays valid for the life of the object, so readers need no lock afterwards
+  static constexpr int kCachedMaxN = 4096;
+  const std::vector<double>* ensure_row(int n);
 
  private:
   const std::vector<double>& row(int n);

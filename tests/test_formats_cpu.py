@@ -139,3 +139,32 @@ def test_finalize_on_cpu_matches_oracle(oracle_lib, small_db):
             res = db.finalize(h, np.array(qk, dtype=np.int32), np.array(ql, dtype=np.int32), params=p)
         assert synth.assert_parity(odb, res, reads, None, op) > 30
     odb.close()
+
+
+def test_finalize_worker_threads_agree(small_db):
+    """A hit list large enough for kmcpg_finalize to fan out over worker threads gives exactly what finalizing the same reads
+    in small single-threaded pieces gives."""
+    from kmcp_amd.lib import HIT_DTYPE, Database, default_params
+    db_dir, _ = small_db
+    rng = np.random.default_rng(3)
+    n_reads, n_hits = 120000, 400000
+    h = np.zeros(n_hits, dtype=HIT_DTYPE)
+    h["read"] = rng.integers(0, n_reads, n_hits)
+    h["col"] = rng.integers(0, 63, n_hits)
+    h["count"] = rng.integers(40, 131, n_hits)
+    # one (read, col) pair at most once, as the GPU emits them
+    _, keep = np.unique(h["read"].astype(np.int64) * 64 + h["col"], return_index=True)
+    h = h[np.sort(keep)]
+    qk = rng.choice([130, 120, 97], n_reads).astype(np.int32)
+    ql = np.full(n_reads, 150, dtype=np.int32)
+    p = default_params(min_qcov=0.35, sort_by=2, top_n_scores=2)
+    with Database.open(db_dir, device=-1) as db:
+        whole = db.finalize(h, qk, ql, params=p)
+        pieces, step = [], 6000
+        for lo in range(0, n_reads, step):
+            sel = h[(h["read"] >= lo) & (h["read"] < lo + step)].copy()
+            sel["read"] -= lo
+            pieces.append(db.finalize(sel, qk[lo:lo + step], ql[lo:lo + step], params=p))
+    assert len(whole.matches) > 100000
+    assert np.array_equal(whole.matches, np.concatenate([x.matches for x in pieces]))
+    assert np.array_equal(np.diff(whole.offs), np.concatenate([np.diff(x.offs) for x in pieces]))
