@@ -1,11 +1,16 @@
 // kernels.hip — hand-written CDNA4 (gfx950) kernels of the kmcp search hot path.
 //
-//   K1  k1_kmers      ntHash canonical k-mer hashes of batched reads (+ FracMinHash filter)
-//                     replaces bio/sketches HashIterator.NextHash behind generateKmers
+//   K1  k1_kmers / k1_kmers_wg   ntHash canonical k-mer hashes of batched reads, FracMinHash filter, Closed-Syncmer and
+//                     Minimizer selection (one wave per short read; one 1024-thread workgroup with LDS tiles per long
+//                     read): replaces bio/sketches NextHash / NextSyncmer / NextMinimizer behind generateKmers
 //                     (kmcp/cmd/util-db-search.go:1037-1107)
-//   K1d k_dedup       per-read sort + unique when #k-mers > -u (util-db-search.go:874-908)
-//   K2  k2_cobs       the COBS query: row = hash % NumSigs, gather rows, AND the h rows, per-column
-//                     match counts, integer threshold, hit emission (util-db-search.go:6611-7742)
+//   K1d k_dedup       per-read sort + unique when #k-mers > -u (util-db-search.go:874-908); whole genomes go to
+//                     sort_huge.hip
+//   K2  k2_cobs       the COBS query: row = hash % NumSigs, gather rows, AND the h rows, per-column match counts in
+//                     bit-sliced counters, integer threshold, hit emission (util-db-search.go:6611-7742); SPLIT form +
+//                     k_threshold_long for long queries
+//   k_repack / k_gather_rows / k_synth_fill / k_plant* / k_build_scatter: load-time layout, parity helpers, synthetic
+//                     index, `kmcp index` scatter (index.go:1107-1309)
 //
 // The path is bitwise/integer and HBM-bound; there is no MFMA here by design.  wave = 64 lanes.
 #include <hip/hip_runtime.h>
