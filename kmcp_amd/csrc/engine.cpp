@@ -236,8 +236,10 @@ int finish_open(kmcpg_db* db) {
 int upload_block(BlockMeta& b) {
   const uint64_t ns = b.h.num_sigs;
   const uint32_t rb = b.h.row_bytes;
-  if (ns + 1 > 0xffffffffULL) return fail(KMCPG_EUNSUPPORTED, "%s: NumSigs %llu exceeds 2^32-2 rows", b.path.c_str(), (unsigned long long)ns);
   b.stride = device_stride(rb);
+  // the kernel addresses rows in 16-byte units with 32 bits
+  if ((ns + 1) * (uint64_t)(b.stride >> 4) > 0xffffffffULL)
+    return fail(KMCPG_EUNSUPPORTED, "%s: block larger than 64 GB in HBM (NumSigs %llu x %u B)", b.path.c_str(), (unsigned long long)ns, b.stride);
   const uint64_t bytes = (ns + 1) * (uint64_t)b.stride;
   HIPCHK(hipMalloc((void**)&b.d_rows, bytes));
   HIPCHK(hipMemset(b.d_rows + ns * b.stride, 0, b.stride));  // the all-zero row
@@ -409,8 +411,8 @@ extern "C" int kmcpg_open_synthetic(const kmcpg_synth_spec* s, const kmcpg_opts*
   for (size_t i = 0; i < db->blocks.size(); i++) {
     BlockMeta& b = db->blocks[i];
     if (!b.local) continue;
-    if (b.h.num_sigs + 1 > 0xffffffffULL) return fail(KMCPG_EUNSUPPORTED, "NumSigs too large");
     b.stride = device_stride(b.h.row_bytes);
+    if ((b.h.num_sigs + 1) * (uint64_t)(b.stride >> 4) > 0xffffffffULL) return fail(KMCPG_EUNSUPPORTED, "synthetic block larger than 64 GB");
     HIPCHK(hipMalloc((void**)&b.d_rows, (b.h.num_sigs + 1) * (uint64_t)b.stride));
     HIPCHK(hipMemset(b.d_rows + b.h.num_sigs * b.stride, 0, b.stride));
     launch_synth_fill(b.d_rows, b.h.num_sigs, b.stride, (uint32_t)b.h.names.size(), s->seed * 0x9e3779b97f4a7c15ULL + i * 0x632be59bd9b4e019ULL + 1, p8,

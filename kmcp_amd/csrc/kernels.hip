@@ -681,18 +681,19 @@ __global__ void __launch_bounds__(256) k2_cobs(const K2Args a) {
       const uint32_t bi = __shfl(slot.block, srcl);
       const BlockDev* __restrict__ bq = a.blocks + bi;
       const uint64_t ns = bq->num_sigs;
+      const uint64_t s16 = bq->stride >> 4;  // rows are addressed in 16-byte units: 32 bits reach 64 GB per block
       const int kidx = c0 + j;
       if (kidx < nq) {
         const uint64_t h = a.hashes[koq + kidx];
         if (!MULTI) {
-          s_rows[wave][0][p] = (uint32_t)fastmod_u64(h, ns, bq->magic_hi, bq->magic_lo);
+          s_rows[wave][0][p] = (uint32_t)(fastmod_u64(h, ns, bq->magic_hi, bq->magic_lo) * s16);
         } else {
           const uint32_t ha = (uint32_t)(h >> 32), hb = (uint32_t)h;
           for (int i = 0; i < nh; i++)
-            s_rows[wave][i][p] = (uint32_t)fastmod_u64((uint64_t)(uint32_t)(ha + hb * (uint32_t)i), ns, bq->magic_hi, bq->magic_lo);
+            s_rows[wave][i][p] = (uint32_t)(fastmod_u64((uint64_t)(uint32_t)(ha + hb * (uint32_t)i), ns, bq->magic_hi, bq->magic_lo) * s16);
         }
       } else {
-        for (int i = 0; i < nh; i++) s_rows[wave][i][p] = (uint32_t)ns;  // the appended all-zero row
+        for (int i = 0; i < nh; i++) s_rows[wave][i][p] = (uint32_t)(ns * s16);  // the appended all-zero row
       }
     }
     wave_lds_fence();
@@ -705,11 +706,11 @@ __global__ void __launch_bounds__(256) k2_cobs(const K2Args a) {
         uint4 v = make_uint4(0, 0, 0, 0);
         if (active) {
           const uint32_t row = s_rows[wave][0][g * CH + j + i];
-          v = load_row16(base + (uint64_t)row * stride, a.nt_loads);
+          v = load_row16(base + ((uint64_t)row << 4), a.nt_loads);
           if (MULTI) {
             for (int hh = 1; hh < nh; hh++) {  // AND of the h rows (pand.AndUnsafe, :6639-6646)
               const uint32_t row2 = s_rows[wave][hh][g * CH + j + i];
-              const uint4 w = load_row16(base + (uint64_t)row2 * stride, a.nt_loads);
+              const uint4 w = load_row16(base + ((uint64_t)row2 << 4), a.nt_loads);
               v.x &= w.x; v.y &= w.y; v.z &= w.z; v.w &= w.w;
             }
           }
