@@ -71,6 +71,7 @@ struct K2Args {
   int32_t min_matched;
   int32_t num_hashes;
   int32_t nt_loads;      // non-temporal row loads
+  int32_t prune;         // stop loading sectors whose columns can no longer reach the threshold
   int32_t split_min;     // >0: queries with more k-mers are handled by the SPLIT launch
   // long-query (SPLIT) form
   const uint32_t* long_list;  // indices of the long queries

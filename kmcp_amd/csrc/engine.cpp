@@ -670,6 +670,7 @@ extern "C" int kmcpg_query_device(kmcpg_db* db, const uint8_t* d_seqs, const uin
   a.min_matched = p.min_matched;
   a.num_hashes = db->info.num_hashes;
   a.nt_loads = getenv("KMCPG_NT_LOADS") ? atoi(getenv("KMCPG_NT_LOADS")) : 1;
+  a.prune = getenv("KMCPG_PRUNE") ? atoi(getenv("KMCPG_PRUNE")) : 1;
   a.split_min = n_long ? split_min : 0;
   a.hits = d_hits;
   a.hit_cap = hit_cap;

@@ -661,6 +661,15 @@ __global__ void __launch_bounds__(256) k2_cobs(const K2Args a) {
   const uint32_t stride = bd->stride;
   const uint32_t boff = (slot.tile * LPR + li) * 16u;
   const bool active = n > 0 && boff < stride;
+  // integer threshold (:7468-7470): count >= minMatched && float64(count) > nHashes*queryCov
+  const double thr = __dmul_rn((double)n, a.min_qcov);
+  uint32_t cmin = (uint32_t)thr + 1u;  // smallest integer c with (double)c > thr  (thr >= 0)
+  if (cmin < (uint32_t)a.min_matched) cmin = (uint32_t)a.min_matched;
+  // Branch and bound: once count + (k-mers still to come) < cmin for every column of a 128-byte sector of the row, nothing
+  // in it can become a hit any more and its lanes stop loading.  Unrelated references are dead after ~80 % of a read's
+  // k-mers (Bloom density <= fpr), so the tail of the row traffic is never fetched; results are unchanged.
+  constexpr int GRP = LPR < 8 ? LPR : 8;  // lanes that share a sector
+  bool live = active;
   const uint8_t* __restrict__ base = bd->rows + boff;
   const uint64_t koff = a.offs[r] + (a.offs2 ? a.offs2[r] : 0) + (uint64_t)k0;
   const int nh = MULTI ? a.num_hashes : 1;
@@ -704,7 +713,7 @@ __global__ void __launch_bounds__(256) k2_cobs(const K2Args a) {
 #pragma unroll
       for (int i = 0; i < 8; i++) {
         uint4 v = make_uint4(0, 0, 0, 0);
-        if (active) {
+        if (live) {
           const uint32_t row = s_rows[wave][0][g * CH + j + i];
           v = load_row16(base + ((uint64_t)row << 4), a.nt_loads);
           if (MULTI) {
@@ -721,11 +730,33 @@ __global__ void __launch_bounds__(256) k2_cobs(const K2Args a) {
       csa8<NPL>(pl[1], x[0].y, x[1].y, x[2].y, x[3].y, x[4].y, x[5].y, x[6].y, x[7].y);
       csa8<NPL>(pl[2], x[0].z, x[1].z, x[2].z, x[3].z, x[4].z, x[5].z, x[6].z, x[7].z);
       csa8<NPL>(pl[3], x[0].w, x[1].w, x[2].w, x[3].w, x[4].w, x[5].w, x[6].w, x[7].w);
+      if (!SPLIT && a.prune) {
+        const int done = min(n, c0 + j + 8);
+        const int need = (int)cmin - (n - done);  // a column must already hold this many to stay in the race
+        bool lane_alive = live;
+        if (live && need > 0) {
+          uint32_t any = 0;
+          if (NPL >= 32 || ((uint32_t)need >> NPL) == 0) {
+#pragma unroll
+            for (int d = 0; d < 4; d++) {
+              uint32_t ge = 0xffffffffu;
+#pragma unroll
+              for (int p = 0; p < NPL; p++) ge = (((uint32_t)need >> p) & 1u) ? (ge & pl[d][p]) : (ge | pl[d][p]);
+              any |= ge;
+            }
+          }
+          lane_alive = any != 0;
+        }
+        const uint64_t alive = __ballot(lane_alive);
+        live = live && ((alive >> (lane & ~(GRP - 1))) & ((1ULL << GRP) - 1ULL)) != 0;
+        if (alive == 0) break;  // the whole wave is done with these rows
+      }
     }
     wave_lds_fence();
+    if (!SPLIT && a.prune && __ballot(live) == 0) break;
   }
 
-  if (!active) return;
+  if (!live) return;
   if (SPLIT) {
     // partial counts of this chunk -> the query's count array (consecutive lanes hit consecutive words)
     uint32_t* __restrict__ acc = a.long_counts + (uint64_t)li_long * a.ncols_total + bd->col_base;
@@ -741,10 +772,6 @@ __global__ void __launch_bounds__(256) k2_cobs(const K2Args a) {
     }
     return;
   }
-  // ---- integer threshold (:7468-7470): count >= minMatched && float64(count) > nHashes*queryCov
-  const double thr = __dmul_rn((double)n, a.min_qcov);
-  uint32_t cmin = (uint32_t)thr + 1u;  // smallest integer c with (double)c > thr  (thr >= 0)
-  if (cmin < (uint32_t)a.min_matched) cmin = (uint32_t)a.min_matched;
   if (NPL < 32 && (cmin >> NPL) != 0) return;  // unreachable count
 #pragma unroll
   for (int d = 0; d < 4; d++) {
