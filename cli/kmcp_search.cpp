@@ -675,8 +675,33 @@ int main(int argc, char** argv) {
     std::string id1, s1, id2, s2;
     if (paired) {
       if (verbose) info("reading from paired-end files: %s, %s", o.read1.c_str(), o.read2.c_str());
-      FastxReader r1(o.read1), r2(o.read2);
-      while (r1.next(&id1, &s1) && r2.next(&id2, &s2)) add(id1, s1, &s2);
+      // the mates are decoded by their own thread (two gzip streams inflate in parallel) and handed over in chunks
+      struct MateChunk { std::vector<std::string> seqs; };
+      Queue<std::unique_ptr<MateChunk>> q2(8);
+      std::thread mate_reader([&] {
+        FastxReader r2(o.read2);
+        std::unique_ptr<MateChunk> c(new MateChunk());
+        std::string mid, ms;
+        while (r2.next(&mid, &ms)) {
+          c->seqs.push_back(ms);
+          if (c->seqs.size() == 4096) { q2.push(std::move(c)); c.reset(new MateChunk()); }
+        }
+        if (!c->seqs.empty()) q2.push(std::move(c));
+        q2.close();
+      });
+      FastxReader r1(o.read1);
+      std::unique_ptr<MateChunk> cur;
+      size_t ci = 0;
+      while (r1.next(&id1, &s1)) {
+        if (!cur || ci == cur->seqs.size()) {
+          ci = 0;
+          if (!q2.pop(&cur)) break;  // read2 ended first: stop like the reference (search.go:818-826)
+        }
+        add(id1, s1, &cur->seqs[ci++]);
+      }
+      // drain whatever read2 still holds so that its thread can finish
+      while (q2.pop(&cur)) {}
+      mate_reader.join();
       if (id == 0) warn("no valid sequences in files: %s, %s", o.read1.c_str(), o.read2.c_str());
     } else {
       const std::string nnn((size_t)std::max(0, dbi.k - 1), 'N');
