@@ -6,6 +6,8 @@ through size-independent properties, plus an oracle check on rows read back from
     (this is also the multi-GPU merge, exercised here with two handles on one GPU);
   * oracle on a sample: for a few reads the 130 x 32 rows they touch are copied back and counted by the oracle.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -111,3 +113,59 @@ def test_oracle_on_rows_read_back(setup, oracle_lib):
                 want.append((r, b * COLS + int(c), int(cnt[c])))
         got = [tuple(int(x) for x in row) for row in h[h[:, 0] == r]]
         assert got == sorted(want), r
+
+
+def test_pruning_keeps_boundary_columns(oracle_lib):
+    """Sector pruning is exact at its boundary: a column whose matches all sit in the LAST cmin k-mers of the read has
+    count + remaining == cmin at every step until the end and must be reported; one k-mer fewer must not.  All three kernel
+    classes (3-, 125- and 1872-byte rows), low Bloom density so that every other sector dies early."""
+    import torch
+    from kmcp_amd import Database, default_params, lib
+    O = oracle_lib
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(11)
+    reads = [bytes(rng.choice(list(b"ACGT"), 150).astype(np.uint8)) for _ in range(64)]
+    cfg = O.sketch_cfg(k=21)
+    kms = [O.generate_kmers(r, cfg) for r in reads]
+    for cols_per_block in (24, 1000, 14976):
+        spec = lib.SynthSpec(k=21, num_hashes=1, fpr=0.3, n_blocks=3, cols_per_block=cols_per_block, num_sigs=200003, kmers_per_col=4000, seed=3)
+        with Database.open_synthetic(spec) as db:  # density 1-exp(-4000/200003) = 2 %
+            want = set()
+            ncols = 3 * cols_per_block
+            for i, km in enumerate(kms):
+                n = len(km)
+                cmin = max(10, int(np.floor(n * 0.55)) + 1)
+                c_hit, c_miss, c_first = (7 * i + 1) % ncols, (7 * i + 3) % ncols, (7 * i + 5) % ncols
+                db.plant(c_hit, km[n - cmin:])        # exactly cmin matches, all at the end
+                db.plant(c_miss, km[n - cmin + 1:])   # cmin - 1
+                db.plant(c_first, km[:cmin])          # exactly cmin matches, all at the start
+            # expected counts from the rows actually resident (plants of different reads may touch the same column)
+            seqs, offs = lib.pack_reads(reads)
+            t_seqs = torch.from_numpy(seqs).to(dev)
+            t_offs = torch.from_numpy(offs.view(np.int64)).to(dev)
+            cap = 4096
+            hits = torch.zeros((cap, 3), dtype=torch.int32, device=dev)
+            cnt = torch.zeros(2, dtype=torch.int64, device=dev)
+            qk = torch.zeros(len(reads), dtype=torch.int32, device=dev)
+            ql = torch.zeros(len(reads), dtype=torch.int32, device=dev)
+            for i, km in enumerate(kms):
+                n = len(km)
+                cmin = max(10, int(np.floor(n * 0.55)) + 1)
+                for b in range(3):
+                    rows = db.read_rows(b, km % np.uint64(200003))
+                    c = np.unpackbits(rows, axis=1)[:, :cols_per_block].sum(axis=0)
+                    for col in np.nonzero(c >= cmin)[0]:
+                        want.add((i, b * cols_per_block + int(col), int(c[col])))
+            got = {}
+            for prune in ("1", "0"):
+                os.environ["KMCPG_PRUNE"] = prune
+                try:
+                    db.query_device(t_seqs.data_ptr(), t_offs.data_ptr(), len(reads), len(seqs), 150, hits.data_ptr(), cap, cnt.data_ptr(),
+                                    qk.data_ptr(), ql.data_ptr(), params=default_params())
+                    torch.cuda.synchronize()
+                finally:
+                    os.environ.pop("KMCPG_PRUNE", None)
+                h = hits[:int(cnt[0].item())].cpu().numpy()
+                got[prune] = {(int(r), int(c), int(k)) for r, c, k in h}
+            assert got["1"] == got["0"] == want
+            assert len(want) >= 2 * len(reads)  # the end-loaded and the start-loaded column of every read
