@@ -43,6 +43,8 @@ struct K1Args {
   int32_t* nk_raw;       // k-mers emitted for read i (both mates)
   int32_t* nk1;          // k-mers emitted for mate 1 (for --try-se)
   int32_t* qlen;
+  int32_t* seg_cnt;      // whole-genome path: kept hashes per (read, segment), n_reads * segs_max entries; else nullptr
+  uint32_t segs_max;
 };
 
 struct DedupArgs {

@@ -124,7 +124,7 @@ struct kmcpg_db {
   std::mutex api_mu;  // serialises kmcpg_search_batch callers (they share the staging buffers)
   // workspace of kmcpg_query_device
   DevBuf<uint64_t> w_hashes, w_scratch;
-  DevBuf<int32_t> w_nk_raw, w_nk1;
+  DevBuf<int32_t> w_nk_raw, w_nk1, w_seg_cnt;
   DevBuf<uint32_t> w_long_list, w_long_meta, w_long_counts;  // long-query (split) path
   DevBuf<uint64_t> w_huge_info;                             // whole-genome queries: (read, n, offset)
   DevBuf<uint8_t> w_huge_temp;                              // hipCUB temporary storage
@@ -439,6 +439,7 @@ extern "C" int kmcpg_close(kmcpg_db* db) {
   db->w_scratch.release();
   db->w_nk_raw.release();
   db->w_nk1.release();
+  db->w_seg_cnt.release();
   db->w_long_list.release();
   db->w_long_meta.release();
   db->w_long_counts.release();
@@ -536,6 +537,13 @@ int run_kmers(kmcpg_db* db, const uint8_t* d_seqs, const uint64_t* d_offs, const
   a.nk_raw = d_nk_raw;
   a.nk1 = d_nk1;
   a.qlen = d_qlen;
+  // whole genomes (single-end, plain or FracMinHash k-mers): segments of a read on their own workgroups
+  const uint32_t segs = (max_read_len + (uint32_t)k1_segment_len() - 1) / (uint32_t)k1_segment_len();
+  if (a.mode == 0 && !d_seqs2 && segs > 1 && d_scratch && (uint64_t)n_reads * segs <= (64ull << 20)) {
+    if (db->w_seg_cnt.ensure((size_t)n_reads * segs)) return fail(KMCPG_ENOMEM, "hipMalloc failed");
+    a.seg_cnt = db->w_seg_cnt.p;
+    a.segs_max = segs;
+  }
   launch_k1(a, max_read_len, st);
   uint64_t ub = max_read_len >= (uint32_t)I.k ? (uint64_t)(max_read_len - I.k + 1) : 0;
   if (d_seqs2) ub *= 2;

@@ -448,6 +448,62 @@ __global__ void __launch_bounds__(K1WG) k1_kmers_wg(const K1Args a) {
   }
 }
 
+// ---- whole genomes (plain / FracMinHash k-mers): segments of K1SEG positions on their own workgroups ----------------
+// Pass 1 hashes a segment and compacts its kept hashes at scratch[offs[r] + seg*K1SEG ...]; pass 2 moves the segments of a
+// read together in order (destination = sum of the counts of the earlier segments).
+constexpr int K1SEG = 65536;
+
+__global__ void __launch_bounds__(K1WG) k1_seg_hash(const K1Args a) {
+  __shared__ uint64_t tab[256];
+  __shared__ int s_wave[K1WG / 64];
+  __shared__ uint8_t bases[K1WG + 256];
+  const int tid = threadIdx.x;
+  if (tid < 256) tab[tid] = seed_of(tid);
+  __syncthreads();
+  const uint32_t r = blockIdx.x / a.segs_max, seg = blockIdx.x % a.segs_max;
+  const uint64_t o1 = a.offs[r];
+  const int len = (int)(a.offs[r + 1] - o1);
+  const int npos = len - a.k + 1;
+  const int p_lo = (int)seg * K1SEG;
+  int cnt = 0;
+  if (len >= a.min_qlen && p_lo < npos) {  // (:778-786 gate; ErrShortSeq => no k-mers)
+    const uint8_t* __restrict__ s = a.seqs + o1;
+    uint64_t* __restrict__ out = a.scratch + o1 + p_lo;
+    const int p_hi = min(npos, p_lo + K1SEG);
+    const bool scaled = a.scaled != 0;
+    for (int p0 = p_lo; p0 < p_hi; p0 += K1WG) {
+      const int nb = min(len - p0, K1WG + a.k - 1);
+      for (int i = tid; i < nb; i += K1WG) bases[i] = s[p0 + i];
+      __syncthreads();
+      const bool v = p0 + tid < p_hi;
+      const uint64_t h = v ? hash_lds(bases, tid, a.k, tab) : 0;
+      cnt = wg_compact(v && h != 0 && (!scaled || h <= a.max_hash), h, out, cnt, s_wave, tid);
+    }
+  }
+  if (tid == 0) a.seg_cnt[blockIdx.x] = cnt;
+}
+
+__global__ void __launch_bounds__(256) k1_seg_pack(const K1Args a) {
+  const uint32_t r = blockIdx.x / a.segs_max, seg = blockIdx.x % a.segs_max;
+  const uint64_t o1 = a.offs[r];
+  const int len = (int)(a.offs[r + 1] - o1);
+  const int npos = len - a.k + 1;
+  const int nsegs = npos > 0 ? (npos + K1SEG - 1) / K1SEG : 1;
+  if ((int)seg >= nsegs) return;
+  const int* __restrict__ sc = a.seg_cnt + (size_t)r * a.segs_max;
+  int dest = 0;
+  for (uint32_t t = 0; t < seg; t++) dest += sc[t];
+  const int cnt = sc[seg];
+  const uint64_t* __restrict__ src = a.scratch + o1 + (uint64_t)seg * K1SEG;
+  uint64_t* __restrict__ dst = a.hashes + o1 + dest;
+  for (int i = threadIdx.x; i < cnt; i += blockDim.x) dst[i] = src[i];
+  if ((int)seg == nsegs - 1 && threadIdx.x == 0) {
+    a.nk_raw[r] = dest + cnt;
+    a.nk1[r] = dest + cnt;
+    a.qlen[r] = len;
+  }
+}
+
 // NumKmers when no read of the batch can exceed the dedup threshold.
 __global__ void k_nk_simple(const int32_t* nk_raw, int32_t* nk_search, uint32_t n, int32_t min_matched) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -902,8 +958,16 @@ void launch_threshold_long(const K2Args& a, hipStream_t st) {
   hipLaunchKernelGGL(k_threshold_long, dim3(blocks), dim3(256), 0, st, a);
 }
 
+int k1_segment_len() { return K1SEG; }
+
 void launch_k1(const K1Args& a, uint32_t max_read_len, hipStream_t st) {
   if (a.n_reads == 0) return;
+  if (a.seg_cnt && a.segs_max > 1) {  // whole genomes: one workgroup per 65536-position segment, then an ordered pack
+    const unsigned blocks = a.n_reads * a.segs_max;
+    hipLaunchKernelGGL(k1_seg_hash, dim3(blocks), dim3(K1WG), 0, st, a);
+    hipLaunchKernelGGL(k1_seg_pack, dim3(blocks), dim3(256), 0, st, a);
+    return;
+  }
   if (max_read_len > 2048) {  // long queries: a whole workgroup per read
     unsigned blocks = a.n_reads > 65536 ? 65536 : a.n_reads;
     hipLaunchKernelGGL(k1_kmers_wg, dim3(blocks), dim3(K1WG), 0, st, a);
