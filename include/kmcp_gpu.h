@@ -190,8 +190,8 @@ int kmcpg_kmers_device(kmcpg_db* db, const uint8_t* d_seqs, const uint64_t* d_of
 /* -- index building on the GPU ("next" row of SURVEY.md §8f): the Bloom-column scatter of `kmcp index`
  *    (kmcp/cmd/index.go:657-682 block layout, :1023 signature size, :1107-1309 scatter, index/serialization.go:159-300 file,
  *    util-db-info.go:46-79 __db.yml) from lists of k-mer hashes — what the .unik files of `kmcp compute` hold.  Writes
- *    <out_dir>/R001/{_blockNNN.uniki, __db.yml, __name_mapping.tsv} byte-compatible with the reference's reader.  Only the
- *    common block layout is implemented (no column above the -x 10M k-mer threshold). */
+ *    <out_dir>/R001/{_blockNNN.uniki, __db.yml, __name_mapping.tsv} byte-compatible with the reference's reader.  The block
+ *    layout includes the big-genome rules (index.go:787-894: smaller blocks above -x/-8, single-column blocks above -1). */
 typedef struct {
   int32_t k;
   int32_t canonical;
@@ -204,6 +204,12 @@ typedef struct {
   uint32_t syncmer_s;
   int32_t split_seq, split_size, split_num, split_overlap; /* recorded in __db.yml */
   const char* alias;
+  /* big-genome block rules, flags -x / -X / -8 / -1 of `kmcp index` (index.go:1453-1463); 0 = the reference's default */
+  uint64_t kmers_x;     /* -x 10M (M = 2^20): columns with more k-mers go to blocks of block_size_x columns */
+  int32_t block_size_x; /* -X 256 */
+  int32_t reserved;
+  uint64_t kmers_8;     /* -8 20M: ... to blocks of 8 columns */
+  uint64_t kmers_1;     /* -1 200M: ... to a block of their own */
 } kmcpg_build_cfg;
 typedef struct {
   const char* name;       /* reference name */

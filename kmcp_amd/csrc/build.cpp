@@ -150,7 +150,6 @@ extern "C" int kmcpg_build_db(const char* out_dir, const kmcpg_build_cfg* cfg, c
   uint64_t total = 0;
   for (uint32_t i = 0; i < n_cols; i++) {
     if (!cols[i].name || (!cols[i].hashes && cols[i].n_hashes)) return kmcpg_fail(KMCPG_EINVAL, "column %u: null name or hashes", i);
-    if (cols[i].n_hashes > 10ull * 1024 * 1024) return kmcpg_fail(KMCPG_EUNSUPPORTED, "big-genome block rules (index.go:813-883) are not implemented");
     order.push_back(&cols[i]);
     total += cols[i].n_hashes;
   }
@@ -161,14 +160,27 @@ extern "C" int kmcpg_build_db(const char* out_dir, const kmcpg_build_cfg* cfg, c
   if (sblock < 8) sblock = 8;
   const std::string dir = std::string(out_dir) + "/R001";
   if (mkdirs(dir) != 0) return kmcpg_fail(KMCPG_EIO, "cannot create %s: %s", dir.c_str(), strerror(errno));
+  // Block layout (index.go:787-894).  The reference walks the ascending list with a small state machine; its effect is that the
+  // columns fall into size tiers — up to -x k-mers, up to -8, up to -1, above — and every tier is cut into blocks of its own size
+  // (-b, -X, 8, 1), a tier change closing the open block.  When -X >= -b the -x tier does not exist (index.go:684-689) and the
+  // columns between -8 and -1 keep blocks of -b columns, still separated from the smaller ones.
+  const uint64_t thr_x = cfg->kmers_x ? cfg->kmers_x : 10ull << 20, thr_8 = cfg->kmers_8 ? cfg->kmers_8 : 20ull << 20,
+                 thr_1 = cfg->kmers_1 ? cfg->kmers_1 : 200ull << 20;
+  if (!(thr_x < thr_8 && thr_8 < thr_1)) return kmcpg_fail(KMCPG_EINVAL, "block thresholds must satisfy -x < -8 < -1");  // index.go:242-257
+  int size_x = cfg->block_size_x ? cfg->block_size_x : 256;
+  if (size_x <= 8 || size_x % 8) return kmcpg_fail(KMCPG_EINVAL, "-X/--block-sizeX should be a multiple of 8 greater than 8: %d", size_x);  // :225-230
+  const bool skip_x = size_x >= sblock;
+  auto tier = [&](uint64_t km) { return km > thr_1 ? 3 : km > thr_8 ? 2 : (!skip_x && km > thr_x) ? 1 : 0; };
+  const int tier_size[4] = {sblock, size_x, skip_x ? sblock : 8, 1};
   std::vector<std::string> files;
   for (size_t i = 0; i < order.size();) {
-    std::vector<const kmcpg_build_col*> batch;
-    while ((int)batch.size() < sblock && i < order.size()) {
-      if (order[i]->n_hashes > 0) batch.push_back(order[i]);  // empty inputs are skipped (index.go:803)
+    if (order[i]->n_hashes == 0) {  // empty inputs are skipped (index.go:799-801)
       i++;
+      continue;
     }
-    if (batch.empty()) break;
+    const int t = tier(order[i]->n_hashes);
+    std::vector<const kmcpg_build_col*> batch;
+    while ((int)batch.size() < tier_size[t] && i < order.size() && tier(order[i]->n_hashes) == t) batch.push_back(order[i++]);
     char name[64];
     snprintf(name, sizeof name, "_block%03zu.uniki", files.size() + 1);  // index.go:1283-1285
     int rc = build_block(dir + "/" + name, *cfg, batch);

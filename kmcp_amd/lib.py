@@ -67,7 +67,8 @@ class BuildCfg(C.Structure):
     _fields_ = [("k", C.c_int32), ("canonical", C.c_int32), ("num_hashes", C.c_int32), ("fpr", C.c_double), ("threads", C.c_int32),
                 ("block_size", C.c_int32), ("scale", C.c_uint32), ("minimizer_w", C.c_uint32), ("syncmer_s", C.c_uint32),
                 ("split_seq", C.c_int32), ("split_size", C.c_int32), ("split_num", C.c_int32), ("split_overlap", C.c_int32),
-                ("alias", C.c_char_p)]
+                ("alias", C.c_char_p), ("kmers_x", C.c_uint64), ("block_size_x", C.c_int32), ("reserved", C.c_int32), ("kmers_8", C.c_uint64),
+                ("kmers_1", C.c_uint64)]
 
 
 class BuildCol(C.Structure):
@@ -155,10 +156,11 @@ def pack_reads(reads):
 
 
 def build_db(out_dir, columns, k=21, num_hashes=1, fpr=0.3, threads=32, block_size=0, scale=1, minimizer_w=0, syncmer_s=0, device=0,
-             alias="kmcp-gpu-db"):
+             alias="kmcp-gpu-db", kmers_x=0, block_size_x=0, kmers_8=0, kmers_1=0):
     """`kmcp index` on the GPU.  columns: list of (name, gsize, chunk_idx, chunks, sorted-unique uint64 hashes)."""
     cfg = BuildCfg(k=k, canonical=1, num_hashes=num_hashes, fpr=fpr, threads=threads, block_size=block_size, scale=scale,
-                   minimizer_w=minimizer_w, syncmer_s=syncmer_s, alias=alias.encode())
+                   minimizer_w=minimizer_w, syncmer_s=syncmer_s, alias=alias.encode(), kmers_x=kmers_x, block_size_x=block_size_x, kmers_8=kmers_8,
+                   kmers_1=kmers_1)
     arr = (BuildCol * len(columns))()
     keep = []
     for i, (name, gsize, ci, nch, h) in enumerate(columns):

@@ -404,17 +404,78 @@ static int mkdir_p(const char* d) {
   return 0;
 }
 
-/* index.go:657-682 block sizing; :787-894 batching (only the common path: no .unik file above the
- * -x 10M k-mer threshold); :1283-1285 file names; :1352-1373 __db.yml; util-db-info.go:46-79 */
+/* index.go:787-894: the loop that cuts the ascending list of columns into blocks.  It runs one step past the end
+ * (i == n) to flush; `last` is the column held back when a size threshold is crossed ("leave this file process in
+ * the next round"), so that the columns already batched are written as a (possibly short) block first. */
+int ko_block_layout(const uint64_t* kmers, uint32_t n, int sblock, const ko_block_rules* rules, int* block_of) {
+  uint64_t thr_x = rules && rules->kmers_x ? rules->kmers_x : 10ull << 20;
+  uint64_t thr_8 = rules && rules->kmers_8 ? rules->kmers_8 : 20ull << 20;
+  uint64_t thr_1 = rules && rules->kmers_1 ? rules->kmers_1 : 200ull << 20;
+  int size_x = rules && rules->block_size_x ? rules->block_size_x : 256;
+  int skip_x = 0;
+  if (size_x >= sblock) { skip_x = 1; size_x = sblock; } /* index.go:684-689 */
+  int flag = 0, flag8 = 0, flagx = 0, nb = 0;
+  long last = -1;
+  int nbatch = 0;               /* columns in the open batch; they are the nbatch most recent non-held-back ones */
+  uint32_t* batch = (uint32_t*)malloc(((size_t)n + 1) * sizeof(uint32_t));
+  for (uint32_t i = 0; i < n; i++) block_of[i] = 0;
+  for (uint32_t i = 0; i <= n; i++) {
+    if (i == n) {
+      if ((flag || flag8 || flagx) && last >= 0) { batch[nbatch++] = (uint32_t)last; last = -1; }
+    } else {
+      uint64_t km = kmers[i];
+      if (km == 0) continue; /* :799-801 */
+      if (flag || flag8 || flagx) {
+        if (last >= 0) { batch[nbatch++] = (uint32_t)last; last = -1; }
+        if (flag) last = i;                                     /* :810-812 one column per block from now on */
+        else if (km > thr_1) { flag = 1; last = i; }            /* :813-817 */
+        else if (skip_x) { batch[nbatch++] = i; if (nbatch < sblock) continue; } /* :818-822 */
+        else if (km > thr_8) {
+          if (flag8) { batch[nbatch++] = i; if (nbatch < sblock) continue; }     /* :825-829 */
+          else { sblock = 8; flag8 = 1; last = i; }             /* :830-836 */
+        } else { batch[nbatch++] = i; if (nbatch < sblock) continue; }           /* :837-842 */
+      } else if (skip_x) {
+        if (km > thr_8) {                                       /* :846-856 */
+          if (km > thr_1) flag = 1;
+          else { sblock = size_x; flagx = 1; }
+          last = i;
+        } else { batch[nbatch++] = i; if (nbatch < sblock) continue; }
+      } else {
+        if (km > thr_x) {                                       /* :864-878 */
+          if (km > thr_1) flag = 1;
+          else if (km > thr_8) { sblock = 8; flag8 = 1; }
+          else { sblock = size_x; flagx = 1; }
+          last = i;
+        } else { batch[nbatch++] = i; if (nbatch < sblock) continue; }
+      }
+    }
+    if (nbatch == 0) {
+      if (last < 0) break; /* :887-893 */
+      continue;
+    }
+    nb++;
+    for (int j = 0; j < nbatch; j++) block_of[batch[j]] = nb;
+    nbatch = 0;
+  }
+  free(batch);
+  return nb;
+}
+
+/* index.go:657-682 block sizing; :787-894 batching; :1283-1285 file names; :1352-1373 __db.yml;
+ * util-db-info.go:46-79 */
 int ko_build_db(const char* out_dir, const ko_sketch_cfg* cfg, int num_hashes, double fpr, int threads,
                 int block_size, const ko_column* cols, uint32_t ncols) {
+  return ko_build_db2(out_dir, cfg, num_hashes, fpr, threads, block_size, NULL, cols, ncols);
+}
+
+int ko_build_db2(const char* out_dir, const ko_sketch_cfg* cfg, int num_hashes, double fpr, int threads,
+                 int block_size, const ko_block_rules* rules, const ko_column* cols, uint32_t ncols) {
   if (ncols == 0) FAIL("no columns");
   const ko_column** order = (const ko_column**)malloc(ncols * sizeof(*order));
   uint64_t total = 0;
   for (uint32_t i = 0; i < ncols; i++) {
     order[i] = &cols[i];
     total += cols[i].n_hashes;
-    if (cols[i].n_hashes > 10u * 1024 * 1024) { free(order); FAIL("big-genome block rules (index.go:813-883) not restated"); }
   }
   qsort(order, ncols, sizeof(*order), cmp_col_by_kmers);
   int sblock;
@@ -427,20 +488,21 @@ int ko_build_db(const char* out_dir, const ko_sketch_cfg* cfg, int num_hashes, d
   char dir[900], path[1024];
   snprintf(dir, sizeof dir, "%s/R001", out_dir);
   if (mkdir_p(dir) != 0) { free(order); FAIL("cannot create %s", dir); }
-  int nb = 0;
-  ko_column* batch = (ko_column*)malloc((size_t)sblock * sizeof(ko_column));
-  for (uint32_t i = 0; i < ncols;) {
+  uint64_t* km = (uint64_t*)malloc(ncols * sizeof(uint64_t));
+  int* block_of = (int*)malloc(ncols * sizeof(int));
+  for (uint32_t i = 0; i < ncols; i++) km[i] = order[i]->n_hashes;
+  int nb = ko_block_layout(km, ncols, sblock, rules, block_of);
+  free(km);
+  ko_column* batch = (ko_column*)malloc((size_t)ncols * sizeof(ko_column));
+  for (int b = 1; b <= nb; b++) {
     uint32_t n = 0;
-    while (n < (uint32_t)sblock && i < ncols) {
-      if (order[i]->n_hashes > 0) batch[n++] = *order[i]; /* empty buckets skipped, index.go:803 */
-      i++;
-    }
-    if (n == 0) break;
-    nb++;
-    snprintf(path, sizeof path, "%s/_block%03d.uniki", dir, nb);
-    if (ko_write_block(path, cfg->k, cfg->canonical, num_hashes, fpr, 0, batch, n) != 0) { free(batch); free(order); return -1; }
+    for (uint32_t i = 0; i < ncols; i++)
+      if (block_of[i] == b) batch[n++] = *order[i];
+    snprintf(path, sizeof path, "%s/_block%03d.uniki", dir, b);
+    if (ko_write_block(path, cfg->k, cfg->canonical, num_hashes, fpr, 0, batch, n) != 0) { free(batch); free(block_of); free(order); return -1; }
   }
   free(batch);
+  free(block_of);
   snprintf(path, sizeof path, "%s/__db.yml", dir);
   FILE* f = fopen(path, "w");
   if (!f) { free(order); FAIL("cannot write %s", path); }

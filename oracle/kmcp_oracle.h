@@ -116,6 +116,19 @@ int ko_write_block(const char* path, int k, int canonical, int num_hashes, doubl
  * block layout of index.go:657-682 (sort by #k-mers ascending, blocks of sBlock). */
 int ko_build_db(const char* out_dir, const ko_sketch_cfg* cfg, int num_hashes, double fpr,
                 int threads_for_block_size, int block_size, const ko_column* cols, uint32_t ncols);
+/* the big-genome rules of `kmcp index` (index.go:787-894; flags -x/-X/-8/-1 at :1453-1463): 0 = the flag's default
+ * (10M / 256 / 20M / 200M, "M" = 2^20 as bytesize.ParseByteSize reads it) */
+typedef struct {
+  uint64_t kmers_x; /* -x: above it blocks shrink to block_size_x columns */
+  int32_t block_size_x; /* -X */
+  uint64_t kmers_8; /* -8: above it blocks shrink to 8 columns */
+  uint64_t kmers_1; /* -1: above it every column gets its own block */
+} ko_block_rules;
+/* kmers[i]: #k-mers of column i in ascending order.  block_of[i] = 1-based block of column i (0: empty, skipped).
+ * sblock = the clamped -b value (index.go:671-682).  Returns the number of blocks. */
+int ko_block_layout(const uint64_t* kmers, uint32_t n, int sblock, const ko_block_rules* rules, int* block_of);
+int ko_build_db2(const char* out_dir, const ko_sketch_cfg* cfg, int num_hashes, double fpr, int threads_for_block_size,
+                 int block_size, const ko_block_rules* rules, const ko_column* cols, uint32_t ncols);
 
 /* ---- database + search ------------------------------------------------------------------------- */
 ko_db* ko_db_open(const char* db_dir); /* db_dir is the R001-style dir holding __db.yml */

@@ -51,6 +51,11 @@ class Column(C.Structure):
                 ("hashes", C.POINTER(C.c_uint64)), ("n_hashes", C.c_uint64)]
 
 
+class BlockRules(C.Structure):
+    """index.go:1453-1463 flags -x / -X / -8 / -1 (0 = default)."""
+    _fields_ = [("kmers_x", C.c_uint64), ("block_size_x", C.c_int32), ("kmers_8", C.c_uint64), ("kmers_1", C.c_uint64)]
+
+
 def default_params(**kw):
     """search.go:1052-1102 defaults."""
     p = SearchParams(min_qlen=30, min_matched=10, min_qcov=0.55, min_tcov=0.0, max_fpr=0.01,
@@ -99,6 +104,9 @@ def lib():
     L.ko_binomial_coeff.argtypes = [C.c_int, C.c_int]
     L.ko_write_block.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_double, C.c_uint64, C.POINTER(Column), C.c_uint32]
     L.ko_build_db.argtypes = [C.c_char_p, C.POINTER(SketchCfg), C.c_int, C.c_double, C.c_int, C.c_int, C.POINTER(Column), C.c_uint32]
+    L.ko_build_db2.argtypes = [C.c_char_p, C.POINTER(SketchCfg), C.c_int, C.c_double, C.c_int, C.c_int, C.POINTER(BlockRules), C.POINTER(Column),
+                               C.c_uint32]
+    L.ko_block_layout.argtypes = [C.POINTER(C.c_uint64), C.c_uint32, C.c_int, C.POINTER(BlockRules), C.POINTER(C.c_int)]
     L.ko_db_open.restype = C.c_void_p
     L.ko_db_open.argtypes = [C.c_char_p]
     L.ko_db_close.argtypes = [C.c_void_p]
@@ -147,7 +155,15 @@ def sort_unique(a: np.ndarray) -> np.ndarray:
     return a[:n]
 
 
-def build_db(out_dir, cfg, columns, num_hashes=1, fpr=0.3, threads=32, block_size=0):
+def block_layout(kmers, sblock, rules=None):
+    """kmers ascending -> (number of blocks, 1-based block of every column; 0 = skipped)."""
+    km = np.ascontiguousarray(kmers, dtype=np.uint64)
+    out = np.zeros(len(km), dtype=np.int32)
+    nb = lib().ko_block_layout(_u64p(km), len(km), sblock, C.byref(rules) if rules is not None else None, out.ctypes.data_as(C.POINTER(C.c_int)))
+    return nb, out
+
+
+def build_db(out_dir, cfg, columns, num_hashes=1, fpr=0.3, threads=32, block_size=0, rules=None):
     """columns: list of (name, gsize, chunk_idx, chunks, np.uint64 sorted-unique hashes)."""
     arr = (Column * len(columns))()
     keep = []
@@ -155,7 +171,8 @@ def build_db(out_dir, cfg, columns, num_hashes=1, fpr=0.3, threads=32, block_siz
         h = np.ascontiguousarray(h, dtype=np.uint64)
         keep.append(h)
         arr[i] = Column(name.encode(), gsize, ci, nchunks, _u64p(h), len(h))
-    rc = lib().ko_build_db(out_dir.encode(), C.byref(cfg), num_hashes, fpr, threads, block_size, arr, len(columns))
+    rc = lib().ko_build_db2(out_dir.encode(), C.byref(cfg), num_hashes, fpr, threads, block_size, C.byref(rules) if rules is not None else None, arr,
+                            len(columns))
     if rc != 0:
         raise RuntimeError(lib().ko_last_error().decode())
     return os.path.join(out_dir, "R001")

@@ -168,3 +168,16 @@ def test_finalize_worker_threads_agree(small_db):
     assert len(whole.matches) > 100000
     assert np.array_equal(whole.matches, np.concatenate([x.matches for x in pieces]))
     assert np.array_equal(np.diff(whole.offs), np.concatenate([np.diff(x.offs) for x in pieces]))
+
+
+def test_dist_search_fastx_reader(tmp_path):
+    """The record reader of kmcp_amd.dist_search: multi-line FASTA, FASTQ with '@' leading a quality line, gzip, empty records."""
+    import gzip
+    from kmcp_amd.dist_search import read_fastx
+    fa = tmp_path / "a.fa"
+    fa.write_text(">s1 desc\nACGT\nAC\n\n>s2\n>s3\tx\nGG\n")
+    assert list(read_fastx(str(fa))) == [(b"s1", b"ACGTAC"), (b"s2", b""), (b"s3", b"GG")]
+    fq = tmp_path / "a.fq.gz"
+    with gzip.open(fq, "wt") as fh:
+        fh.write("@q1 d\nACGT\n+\n@III\n@q2\n\n+\n\n@q3\nAC\nGT\n+q3\n>I\n@@\r\n")
+    assert list(read_fastx(str(fq))) == [(b"q1", b"ACGT"), (b"q2", b""), (b"q3", b"ACGT")]

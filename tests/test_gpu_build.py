@@ -59,6 +59,39 @@ def test_gpu_built_database_is_byte_identical(oracle_lib, tmp_path, case):
         odb.close()
 
 
+@pytest.mark.parametrize("size_x", [16, 256])
+def test_big_genome_block_rules(oracle_lib, tmp_path, size_x):
+    """index.go:787-894 with thresholds scaled down (-x 1500 -8 3000 -1 6000 k-mers): genomes of four size classes end up in
+    blocks of -b, -X, 8 and 1 columns; 1-column blocks (1-byte rows) are searched like any other."""
+    from kmcp_amd import Database, default_params, lib
+    O = oracle_lib
+    base = synth.random_genomes(75, 9000, seed=81)
+    lens = [1000] * 40 + [2200] * 20 + [4500] * 11 + [8000] * 4
+    genomes = [g[:n] for g, n in zip(base, lens)]
+    cfg = O.sketch_cfg(k=21)
+    cols = synth.make_columns(genomes, cfg)
+    rules = dict(kmers_x=1500, block_size_x=size_x, kmers_8=3000, kmers_1=6000)
+    ref = O.build_db(str(tmp_path / "oracle"), cfg, cols, threads=2, block_size=32, rules=O.BlockRules(**rules))
+    got = lib.build_db(str(tmp_path / "gpu"), cols, k=21, threads=2, block_size=32, **rules)
+    yr, yg = _yml(os.path.join(ref, "__db.yml")), _yml(os.path.join(got, "__db.yml"))
+    # -X 16: 40 -> 32+8 | 20 -> 16+4 | 11 -> 8+3 | 4 x 1 = 10 blocks;  -X 256 >= -b 32: 60 -> 32+28 | 11 -> 11 | 4 x 1 = 7 blocks
+    assert yr["files"] == yg["files"] and len(yr["files"]) == (10 if size_x == 16 else 7)
+    assert yr["blocksize"] == yg["blocksize"] == "32"
+    for f in yr["files"]:
+        assert filecmp.cmp(os.path.join(ref, f), os.path.join(got, f), shallow=False), f
+    reads = synth.sample_reads(genomes, 300, 150, sub_rate=0.01, seed=82, frac_random=0.1)
+    odb = O.OracleDB(ref)
+    try:
+        with Database.open(got, device=0) as db:
+            assert db.info.n_blocks == len(yr["files"])
+            res = db.search(reads, params=default_params())
+        assert synth.assert_parity(odb, res, reads, None, O.default_params()) > 100
+    finally:
+        odb.close()
+    with pytest.raises(lib.KmcpGpuError):
+        lib.build_db(str(tmp_path / "bad"), cols, kmers_x=5000, kmers_8=3000, kmers_1=6000)
+
+
 def test_build_refuses_bad_input(tmp_path):
     import numpy as np
     from kmcp_amd import lib

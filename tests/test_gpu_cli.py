@@ -140,6 +140,30 @@ def test_cli_paired_end_and_whole_file(oracle_lib, tmp_path):
     odb.close()
 
 
+def test_dist_search_module_matches_oracle(oracle_lib, tmp_path):
+    """python -m kmcp_amd.dist_search (the one-process-per-GPU driver; one rank here) prints the same TSV."""
+    import sys
+    O = oracle_lib
+    genomes = synth.random_genomes(12, 9000, seed=46)
+    db_dir = synth.make_db(tmp_path / "db", genomes, k=21, n_chunks=2, overlap=150, threads=3)
+    reads = synth.sample_reads(genomes, 400, 150, sub_rate=0.01, seed=47, frac_random=0.2) + [b"", b"ACGTACGT"]
+    ids = [f"r{i}" for i in range(len(reads))]
+    fq = str(tmp_path / "reads.fq.gz")
+    write_fastq(fq, ids, reads, gz=True)
+    odb = O.OracleDB(db_dir)
+    p = O.default_params(min_qcov=0.45, sort_by=1)
+    want, trailer = oracle_tsv(O, odb, ids, reads, params=p, keep_unmatched=True)
+    odb.close()
+    out = str(tmp_path / "d.tsv")
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, "-m", "kmcp_amd.dist_search", "-d", os.path.dirname(db_dir), fq, "-o", out, "-t", "0.45", "-s", "tcov", "-K",
+                        "--gpu-batch", "128"], capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr
+    compare(open(out).read().split("\n"), want, trailer)
+
+
 def test_cli_errors(tmp_path, oracle_lib):
     O = oracle_lib
     genomes = synth.random_genomes(3, 3000, seed=45)
