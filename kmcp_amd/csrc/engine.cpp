@@ -8,9 +8,13 @@
 #include <stdarg.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <errno.h>
+#include <fcntl.h>
 #include <string.h>
+#include <unistd.h>
 
 #include <algorithm>
+#include <atomic>
 #include <memory>
 #include <mutex>
 #include <string>
@@ -232,44 +236,112 @@ int finish_open(kmcpg_db* db) {
   return 0;
 }
 
-// upload one block: file rows -> temp device buffer (chunked) -> padded HBM rows
-int upload_block(BlockMeta& b) {
-  const uint64_t ns = b.h.num_sigs;
-  const uint32_t rb = b.h.row_bytes;
-  b.stride = device_stride(rb);
-  // the kernel addresses rows in 16-byte units with 32 bits
-  if ((ns + 1) * (uint64_t)(b.stride >> 4) > 0xffffffffULL)
-    return fail(KMCPG_EUNSUPPORTED, "%s: block larger than 64 GB in HBM (NumSigs %llu x %u B)", b.path.c_str(), (unsigned long long)ns, b.stride);
-  const uint64_t bytes = (ns + 1) * (uint64_t)b.stride;
-  HIPCHK(hipMalloc((void**)&b.d_rows, bytes));
-  HIPCHK(hipMemset(b.d_rows + ns * b.stride, 0, b.stride));  // the all-zero row
-  FILE* f = fopen(b.path.c_str(), "rb");
-  if (!f) return fail(KMCPG_EIO, "kmcp index file missing: %s", b.path.c_str());
-  fseeko(f, (off_t)b.h.offset0, SEEK_SET);
-  const uint64_t chunk_rows = std::max<uint64_t>(1, (256ull << 20) / rb);
-  std::vector<uint8_t> host(std::min(chunk_rows, ns) * rb);
-  uint8_t* d_tmp = nullptr;
-  HIPCHK(hipMalloc((void**)&d_tmp, host.size() ? host.size() : 1));
-  for (uint64_t r0 = 0; r0 < ns; r0 += chunk_rows) {
-    const uint64_t nr = std::min(chunk_rows, ns - r0);
-    if (fread(host.data(), 1, nr * rb, f) != nr * rb) {
-      fclose(f);
-      (void)hipFree(d_tmp);
-      return fail(KMCPG_EFORMAT, "kmcp: truncated index file: %s", b.path.c_str());
-    }
-    hipError_t he = hipMemcpy(d_tmp, host.data(), nr * rb, hipMemcpyHostToDevice);
-    if (he == hipSuccess) {
-      launch_repack(d_tmp, b.d_rows + r0 * b.stride, nr, rb, b.stride, nullptr);
-      he = hipDeviceSynchronize();
-    }
-    if (he != hipSuccess) {
-      fclose(f);
-      (void)hipFree(d_tmp);
-      return fail(KMCPG_EDEVICE, "uploading %s: %s", b.path.c_str(), hipGetErrorString(he));
+// Upload of the local blocks: file rows -> pinned staging -> temp device buffer -> padded HBM rows (k_repack).
+// The matrix is cut into 64 MB chunks handed to a few loader threads; each owns a pinned buffer, a device staging buffer and
+// a stream, so that preads (page cache or disk), PCIe copies and repacks of different chunks overlap.
+struct UploadChunk {
+  BlockMeta* b;
+  uint64_t r0, nr;
+};
+
+int upload_blocks(kmcpg_db* db) {
+  const uint64_t kChunkBytes = 64ull << 20;
+  std::vector<UploadChunk> chunks;
+  uint64_t cap = 1;
+  for (auto& b : db->blocks) {
+    if (!b.local) continue;
+    const uint64_t ns = b.h.num_sigs;
+    const uint32_t rb = b.h.row_bytes;
+    b.stride = device_stride(rb);
+    // the kernel addresses rows in 16-byte units with 32 bits
+    if ((ns + 1) * (uint64_t)(b.stride >> 4) > 0xffffffffULL)
+      return fail(KMCPG_EUNSUPPORTED, "%s: block larger than 64 GB in HBM (NumSigs %llu x %u B)", b.path.c_str(), (unsigned long long)ns, b.stride);
+    HIPCHK(hipMalloc((void**)&b.d_rows, (ns + 1) * (uint64_t)b.stride));
+    HIPCHK(hipMemset(b.d_rows + ns * b.stride, 0, b.stride));  // the all-zero row
+    const uint64_t chunk_rows = std::max<uint64_t>(1, kChunkBytes / rb);
+    for (uint64_t r0 = 0; r0 < ns; r0 += chunk_rows) {
+      chunks.push_back(UploadChunk{&b, r0, std::min(chunk_rows, ns - r0)});
+      cap = std::max(cap, chunks.back().nr * rb);
     }
   }
-  fclose(f);
-  HIPCHK(hipFree(d_tmp));
+  if (chunks.empty()) return 0;
+  int T = (int)std::min<size_t>(std::max(1u, std::min(8u, std::thread::hardware_concurrency())), chunks.size());
+  if (const char* e = getenv("KMCPG_LOAD_THREADS")) T = std::max(1, std::min(atoi(e), 64));
+  std::atomic<size_t> next{0};
+  std::atomic<int> failed{0};
+  std::mutex emu;
+  int ecode = 0;
+  std::string emsg;
+  auto set_err = [&](int code, const std::string& m) {
+    std::lock_guard<std::mutex> g(emu);
+    if (!failed.exchange(1)) {
+      ecode = code;
+      emsg = m;
+    }
+  };
+  const int dev = db->opts.device;
+  auto worker = [&]() {
+    uint8_t *h_buf = nullptr, *d_tmp = nullptr;
+    hipStream_t st = nullptr;
+    int fd = -1;
+    const BlockMeta* fd_of = nullptr;
+    hipError_t he = hipSetDevice(dev);
+    if (he == hipSuccess) he = hipHostMalloc((void**)&h_buf, cap, hipHostMallocDefault);
+    if (he == hipSuccess) he = hipMalloc((void**)&d_tmp, cap);
+    if (he == hipSuccess) he = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
+    if (he != hipSuccess) set_err(KMCPG_EDEVICE, std::string("upload staging: ") + hipGetErrorString(he));
+    while (!failed.load()) {
+      const size_t i = next.fetch_add(1);
+      if (i >= chunks.size()) break;
+      const UploadChunk& c = chunks[i];
+      const uint32_t rb = c.b->h.row_bytes;
+      if (fd_of != c.b) {
+        if (fd >= 0) close(fd);
+        fd = open(c.b->path.c_str(), O_RDONLY);
+        fd_of = c.b;
+        if (fd < 0) {
+          set_err(KMCPG_EIO, "kmcp index file missing: " + c.b->path);
+          break;
+        }
+      }
+      he = hipStreamSynchronize(st);  // the previous chunk has left the staging buffers
+      if (he != hipSuccess) {
+        set_err(KMCPG_EDEVICE, "uploading " + c.b->path + ": " + hipGetErrorString(he));
+        break;
+      }
+      const uint64_t want = c.nr * rb;
+      uint64_t got = 0;
+      while (got < want) {
+        ssize_t n = pread(fd, h_buf + got, want - got, (off_t)(c.b->h.offset0 + c.r0 * rb + got));
+        if (n < 0 && errno == EINTR) continue;
+        if (n <= 0) break;
+        got += (uint64_t)n;
+      }
+      if (got != want) {
+        set_err(KMCPG_EFORMAT, "kmcp: truncated index file: " + c.b->path);
+        break;
+      }
+      he = hipMemcpyAsync(d_tmp, h_buf, want, hipMemcpyHostToDevice, st);
+      if (he != hipSuccess) {
+        set_err(KMCPG_EDEVICE, "uploading " + c.b->path + ": " + hipGetErrorString(he));
+        break;
+      }
+      launch_repack(d_tmp, c.b->d_rows + c.r0 * c.b->stride, c.nr, rb, c.b->stride, st);
+    }
+    if (st) {
+      he = hipStreamSynchronize(st);
+      if (he != hipSuccess) set_err(KMCPG_EDEVICE, std::string("upload: ") + hipGetErrorString(he));
+      (void)hipStreamDestroy(st);
+    }
+    if (fd >= 0) close(fd);
+    if (d_tmp) (void)hipFree(d_tmp);
+    if (h_buf) (void)hipHostFree(h_buf);
+  };
+  std::vector<std::thread> th;
+  for (int t = 1; t < T; t++) th.emplace_back(worker);
+  worker();
+  for (auto& t : th) t.join();
+  if (failed.load()) return fail(ecode, "%s", emsg.c_str());
   return 0;
 }
 
@@ -342,13 +414,13 @@ extern "C" int kmcpg_open(const char* db_dir, const kmcpg_opts* opts, kmcpg_db**
   I.n_cols = base;
   if (I.num_hashes < 1 || I.num_hashes > 4) return fail(KMCPG_EUNSUPPORTED, "hashes=%d (kmcp index allows 1..4)", I.num_hashes);
   assign_shards(db.get());
-  for (auto& b : db->blocks)
-    if (b.local && !meta_only) {
-      rc = upload_block(b);
-      if (rc) return rc;
-    } else if (b.local) {
-      b.stride = device_stride(b.h.row_bytes);
-    }
+  if (!meta_only) {
+    rc = upload_blocks(db.get());
+    if (rc) return rc;
+  } else {
+    for (auto& b : db->blocks)
+      if (b.local) b.stride = device_stride(b.h.row_bytes);
+  }
   rc = finish_open(db.get());
   if (rc) return rc;
   *out = db.release();
