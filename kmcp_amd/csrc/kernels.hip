@@ -62,12 +62,119 @@ __device__ __forceinline__ void wave_lds_fence() {
 }
 
 // ------------------------------------------------------------------------------------------------
-// K1: k-mer generation.  One wave per read; lane i hashes the k-mer at position base+i by the closed
-// form fh = XOR_j rol(seed[b_j], k-1-j), rh = XOR_j rol(seed[comp b_j], j); kept hashes are compacted
-// in order with a wave ballot.
+// K1: k-mer generation.  ntHash of the k-mer at position i in closed form:
+//     fh(i) = XOR_j rol(F[i+j], k-1-j),   rh(i) = XOR_j rol(R[i+j], j)      (F = seed of the base, R = of its complement)
+// Every term is a rotation of a per-position value by an amount that depends on i+j only up to a common rotation, so with
+// the prefix XORs  P(n) = XOR_{m<n} ror(F[m], m)  and  Q(n) = XOR_{m<n} rol(R[m], m)
+//     fh(i) = rol(P(i+k) ^ P(i), k-1+i),   rh(i) = ror(Q(i+k) ^ Q(i), i)
+// i.e. one XOR scan over the bases gives the hashes of every k (and of the s-mers of a syncmer) for two look-ups each,
+// instead of k table look-ups per k-mer.  The scans run on DPP within a wave (row_shr 1/2/4/8, row_bcast 15/31).
 // ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t rolv(uint64_t x, int n) {
+  n &= 63;
+  return (x << n) | (x >> ((64 - n) & 63));
+}
+__device__ __forceinline__ uint64_t rorv(uint64_t x, int n) {
+  n &= 63;
+  return (x >> n) | (x << ((64 - n) & 63));
+}
+
+// inclusive XOR scan over the 64 lanes of a wave (all lanes must be active)
+__device__ __forceinline__ uint32_t wave_xor_scan32(uint32_t v) {
+  v ^= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);  // row_shr:1
+  v ^= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);  // row_shr:2
+  v ^= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);  // row_shr:4
+  v ^= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);  // row_shr:8: scan within rows of 16
+  v ^= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);  // row_bcast:15 into rows 1 and 3
+  v ^= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);  // row_bcast:31 into rows 2 and 3
+  return v;
+}
+__device__ __forceinline__ uint64_t wave_xor_scan(uint64_t v) {
+  const uint32_t lo = wave_xor_scan32((uint32_t)v), hi = wave_xor_scan32((uint32_t)(v >> 32));
+  return ((uint64_t)hi << 32) | lo;
+}
+__device__ __forceinline__ uint64_t wave_last(uint64_t v) {  // lane 63's value, uniform
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, 63), hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), 63);
+  return ((uint64_t)hi << 32) | lo;
+}
+
+// One wave per read: a tile is 64 consecutive bases, lane = base index & 63 (also its rotation amount).
+struct WTile {
+  uint64_t ip, iq;  // inclusive prefixes P(e+1), Q(e+1) at this lane's base e
+  uint64_t xp, xq;  // this base's own terms
+};
+constexpr int K1_SCAN_MAX_K = 65;  // a k-mer may reach into the next tile only
+
+__device__ __forceinline__ WTile wave_tile(const uint8_t* __restrict__ s, int len, int e0, const uint64_t* tab, uint64_t& cp, uint64_t& cq, int lane) {
+  const int e = e0 + lane;
+  uint64_t F = 0, R = 0;
+  if (e < len) {
+    const uint8_t b = s[e];
+    F = tab[b];
+    R = tab[b & 7];
+  }
+  WTile t;
+  t.xp = rorv(F, lane);
+  t.xq = rolv(R, lane);
+  t.ip = wave_xor_scan(t.xp) ^ cp;
+  t.iq = wave_xor_scan(t.xq) ^ cq;
+  cp = wave_last(t.ip);
+  cq = wave_last(t.iq);
+  return t;
+}
+
+// canonical hash of the kk-mer starting at this lane's base of tile c (n = the following tile); every lane must call it
+__device__ __forceinline__ uint64_t wave_hash(const WTile& c, const WTile& n, int kk, int lane) {
+  const int src = lane + kk - 1;  // the k-mer's last base
+  const uint64_t ec = __shfl(c.ip, src & 63), en = __shfl(n.ip, src & 63);
+  const uint64_t qc = __shfl(c.iq, src & 63), qn = __shfl(n.iq, src & 63);
+  const uint64_t dp = (src >= 64 ? en : ec) ^ c.ip ^ c.xp;
+  const uint64_t dq = (src >= 64 ? qn : qc) ^ c.iq ^ c.xq;
+  const uint64_t f = rolv(dp, kk - 1 + lane), r = rorv(dq, lane);
+  return f < r ? f : r;
+}
+
+__device__ __forceinline__ int hash_mate_scan(const uint8_t* __restrict__ s, int len, int k, const uint64_t* tab, bool scaled, uint64_t max_hash,
+                                              uint64_t* __restrict__ out, int cnt, int lane) {
+  const int npos = len - k + 1;
+  if (npos <= 0) return cnt;  // ErrShortSeq => no k-mers (util-db-search.go:1060-1062)
+  uint64_t cp = 0, cq = 0;
+  WTile cur = wave_tile(s, len, 0, tab, cp, cq, lane);
+  for (int base = 0; base < npos; base += 64) {
+    const WTile nxt = wave_tile(s, len, base + 64, tab, cp, cq, lane);
+    const uint64_t h = wave_hash(cur, nxt, k, lane);
+    const bool keep = base + lane < npos && h != 0 && (!scaled || h <= max_hash);  // :1097-1103
+    const uint64_t m = __ballot(keep);
+    if (keep) out[cnt + __popcll(m & ((1ULL << lane) - 1ULL))] = h;
+    cnt += __popcll(m);
+    cur = nxt;
+  }
+  return cnt;
+}
+
+// all canonical k1-mer (and, if out2, k2-mer) hashes of s, uncompacted (input of the window sketches)
+__device__ __forceinline__ void hash_positions_scan(const uint8_t* __restrict__ s, int len, int k1, uint64_t* __restrict__ out1, int k2,
+                                                    uint64_t* __restrict__ out2, const uint64_t* tab, int lane) {
+  const int n1 = len - k1 + 1, n2 = out2 ? len - k2 + 1 : 0;
+  const int nmax = n1 > n2 ? n1 : n2;
+  uint64_t cp = 0, cq = 0;
+  WTile cur = wave_tile(s, len, 0, tab, cp, cq, lane);
+  for (int base = 0; base < nmax; base += 64) {
+    const WTile nxt = wave_tile(s, len, base + 64, tab, cp, cq, lane);
+    const uint64_t h1 = wave_hash(cur, nxt, k1, lane);
+    if (base + lane < n1) out1[base + lane] = h1;
+    if (out2) {
+      const uint64_t h2 = wave_hash(cur, nxt, k2, lane);
+      if (base + lane < n2) out2[base + lane] = h2;
+    }
+    cur = nxt;
+  }
+}
+
+// Fallback for k > 65 (the closed form evaluated per k-mer); kept hashes are compacted in order with a wave ballot.
 __device__ __forceinline__ int hash_mate(const uint8_t* __restrict__ s, int len, int k, const uint64_t* tab, bool scaled,
                                          uint64_t max_hash, uint64_t* __restrict__ out, int cnt, int lane) {
+  if (k <= K1_SCAN_MAX_K) return hash_mate_scan(s, len, k, tab, scaled, max_hash, out, cnt, lane);
   const int npos = len - k + 1;
   if (npos <= 0) return cnt;  // ErrShortSeq => no k-mers (util-db-search.go:1060-1062)
   for (int base = 0; base < npos; base += 64) {
@@ -124,8 +231,12 @@ __device__ __forceinline__ int syncmer_mate(const uint8_t* __restrict__ s, int l
                                             uint64_t max_hash, uint64_t* hk, uint64_t* hs, uint64_t* __restrict__ out, int cnt, int lane) {
   const int L = 2 * k - sm - 1;
   if (sm < 1 || sm > k || len < L || len < k) return cnt;  // ErrShortSeq
-  hash_positions(s, len, k, tab, hk, lane);
-  hash_positions(s, len, sm, tab, hs, lane);
+  if (k <= K1_SCAN_MAX_K) {
+    hash_positions_scan(s, len, k, hk, sm, hs, tab, lane);
+  } else {
+    hash_positions(s, len, k, tab, hk, lane);
+    hash_positions(s, len, sm, tab, hs, lane);
+  }
   __threadfence_block();
   const int wsz = 2 * (k - sm);
   const int nw = wsz > 0 ? len - L + 1 : len - k + 1;  // s == k: every k-mer is its own window
@@ -154,7 +265,8 @@ __device__ __forceinline__ int syncmer_mate(const uint8_t* __restrict__ s, int l
 __device__ __forceinline__ int minimizer_mate(const uint8_t* __restrict__ s, int len, int k, int w, const uint64_t* tab, bool scaled,
                                               uint64_t max_hash, uint64_t* hk, uint64_t* __restrict__ out, int cnt, int lane) {
   if (w < 1 || len < k + w - 1) return cnt;  // ErrShortSeq
-  hash_positions(s, len, k, tab, hk, lane);
+  if (k <= K1_SCAN_MAX_K) hash_positions_scan(s, len, k, hk, 0, nullptr, tab, lane);
+  else hash_positions(s, len, k, tab, hk, lane);
   __threadfence_block();
   const int nw = len - k + 1 - w + 1;
   for (int base = 0; base < nw; base += 64) {
@@ -313,22 +425,68 @@ __device__ __forceinline__ int wg_sketch_mate(const K1Args& a, const uint8_t* __
   return cnt;
 }
 
-// LDS-tiled form of wg_sketch_mate: the bases of one tile (1024 positions + halo) and the k-/s-mer hashes the tile's windows
-// need are staged in LDS, so the window scans never go to global memory.  Usable while the halo fits (L = 2k-s-1 <= 512 for
-// syncmers, w < 512 for minimizers); otherwise the scratch-buffer version above is used.
+// LDS-tiled form of wg_sketch_mate: the prefix XORs P, Q (see the K1 header) of one tile — 1024 positions + halo — are
+// built in LDS by wave scans + a scan of the 64-base group totals, after which any k-mer or s-mer hash of the tile costs
+// four LDS reads; the window scans never go to global memory.  Usable while the halo fits (L = 2k-s-1 <= 512 for syncmers,
+// w < 512 for minimizers); otherwise the scratch-buffer version above is used.
 constexpr int K1H = 512;
+constexpr int K1CAP = 2 * K1WG;  // bases per tile: 1024 positions + a halo of at most 1024
 struct K1Lds {
-  uint64_t hk[K1WG + K1H];
-  uint64_t hs[K1WG + K1H];
-  uint8_t bases[K1WG + 2 * K1H];
+  uint64_t ip[K1CAP + 1];                   // ip[n] = P(n) = XOR_{m<n} ror(F[m], m) over the tile's bases, ip[0] = 0
+  uint64_t iq[K1CAP + 1];                   // iq[n] = Q(n)
+  uint64_t tp[K1CAP / 64], tq[K1CAP / 64];  // totals of the 64-base groups, then their exclusive prefixes
+  uint64_t hw[K1WG + K1H];                  // the hashes the windows scan: s-mers (syncmer) or k-mers (minimizer)
 };
 
-__device__ __forceinline__ uint64_t hash_lds(const uint8_t* b, int i, int kk, const uint64_t* tab) {
-  uint64_t f = 0, r = 0;
-  for (int j = 0; j < kk; j++) {
-    f = rol1(f) ^ tab[b[i + j]];
-    r = rol1(r) ^ tab[b[i + kk - 1 - j] & 7];
+// builds L.ip / L.iq over the nb (<= K1CAP) bases at s; all K1WG threads call it; ends with a barrier
+__device__ __forceinline__ void wg_prefix(const uint8_t* __restrict__ s, int nb, const uint64_t* tab, K1Lds& L, int tid) {
+  const int lane = tid & 63;
+  const int rounds = nb > K1WG ? 2 : 1;
+  uint64_t ip[2] = {0, 0}, iq[2] = {0, 0};
+#pragma unroll
+  for (int r = 0; r < 2; r++) {
+    if (r < rounds) {
+      const int e = r * K1WG + tid;
+      uint64_t F = 0, R = 0;
+      if (e < nb) {
+        const uint8_t b = s[e];
+        F = tab[b];
+        R = tab[b & 7];
+      }
+      ip[r] = wave_xor_scan(rorv(F, lane));  // K1WG % 64 == 0: e & 63 == lane
+      iq[r] = wave_xor_scan(rolv(R, lane));
+      if (lane == 63) {
+        L.tp[e >> 6] = ip[r];
+        L.tq[e >> 6] = iq[r];
+      }
+    }
   }
+  __syncthreads();
+  if (tid < 64) {  // one wave scans the group totals
+    const int ng = rounds * (K1WG / 64);
+    const uint64_t a = tid < ng ? L.tp[tid] : 0, b = tid < ng ? L.tq[tid] : 0;
+    const uint64_t sa = wave_xor_scan(a), sb = wave_xor_scan(b);
+    if (tid < ng) {
+      L.tp[tid] = sa ^ a;
+      L.tq[tid] = sb ^ b;
+    }
+    if (tid == 0) L.ip[0] = L.iq[0] = 0;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < 2; r++) {
+    if (r < rounds) {
+      const int e = r * K1WG + tid;
+      L.ip[e + 1] = ip[r] ^ L.tp[e >> 6];
+      L.iq[e + 1] = iq[r] ^ L.tq[e >> 6];
+    }
+  }
+  __syncthreads();
+}
+
+// canonical hash of the kk-mer at tile position i (i + kk <= nb of the last wg_prefix)
+__device__ __forceinline__ uint64_t lds_hash(const K1Lds& L, int i, int kk) {
+  const uint64_t f = rolv(L.ip[i + kk] ^ L.ip[i], kk - 1 + i), r = rorv(L.iq[i + kk] ^ L.iq[i], i);
   return f < r ? f : r;
 }
 
@@ -347,11 +505,9 @@ __device__ __forceinline__ int wg_sketch_mate_lds(const K1Args& a, const uint8_t
   if (nk <= 0) return cnt;
   if (a.mode == 0) {
     for (int p0 = 0; p0 < nk; p0 += K1WG) {
-      const int nb = min(len - p0, K1WG + k - 1);
-      for (int i = tid; i < nb; i += K1WG) L.bases[i] = s[p0 + i];
-      __syncthreads();
+      wg_prefix(s + p0, min(len - p0, K1WG + k - 1), tab, L, tid);
       const bool v = p0 + tid < nk;
-      const uint64_t h = v ? hash_lds(L.bases, tid, k, tab) : 0;
+      const uint64_t h = v ? lds_hash(L, tid, k) : 0;
       cnt = wg_compact(v && h != 0 && (!scaled || h <= a.max_hash), h, out, cnt, s_wave, tid);
     }
     return cnt;
@@ -363,22 +519,19 @@ __device__ __forceinline__ int wg_sketch_mate_lds(const K1Args& a, const uint8_t
     const int nw = wsz > 0 ? len - Lw + 1 : nk;
     const int ns = len - sm + 1;
     for (int p0 = 0; p0 < nw; p0 += K1WG) {
-      const int nb = min(len - p0, K1WG + Lw);
-      for (int i = tid; i < nb; i += K1WG) L.bases[i] = s[p0 + i];
-      __syncthreads();
-      const int nkt = min(nk - p0, K1WG + (k - sm)), nst = min(ns - p0, K1WG + max(wsz - 1, 0));
-      for (int i = tid; i < nkt; i += K1WG) L.hk[i] = hash_lds(L.bases, i, k, tab);
-      for (int i = tid; i < nst; i += K1WG) L.hs[i] = hash_lds(L.bases, i, sm, tab);
+      wg_prefix(s + p0, min(len - p0, K1WG + Lw), tab, L, tid);
+      const int nst = min(ns - p0, K1WG + max(wsz - 1, 0));
+      for (int i = tid; i < nst; i += K1WG) L.hw[i] = lds_hash(L, i, sm);
       __syncthreads();
       const bool v = p0 + tid < nw;
       uint64_t h = 0;
       if (v) {
         int pos = tid;
         if (wsz > 0) {
-          const int m = argmin_left(L.hs, tid, wsz);
+          const int m = argmin_left(L.hw, tid, wsz);
           pos = (m - tid < k - sm) ? m : m + sm - k;
         }
-        h = L.hk[pos];
+        h = lds_hash(L, pos, k);
       }
       cnt = wg_compact(v && h != 0 && (!scaled || h <= a.max_hash), h, out, cnt, s_wave, tid);
     }
@@ -390,20 +543,18 @@ __device__ __forceinline__ int wg_sketch_mate_lds(const K1Args& a, const uint8_t
   const int nw = nk - w + 1;
   for (int p0 = 0; p0 < nw; p0 += K1WG) {
     const int b0 = p0 > 0 ? p0 - 1 : 0, off = p0 - b0;  // the window before the tile's first one is needed too
-    const int nb = min(len - b0, K1WG + w + k);
-    for (int i = tid; i < nb; i += K1WG) L.bases[i] = s[b0 + i];
-    __syncthreads();
+    wg_prefix(s + b0, min(len - b0, K1WG + w + k), tab, L, tid);
     const int nkt = min(nk - b0, K1WG + w);
-    for (int i = tid; i < nkt; i += K1WG) L.hk[i] = hash_lds(L.bases, i, k, tab);
+    for (int i = tid; i < nkt; i += K1WG) L.hw[i] = lds_hash(L, i, k);
     __syncthreads();
     const int w0 = p0 + tid;
     const bool v = w0 < nw;
     int m = -1, pm = -2;
     if (v) {
-      m = argmin_left(L.hk, off + tid, w);
-      pm = w0 > 0 ? argmin_left(L.hk, off + tid - 1, w) : -2;
+      m = argmin_left(L.hw, off + tid, w);
+      pm = w0 > 0 ? argmin_left(L.hw, off + tid - 1, w) : -2;
     }
-    const uint64_t h = (v && m != pm) ? L.hk[m] : 0;
+    const uint64_t h = (v && m != pm) ? L.hw[m] : 0;
     cnt = wg_compact(v && m != pm && h != 0 && (!scaled || h <= a.max_hash), h, out, cnt, s_wave, tid);
   }
   return cnt;
@@ -456,7 +607,7 @@ constexpr int K1SEG = 65536;
 __global__ void __launch_bounds__(K1WG) k1_seg_hash(const K1Args a) {
   __shared__ uint64_t tab[256];
   __shared__ int s_wave[K1WG / 64];
-  __shared__ uint8_t bases[K1WG + 256];
+  __shared__ K1Lds lds;
   const int tid = threadIdx.x;
   if (tid < 256) tab[tid] = seed_of(tid);
   __syncthreads();
@@ -472,11 +623,9 @@ __global__ void __launch_bounds__(K1WG) k1_seg_hash(const K1Args a) {
     const int p_hi = min(npos, p_lo + K1SEG);
     const bool scaled = a.scaled != 0;
     for (int p0 = p_lo; p0 < p_hi; p0 += K1WG) {
-      const int nb = min(len - p0, K1WG + a.k - 1);
-      for (int i = tid; i < nb; i += K1WG) bases[i] = s[p0 + i];
-      __syncthreads();
+      wg_prefix(s + p0, min(len - p0, K1WG + a.k - 1), tab, lds, tid);
       const bool v = p0 + tid < p_hi;
-      const uint64_t h = v ? hash_lds(bases, tid, a.k, tab) : 0;
+      const uint64_t h = v ? lds_hash(lds, tid, a.k) : 0;
       cnt = wg_compact(v && h != 0 && (!scaled || h <= a.max_hash), h, out, cnt, s_wave, tid);
     }
   }

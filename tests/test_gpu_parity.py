@@ -301,3 +301,41 @@ def test_long_query_split_path(G, oracle_lib, tmp_path, monkeypatch, split_min):
     reads = synth.sample_reads(genomes, 300, 300, sub_rate=0.01, seed=93)
     n, _ = _run(G, O, db_dir, reads)
     assert n > 150
+
+
+@pytest.mark.parametrize("k", [11, 21, 33, 64, 65, 66, 90, 130])
+def test_k1_all_forms_across_k(G, oracle_lib, k):
+    """K1 vs the oracle's generateKmers for every kernel form — one wave per read (prefix-XOR scan for k <= 65, closed form
+    above), one workgroup per read (LDS prefix arrays), one workgroup per 65536-position segment — in plain, scaled,
+    syncmer and minimizer mode; rotation amounts wrap at 64, tiles end inside k-mers, reads end inside tiles."""
+    import torch
+    O = oracle_lib
+    lib = G["lib"]
+    dev = torch.device("cuda:0")
+    genomes = synth.random_genomes(2, 150000, seed=200 + k)
+    short = synth.sample_reads(genomes, 40, 150, seed=201, n_rate=0.02) + [genomes[0][:n] for n in (k - 1, k, k + 1, 63, 64, 65, 127, 128, 129, 191, 192, 193, 1000, 2048)]
+    long_ = [genomes[0][:n] for n in (2049, 3000, 1024 + k - 1, 1024 + k, 2 * 1024 + k - 1, 5000)] + short[:5]
+    huge = [genomes[1][:140000], genomes[0][:65536 + k - 1], genomes[0][:65536 + k], genomes[1][:70000]]
+    modes = [dict(), dict(scale=5), dict(syncmer_s=max(1, k // 2)), dict(minimizer_w=5)]
+    for kw in modes:
+        spec = lib.SynthSpec(k=k, num_hashes=1, fpr=0.3, n_blocks=1, cols_per_block=8, num_sigs=1000, kmers_per_col=10, seed=1,
+                             scale=kw.get("scale", 1), syncmer_s=kw.get("syncmer_s", 0), minimizer_w=kw.get("minimizer_w", 0))
+        cfg = O.sketch_cfg(k=k, **kw)
+        with G["Database"].open_synthetic(spec) as db:
+            for reads in (short, long_, huge):
+                seqs, offs = lib.pack_reads(reads)
+                t_seqs = torch.from_numpy(seqs).to(dev)
+                t_offs = torch.from_numpy(offs.view(np.int64)).to(dev)
+                t_h = torch.zeros(len(seqs) + 8, dtype=torch.int64, device=dev)
+                t_nk = torch.zeros(len(reads), dtype=torch.int32, device=dev)
+                p = G["default_params"](min_qlen=0, min_matched=1, dedup_threshold=1 << 30)
+                db.kmers_device(t_seqs.data_ptr(), t_offs.data_ptr(), len(reads), len(seqs), max(len(r) for r in reads),
+                                t_h.data_ptr(), t_h.numel(), None, t_nk.data_ptr(), params=p)
+                torch.cuda.synchronize()
+                h = t_h.cpu().numpy().view(np.uint64)
+                nk = t_nk.cpu().numpy()
+                for i, r in enumerate(reads):
+                    want = O.generate_kmers(r, cfg)
+                    got = h[int(offs[i]):int(offs[i]) + int(nk[i])]
+                    assert len(want) == nk[i], (kw, i, len(r), len(want), nk[i])
+                    assert np.array_equal(got, want), (kw, i, len(r))
