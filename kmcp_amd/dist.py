@@ -88,6 +88,8 @@ class ShardedSearcher:
                                  d_offs2=o2.data_ptr() if o2 is not None else None, stream=torch.cuda.current_stream(self.dev).cuda_stream)
             need = cnt[:1].clone()
             if self.world > 1:
+                if dist.get_backend(self.group) == "gloo":
+                    need = need.cpu()  # debugging aid, see gather_hits
                 dist.all_reduce(need, op=dist.ReduceOp.MAX, group=self.group)
             if int(need.item()) <= cap:
                 break

@@ -76,10 +76,18 @@ def main(argv=None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # KMCP_DIST_SAME_GPU=1 (tests on a 1-GPU box): every rank uses GPU 0 and the exchange runs over gloo, because RCCL refuses
+    # two ranks on one device.  The production path is nccl = RCCL over xGMI, one GPU per rank.
+    same_gpu = os.environ.get("KMCP_DIST_SAME_GPU") == "1"
+    if same_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if same_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     sub = [os.path.join(a.db_dir, d) for d in sorted(os.listdir(a.db_dir)) if os.path.exists(os.path.join(a.db_dir, d, "__db.yml"))]
     if not sub:
         raise SystemExit(f"invalid kmcp database: {a.db_dir}")

@@ -162,6 +162,14 @@ def test_dist_search_module_matches_oracle(oracle_lib, tmp_path):
                         "--gpu-batch", "128"], capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stderr
     compare(open(out).read().split("\n"), want, trailer)
+    # three processes, each holding a shard of the blocks (all on GPU 0 here, exchange over gloo instead of RCCL)
+    out3 = str(tmp_path / "d3.tsv")
+    env["KMCP_DIST_SAME_GPU"] = "1"
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "3", "--master-addr", "127.0.0.1",
+                        "--master-port", "29731", "-m", "kmcp_amd.dist_search", "-d", os.path.dirname(db_dir), fq, "-o", out3, "-t", "0.45", "-s", "tcov",
+                        "-K", "--gpu-batch", "128"], capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert open(out3).read() == open(out).read()
 
 
 def test_cli_errors(tmp_path, oracle_lib):
