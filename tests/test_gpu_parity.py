@@ -339,3 +339,48 @@ def test_k1_all_forms_across_k(G, oracle_lib, k):
                     got = h[int(offs[i]):int(offs[i]) + int(nk[i])]
                     assert len(want) == nk[i], (kw, i, len(r), len(want), nk[i])
                     assert np.array_equal(got, want), (kw, i, len(r))
+
+
+def test_dedup_classes_at_their_boundaries(G, oracle_lib):
+    """K1d: sort + unique of queries above -u in every size class — one wave (n <= 512), 256-thread workgroup (<= 4096),
+    1024-thread workgroup (LDS <= 16384, global memory above), device-wide sort (> 65536) — at the class boundaries, on reads
+    full of repeated k-mers; at or below -u the raw list is kept."""
+    import torch
+    O = oracle_lib
+    lib = G["lib"]
+    dev = torch.device("cuda:0")
+    k = 21
+    rng = np.random.default_rng(77)
+    unit = synth.random_genomes(1, 400, seed=78)[0]
+
+    def repetitive(n_kmers):
+        length = n_kmers + k - 1
+        s = bytearray((unit[:137] * (length // 137 + 1))[:length])  # tandem repeat: most k-mers occur several times
+        for p in rng.integers(0, length, max(1, length // 60)):
+            s[p] = b"ACGT"[int(rng.integers(0, 4))]
+        return bytes(s)
+
+    sizes = [1, 9, 64, 255, 256, 257, 300, 511, 512, 513, 1000, 4095, 4096, 4097, 9000, 16384, 16385, 20000]
+    reads = [repetitive(n) for n in sizes] + [synth.random_genomes(1, n + k - 1, seed=79 + n)[0] for n in (260, 512, 513, 4096, 4097)]
+    spec = lib.SynthSpec(k=k, num_hashes=1, fpr=0.3, n_blocks=1, cols_per_block=8, num_sigs=1000, kmers_per_col=10, seed=1)
+    cfg = O.sketch_cfg(k=k)
+    with G["Database"].open_synthetic(spec) as db:
+        for thr in (0, 256, 600):
+            for batch in (reads, reads[:9], reads + [repetitive(70000)]):  # max length decides which classes are launched
+                seqs, offs = lib.pack_reads(batch)
+                t_seqs = torch.from_numpy(seqs).to(dev)
+                t_offs = torch.from_numpy(offs.view(np.int64)).to(dev)
+                t_h = torch.zeros(len(seqs) + 8, dtype=torch.int64, device=dev)
+                t_nk = torch.zeros(len(batch), dtype=torch.int32, device=dev)
+                p = G["default_params"](min_qlen=0, min_matched=1, dedup_threshold=thr)
+                db.kmers_device(t_seqs.data_ptr(), t_offs.data_ptr(), len(batch), len(seqs), max(len(r) for r in batch),
+                                t_h.data_ptr(), t_h.numel(), None, t_nk.data_ptr(), params=p)
+                torch.cuda.synchronize()
+                h = t_h.cpu().numpy().view(np.uint64)
+                nk = t_nk.cpu().numpy()
+                for i, r in enumerate(batch):
+                    raw = O.generate_kmers(r, cfg)
+                    want = O.sort_unique(raw) if len(raw) > thr else raw
+                    got = h[int(offs[i]):int(offs[i]) + int(nk[i])]
+                    assert nk[i] == len(want), (thr, i, len(raw), nk[i], len(want))
+                    assert np.array_equal(got, want), (thr, i, len(raw))
