@@ -490,6 +490,9 @@ __device__ __forceinline__ uint64_t lds_hash(const K1Lds& L, int i, int kk) {
   return f < r ? f : r;
 }
 
+// positions per tile: with a small halo the tile shrinks so that positions + halo fit one scan round of K1WG bases
+__device__ __forceinline__ int wg_tile_step(int halo) { return halo <= K1WG / 2 ? K1WG - halo : K1WG; }
+
 __device__ __forceinline__ bool wg_lds_usable(const K1Args& a) {
   if (a.k > 255) return false;
   if (a.mode == 2) return 2 * a.k - (int)a.w_or_s - 1 <= K1H && (int)a.w_or_s >= 1 && (int)a.w_or_s <= a.k;
@@ -504,9 +507,10 @@ __device__ __forceinline__ int wg_sketch_mate_lds(const K1Args& a, const uint8_t
   const int nk = len - k + 1;  // k-mer positions
   if (nk <= 0) return cnt;
   if (a.mode == 0) {
-    for (int p0 = 0; p0 < nk; p0 += K1WG) {
-      wg_prefix(s + p0, min(len - p0, K1WG + k - 1), tab, L, tid);
-      const bool v = p0 + tid < nk;
+    const int T = wg_tile_step(k - 1);
+    for (int p0 = 0; p0 < nk; p0 += T) {
+      wg_prefix(s + p0, min(len - p0, T + k - 1), tab, L, tid);
+      const bool v = tid < T && p0 + tid < nk;
       const uint64_t h = v ? lds_hash(L, tid, k) : 0;
       cnt = wg_compact(v && h != 0 && (!scaled || h <= a.max_hash), h, out, cnt, s_wave, tid);
     }
@@ -518,12 +522,13 @@ __device__ __forceinline__ int wg_sketch_mate_lds(const K1Args& a, const uint8_t
     const int wsz = 2 * (k - sm);
     const int nw = wsz > 0 ? len - Lw + 1 : nk;
     const int ns = len - sm + 1;
-    for (int p0 = 0; p0 < nw; p0 += K1WG) {
-      wg_prefix(s + p0, min(len - p0, K1WG + Lw), tab, L, tid);
-      const int nst = min(ns - p0, K1WG + max(wsz - 1, 0));
+    const int T = wg_tile_step(Lw);
+    for (int p0 = 0; p0 < nw; p0 += T) {
+      wg_prefix(s + p0, min(len - p0, T + Lw), tab, L, tid);
+      const int nst = min(ns - p0, T + max(wsz - 1, 0));
       for (int i = tid; i < nst; i += K1WG) L.hw[i] = lds_hash(L, i, sm);
       __syncthreads();
-      const bool v = p0 + tid < nw;
+      const bool v = tid < T && p0 + tid < nw;
       uint64_t h = 0;
       if (v) {
         int pos = tid;
@@ -541,14 +546,15 @@ __device__ __forceinline__ int wg_sketch_mate_lds(const K1Args& a, const uint8_t
   const int w = (int)a.w_or_s;
   if (len < k + w - 1) return cnt;
   const int nw = nk - w + 1;
-  for (int p0 = 0; p0 < nw; p0 += K1WG) {
+  const int T = wg_tile_step(w + k);
+  for (int p0 = 0; p0 < nw; p0 += T) {
     const int b0 = p0 > 0 ? p0 - 1 : 0, off = p0 - b0;  // the window before the tile's first one is needed too
-    wg_prefix(s + b0, min(len - b0, K1WG + w + k), tab, L, tid);
-    const int nkt = min(nk - b0, K1WG + w);
+    wg_prefix(s + b0, min(len - b0, T + w + k), tab, L, tid);
+    const int nkt = min(nk - b0, T + w);
     for (int i = tid; i < nkt; i += K1WG) L.hw[i] = lds_hash(L, i, k);
     __syncthreads();
     const int w0 = p0 + tid;
-    const bool v = w0 < nw;
+    const bool v = tid < T && w0 < nw;
     int m = -1, pm = -2;
     if (v) {
       m = argmin_left(L.hw, off + tid, w);
@@ -622,9 +628,10 @@ __global__ void __launch_bounds__(K1WG) k1_seg_hash(const K1Args a) {
     uint64_t* __restrict__ out = a.scratch + o1 + p_lo;
     const int p_hi = min(npos, p_lo + K1SEG);
     const bool scaled = a.scaled != 0;
-    for (int p0 = p_lo; p0 < p_hi; p0 += K1WG) {
-      wg_prefix(s + p0, min(len - p0, K1WG + a.k - 1), tab, lds, tid);
-      const bool v = p0 + tid < p_hi;
+    const int T = wg_tile_step(a.k - 1);
+    for (int p0 = p_lo; p0 < p_hi; p0 += T) {
+      wg_prefix(s + p0, min(len - p0, T + a.k - 1), tab, lds, tid);
+      const bool v = tid < T && p0 + tid < p_hi;
       const uint64_t h = v ? lds_hash(lds, tid, a.k) : 0;
       cnt = wg_compact(v && h != 0 && (!scaled || h <= a.max_hash), h, out, cnt, s_wave, tid);
     }
