@@ -64,3 +64,49 @@ def test_random_configuration(oracle_lib, tmp_path, seed):
         synth.assert_parity(odb, res, reads, reads2, O.default_params(**flags))
     finally:
         odb.close()
+
+
+@pytest.mark.parametrize("seed", list(range(int(os.environ.get("KMCP_FUZZ_LONG_SEEDS", "8")))))
+def test_random_long_queries(oracle_lib, tmp_path, seed):
+    """Long queries (1 kb .. 200 kb: HiFi reads, contigs, small genomes) mixed with short ones in one batch: the workgroup
+    and segment forms of K1, every dedup class, 16/24-plane counters and the SPLIT form of the COBS kernel, in all sketch
+    modes, with -u at its default, tiny or off."""
+    from kmcp_amd import Database, default_params
+    O = oracle_lib
+    rng = np.random.default_rng(5000 + seed)
+    k = int(rng.choice([15, 21, 31, 33, 64, 66]))
+    mode = rng.choice(["plain", "scaled", "syncmer", "minimizer"])
+    kw = {}
+    if mode == "scaled":
+        kw["scale"] = int(rng.choice([3, 20, 200]))
+    elif mode == "syncmer":
+        kw["syncmer_s"] = int(rng.integers(max(1, k - 14), k + 1))
+    elif mode == "minimizer":
+        kw["minimizer_w"] = int(rng.integers(1, 40))
+    nh = int(rng.choice([1, 1, 3]))
+    fpr = 0.3 if nh == 1 else 0.01
+    n_genomes = int(rng.choice([6, 30]))
+    glen = int(rng.choice([30000, 220000])) if n_genomes == 6 else 30000
+    genomes = synth.random_genomes(n_genomes, glen, seed=6000 + seed)
+    db_dir = synth.make_db(tmp_path, genomes, k=k, n_chunks=int(rng.choice([1, 4])), overlap=150, num_hashes=nh, fpr=fpr, threads=int(rng.choice([1, 4])), **kw)
+    reads = []
+    for _ in range(int(rng.integers(3, 14))):
+        L = int(min(glen - 1, rng.choice([1000, 2047, 2048, 2049, 5000, 12000, 29999, 70000, 200000])))
+        reads += synth.sample_reads(genomes, 1, L, sub_rate=float(rng.choice([0, 0.01, 0.1])), seed=int(rng.integers(1 << 30)), frac_random=0.1,
+                                    n_rate=float(rng.choice([0, 0.001])))
+    reads += synth.sample_reads(genomes, 20, 150, seed=int(rng.integers(1 << 30)))
+    if rng.random() < 0.3:
+        reads.append(genomes[0] + genomes[1][: glen // 2])  # longer than any reference
+    order = rng.permutation(len(reads))
+    reads = [reads[i] for i in order]
+    t = max(float(rng.choice([0.55, 0.3, 0.8])), fpr + 0.05)
+    flags = dict(min_qcov=t, min_matched=int(rng.choice([1, 10])), dedup_threshold=int(rng.choice([256, 0, 1 << 30])), sort_by=int(rng.integers(0, 3)),
+                 max_fpr=float(rng.choice([0.01, 1.0])))
+    odb = O.OracleDB(db_dir)
+    try:
+        with Database.open(db_dir, device=0) as db:
+            res = db.search(reads, None, params=default_params(**flags))
+        n = synth.assert_parity(odb, res, reads, None, O.default_params(**flags))
+        assert n > 0 or t >= 0.8  # reads with matches were compared (at -t 0.8 the 1 %-error reads may all fall short)
+    finally:
+        odb.close()
