@@ -15,9 +15,11 @@
 #include <zlib.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <condition_variable>
 #include <deque>
+#include <map>
 #include <memory>
 #include <mutex>
 #include <string>
@@ -303,6 +305,7 @@ class FastxReader {
 // pipeline
 // ------------------------------------------------------------------------------------------------
 struct Batch {
+  uint64_t seq = 0;  // position in the input: the writer emits batches in this order
   uint64_t first_idx = 0;
   std::vector<std::string> ids;
   std::vector<uint8_t> seqs, seqs2;
@@ -651,11 +654,12 @@ int main(int argc, char** argv) {
   const size_t max_bases = 64u << 20;  // a batch also closes at 64 Mbases (long queries)
 
   std::thread reader([&] {
-    uint64_t id = 0;
+    uint64_t id = 0, seq = 0;
     std::unique_ptr<Batch> b(new Batch());
     b->paired = paired;
     auto flush = [&] {
       if (b->size() == 0) return;
+      b->seq = seq++;
       q_in.push(std::move(b));
       b.reset(new Batch());
       b->paired = paired;
@@ -735,29 +739,57 @@ int main(int argc, char** argv) {
   });
 
   double t_gpu = 0, t_fmt = 0, t_read_wait = 0;  // seconds spent inside libkmcpgpu / formatting+writing / waiting for input
-  std::thread searcher([&] {
-    std::unique_ptr<Batch> b;
-    for (;;) {
-      const auto tw = std::chrono::steady_clock::now();
-      if (!q_in.pop(&b)) break;
-      const auto t0 = std::chrono::steady_clock::now();
-      t_read_wait += std::chrono::duration<double>(t0 - tw).count();
-      int rc = kmcpg_search_batch(db, b->seqs.data(), b->offs.data(), b->paired ? b->seqs2.data() : nullptr, b->paired ? b->offs2.data() : nullptr,
-                                  (uint32_t)b->size(), &params, &b->res);
-      if (rc != 0) die("%s", kmcpg_last_error());
-      t_gpu += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-      q_out.push(std::move(b));
-    }
-    q_out.close();
-  });
+  // two searchers: libkmcpgpu serialises their GPU halves and runs the host half (thresholds, FPR, sorting) outside that lock,
+  // so one batch is finalized while the next one's kernels run
+  const int n_search = 2;
+  std::mutex t_mu;
+  std::atomic<int> live{n_search};
+  std::vector<std::thread> searchers;
+  for (int si = 0; si < n_search; si++)
+    searchers.emplace_back([&] {
+      std::unique_ptr<Batch> b;
+      double my_gpu = 0, my_wait = 0;
+      for (;;) {
+        const auto tw = std::chrono::steady_clock::now();
+        if (!q_in.pop(&b)) break;
+        const auto t0 = std::chrono::steady_clock::now();
+        my_wait += std::chrono::duration<double>(t0 - tw).count();
+        int rc = kmcpg_search_batch(db, b->seqs.data(), b->offs.data(), b->paired ? b->seqs2.data() : nullptr, b->paired ? b->offs2.data() : nullptr,
+                                    (uint32_t)b->size(), &params, &b->res);
+        if (rc != 0) die("%s", kmcpg_last_error());
+        my_gpu += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        q_out.push(std::move(b));
+      }
+      {
+        std::lock_guard<std::mutex> g(t_mu);
+        t_gpu += my_gpu;
+        t_read_wait += my_wait;
+      }
+      if (live.fetch_sub(1) == 1) q_out.close();
+    });
 
   // writer: rows exactly as search.go:517-575 / :458-512.  A batch is formatted by several threads (contiguous ranges of
   // queries, concatenated in order); with -o *.gz each range becomes its own gzip member, compressed in the same thread
   // (a multi-member .gz is what pgzip/gzip readers, `kmcp profile` included, accept).
   {
     const int nfmt = std::max(1, std::min(o.threads > 0 ? o.threads : 8, 16));
-    std::unique_ptr<Batch> b;
-    while (q_out.pop(&b)) {
+    std::unique_ptr<Batch> b, got;
+    std::map<uint64_t, std::unique_ptr<Batch>> pending;  // batches that finished ahead of their turn
+    uint64_t next_seq = 0;
+    for (;;) {
+      auto it = pending.find(next_seq);
+      if (it != pending.end()) {
+        b = std::move(it->second);
+        pending.erase(it);
+      } else {
+        if (!q_out.pop(&got)) break;
+        if (got->seq != next_seq) {
+          pending.emplace(got->seq, std::move(got));
+          continue;
+        }
+        b = std::move(got);
+      }
+      next_seq++;
       const auto tf0 = std::chrono::steady_clock::now();
       const kmcpg_result& r = b->res;
       const uint32_t n = r.n_reads;
@@ -801,7 +833,7 @@ int main(int argc, char** argv) {
     }
   }
   reader.join();
-  searcher.join();
+  for (auto& t : searchers) t.join();
 
   if (verbose) {
     fprintf(stderr, "\n");

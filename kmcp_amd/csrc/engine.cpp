@@ -125,7 +125,8 @@ struct kmcpg_db {
   std::vector<uint32_t> col_block;  // global column -> block index
   std::unique_ptr<QueryFpr> fpr;
   std::mutex mu;      // guards the device workspace of one GPU-half call
-  std::mutex api_mu;  // serialises kmcpg_search_batch callers (they share the staging buffers)
+  std::mutex api_mu;  // serialises the GPU halves of kmcpg_search_batch callers (they share the staging buffers); the host
+                      // half (kmcpg_finalize) runs outside it, so two callers overlap one's finalize with the other's kernels
   // workspace of kmcpg_query_device
   DevBuf<uint64_t> w_hashes, w_scratch;
   DevBuf<int32_t> w_nk_raw, w_nk1, w_seg_cnt;
@@ -1108,9 +1109,12 @@ extern "C" int kmcpg_search_batch(kmcpg_db* db, const uint8_t* seqs, const uint6
     return fail(KMCPG_EINVAL, "kmcpg_search_batch needs the whole database: open it on one GPU or with kmcpg_open_devices; use kmcpg_query_device + kmcpg_finalize per shard");
   kmcpg_params p = params ? *params : default_params();
   memset(out, 0, sizeof *out);
-  std::lock_guard<std::mutex> api_guard(db->api_mu);
   RawBatch rb;
-  int rc = run_raw_any(db, seqs, offs, seqs2, offs2, n_reads, p, &rb);
+  int rc;
+  {
+    std::lock_guard<std::mutex> api_guard(db->api_mu);
+    rc = run_raw_any(db, seqs, offs, seqs2, offs2, n_reads, p, &rb);
+  }
   if (rc) return rc;
   rc = kmcpg_finalize(db, rb.hits.data(), rb.hits.size(), rb.qk.data(), rb.ql.data(), n_reads, &p, out);
   if (rc) return rc;
@@ -1136,7 +1140,10 @@ extern "C" int kmcpg_search_batch(kmcpg_db* db, const uint8_t* seqs, const uint6
     q.min_qlen = 0;
     q.try_se = 0;
     RawBatch rb2;
-    rc = run_raw_any(db, sub.data(), so.data(), nullptr, nullptr, (uint32_t)todo.size(), q, &rb2);
+    {
+      std::lock_guard<std::mutex> api_guard(db->api_mu);
+      rc = run_raw_any(db, sub.data(), so.data(), nullptr, nullptr, (uint32_t)todo.size(), q, &rb2);
+    }
     if (rc) return rc;
     kmcpg_result r2;
     rc = kmcpg_finalize(db, rb2.hits.data(), rb2.hits.size(), rb2.qk.data(), rb2.ql.data(), (uint32_t)todo.size(), &q, &r2);

@@ -1,0 +1,18 @@
+#!/bin/bash
+# End-to-end run of kmcp-search on the GPU box: FASTQ file in, TSV file out, database loaded from disk.
+#   usage: tools/bench_cli.sh [reads=4000000]
+set -u
+N=${1:-4000000}
+D=/tmp/kmcp_cli_bench
+rm -rf $D
+python tools/make_testdata.py $D --reads $N 2>&1 | tail -2
+for i in 1 2 3; do
+  s=$(date +%s%N)
+  kmcp_amd/kmcp-search -d $D/db $D/reads.fq -o $D/out.tsv 2> $D/log.txt
+  e=$(date +%s%N)
+  echo "run $i: $(( (e - s) / 1000000 )) ms wall; $(grep -o 'pipeline:.*' $D/log.txt)"
+done
+kmcp_amd/kmcp-search -d $D/db $D/reads.fq -o $D/out2.tsv --gpu-batch 100000 -q
+cmp $D/out.tsv $D/out2.tsv && echo "batch size does not change the output"
+tail -3 $D/out.tsv
+rm -rf $D
