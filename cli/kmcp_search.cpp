@@ -23,11 +23,14 @@
 #include <memory>
 #include <mutex>
 #include <string>
+#include <string_view>
 #include <thread>
 #include <unordered_map>
 #include <vector>
 
 #include <dirent.h>
+#include <fcntl.h>
+#include <unistd.h>
 #include <sys/stat.h>
 
 #include "../include/kmcp_gpu.h"
@@ -217,88 +220,159 @@ static Options parse_args(int argc, char** argv) {
 // FASTA/Q reader (what bio/seqio/fastx delivers to search.go: ID = header up to the first blank, sequence
 // with line breaks removed; gzip transparently)
 // ------------------------------------------------------------------------------------------------
+// One record of a FASTA/FASTQ stream.  The pointers stay valid until the next call of FastxReader::next.
+struct FastxRec {
+  const char* id = nullptr;
+  size_t id_len = 0;
+  const char* seq = nullptr;
+  size_t seq_len = 0;
+};
+
+// Block-buffered FASTA/FASTQ reader (plain files through read(2), gzip through zlib).  A record whose sequence sits on one
+// line — every FASTQ in practice — is handed out as pointers into the block buffer: no per-record allocation or copy; wrapped
+// sequences (FASTA) are joined in a scratch string.  ID = header up to the first blank (fastx: `record.ID`).
 class FastxReader {
  public:
-  explicit FastxReader(const std::string& path) : buf_(4u << 20) {
-    gz_ = (path == "-") ? gzdopen(0, "rb") : gzopen(path.c_str(), "rb");
-    if (!gz_) die("%s: %s", path.c_str(), strerror(errno));
-    gzbuffer(gz_, 1 << 20);
+  explicit FastxReader(const std::string& path) : buf_(8u << 20) {
+    if (path == "-") {
+      gz_ = gzdopen(0, "rb");
+      if (!gz_) die("stdin: %s", strerror(errno));
+    } else {
+      fd_ = open(path.c_str(), O_RDONLY);
+      if (fd_ < 0) die("%s: %s", path.c_str(), strerror(errno));
+      unsigned char magic[2] = {0, 0};
+      const ssize_t got = pread(fd_, magic, 2, 0);
+      if (got < 0 || (got == 2 && magic[0] == 0x1f && magic[1] == 0x8b)) {  // gzip, or not seekable (a pipe): let zlib look
+        gz_ = gzdopen(fd_, "rb");
+        if (!gz_) die("%s: %s", path.c_str(), strerror(errno));
+        fd_ = -1;  // owned by zlib now
+      }
+    }
+    if (gz_) gzbuffer(gz_, 1 << 20);
   }
-  ~FastxReader() { if (gz_) gzclose(gz_); }
+  ~FastxReader() {
+    if (gz_) gzclose(gz_);
+    if (fd_ >= 0) close(fd_);
+  }
+  FastxReader(const FastxReader&) = delete;
+  FastxReader& operator=(const FastxReader&) = delete;
+
   // returns false at EOF
-  bool next(std::string* id, std::string* seq) {
-    id->clear();
-    seq->clear();
-    const char* l;
-    size_t n;
-    if (!have_hdr_) {
-      while (getline(&l, &n)) {
-        if (n == 0) continue;
-        if (l[0] == '>' || l[0] == '@') { hdr_.assign(l, n); have_hdr_ = true; break; }
+  bool next(FastxRec* r) {
+    size_t lo, ln;
+    if (have_next_) {  // a FASTA record ended on this header line; it is still in the buffer
+      have_next_ = false;
+      keep_ = next_keep_;
+      hdr_off_ = next_hdr_off_;
+      hdr_len_ = next_hdr_len_;
+    } else {
+      for (;;) {
+        keep_ = pos_;  // nothing before this line is needed any more
+        if (!getline(&lo, &ln)) return false;
+        if (ln && (buf_[lo] == '>' || buf_[lo] == '@')) break;
       }
-      if (!have_hdr_) return false;
+      hdr_off_ = lo;
+      hdr_len_ = ln;
     }
-    const bool fastq = hdr_[0] == '@';
+    const bool fastq = buf_[hdr_off_] == '@';
     size_t e = 1;
-    while (e < hdr_.size() && hdr_[e] != ' ' && hdr_[e] != '\t') e++;
-    id->assign(hdr_, 1, e - 1);
-    have_hdr_ = false;
+    while (e < hdr_len_ && buf_[hdr_off_ + e] != ' ' && buf_[hdr_off_ + e] != '\t') e++;
+    const size_t id_len = e - 1;
+    bool have_seq = false, joined = false;  // joined: sequence on more than one line, collected in tmp_
+    seq_off_ = 0;
+    seq_len_ = 0;
     if (!fastq) {
-      while (getline(&l, &n)) {
-        if (n && l[0] == '>') { hdr_.assign(l, n); have_hdr_ = true; break; }
-        seq->append(l, n);
+      while (getline(&lo, &ln)) {
+        if (ln && buf_[lo] == '>') {  // the next record's header: stays in the buffer for the next call
+          have_next_ = true;
+          next_keep_ = next_hdr_off_ = lo;
+          next_hdr_len_ = ln;
+          break;
+        }
+        append_line(lo, ln, &have_seq, &joined);
       }
-      return true;
+    } else {
+      // FASTQ: sequence lines up to '+', then as many quality characters as bases
+      while (getline(&lo, &ln)) {
+        if (ln && buf_[lo] == '+') break;
+        append_line(lo, ln, &have_seq, &joined);
+      }
+      const size_t need = joined ? tmp_.size() : seq_len_;
+      size_t q = 0;
+      while (q < need && getline(&lo, &ln)) q += ln;
     }
-    // FASTQ: sequence lines up to '+', then as many quality characters as bases
-    while (getline(&l, &n)) {
-      if (n && l[0] == '+') break;
-      seq->append(l, n);
-    }
-    size_t q = 0;
-    while (q < seq->size() && getline(&l, &n)) q += n;
+    r->id = buf_.data() + hdr_off_ + 1;
+    r->id_len = id_len;
+    r->seq = joined ? tmp_.data() : buf_.data() + seq_off_;
+    r->seq_len = joined ? tmp_.size() : seq_len_;
+    return true;
+  }
+  // std::string flavour for callers that keep the record
+  bool next(std::string* id, std::string* seq) {
+    FastxRec r;
+    if (!next(&r)) return false;
+    id->assign(r.id, r.id_len);
+    seq->assign(r.seq, r.seq_len);
     return true;
   }
 
  private:
-  // next line without its terminator ("\n" or "\r\n"); the pointer is valid until the next call
-  bool getline(const char** out, size_t* n) {
+  void append_line(size_t lo, size_t ln, bool* have_seq, bool* joined) {
+    if (!*have_seq) {
+      seq_off_ = lo;
+      seq_len_ = ln;
+      *have_seq = true;
+    } else {
+      if (!*joined) {
+        tmp_.assign(buf_.data() + seq_off_, seq_len_);
+        *joined = true;
+      }
+      tmp_.append(buf_.data() + lo, ln);
+    }
+  }
+  // next line without its terminator ("\n" or "\r\n") as offset + length into buf_.  Refills keep everything from keep_ on
+  // (the current record) and shift the remembered offsets.
+  bool getline(size_t* off, size_t* n) {
     for (;;) {
       const char* nl = pos_ < end_ ? (const char*)memchr(buf_.data() + pos_, '\n', end_ - pos_) : nullptr;
-      if (nl) {
-        size_t len = (size_t)(nl - (buf_.data() + pos_));
-        *out = buf_.data() + pos_;
-        pos_ += len + 1;
-        while (len && (*out)[len - 1] == '\r') len--;
+      if (nl || (eof_ && pos_ < end_)) {
+        size_t len = nl ? (size_t)(nl - (buf_.data() + pos_)) : end_ - pos_;
+        *off = pos_;
+        pos_ += len + (nl ? 1 : 0);
+        while (len && buf_[*off + len - 1] == '\r') len--;
         *n = len;
         return true;
       }
-      if (eof_) {
-        if (pos_ >= end_) return false;
-        size_t len = end_ - pos_;
-        *out = buf_.data() + pos_;
-        pos_ = end_;
-        while (len && (*out)[len - 1] == '\r') len--;
-        *n = len;
-        return true;
+      if (eof_) return false;
+      const size_t shift = keep_;
+      if (shift) {
+        memmove(&buf_[0], buf_.data() + shift, end_ - shift);
+        pos_ -= shift;
+        end_ -= shift;
+        hdr_off_ = hdr_off_ >= shift ? hdr_off_ - shift : 0;
+        seq_off_ = seq_off_ >= shift ? seq_off_ - shift : 0;
+        keep_ = 0;
       }
-      // keep the partial line, refill behind it
-      const size_t tail = end_ - pos_;
-      if (tail && pos_) memmove(&buf_[0], buf_.data() + pos_, tail);
-      pos_ = 0;
-      end_ = tail;
-      if (end_ == buf_.size()) buf_.resize(buf_.size() * 2);  // a line longer than the buffer (whole-genome FASTA on one line)
-      const int got = gzread(gz_, &buf_[end_], (unsigned)std::min<size_t>(buf_.size() - end_, 1u << 30));
+      if (end_ == buf_.size()) buf_.resize(buf_.size() * 2);  // a record longer than the buffer (a genome on one line)
+      const size_t room = std::min<size_t>(buf_.size() - end_, 1u << 30);
+      ssize_t got;
+      if (gz_) got = gzread(gz_, &buf_[end_], (unsigned)room);
+      else
+        do got = read(fd_, &buf_[end_], room);
+        while (got < 0 && errno == EINTR);
       if (got <= 0) eof_ = true;
       else end_ += (size_t)got;
     }
   }
   gzFile gz_ = nullptr;
+  int fd_ = -1;
   std::vector<char> buf_;
-  size_t pos_ = 0, end_ = 0;
+  size_t pos_ = 0, end_ = 0, keep_ = 0;
   bool eof_ = false;
-  std::string hdr_;
-  bool have_hdr_ = false;
+  size_t hdr_off_ = 0, hdr_len_ = 0, seq_off_ = 0, seq_len_ = 0;
+  bool have_next_ = false;
+  size_t next_hdr_off_ = 0, next_hdr_len_ = 0, next_keep_ = 0;
+  std::string tmp_;
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -307,12 +381,14 @@ class FastxReader {
 struct Batch {
   uint64_t seq = 0;  // position in the input: the writer emits batches in this order
   uint64_t first_idx = 0;
-  std::vector<std::string> ids;
+  std::vector<char> id_buf;  // query IDs back to back
+  std::vector<uint64_t> id_offs{0};
   std::vector<uint8_t> seqs, seqs2;
   std::vector<uint64_t> offs{0}, offs2{0};
   kmcpg_result res{};
   bool paired = false;
-  size_t size() const { return ids.size(); }
+  size_t size() const { return id_offs.size() - 1; }
+  std::string_view id(size_t i) const { return std::string_view(id_buf.data() + id_offs[i], (size_t)(id_offs[i + 1] - id_offs[i])); }
 };
 
 template <typename T>
@@ -434,7 +510,7 @@ struct RowFormatter {
     if (fpr_cache.size() > (1u << 20)) fpr_cache.clear();
     return fpr_cache.emplace(key, std::string(tmp, (size_t)snprintf(tmp, sizeof tmp, "%.4e", v))).first->second;
   }
-  void row(std::string& b, const std::string& id, int qlen, int qkmers, uint64_t hits, const std::string& target, const kmcpg_match& m, int k,
+  void row(std::string& b, std::string_view id, int qlen, int qkmers, uint64_t hits, const std::string& target, const kmcpg_match& m, int k,
            uint64_t qidx) {
     b += id; b.push_back('\t'); put_i(b, qlen); b.push_back('\t'); put_i(b, qkmers); b.push_back('\t');
     b += fpr(qkmers, m.mkmers, m.fpr); b.push_back('\t'); put_u64(b, hits); b.push_back('\t');
@@ -443,7 +519,7 @@ struct RowFormatter {
     put_f4(b, m.qcov); b.push_back('\t'); put_f4(b, m.tcov); b.push_back('\t'); put_f4(b, m.jacc); b.push_back('\t');
     put_u64(b, qidx); b.push_back('\n');
   }
-  void unmatched(std::string& b, const std::string& id, int qlen, int qkmers, int k, uint64_t qidx) {
+  void unmatched(std::string& b, std::string_view id, int qlen, int qkmers, int k, uint64_t qidx) {
     b += id; b.push_back('\t'); put_i(b, qlen); b.push_back('\t'); put_i(b, qkmers);
     b += "\t0\t0\t\t-1\t0\t0\t"; put_i(b, k); b += "\t0\t0\t0\t0\t"; put_u64(b, qidx); b.push_back('\n');
   }
@@ -653,20 +729,25 @@ int main(int argc, char** argv) {
   uint64_t total = 0, matched = 0;
   const size_t max_bases = 64u << 20;  // a batch also closes at 64 Mbases (long queries)
 
+  double t_reader_blocked = 0, t_reader_total = 0;  // the reader thread: waiting for a free queue slot / its whole life
   std::thread reader([&] {
+    const auto tr0 = std::chrono::steady_clock::now();
     uint64_t id = 0, seq = 0;
     std::unique_ptr<Batch> b(new Batch());
     b->paired = paired;
     auto flush = [&] {
       if (b->size() == 0) return;
       b->seq = seq++;
+      const auto tp = std::chrono::steady_clock::now();
       q_in.push(std::move(b));
+      t_reader_blocked += std::chrono::duration<double>(std::chrono::steady_clock::now() - tp).count();
       b.reset(new Batch());
       b->paired = paired;
       b->first_idx = id;
     };
-    auto add = [&](const std::string& qid, const std::string& s1, const std::string* s2) {
-      b->ids.push_back(qid);
+    auto add = [&](std::string_view qid, std::string_view s1, const std::string* s2) {
+      b->id_buf.insert(b->id_buf.end(), qid.begin(), qid.end());
+      b->id_offs.push_back(b->id_buf.size());
       b->seqs.insert(b->seqs.end(), s1.begin(), s1.end());
       b->offs.push_back(b->seqs.size());
       if (s2) {
@@ -696,12 +777,13 @@ int main(int argc, char** argv) {
       FastxReader r1(o.read1);
       std::unique_ptr<MateChunk> cur;
       size_t ci = 0;
-      while (r1.next(&id1, &s1)) {
+      FastxRec rec;
+      while (r1.next(&rec)) {
         if (!cur || ci == cur->seqs.size()) {
           ci = 0;
           if (!q2.pop(&cur)) break;  // read2 ended first: stop like the reference (search.go:818-826)
         }
-        add(id1, s1, &cur->seqs[ci++]);
+        add(std::string_view(rec.id, rec.id_len), std::string_view(rec.seq, rec.seq_len), &cur->seqs[ci++]);
       }
       // drain whatever read2 still holds so that its thread can finish
       while (q2.pop(&cur)) {}
@@ -730,12 +812,14 @@ int main(int argc, char** argv) {
           continue;
         }
         const uint64_t id0 = id;
-        while (r.next(&id1, &s1)) add(id1, s1, nullptr);
+        FastxRec rec;
+        while (r.next(&rec)) add(std::string_view(rec.id, rec.id_len), std::string_view(rec.seq, rec.seq_len), nullptr);
         if (id0 == id) warn("no valid sequences in file: %s", file.c_str());
       }
     }
     flush();
     q_in.close();
+    t_reader_total = std::chrono::duration<double>(std::chrono::steady_clock::now() - tr0).count();
   });
 
   double t_gpu = 0, t_fmt = 0, t_read_wait = 0;  // seconds spent inside libkmcpgpu / formatting+writing / waiting for input
@@ -805,11 +889,11 @@ int main(int argc, char** argv) {
           const uint64_t qidx = b->first_idx + i;
           const uint64_t m0 = r.match_offs[i], m1 = r.match_offs[i + 1];
           if (m0 == m1) {
-            if (o.keep_unmatched) F.unmatched(buf, b->ids[i], r.qlen[i], r.qkmers[i], r.k, qidx);
+            if (o.keep_unmatched) F.unmatched(buf, b->id(i), r.qlen[i], r.qkmers[i], r.k, qidx);
             continue;
           }
           part_matched[(size_t)pi]++;
-          for (uint64_t j = m0; j < m1; j++) F.row(buf, b->ids[i], r.qlen[i], r.qkmers[i], m1 - m0, target[r.matches[j].col], r.matches[j], r.k, qidx);
+          for (uint64_t j = m0; j < m1; j++) F.row(buf, b->id(i), r.qlen[i], r.qkmers[i], m1 - m0, target[r.matches[j].col], r.matches[j], r.k, qidx);
         }
         if (out.gz()) buf = gzip_member(buf);
       };
@@ -841,7 +925,9 @@ int main(int argc, char** argv) {
     info("");
     info("processed queries: %llu, speed: %.3f million queries per minute", (unsigned long long)total, total / 1e6 / min);
     info("%.4f%% (%llu/%llu) queries matched", total ? (double)matched / (double)total * 100 : NAN, (unsigned long long)matched, (unsigned long long)total);
-    info("done searching (pipeline: %.3f s in the GPU library, %.3f s formatting/writing, %.3f s waiting for the reader)", t_gpu, t_fmt, t_read_wait);
+    info("done searching (pipeline: %.3f s in the GPU library, %.3f s formatting/writing, %.3f s waiting for the reader; reader: %.3f s parsing, %.3f s "
+         "blocked; %.3f s before the search started)",
+         t_gpu, t_fmt, t_read_wait, t_reader_total - t_reader_blocked, t_reader_blocked, std::chrono::duration<double>(t_search - t_start).count());
     if (o.out_file != "-") info("search results saved to: %s", o.out_file.c_str());
   }
   // trailer read by `kmcp profile` (profile.go:1945-1951)

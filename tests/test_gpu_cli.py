@@ -5,6 +5,7 @@ import gzip
 import os
 import subprocess
 
+import numpy as np
 import pytest
 
 from tests import synth
@@ -187,3 +188,49 @@ def test_cli_errors(tmp_path, oracle_lib):
     r = subprocess.run([CLI, "-d", str(tmp_path), fq], capture_output=True, text=True)
     assert r.returncode == 255 and "invalid kmcp database" in r.stderr
     _ = O
+
+
+def test_cli_reader_torture(oracle_lib, tmp_path):
+    """The block-buffered reader: wrapped FASTA with CRLF line ends, a 9-Mbp record on one line (longer than the 8-MB block
+    buffer), an empty record, no newline at the end of the file; and a FASTQ whose records straddle block refills, with wrapped
+    sequence/quality lines and '@'/'+' as first quality characters."""
+    O = oracle_lib
+    genomes = synth.random_genomes(6, 30000, seed=90)
+    db_dir = synth.make_db(tmp_path / "db", genomes, k=21, threads=2)
+    db_root = os.path.dirname(db_dir)
+    odb = O.OracleDB(db_dir)
+    rng = np.random.default_rng(91)
+    big = bytes(rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), 9_000_000))
+    big = big[:4_000_000] + genomes[2][1000:21000] + big[4_000_000:]
+    recs = [("w0", genomes[0][:3000]), ("big", big), ("w2", genomes[1][500:1000]), ("s3", genomes[3][:777]), ("e4", b""), ("last", genomes[4][100:400])]
+    fa = str(tmp_path / "t.fa")
+    with open(fa, "wb") as fh:
+        for i, (name, s) in enumerate(recs):
+            nl = b"\r\n" if i % 2 == 0 else b"\n"
+            fh.write(b">" + name.encode() + b" desc" + nl)
+            if name in ("big", "s3"):
+                fh.write(s + nl)
+            else:
+                for p in range(0, len(s), 60):
+                    fh.write(s[p:p + 60] + nl)
+        fh.seek(fh.tell() - 1)
+        fh.truncate()  # no newline at the end of the file
+    ids = [n for n, _ in recs]
+    seqs = [s for _, s in recs]
+    p = O.default_params(min_qcov=0.35)
+    want, trailer = oracle_tsv(O, odb, ids, seqs, params=p, keep_unmatched=True)
+    compare(run_cli(["-d", db_root, "-t", "0.35", "-K", fa], str(tmp_path / "fa.tsv")), want, trailer)
+    # FASTQ: 60k records (~13 MB: several block refills), every 7th wrapped over three lines, quality lines starting with @ or +
+    reads = synth.sample_reads(genomes, 60000, 100, seed=92, frac_random=0.2)
+    fq = str(tmp_path / "t.fq")
+    with open(fq, "wb") as fh:
+        for i, r in enumerate(reads):
+            q = (b"@" if i % 3 == 0 else b"+" if i % 3 == 1 else b"I") + b"I" * (len(r) - 1)
+            if i % 7 == 0:
+                fh.write(b"@q%d x\n" % i + r[:40] + b"\n" + r[40:80] + b"\n" + r[80:] + b"\n+q%d\n" % i + q[:50] + b"\n" + q[50:] + b"\n")
+            else:
+                fh.write(b"@q%d\n" % i + r + b"\n+\n" + q + b"\n")
+    ids = [f"q{i}" for i in range(len(reads))]
+    want, trailer = oracle_tsv(O, odb, ids, reads)
+    compare(run_cli(["-d", db_root, fq], str(tmp_path / "fq.tsv")), want, trailer)
+    odb.close()
