@@ -53,7 +53,9 @@ struct DedupArgs {
   uint32_t n_reads;
   int32_t dedup_threshold;
   int32_t min_matched;
-  int32_t lo, hi;        // this launch handles queries with lo < n <= hi
+  int32_t lo, hi;        // this workgroup-class launch sorts queries with lo < m <= hi elements (m: after k_adj_unique)
+  int32_t n_lo, n_hi;    // ... among those whose raw count n is in (n_lo, n_hi]
+  int32_t pre;           // window-sketch database: k_adj_unique runs first (input of the sort = scratch, m in nk_search)
   uint64_t* hashes;
   uint64_t* scratch;
   const int32_t* nk_raw;

@@ -632,6 +632,7 @@ int run_kmers(kmcpg_db* db, const uint8_t* d_seqs, const uint64_t* d_offs, const
     d.scratch = d_scratch;
     d.nk_raw = d_nk_raw;
     d.nk_search = d_nk_search;
+    d.pre = a.mode != 0;
     launch_dedup(d, ub, st);
     if (ub > HUGE_MIN) {
       // whole-genome queries: which ones they are is only known on the device -> one small read-back, then a device-wide

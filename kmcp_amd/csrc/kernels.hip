@@ -823,38 +823,62 @@ __global__ void __launch_bounds__(256) k_dedup_wave(const DedupArgs a) {
   if (lane == 0) a.nk_search[r] = n >= a.min_matched ? total : 0;
 }
 
-// Two size classes: n <= 4096 sorts in 32 KB of LDS with 256 threads; larger queries use 1024 threads and 128 KB of
-// LDS (n <= 16384), beyond that the network runs in global memory.
+// Window sketches emit the same k-mer for runs of consecutive windows (10 k syncmer emissions of a HiFi read hold ~1.4 k
+// distinct adjacent values), so for such databases an order-preserving pass drops adjacent repeats first: hashes -> scratch,
+// the shortened length parked in nk_search[r] until the sort of that query overwrites it with NumKmers.
+constexpr int ADJ_NT = 512;
+__global__ void __launch_bounds__(ADJ_NT) k_adj_unique(const DedupArgs a) {
+  __shared__ int s_wave[ADJ_NT / 64];
+  const uint32_t r = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int n = a.nk_raw[r];
+  if (n <= a.dedup_threshold || n <= a.n_lo || n > a.n_hi) return;
+  const uint64_t koff = a.offs[r] + (a.offs2 ? a.offs2[r] : 0);
+  const uint64_t* __restrict__ g = a.hashes + koff;
+  uint64_t* __restrict__ dst = a.scratch + koff;
+  int m = 0;
+  for (int t0 = 0; t0 < n; t0 += ADJ_NT) {  // tiles of consecutive elements: coalesced reads, ordered compaction
+    const int i = t0 + tid;
+    uint64_t x = 0;
+    bool keep = false;
+    if (i < n) {
+      x = g[i];
+      keep = i == 0 || x != g[i - 1];
+    }
+    const uint64_t mask = __ballot(keep);
+    if (lane == 0) s_wave[w] = __popcll(mask);
+    __syncthreads();
+    int before = 0, total = 0;
+#pragma unroll
+    for (int j = 0; j < ADJ_NT / 64; j++) {
+      const int c = s_wave[j];
+      if (j < w) before += c;
+      total += c;
+    }
+    if (keep) dst[m + before + __popcll(mask & ((1ULL << lane) - 1ULL))] = x;
+    m += total;
+    __syncthreads();
+  }
+  if (tid == 0) a.nk_search[r] = m;
+}
+
+// Workgroup classes for queries of more than 512 k-mers (raw count in (n_lo, n_hi]), chosen by the number m of elements
+// left to sort: m <= 4096 in 32 KB of LDS with 256 threads; above that 1024 threads and 128 KB of LDS (m <= 16384), beyond
+// that the network runs in global memory.
 template <int NT, int CAP>
 __global__ void __launch_bounds__(NT) k_dedup(const DedupArgs a) {
   __shared__ uint64_t s[CAP];
-  __shared__ int scan[NT];
+  __shared__ int scan[NT / 64];
   const uint32_t r = blockIdx.x;
   const int tid = threadIdx.x;
   const int n = a.nk_raw[r];
-  if (n <= a.lo || n > a.hi) {
-    // not this launch's size class; queries at or below the dedup threshold are settled by the small-class launch
-    if (a.lo == 0 && tid == 0 && n <= a.dedup_threshold) a.nk_search[r] = n >= a.min_matched ? n : 0;
-    if (!(a.lo == 0 && n <= a.dedup_threshold)) return;
-    return;
-  }
-  if (n <= a.dedup_threshold) {
-    if (tid == 0) a.nk_search[r] = n >= a.min_matched ? n : 0;
-    return;
-  }
+  if (n <= a.dedup_threshold || n <= a.n_lo || n > a.n_hi) return;  // settled by k_dedup_wave / sorted by sort_huge.hip
+  const int m = a.pre ? a.nk_search[r] : n;  // (a query the smaller class finished shows its NumKmers <= 4096 here)
+  if (m <= a.lo || m > a.hi) return;
   const uint64_t koff = a.offs[r] + (a.offs2 ? a.offs2[r] : 0);
   uint64_t* g = a.hashes + koff;
   uint64_t* tmp = a.scratch + koff;
-  int m = n;  // elements still to sort
-  const uint64_t* in = g;
-  if (NT == 1024) {
-    // long queries: window sketches emit the same k-mer for runs of consecutive windows, so a first order-preserving
-    // pass that drops adjacent repeats shrinks the sort several-fold (10 k syncmer emissions of a HiFi read -> ~2 k)
-    m = block_unique<NT>(g, n, tmp, scan, tid);
-    __threadfence_block();
-    __syncthreads();
-    in = tmp;
-  }
+  const uint64_t* in = a.pre ? tmp : g;
   int total;
   if (m <= CAP) {
     for (int i = tid; i < m; i += NT) s[i] = in[i];
@@ -1240,17 +1264,17 @@ void launch_nk_simple(const int32_t* nk_raw, int32_t* nk_search, uint32_t n, int
 void launch_dedup(DedupArgs a, uint64_t max_n, hipStream_t st) {
   if (a.n_reads == 0) return;
   // the wave class settles every query at or below the dedup threshold and sorts those of at most 512 k-mers
-  a.lo = 0;
-  a.hi = DW_CAP;
   hipLaunchKernelGGL(k_dedup_wave, dim3((a.n_reads + 3) / 4), dim3(256), 0, st, a);
-  if (max_n > DW_CAP) {
-    a.lo = DW_CAP;
-    a.hi = max_n > 4096 ? 4096 : 0x7fffffff;
-    hipLaunchKernelGGL((k_dedup<256, 4096>), dim3(a.n_reads), dim3(256), 0, st, a);
-  }
+  if (max_n <= DW_CAP) return;
+  a.n_lo = DW_CAP;
+  a.n_hi = max_n > HUGE_MIN ? (int32_t)HUGE_MIN : 0x7fffffff;  // beyond that: device-wide sort (sort_huge.hip)
+  if (a.pre) hipLaunchKernelGGL(k_adj_unique, dim3(a.n_reads), dim3(ADJ_NT), 0, st, a);
+  a.lo = 0;
+  a.hi = 4096;
+  hipLaunchKernelGGL((k_dedup<256, 4096>), dim3(a.n_reads), dim3(256), 0, st, a);
   if (max_n > 4096) {
     a.lo = 4096;
-    a.hi = max_n > HUGE_MIN ? (int32_t)HUGE_MIN : 0x7fffffff;  // beyond that: device-wide sort (sort_huge.hip)
+    a.hi = 0x7fffffff;
     hipLaunchKernelGGL((k_dedup<1024, 16384>), dim3(a.n_reads), dim3(1024), 0, st, a);
   }
 }
