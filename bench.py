@@ -247,7 +247,7 @@ def run_workload(name, ctx, steps, warmup, batch_reads=0, cpu_baseline=True, cpu
     #      sample: the first S blocks copied back from HBM and the first R reads of the last batch.
     if rank == 0 and world == 1 and cpu_baseline:
         from oracle import oracle as O
-        S = 1 if name == "gtdb" else wl["n_blocks"]
+        S = 2 if name == "gtdb" else wl["n_blocks"]  # gtdb: 2 of the 32 blocks x the whole batch is ~10 s on 16 threads
         blocks = []
         for b in range(S):
             bi = db.block_info(b)
