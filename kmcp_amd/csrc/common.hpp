@@ -84,6 +84,7 @@ struct K2Args {
   uint32_t split_chunks;      // chunks per long query (from the largest one)
   uint32_t* long_counts;      // [n_long][ncols_total] match counts
   uint32_t ncols_total;
+  uint64_t unit_base;     // first work unit of this launch (a batch may take several launches)
   kmcpg_hit* hits;
   uint64_t hit_cap;
   unsigned long long* counter;

@@ -15,6 +15,8 @@
 // The path is bitwise/integer and HBM-bound; there is no MFMA here by design.  wave = 64 lanes.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+
 #include "common.hpp"
 #include "kernels.hpp"
 
@@ -966,7 +968,7 @@ __global__ void __launch_bounds__(256) k2_cobs(const K2Args a) {
   const int g = lane / LPR, li = lane % LPR;
   const uint64_t per_read = SPLIT ? (uint64_t)a.nslots * a.split_chunks : (uint64_t)a.nslots;
   const uint64_t total_units = (SPLIT ? (uint64_t)a.n_long : (uint64_t)a.n_reads) * per_read;
-  const uint64_t u = ((uint64_t)blockIdx.x * 4 + wave) * G + g;
+  const uint64_t u = a.unit_base + ((uint64_t)blockIdx.x * 4 + wave) * G + g;
   const bool valid = u < total_units;
   uint32_t r = 0, sidx = 0, li_long = 0;
   int k0 = 0;
@@ -1134,17 +1136,23 @@ __global__ void __launch_bounds__(256) k2_cobs(const K2Args a) {
   }
 }
 
+constexpr uint64_t K2_MAX_BLOCKS = 1ull << 23;  // x 256 threads = 2^31
+
 template <int LPR, int NPL>
 static void launch_k2_t(const K2Args& a, bool multi, hipStream_t st) {
   constexpr int G = 64 / LPR;
   const uint64_t units = (uint64_t)a.n_reads * a.nslots;
   const uint64_t waves = (units + G - 1) / G;
   const uint64_t blocks = (waves + 3) / 4;
-  if (blocks == 0) return;
-  if (multi)
-    hipLaunchKernelGGL((k2_cobs<LPR, NPL, true, false>), dim3((unsigned)blocks), dim3(256), 0, st, a);
-  else
-    hipLaunchKernelGGL((k2_cobs<LPR, NPL, false, false>), dim3((unsigned)blocks), dim3(256), 0, st, a);
+  K2Args b = a;
+  for (uint64_t b0 = 0; b0 < blocks; b0 += K2_MAX_BLOCKS) {  // a launch holds fewer than 2^32 threads
+    const unsigned nb = (unsigned)std::min<uint64_t>(K2_MAX_BLOCKS, blocks - b0);
+    b.unit_base = b0 * 4 * G;
+    if (multi)
+      hipLaunchKernelGGL((k2_cobs<LPR, NPL, true, false>), dim3(nb), dim3(256), 0, st, b);
+    else
+      hipLaunchKernelGGL((k2_cobs<LPR, NPL, false, false>), dim3(nb), dim3(256), 0, st, b);
+  }
 }
 
 template <int LPR>
@@ -1159,7 +1167,6 @@ static int launch_k2_l(const K2Args& a, int npl, bool multi, hipStream_t st) {
 
 int launch_k2(const K2Args& a, int lpr, int npl, hipStream_t st) {
   const bool multi = a.num_hashes > 1;
-  if ((uint64_t)a.n_reads * a.nslots / (256 / lpr) > 0x7fffffffULL) return -2;
   switch (lpr) {
     case 4: return launch_k2_l<4>(a, npl, multi, st);
     case 16: return launch_k2_l<16>(a, npl, multi, st);
@@ -1173,16 +1180,19 @@ static void launch_k2_split_t(const K2Args& a, bool multi, hipStream_t st) {
   constexpr int G = 64 / LPR;
   const uint64_t units = (uint64_t)a.n_long * a.nslots * a.split_chunks;
   const uint64_t blocks = ((units + G - 1) / G + 3) / 4;
-  if (blocks == 0) return;
-  if (multi)
-    hipLaunchKernelGGL((k2_cobs<LPR, 16, true, true>), dim3((unsigned)blocks), dim3(256), 0, st, a);
-  else
-    hipLaunchKernelGGL((k2_cobs<LPR, 16, false, true>), dim3((unsigned)blocks), dim3(256), 0, st, a);
+  K2Args b = a;
+  for (uint64_t b0 = 0; b0 < blocks; b0 += K2_MAX_BLOCKS) {
+    const unsigned nb = (unsigned)std::min<uint64_t>(K2_MAX_BLOCKS, blocks - b0);
+    b.unit_base = b0 * 4 * G;
+    if (multi)
+      hipLaunchKernelGGL((k2_cobs<LPR, 16, true, true>), dim3(nb), dim3(256), 0, st, b);
+    else
+      hipLaunchKernelGGL((k2_cobs<LPR, 16, false, true>), dim3(nb), dim3(256), 0, st, b);
+  }
 }
 
 int launch_k2_split(const K2Args& a, int lpr, hipStream_t st) {
   const bool multi = a.num_hashes > 1;
-  if ((uint64_t)a.n_long * a.nslots * a.split_chunks / (256 / lpr) > 0x7fffffffULL) return -2;
   switch (lpr) {
     case 4: launch_k2_split_t<4>(a, multi, st); return 0;
     case 16: launch_k2_split_t<16>(a, multi, st); return 0;

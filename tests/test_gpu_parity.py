@@ -384,3 +384,47 @@ def test_dedup_classes_at_their_boundaries(G, oracle_lib):
                     got = h[int(offs[i]):int(offs[i]) + int(nk[i])]
                     assert nk[i] == len(want), (thr, i, len(raw), nk[i], len(want))
                     assert np.array_equal(got, want), (thr, i, len(raw))
+
+
+def test_batch_larger_than_one_launch(G):
+    """300 k reads x 128 slots = 9.6 M workgroups of k2_cobs: more than one launch may hold (2^32 threads) — the engine splits
+    it; the hit list must equal the union of the hit lists of the two half batches."""
+    import torch
+    lib = G["lib"]
+    dev = torch.device("cuda:0")
+    spec = lib.SynthSpec(k=21, num_hashes=1, fpr=0.3, n_blocks=128, cols_per_block=2100, num_sigs=40009, kmers_per_col=14270, seed=5)
+    B, L = 300000, 150
+    with G["Database"].open_synthetic(spec) as db:
+        g = torch.Generator(device=dev)
+        g.manual_seed(3)
+        acgt = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=dev)
+        reads = acgt[torch.randint(0, 4, (B, L), generator=g, device=dev)].contiguous().view(-1)
+        cols = torch.randint(0, 128 * 2100, (B,), generator=g, device=dev).to(torch.int32)
+        cols[torch.rand(B, generator=g, device=dev) < 0.5] = -1
+        offs = (torch.arange(B + 1, device=dev, dtype=torch.int64) * L).contiguous()
+        db.plant_reads_device(reads.data_ptr(), offs.data_ptr(), B, B * L, L, cols.data_ptr())
+
+        def query(lo, hi):
+            n = hi - lo
+            cap = 64 * n
+            hits = torch.zeros((cap, 3), dtype=torch.int32, device=dev)
+            cnt = torch.zeros(2, dtype=torch.int64, device=dev)
+            qk = torch.zeros(n, dtype=torch.int32, device=dev)
+            ql = torch.zeros(n, dtype=torch.int32, device=dev)
+            sub = reads[lo * L:hi * L]
+            db.query_device(sub.data_ptr(), offs.data_ptr(), n, n * L, L, hits.data_ptr(), cap, cnt.data_ptr(), qk.data_ptr(), ql.data_ptr(),
+                            params=G["default_params"]())
+            torch.cuda.synchronize()
+            c = int(cnt[0].item())
+            assert c <= cap
+            h = hits[:c].cpu().numpy().astype(np.int64)
+            h[:, 0] += lo
+            return h[np.lexsort((h[:, 1], h[:, 0]))]
+
+        whole = query(0, B)
+        halves = np.concatenate([query(0, B // 2), query(B // 2, B)])
+        assert np.array_equal(whole, halves)
+        planted = np.nonzero(cols.cpu().numpy() >= 0)[0]
+        got = set(zip(whole[:, 0].tolist(), whole[:, 1].tolist()))
+        c_host = cols.cpu().numpy()
+        assert all((int(r), int(c_host[r])) in got for r in planted[-2000:])  # the reads of the last launch are served too
