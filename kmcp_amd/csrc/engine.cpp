@@ -612,7 +612,7 @@ int run_kmers(kmcpg_db* db, const uint8_t* d_seqs, const uint64_t* d_offs, const
   a.qlen = d_qlen;
   // whole genomes (single-end, plain or FracMinHash k-mers): segments of a read on their own workgroups
   const uint32_t segs = (max_read_len + (uint32_t)k1_segment_len() - 1) / (uint32_t)k1_segment_len();
-  if (a.mode == 0 && !d_seqs2 && segs > 1 && d_scratch && (uint64_t)n_reads * segs <= (64ull << 20)) {
+  if (a.mode == 0 && !d_seqs2 && segs > 1 && d_scratch && (uint64_t)n_reads * segs <= (1ull << 21)) {  // one workgroup of 1024 threads per segment, < 2^32 threads per launch
     if (db->w_seg_cnt.ensure((size_t)n_reads * segs)) return fail(KMCPG_ENOMEM, "hipMalloc failed");
     a.seg_cnt = db->w_seg_cnt.p;
     a.segs_max = segs;

@@ -831,10 +831,10 @@ __global__ void __launch_bounds__(256) k_dedup_wave(const DedupArgs a) {
 constexpr int ADJ_NT = 512;
 __global__ void __launch_bounds__(ADJ_NT) k_adj_unique(const DedupArgs a) {
   __shared__ int s_wave[ADJ_NT / 64];
-  const uint32_t r = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  for (uint32_t r = blockIdx.x; r < a.n_reads; r += gridDim.x) {
   const int n = a.nk_raw[r];
-  if (n <= a.dedup_threshold || n <= a.n_lo || n > a.n_hi) return;
+  if (n <= a.dedup_threshold || n <= a.n_lo || n > a.n_hi) continue;
   const uint64_t koff = a.offs[r] + (a.offs2 ? a.offs2[r] : 0);
   const uint64_t* __restrict__ g = a.hashes + koff;
   uint64_t* __restrict__ dst = a.scratch + koff;
@@ -862,6 +862,7 @@ __global__ void __launch_bounds__(ADJ_NT) k_adj_unique(const DedupArgs a) {
     __syncthreads();
   }
   if (tid == 0) a.nk_search[r] = m;
+  }
 }
 
 // Workgroup classes for queries of more than 512 k-mers (raw count in (n_lo, n_hi]), chosen by the number m of elements
@@ -871,12 +872,12 @@ template <int NT, int CAP>
 __global__ void __launch_bounds__(NT) k_dedup(const DedupArgs a) {
   __shared__ uint64_t s[CAP];
   __shared__ int scan[NT / 64];
-  const uint32_t r = blockIdx.x;
   const int tid = threadIdx.x;
+  for (uint32_t r = blockIdx.x; r < a.n_reads; r += gridDim.x) {
   const int n = a.nk_raw[r];
-  if (n <= a.dedup_threshold || n <= a.n_lo || n > a.n_hi) return;  // settled by k_dedup_wave / sorted by sort_huge.hip
+  if (n <= a.dedup_threshold || n <= a.n_lo || n > a.n_hi) continue;  // settled by k_dedup_wave / sorted by sort_huge.hip
   const int m = a.pre ? a.nk_search[r] : n;  // (a query the smaller class finished shows its NumKmers <= 4096 here)
-  if (m <= a.lo || m > a.hi) return;
+  if (m <= a.lo || m > a.hi) continue;
   const uint64_t koff = a.offs[r] + (a.offs2 ? a.offs2[r] : 0);
   uint64_t* g = a.hashes + koff;
   uint64_t* tmp = a.scratch + koff;
@@ -901,6 +902,7 @@ __global__ void __launch_bounds__(NT) k_dedup(const DedupArgs a) {
   }
   // MinMatched is tested on the raw count (:854), NumKmers is the unique count (:910)
   if (tid == 0) a.nk_search[r] = n >= a.min_matched ? total : 0;
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1278,14 +1280,15 @@ void launch_dedup(DedupArgs a, uint64_t max_n, hipStream_t st) {
   if (max_n <= DW_CAP) return;
   a.n_lo = DW_CAP;
   a.n_hi = max_n > HUGE_MIN ? (int32_t)HUGE_MIN : 0x7fffffff;  // beyond that: device-wide sort (sort_huge.hip)
-  if (a.pre) hipLaunchKernelGGL(k_adj_unique, dim3(a.n_reads), dim3(ADJ_NT), 0, st, a);
+  const unsigned grid = a.n_reads > (1u << 20) ? (1u << 20) : a.n_reads;  // the workgroup kernels stride over the reads
+  if (a.pre) hipLaunchKernelGGL(k_adj_unique, dim3(grid), dim3(ADJ_NT), 0, st, a);
   a.lo = 0;
   a.hi = 4096;
-  hipLaunchKernelGGL((k_dedup<256, 4096>), dim3(a.n_reads), dim3(256), 0, st, a);
+  hipLaunchKernelGGL((k_dedup<256, 4096>), dim3(grid), dim3(256), 0, st, a);
   if (max_n > 4096) {
     a.lo = 4096;
     a.hi = 0x7fffffff;
-    hipLaunchKernelGGL((k_dedup<1024, 16384>), dim3(a.n_reads), dim3(1024), 0, st, a);
+    hipLaunchKernelGGL((k_dedup<1024, 16384>), dim3(grid), dim3(1024), 0, st, a);
   }
 }
 
