@@ -12,10 +12,12 @@ namespace {
 
 struct BeReader {
   FILE* f;
+  uint64_t left;  // bytes of the file not consumed yet: every count read from the header is checked against it
   bool ok = true;
   bool read(void* p, size_t n) {
     if (!ok) return false;
-    if (fread(p, 1, n, f) != n) ok = false;
+    if (n > left || fread(p, 1, n, f) != n) ok = false;
+    else left -= n;
     return ok;
   }
   uint32_t u32() {
@@ -26,6 +28,11 @@ struct BeReader {
   uint64_t u64() {
     uint64_t hi = u32();
     return (hi << 32) | u32();
+  }
+  // a count of items of at least `item_bytes` each that still have to fit in the file
+  bool fits(uint64_t count, uint64_t item_bytes) {
+    if (ok && count > left / item_bytes) ok = false;
+    return ok;
   }
 };
 
@@ -45,7 +52,10 @@ bool as_bool(const std::string& v) { return v == "true" || v == "True" || v == "
 std::string read_uniki_header(const std::string& path, UnikiHeader* h) {
   FILE* f = fopen(path.c_str(), "rb");
   if (!f) return "kmcp index file missing: " + path;
-  BeReader r{f};
+  fseeko(f, 0, SEEK_END);
+  const uint64_t file_size = (uint64_t)ftello(f);
+  fseeko(f, 0, SEEK_SET);
+  BeReader r{f, file_size};
   uint8_t magic[8], meta[4];
   if (!r.read(magic, 8) || memcmp(magic, ".kmcpidx", 8) != 0) {
     fclose(f);
@@ -63,10 +73,12 @@ std::string read_uniki_header(const std::string& path, UnikiHeader* h) {
   h->num_hashes = meta[3];
   h->num_sigs = r.u64();
   const uint32_t n = r.u32();
-  h->names.assign(n, "");
+  // every name group costs >= 4 bytes here, >= 4 in the genome-size and index tables and 8 in the size table
+  if (r.fits(n, 20)) h->names.assign(n, "");
   std::vector<char> buf;
   for (uint32_t i = 0; i < n && r.ok; i++) {
     const uint32_t len = r.u32();
+    if (!r.fits(len, 1)) break;
     buf.resize(len);
     if (len) r.read(buf.data(), len);
     size_t e = 0;
@@ -74,35 +86,37 @@ std::string read_uniki_header(const std::string& path, UnikiHeader* h) {
     h->names[i].assign(buf.data(), e);
   }
   const uint32_t ng = r.u32();
-  h->gsizes.assign(n, 0);
+  if (r.fits(ng, 4)) h->gsizes.assign(n, 0);
   for (uint32_t i = 0; i < ng && r.ok; i++) {
     const uint32_t m = r.u32();
-    for (uint32_t j = 0; j < m; j++) {
+    if (!r.fits(m, 8)) break;
+    for (uint32_t j = 0; j < m && r.ok; j++) {
       const uint64_t v = r.u64();
       if (j == 0 && i < n) h->gsizes[i] = v;
     }
   }
   const uint32_t ni = r.u32();
-  h->indices.assign(n, 0);
+  if (r.fits(ni, 4)) h->indices.assign(n, 0);
   for (uint32_t i = 0; i < ni && r.ok; i++) {
     const uint32_t m = r.u32();
-    for (uint32_t j = 0; j < m; j++) {
+    if (!r.fits(m, 4)) break;
+    for (uint32_t j = 0; j < m && r.ok; j++) {
       const uint32_t v = r.u32();
       if (j == 0 && i < n) h->indices[i] = v;
     }
   }
-  h->sizes.assign(n, 0);
+  if (r.fits(n, 8)) h->sizes.assign(n, 0);
   for (uint32_t i = 0; i < n && r.ok; i++) h->sizes[i] = r.u64();
   if (!r.ok) {
     fclose(f);
     return "kmcp: truncated index file: " + path;
   }
   h->row_bytes = (n + 7) / 8;
-  h->offset0 = (uint64_t)ftello(f);
-  fseeko(f, 0, SEEK_END);
-  h->file_size = (uint64_t)ftello(f);
+  h->offset0 = file_size - r.left;
+  h->file_size = file_size;
   fclose(f);
-  if (h->offset0 + h->num_sigs * (uint64_t)h->row_bytes > h->file_size) return "kmcp: truncated index file: " + path;  // ErrTruncateIndexFile
+  // ErrTruncateIndexFile; written without the product so that a corrupt NumSigs cannot overflow it
+  if (h->row_bytes && h->num_sigs > r.left / h->row_bytes) return "kmcp: truncated index file: " + path;
   return "";
 }
 

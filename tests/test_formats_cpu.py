@@ -181,3 +181,48 @@ def test_dist_search_fastx_reader(tmp_path):
     with gzip.open(fq, "wt") as fh:
         fh.write("@q1 d\nACGT\n+\n@III\n@q2\n\n+\n\n@q3\nAC\nGT\n+q3\n>I\n@@\r\n")
     assert list(read_fastx(str(fq))) == [(b"q1", b"ACGT"), (b"q2", b""), (b"q3", b"ACGT")]
+
+
+@pytest.mark.timeout(120)
+def test_mutated_headers_never_hang_or_crash(small_db, tmp_path):
+    """Random corruption of a block header (flipped bytes, truncation, all-ones and random 32/64-bit counts) and of __db.yml:
+    every count read from the file is checked against the bytes that are left, so a bad database is refused (or, if the
+    damage is harmless, opened) at once — never a multi-gigabyte allocation or a loop over 2^32 phantom entries."""
+    from kmcp_amd import lib
+    rng = np.random.default_rng(3)
+    db_dir, _ = small_db
+    good_blk = open(os.path.join(db_dir, "_block001.uniki"), "rb").read()
+    good_yml = open(os.path.join(db_dir, "__db.yml"), "rb").read()
+    with lib.Database.open(db_dir, device=-1) as h:
+        bi = h.block_info(0)
+    hdr = len(good_blk) - bi["num_sigs"] * bi["row_bytes"]  # header bytes in front of the matrix
+    d = tmp_path / "db"
+    shutil.copytree(db_dir, d)
+    refused = opened = 0
+    for i in range(400):
+        b, y = bytearray(good_blk), bytearray(good_yml)
+        mode = int(rng.integers(0, 6))
+        if mode == 0:
+            for _ in range(int(rng.integers(1, 6))):
+                b[int(rng.integers(0, hdr))] = int(rng.integers(0, 256))
+        elif mode == 1:
+            b = b[:int(rng.integers(0, hdr))]
+        elif mode == 2:
+            p = int(rng.integers(8, hdr - 8))
+            b[p:p + 4] = b"\xff\xff\xff\xff"
+        elif mode == 3:
+            p = int(rng.integers(8, hdr - 8))
+            b[p:p + 8] = int(rng.integers(0, 2**63)).to_bytes(8, "big")
+        elif mode == 4:
+            for _ in range(int(rng.integers(1, 6))):
+                y[int(rng.integers(0, len(y)))] = int(rng.integers(0, 256))
+        else:
+            y = y[:int(rng.integers(0, len(y)))]
+        (d / "_block001.uniki").write_bytes(bytes(b))
+        (d / "__db.yml").write_bytes(bytes(y))
+        try:
+            lib.Database.open(str(d), device=-1).close()
+            opened += 1
+        except lib.KmcpGpuError:
+            refused += 1
+    assert refused > 200 and refused + opened == 400
