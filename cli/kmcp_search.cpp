@@ -81,7 +81,7 @@ struct Options {
   std::vector<int32_t> gpu_ids;
   double min_qcov = 0.55, min_tcov = 0, max_fpr = 0.01;
   bool load_whole = false, low_mem = false, whole_file = false, use_filename = false, keep_unmatched = false, no_header = false,
-       do_not_sort = false, default_name_map = false, try_se = false, quiet = false;
+       do_not_sort = false, default_name_map = false, try_se = false, quiet = false, parse_only = false;
 };
 
 static void usage() {
@@ -101,7 +101,8 @@ static void usage() {
       "  -w, --load-whole-db / --low-mem  accepted for compatibility (the index is always resident in HBM)\n"
       "  -j, --threads int  -i, --infile-list file  -q, --quiet  --log file\n"
       "GPU flags: --gpu int (device, default 0)  --gpus int (use devices 0..N-1, index blocks partitioned over them)\n"
-      "           --gpu-ids a,b,c (explicit device list)  --gpu-batch int (queries per GPU call, default 131072)\n",
+      "           --gpu-ids a,b,c (explicit device list)  --gpu-batch int (queries per GPU call, default 131072)\n"
+      "           --parse-only (read the inputs and print records / bases / checksum per file; no database, no GPU)\n",
       stderr);
 }
 
@@ -127,7 +128,7 @@ static Options parse_args(int argc, char** argv) {
       {"min-kmers", 'c', 1}, {"min-query-len", 'm', 1}, {"min-query-cov", 't', 1}, {"min-target-cov", 'T', 1}, {"max-fpr", 'f', 1},
       {"name-map", 'N', 1}, {"default-name-map", 'D', 0}, {"keep-unmatched", 'K', 0}, {"keep-top-scores", 'n', 1}, {"no-header-row", 'H', 0},
       {"sort-by", 's', 1}, {"do-not-sort", 'S', 0}, {"threads", 'j', 1}, {"quiet", 'q', 0}, {"infile-list", 'i', 1}, {"log", 0, 1},
-      {"gpu", 0, 1}, {"gpu-batch", 0, 1}, {"gpus", 0, 1}, {"gpu-ids", 0, 1}, {"help", 'h', 0}, {"version", 'V', 0}};
+      {"gpu", 0, 1}, {"gpu-batch", 0, 1}, {"gpus", 0, 1}, {"gpu-ids", 0, 1}, {"parse-only", 0, 0}, {"help", 'h', 0}, {"version", 'V', 0}};
   auto apply = [&](const std::string& name, const std::string& v) {
     if (name == "db-dir") o.db_dir = v;
     else if (name == "out-file") o.out_file = v;
@@ -165,6 +166,7 @@ static Options parse_args(int argc, char** argv) {
     else if (name == "log") o.log_file = v;
     else if (name == "gpu") o.device = to_i(name, v);
     else if (name == "gpu-batch") o.batch = to_i(name, v);
+    else if (name == "parse-only") o.parse_only = true;
     else if (name == "gpus") o.gpus = to_i(name, v);
     else if (name == "gpu-ids") {
       size_t b = 0;
@@ -233,7 +235,13 @@ struct FastxRec {
 // sequences (FASTA) are joined in a scratch string.  ID = header up to the first blank (fastx: `record.ID`).
 class FastxReader {
  public:
-  explicit FastxReader(const std::string& path) : buf_(8u << 20) {
+  // KMCP_READER_BUF (bytes) shrinks the initial block buffer so that tests cross refill boundaries with small files
+  static size_t initial_buffer() {
+    const char* e = getenv("KMCP_READER_BUF");
+    const long v = e ? atol(e) : 0;
+    return v >= 16 ? (size_t)v : (size_t)(8u << 20);
+  }
+  explicit FastxReader(const std::string& path) : buf_(initial_buffer()) {
     if (path == "-") {
       gz_ = gzdopen(0, "rb");
       if (!gz_) die("stdin: %s", strerror(errno));
@@ -564,6 +572,28 @@ int main(int argc, char** argv) {
   }
   const bool verbose = !o.quiet;
   const auto t_start = std::chrono::steady_clock::now();
+  if (o.parse_only) {  // reader check, no database and no GPU: one summary line per input file
+    for (const auto& file : o.files) {
+      FastxReader r(file);
+      FastxRec rec;
+      uint64_t n = 0, bases = 0, id_bytes = 0, sum = 1469598103934665603ULL;  // FNV-1a over "id\tseq\n"
+      auto mix = [&](const char* p, size_t len) {
+        for (size_t i = 0; i < len; i++) sum = (sum ^ (uint8_t)p[i]) * 1099511628211ULL;
+      };
+      while (r.next(&rec)) {
+        n++;
+        bases += rec.seq_len;
+        id_bytes += rec.id_len;
+        mix(rec.id, rec.id_len);
+        mix("\t", 1);
+        mix(rec.seq, rec.seq_len);
+        mix("\n", 1);
+      }
+      printf("%s\trecords=%llu\tbases=%llu\tid_bytes=%llu\tfnv1a=%016llx\n", file.c_str(), (unsigned long long)n, (unsigned long long)bases,
+             (unsigned long long)id_bytes, (unsigned long long)sum);
+    }
+    return 0;
+  }
   if (o.db_dir.empty()) die("flag -d/--db-dir needed");
   if (o.min_kmers < 1) die("value of flag --min-kmers should be positive: %d", o.min_kmers);
   if (o.dedup < 1) die("value of flag --kmer-dedup-threshold should be positive: %d", o.dedup);

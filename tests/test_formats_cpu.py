@@ -226,3 +226,64 @@ def test_mutated_headers_never_hang_or_crash(small_db, tmp_path):
         except lib.KmcpGpuError:
             refused += 1
     assert refused > 200 and refused + opened == 400
+
+
+def test_cli_reader_against_python_reader(tmp_path):
+    """`kmcp-search --parse-only` (the CLI's block-buffered FASTA/Q reader alone: no database, no GPU) vs the independent Python
+    reader of kmcp_amd.dist_search on random inputs — FASTA/FASTQ, wrapped or not, CRLF, blank lines, empty records, quality
+    lines starting with '@' or '+', missing final newline, gzip — with block buffers of 16 bytes .. 1 MB so that refills land
+    everywhere inside records."""
+    import gzip
+    import subprocess
+    from kmcp_amd.dist_search import read_fastx
+    cli = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "kmcp_amd", "kmcp-search")
+    if not os.path.exists(cli):
+        import __graft_entry__ as g
+        g.build()
+    rng = np.random.default_rng(21)
+
+    def fnv(recs):
+        h = 1469598103934665603
+        for i, s in recs:
+            for b in i + b"\t" + s + b"\n":
+                h = ((h ^ b) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+        return h
+
+    for it in range(120):
+        fastq = rng.random() < 0.6
+        nl = b"\r\n" if rng.random() < 0.3 else b"\n"
+        out = bytearray()
+        for r in range(int(rng.integers(0, 30))):
+            L = int(rng.choice([0, 1, 5, 30, 150, 151, 400, 3000]))
+            s = bytes(rng.choice(np.frombuffer(b"ACGTNacgt", dtype=np.uint8), L))
+            name = b"r%d" % r + (b" some text" if rng.random() < 0.5 else b"")
+            wrap = int(rng.choice([0, 0, 7, 60]))
+
+            def lines(x):
+                if wrap == 0 or len(x) == 0:
+                    return x + nl
+                return b"".join(x[p:p + wrap] + nl for p in range(0, len(x), wrap))
+            if fastq:
+                q = bytes(rng.choice(np.frombuffer(b"@+I#5>", dtype=np.uint8), L))
+                out += b"@" + name + nl + lines(s) + b"+" + (name if rng.random() < 0.3 else b"") + nl + lines(q)
+            else:
+                out += b">" + name + nl + lines(s)
+            if rng.random() < 0.1:
+                out += nl
+        if out and rng.random() < 0.3:
+            while out and out[-1:] in (b"\n", b"\r"):
+                out = out[:-1]
+        p = str(tmp_path / ("f%d.%s" % (it, "fq" if fastq else "fa")))
+        if rng.random() < 0.2:
+            p += ".gz"
+            with gzip.open(p, "wb") as fh:
+                fh.write(bytes(out))
+        else:
+            open(p, "wb").write(bytes(out))
+        want = list(read_fastx(p))
+        env = dict(os.environ, KMCP_READER_BUF=str(int(rng.choice([16, 17, 31, 64, 100, 257, 4096, 1 << 20]))))
+        r = subprocess.run([cli, "--parse-only", p], capture_output=True, text=True, env=env, timeout=60)
+        assert r.returncode == 0, (p, r.stderr)
+        got = dict(x.split("=") for x in r.stdout.strip().split("\t")[1:])
+        assert got == dict(records=str(len(want)), bases=str(sum(len(s) for _, s in want)), id_bytes=str(sum(len(i) for i, _ in want)),
+                           fnv1a="%016x" % fnv(want)), (p, env["KMCP_READER_BUF"])
