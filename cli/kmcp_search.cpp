@@ -248,9 +248,13 @@ class FastxReader {
     } else {
       fd_ = open(path.c_str(), O_RDONLY);
       if (fd_ < 0) die("%s: %s", path.c_str(), strerror(errno));
-      unsigned char magic[2] = {0, 0};
-      const ssize_t got = pread(fd_, magic, 2, 0);
-      if (got < 0 || (got == 2 && magic[0] == 0x1f && magic[1] == 0x8b)) {  // gzip, or not seekable (a pipe): let zlib look
+      unsigned char magic[6] = {0, 0, 0, 0, 0, 0};
+      const ssize_t got = pread(fd_, magic, 6, 0);
+      // the reference's xopen also reads xz, zstd and bzip2; here only gzip is built in: refuse the others instead of parsing noise
+      if (got >= 6 && memcmp(magic, "\xfd" "7zXZ\0", 6) == 0) die("%s: xz input is not supported (decompress it: xz -dc file | kmcp-search ... -)", path.c_str());
+      if (got >= 4 && memcmp(magic, "\x28\xb5\x2f\xfd", 4) == 0) die("%s: zstd input is not supported (zstd -dc file | kmcp-search ... -)", path.c_str());
+      if (got >= 3 && memcmp(magic, "BZh", 3) == 0) die("%s: bzip2 input is not supported (bzip2 -dc file | kmcp-search ... -)", path.c_str());
+      if (got < 0 || (got >= 2 && magic[0] == 0x1f && magic[1] == 0x8b)) {  // gzip, or not seekable (a pipe): let zlib look
         gz_ = gzdopen(fd_, "rb");
         if (!gz_) die("%s: %s", path.c_str(), strerror(errno));
         fd_ = -1;  // owned by zlib now
