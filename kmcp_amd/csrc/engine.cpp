@@ -890,9 +890,12 @@ extern "C" int kmcpg_finalize(const kmcpg_db* db, const kmcpg_hit* hits, uint64_
   // FPR rows of the NumKmers values present (a handful for short reads), fetched once so that the workers below never lock
   QueryFpr* F = db->fpr.get();
   std::unordered_map<int, const std::vector<double>*> fpr_rows;
+  int last_n = -1;  // reads of one batch mostly share their NumKmers: skip the map for runs of the same value
   for (uint32_t r = 0; r < n_reads; r++) {
     const int n = qkmers[r];
-    if (n > 0 && n <= QueryFpr::kCachedMaxN && start[r + 1] > start[r] && !fpr_rows.count(n)) fpr_rows.emplace(n, F->ensure_row(n));
+    if (n == last_n || n <= 0 || n > QueryFpr::kCachedMaxN || start[r + 1] == start[r]) continue;
+    last_n = n;
+    if (!fpr_rows.count(n)) fpr_rows.emplace(n, F->ensure_row(n));
   }
   // reads are independent: contiguous ranges of reads per worker thread, results concatenated in order
   const int workers = (int)std::max<uint64_t>(1, std::min<uint64_t>(8, n_hits / 32768));
@@ -902,13 +905,21 @@ extern "C" int kmcpg_finalize(const kmcpg_db* db, const kmcpg_hit* hits, uint64_
     const uint32_t lo = (uint32_t)((uint64_t)n_reads * w / workers), hi = (uint32_t)((uint64_t)n_reads * (w + 1) / workers);
     std::vector<kmcpg_match>& ms = part[(size_t)w];
     ms.reserve((size_t)(start[hi] - start[lo]));
+    int row_n = -1;
+    const std::vector<double>* row_of_n = nullptr;
     for (uint32_t r = lo; r < hi; r++) {
       const size_t first = ms.size();
       const int n = qkmers[r];
       const double nh = (double)n;
       const double thr = nh * p.min_qcov;
       const std::vector<double>* row = nullptr;
-      if (start[r + 1] > start[r] && n > 0 && n <= QueryFpr::kCachedMaxN) row = fpr_rows.find(n)->second;
+      if (start[r + 1] > start[r] && n > 0 && n <= QueryFpr::kCachedMaxN) {
+        if (n != row_n) {
+          row_n = n;
+          row_of_n = fpr_rows.find(n)->second;
+        }
+        row = row_of_n;
+      }
       for (uint64_t i = start[r]; i < start[r + 1]; i++) {
         const kmcpg_hit& h = sorted[i];
         const int count = (int)h.count;
