@@ -31,7 +31,8 @@ def _draw(rng):
     return k, kw, nh, fpr, n_genomes, glen, n_chunks, threads
 
 
-# KMCP_FUZZ_SEEDS=N widens the sweep (32 by default; a 5000-seed soak run passed on MI355X in round 1)
+# KMCP_FUZZ_SEEDS=N / KMCP_FUZZ_LONG_SEEDS=N widen the sweeps (32 / 8 by default; the final round-1 build passed a soak run of
+# 20 000 + 6 000 seeds on MI355X: `pytest tests/test_gpu_fuzz.py -m gpu -n 14`, 3 minutes)
 @pytest.mark.parametrize("seed", list(range(int(os.environ.get("KMCP_FUZZ_SEEDS", "32")))))
 def test_random_configuration(oracle_lib, tmp_path, seed):
     from kmcp_amd import Database, default_params
