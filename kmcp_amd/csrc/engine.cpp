@@ -846,10 +846,58 @@ extern "C" int kmcpg_plant_reads_device(kmcpg_db* db, const uint8_t* d_seqs, con
 // ------------------------------------------------------------------------------------------------
 namespace {
 
+// std::vector whose resize() leaves trivially-constructible elements uninitialised (no 60-MB memset per batch)
+template <class T>
+struct NoInitAlloc : std::allocator<T> {
+  template <class U>
+  struct rebind {
+    using other = NoInitAlloc<U>;
+  };
+  template <class U, class... A>
+  void construct(U* q, A&&... a) {
+    if constexpr (sizeof...(A) == 0) ::new ((void*)q) U;
+    else ::new ((void*)q) U(std::forward<A>(a)...);
+  }
+};
+typedef std::vector<kmcpg_match, NoInitAlloc<kmcpg_match>> MatchVec;
+
 struct ResultOwner {
   std::vector<int32_t> qlen, qkmers;
   std::vector<uint64_t> offs;
-  std::vector<kmcpg_match> matches;
+  MatchVec matches;
+};
+
+// Results are tens of MB per batch; handing freshly mmap'ed (page-faulting) vectors to every call costs more than filling
+// them, so kmcpg_result_free parks a few owners here with their capacity and kmcpg_finalize takes them back.
+std::mutex g_owner_mu;
+std::vector<ResultOwner*> g_owner_pool;
+
+ResultOwner* take_owner() {
+  {
+    std::lock_guard<std::mutex> g(g_owner_mu);
+    if (!g_owner_pool.empty()) {
+      ResultOwner* o = g_owner_pool.back();
+      g_owner_pool.pop_back();
+      return o;
+    }
+  }
+  return new ResultOwner();
+}
+
+void give_owner(ResultOwner* o) {
+  const size_t bytes = o->matches.capacity() * sizeof(kmcpg_match) + (o->qlen.capacity() + o->qkmers.capacity()) * 4 + o->offs.capacity() * 8;
+  {
+    std::lock_guard<std::mutex> g(g_owner_mu);
+    if (g_owner_pool.size() < 4 && bytes <= (1ull << 30)) {
+      g_owner_pool.push_back(o);
+      return;
+    }
+  }
+  delete o;
+}
+
+struct OwnerReturn {
+  void operator()(ResultOwner* o) const { give_owner(o); }
 };
 
 bool match_less(const kmcpg_match& x, const kmcpg_match& y, int sort_by) {
@@ -870,23 +918,23 @@ extern "C" int kmcpg_finalize(const kmcpg_db* db, const kmcpg_hit* hits, uint64_
                               const kmcpg_params* params, kmcpg_result* out) {
   if (!db || !out || (!hits && n_hits) || !qkmers || !qlen) return fail(KMCPG_EINVAL, "null argument");
   const kmcpg_params p = params ? *params : default_params();
-  std::unique_ptr<ResultOwner> o(new ResultOwner());
+  std::unique_ptr<ResultOwner, OwnerReturn> o(take_owner());
   o->qlen.assign(qlen, qlen + n_reads);
   o->qkmers.assign(qkmers, qkmers + n_reads);
+  // scratch of this thread, kept between calls (a caller thread finalizes batch after batch)
+  static thread_local std::vector<uint64_t> start, cur, per_read;
+  static thread_local std::vector<kmcpg_hit, NoInitAlloc<kmcpg_hit>> sorted;
   // bucket hits by read (counting sort), then order each bucket by column
-  std::vector<uint64_t> start((size_t)n_reads + 1, 0);
+  start.assign((size_t)n_reads + 1, 0);
   for (uint64_t i = 0; i < n_hits; i++) {
     if (hits[i].read >= n_reads) return fail(KMCPG_EINVAL, "hit %llu names read %u of %u", (unsigned long long)i, hits[i].read, n_reads);
+    if (hits[i].col >= db->col_block.size()) return fail(KMCPG_EINVAL, "hit names column %u of %zu", hits[i].col, db->col_block.size());
     start[hits[i].read + 1]++;
   }
   for (uint32_t r = 0; r < n_reads; r++) start[r + 1] += start[r];
-  std::vector<kmcpg_hit> sorted(n_hits);
-  {
-    std::vector<uint64_t> cur(start.begin(), start.end() - 1);
-    for (uint64_t i = 0; i < n_hits; i++) sorted[cur[hits[i].read]++] = hits[i];
-  }
-  for (uint64_t i = 0; i < n_hits; i++)
-    if (hits[i].col >= db->col_block.size()) return fail(KMCPG_EINVAL, "hit names column %u of %zu", hits[i].col, db->col_block.size());
+  sorted.resize(n_hits);
+  cur.assign(start.begin(), start.end() - 1);
+  for (uint64_t i = 0; i < n_hits; i++) sorted[cur[hits[i].read]++] = hits[i];
   // FPR rows of the NumKmers values present (a handful for short reads), fetched once so that the workers below never lock
   QueryFpr* F = db->fpr.get();
   std::unordered_map<int, const std::vector<double>*> fpr_rows;
@@ -897,31 +945,36 @@ extern "C" int kmcpg_finalize(const kmcpg_db* db, const kmcpg_hit* hits, uint64_
     last_n = n;
     if (!fpr_rows.count(n)) fpr_rows.emplace(n, F->ensure_row(n));
   }
-  // reads are independent: contiguous ranges of reads per worker thread, results concatenated in order
+  // Reads are independent: contiguous ranges of reads per worker thread.  A hit yields at most one match, so worker w writes
+  // its matches straight into the result array from position start[lo_w] on; the ranges are closed up afterwards.
   const int workers = (int)std::max<uint64_t>(1, std::min<uint64_t>(8, n_hits / 32768));
-  std::vector<std::vector<kmcpg_match>> part((size_t)workers);
-  std::vector<uint64_t> per_read((size_t)n_reads, 0);
-  auto work = [&](int w) {
+  o->matches.resize(n_hits);
+  kmcpg_match* const mbase = o->matches.data();
+  per_read.assign((size_t)n_reads, 0);
+  uint64_t* const per_read_p = per_read.data();
+  const uint64_t* const start_p = start.data();
+  const kmcpg_hit* const sorted_p = sorted.data();
+  std::vector<uint64_t> wcount((size_t)workers, 0);
+  auto work = [&, mbase, per_read_p, start_p, sorted_p](int w) {
     const uint32_t lo = (uint32_t)((uint64_t)n_reads * w / workers), hi = (uint32_t)((uint64_t)n_reads * (w + 1) / workers);
-    std::vector<kmcpg_match>& ms = part[(size_t)w];
-    ms.reserve((size_t)(start[hi] - start[lo]));
+    uint64_t pos = start_p[lo];
     int row_n = -1;
     const std::vector<double>* row_of_n = nullptr;
     for (uint32_t r = lo; r < hi; r++) {
-      const size_t first = ms.size();
+      const uint64_t first = pos;
       const int n = qkmers[r];
       const double nh = (double)n;
       const double thr = nh * p.min_qcov;
       const std::vector<double>* row = nullptr;
-      if (start[r + 1] > start[r] && n > 0 && n <= QueryFpr::kCachedMaxN) {
+      if (start_p[r + 1] > start_p[r] && n > 0 && n <= QueryFpr::kCachedMaxN) {
         if (n != row_n) {
           row_n = n;
           row_of_n = fpr_rows.find(n)->second;
         }
         row = row_of_n;
       }
-      for (uint64_t i = start[r]; i < start[r + 1]; i++) {
-        const kmcpg_hit& h = sorted[i];
+      for (uint64_t i = start_p[r]; i < start_p[r + 1]; i++) {
+        const kmcpg_hit& h = sorted_p[i];
         const int count = (int)h.count;
         if (count < p.min_matched) continue;
         const double c = (double)count;
@@ -942,21 +995,21 @@ extern "C" int kmcpg_finalize(const kmcpg_db* db, const kmcpg_hit* hits, uint64_
         m.qcov = c / nh;
         m.tcov = T;
         m.jacc = c / (nh + nt - c);
-        ms.push_back(m);
+        mbase[pos++] = m;
       }
-      size_t cnt = ms.size() - first;
+      uint64_t cnt = pos - first;
       if (cnt > 1 && !p.do_not_sort) {
         const int sb = p.sort_by;
-        std::sort(ms.begin() + (ptrdiff_t)first, ms.end(), [sb](const kmcpg_match& x, const kmcpg_match& y) { return match_less(x, y, sb); });
+        std::sort(mbase + first, mbase + pos, [sb](const kmcpg_match& x, const kmcpg_match& y) { return match_less(x, y, sb); });
       } else if (cnt > 1) {
-        std::sort(ms.begin() + (ptrdiff_t)first, ms.end(), [](const kmcpg_match& x, const kmcpg_match& y) { return x.col < y.col; });
+        std::sort(mbase + first, mbase + pos, [](const kmcpg_match& x, const kmcpg_match& y) { return x.col < y.col; });
       }
       if (cnt > 0 && p.top_n_scores > 0 && !p.do_not_sort) {  // --keep-top-scores (:285-311), including its [:i+1]
         int nn = 0;
-        size_t i = 0;
+        uint64_t i = 0;
         double pscore = 1024;
         for (; i < cnt; i++) {
-          const kmcpg_match& m = ms[first + i];
+          const kmcpg_match& m = mbase[first + i];
           const double score = p.sort_by == 1 ? m.tcov : (p.sort_by == 2 ? m.jacc : m.qcov);
           if (score < pscore) {
             nn++;
@@ -965,10 +1018,11 @@ extern "C" int kmcpg_finalize(const kmcpg_db* db, const kmcpg_hit* hits, uint64_
           }
         }
         if (i >= cnt) i = cnt - 1;
-        ms.resize(first + i + 1);
+        pos = first + i + 1;
       }
-      per_read[r] = ms.size() - first;
+      per_read_p[r] = pos - first;
     }
+    wcount[(size_t)w] = pos - start_p[lo];
   };
   if (workers == 1) work(0);
   else {
@@ -976,10 +1030,16 @@ extern "C" int kmcpg_finalize(const kmcpg_db* db, const kmcpg_hit* hits, uint64_
     for (int w = 0; w < workers; w++) th.emplace_back(work, w);
     for (auto& t : th) t.join();
   }
-  o->offs.assign((size_t)n_reads + 1, 0);
+  uint64_t total = 0;
+  for (int w = 0; w < workers; w++) {  // close the gaps the filters left between the workers' ranges
+    const uint32_t lo = (uint32_t)((uint64_t)n_reads * w / workers);
+    if (start[lo] != total && wcount[(size_t)w]) memmove(mbase + total, mbase + start[lo], wcount[(size_t)w] * sizeof(kmcpg_match));
+    total += wcount[(size_t)w];
+  }
+  o->matches.resize(total);
+  o->offs.resize((size_t)n_reads + 1);
+  o->offs[0] = 0;
   for (uint32_t r = 0; r < n_reads; r++) o->offs[r + 1] = o->offs[r] + per_read[r];
-  o->matches.reserve((size_t)o->offs[n_reads]);
-  for (auto& ms : part) o->matches.insert(o->matches.end(), ms.begin(), ms.end());
   out->n_reads = n_reads;
   out->k = db->info.k;
   out->qlen = o->qlen.data();
@@ -992,7 +1052,7 @@ extern "C" int kmcpg_finalize(const kmcpg_db* db, const kmcpg_hit* hits, uint64_
 
 extern "C" void kmcpg_result_free(kmcpg_result* r) {
   if (!r || !r->owner) return;
-  delete (ResultOwner*)r->owner;
+  give_owner((ResultOwner*)r->owner);
   memset(r, 0, sizeof *r);
 }
 
@@ -1162,7 +1222,7 @@ extern "C" int kmcpg_search_batch(kmcpg_db* db, const uint8_t* seqs, const uint6
     if (rc) return rc;
     // splice the retried queries back in
     std::vector<uint64_t> noffs((size_t)n_reads + 1, 0);
-    std::vector<kmcpg_match> nm;
+    MatchVec nm;
     size_t t = 0;
     std::vector<char> stop(n_reads, 0);
     for (uint32_t r = 0; r < n_reads; r++) {

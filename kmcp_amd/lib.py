@@ -272,6 +272,16 @@ class Database:
                                          offs2.ctypes.data if offs2 is not None else None, n, C.byref(p), C.byref(r)))
         return _copy_result(r)
 
+    def search_packed_count(self, seqs, offs, params=None):
+        """kmcpg_search_batch without copying the result into numpy: returns the number of matches (timing of the C boundary)."""
+        p = params or default_params()
+        r = Result()
+        n = len(offs) - 1
+        _check(load().kmcpg_search_batch(self._h, seqs.ctypes.data, offs.ctypes.data, None, None, n, C.byref(p), C.byref(r)))
+        m = int(r.match_offs[n])
+        load().kmcpg_result_free(C.byref(r))
+        return m
+
     # ---- GPU half on device pointers (torch tensors' data_ptr()) ----------------------------------
     def query_device(self, d_seqs, d_offs, n_reads, total_bases, max_read_len, d_hits, hit_cap, d_counters, d_qkmers,
                      d_qlen, params=None, d_seqs2=None, d_offs2=None, stream=None):
