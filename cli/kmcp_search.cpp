@@ -260,9 +260,43 @@ class FastxReader {
         fd_ = -1;  // owned by zlib now
       }
     }
-    if (gz_) gzbuffer(gz_, 1 << 20);
+    if (gz_) {
+      gzbuffer(gz_, 1 << 20);
+      // inflate runs ahead on its own thread (4 chunks of 4 MB in flight) while this thread parses
+      for (int i = 0; i < 4; i++) spare_.emplace_back(new Chunk());
+      inflater_ = std::thread([this] {
+        for (;;) {
+          std::unique_ptr<Chunk> c;
+          {
+            std::unique_lock<std::mutex> l(im_);
+            icv_.wait(l, [&] { return !spare_.empty() || istop_; });
+            if (istop_) return;
+            c = std::move(spare_.front());
+            spare_.pop_front();
+          }
+          const int n = gzread(gz_, c->data.data(), (unsigned)c->data.size());
+          std::lock_guard<std::mutex> l(im_);
+          if (n <= 0) {
+            idone_ = true;
+            icv_.notify_all();
+            return;
+          }
+          c->n = (size_t)n;
+          ready_.push_back(std::move(c));
+          icv_.notify_all();
+        }
+      });
+    }
   }
   ~FastxReader() {
+    if (inflater_.joinable()) {
+      {
+        std::lock_guard<std::mutex> l(im_);
+        istop_ = true;
+        icv_.notify_all();
+      }
+      inflater_.join();
+    }
     if (gz_) gzclose(gz_);
     if (fd_ >= 0) close(fd_);
   }
@@ -368,7 +402,7 @@ class FastxReader {
       if (end_ == buf_.size()) buf_.resize(buf_.size() * 2);  // a record longer than the buffer (a genome on one line)
       const size_t room = std::min<size_t>(buf_.size() - end_, 1u << 30);
       ssize_t got;
-      if (gz_) got = gzread(gz_, &buf_[end_], (unsigned)room);
+      if (gz_) got = (ssize_t)take_inflated(&buf_[end_], room);
       else
         do got = read(fd_, &buf_[end_], room);
         while (got < 0 && errno == EINTR);
@@ -376,8 +410,38 @@ class FastxReader {
       else end_ += (size_t)got;
     }
   }
+  // up to `room` inflated bytes from the helper thread's chunks; 0 at the end of the stream
+  size_t take_inflated(char* dst, size_t room) {
+    if (!cur_ || cur_pos_ == cur_->n) {
+      std::unique_lock<std::mutex> l(im_);
+      if (cur_) {
+        spare_.push_back(std::move(cur_));
+        icv_.notify_all();
+      }
+      icv_.wait(l, [&] { return !ready_.empty() || idone_; });
+      if (ready_.empty()) return 0;
+      cur_ = std::move(ready_.front());
+      ready_.pop_front();
+      cur_pos_ = 0;
+    }
+    const size_t n = std::min(room, cur_->n - cur_pos_);
+    memcpy(dst, cur_->data.data() + cur_pos_, n);
+    cur_pos_ += n;
+    return n;
+  }
+  struct Chunk {
+    std::vector<char> data = std::vector<char>(4u << 20);
+    size_t n = 0;
+  };
   gzFile gz_ = nullptr;
   int fd_ = -1;
+  std::thread inflater_;
+  std::mutex im_;
+  std::condition_variable icv_;
+  std::deque<std::unique_ptr<Chunk>> ready_, spare_;
+  std::unique_ptr<Chunk> cur_;
+  size_t cur_pos_ = 0;
+  bool idone_ = false, istop_ = false;
   std::vector<char> buf_;
   size_t pos_ = 0, end_ = 0, keep_ = 0;
   bool eof_ = false;
