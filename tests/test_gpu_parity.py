@@ -428,3 +428,40 @@ def test_batch_larger_than_one_launch(G):
         got = set(zip(whole[:, 0].tolist(), whole[:, 1].tolist()))
         c_host = cols.cpu().numpy()
         assert all((int(r), int(c_host[r])) in got for r in planted[-2000:])  # the reads of the last launch are served too
+
+
+def test_more_shards_than_blocks(G, oracle_lib, tmp_path):
+    """A one-block database opened over three shards (in process) and as shard 2 of 3 (one process per GPU): shards without
+    any resident block take part and contribute nothing."""
+    import torch
+    O = oracle_lib
+    genomes = synth.random_genomes(6, 8000, seed=85)
+    db_dir = synth.make_db(tmp_path, genomes, k=21, threads=1)
+    reads = synth.sample_reads(genomes, 300, 150, seed=86, frac_random=0.1)
+    odb = O.OracleDB(db_dir)
+    try:
+        with G["Database"].open_devices(db_dir, [0, 0, 0]) as db:
+            assert db.info.n_blocks == 1
+            res = db.search(reads, params=G["default_params"]())
+            assert synth.assert_parity(odb, res, reads) > 200
+    finally:
+        odb.close()
+    dev = torch.device("cuda:0")
+    seqs, offs = G["lib"].pack_reads(reads)
+    t_seqs = torch.from_numpy(seqs).to(dev)
+    t_offs = torch.from_numpy(offs.view(np.int64)).to(dev)
+    total = 0
+    for rank in range(3):
+        with G["Database"].open(db_dir, device=0, shard_rank=rank, shard_count=3) as sh:
+            hits = torch.zeros((4096, 3), dtype=torch.int32, device=dev)
+            cnt = torch.zeros(2, dtype=torch.int64, device=dev)
+            qk = torch.zeros(len(reads), dtype=torch.int32, device=dev)
+            ql = torch.zeros(len(reads), dtype=torch.int32, device=dev)
+            sh.query_device(t_seqs.data_ptr(), t_offs.data_ptr(), len(reads), len(seqs), 150, hits.data_ptr(), 4096, cnt.data_ptr(), qk.data_ptr(),
+                            ql.data_ptr(), params=G["default_params"]())
+            torch.cuda.synchronize()
+            c = int(cnt[0].item())
+            assert (c > 0) == (sh.info.n_blocks_local == 1)
+            assert int(qk.sum().item()) > 0  # k-mers are generated on every shard
+            total += c
+    assert total > 200
