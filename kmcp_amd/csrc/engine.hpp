@@ -1,0 +1,143 @@
+// engine.hpp — internals shared by the host-side translation units of libkmcpgpu.so (engine.cpp: residency;
+// query.cpp: GPU half; finalize.cpp: host half; host.cpp: the whole pipeline on host buffers).  Not part of the ABI.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <memory>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/kmcp_gpu.h"
+#include "common.hpp"
+#include "dbformat.hpp"
+#include "fpr.hpp"
+
+// error sink: sets the thread-local message behind kmcpg_last_error() and returns `code`
+int kmcpg_fail(int code, const char* fmt, ...);
+std::string& kmcpg_err_ref();  // the calling thread's message (workers hand theirs to the caller)
+
+#define HIPCHK(expr)                                                                               \
+  do {                                                                                             \
+    hipError_t e_ = (expr);                                                                        \
+    if (e_ != hipSuccess) return kmcpg_fail(KMCPG_EDEVICE, "%s: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+  } while (0)
+
+// GPU work on a handle: refused for metadata-only handles (opts.device == -1)
+#define KMCPG_USE_DEVICE(db)                                                                                      \
+  do {                                                                                                            \
+    if ((db)->opts.device < 0) return kmcpg_fail(KMCPG_EDEVICE, "metadata-only handle (device -1): no GPU work possible"); \
+    HIPCHK(hipSetDevice((db)->opts.device));                                                                      \
+  } while (0)
+
+namespace kmcpg {
+
+struct BlockMeta {
+  std::string path;
+  UnikiHeader h;
+  uint32_t col_base = 0;
+  bool local = false;
+  int local_idx = -1;
+  uint32_t stride = 0;
+  uint8_t* d_rows = nullptr;
+};
+
+struct SlotClass {
+  int lpr = 0;
+  std::vector<Slot> slots;
+  Slot* d_slots = nullptr;
+};
+
+template <typename T>
+struct DevBuf {
+  T* p = nullptr;
+  size_t cap = 0;
+  int ensure(size_t n) {
+    if (n <= cap) return 0;
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+    size_t want = n + n / 8 + 64;
+    if (hipMalloc((void**)&p, want * sizeof(T)) != hipSuccess) return -1;
+    cap = want;
+    return 0;
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+  }
+};
+
+}  // namespace kmcpg
+
+struct kmcpg_db {
+  kmcpg_opts opts{};
+  kmcpg_info info{};
+  std::vector<kmcpg::BlockMeta> blocks;
+  std::vector<int> local;  // global indices of resident blocks, in kmcpg::BlockDev order
+  std::vector<kmcpg::BlockDev> h_blockdev;
+  kmcpg::BlockDev* d_blockdev = nullptr;
+  std::vector<kmcpg::SlotClass> classes;
+  std::vector<uint32_t> col_block;  // global column -> block index
+  std::unique_ptr<kmcpg::QueryFpr> fpr;
+  std::mutex mu;      // guards the device workspace of one GPU-half call
+  std::mutex api_mu;  // serialises the GPU halves of kmcpg_search_batch callers (they share the staging buffers); the host
+                      // half (kmcpg_finalize) runs outside it, so two callers overlap one's finalize with the other's kernels
+  // workspace of kmcpg_query_device
+  kmcpg::DevBuf<uint64_t> w_hashes, w_scratch;
+  kmcpg::DevBuf<int32_t> w_nk_raw, w_nk1, w_seg_cnt;
+  kmcpg::DevBuf<uint32_t> w_long_list, w_long_meta, w_long_counts;  // long-query (split) path
+  kmcpg::DevBuf<uint64_t> w_huge_info;                             // whole-genome queries: (read, n, offset)
+  kmcpg::DevBuf<uint8_t> w_huge_temp;                              // hipCUB temporary storage
+  // workspace of kmcpg_search_batch
+  kmcpg::DevBuf<uint8_t> s_seqs, s_seqs2;
+  kmcpg::DevBuf<uint64_t> s_offs, s_offs2, s_counter;
+  kmcpg::DevBuf<kmcpg_hit> s_hits;
+  kmcpg::DevBuf<int32_t> s_qk, s_ql;
+  bool synthetic = false;
+  // in-process multi-GPU front handle (kmcpg_open_devices): metadata only itself, one resident shard handle per device
+  std::vector<kmcpg_db*> shards;
+  // optional HIP-event timing of the last kmcpg_query_device call
+  bool profiling = false;
+  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  bool ev_valid = false;
+};
+
+
+namespace kmcpg {
+
+inline kmcpg_params default_params() {
+  kmcpg_params p{};
+  p.min_qlen = 30;
+  p.min_matched = 10;
+  p.min_qcov = 0.55;
+  p.min_tcov = 0;
+  p.max_fpr = 0.01;
+  p.dedup_threshold = 256;
+  return p;
+}
+
+// std::vector whose resize() leaves trivially-constructible elements uninitialised (no 60-MB memset per batch)
+template <class T>
+struct NoInitAlloc : std::allocator<T> {
+  template <class U>
+  struct rebind {
+    using other = NoInitAlloc<U>;
+  };
+  template <class U, class... A>
+  void construct(U* q, A&&... a) {
+    if constexpr (sizeof...(A) == 0) ::new ((void*)q) U;
+    else ::new ((void*)q) U(std::forward<A>(a)...);
+  }
+};
+typedef std::vector<kmcpg_match, NoInitAlloc<kmcpg_match>> MatchVec;
+
+struct ResultOwner {
+  std::vector<int32_t> qlen, qkmers;
+  std::vector<uint64_t> offs;
+  MatchVec matches;
+};
+
+}  // namespace kmcpg

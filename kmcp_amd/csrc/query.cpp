@@ -1,0 +1,296 @@
+// query.cpp — the GPU half behind the C ABI: k-mer generation (K1, K1d) and the COBS query (K2) on device pointers.
+// Reference counterparts: generateKmers (util-db-search.go:1037-1107), dedup (:874-908), the UnikIndex workers (:6611-7742).
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <errno.h>
+#include <fcntl.h>
+#include <string.h>
+#include <unistd.h>
+
+#include <algorithm>
+#include <atomic>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <unordered_map>
+#include <vector>
+
+#include "common.hpp"
+#include "dbformat.hpp"
+#include "engine.hpp"
+#include "fpr.hpp"
+#include "kernels.hpp"
+
+using namespace kmcpg;
+
+// ------------------------------------------------------------------------------------------------
+// GPU half
+// ------------------------------------------------------------------------------------------------
+namespace {
+
+uint64_t max_hash_for(uint32_t scale) {
+  // uint64(float64(^uint64(0)) / float64(scale))  (util-db-search.go:1040-1043)
+  const double d = 18446744073709551616.0 / (double)scale;
+  if (d >= 18446744073709551616.0) return ~0ULL;
+  return (uint64_t)d;
+}
+
+// K1 (+K1d): hashes of read i end up at d_hashes[offs[i] + offs2[i] ...], NumKmers in d_nk_search
+int run_kmers(kmcpg_db* db, const uint8_t* d_seqs, const uint64_t* d_offs, const uint8_t* d_seqs2, const uint64_t* d_offs2, uint32_t n_reads,
+              uint32_t max_read_len, const kmcpg_params& p, uint64_t* d_hashes, uint64_t* d_scratch, uint64_t scratch_half, int32_t* d_nk_raw, int32_t* d_nk1,
+              int32_t* d_nk_search, int32_t* d_qlen, hipStream_t st, uint64_t* max_n_out) {
+  const kmcpg_info& I = db->info;
+  if (!I.canonical) return kmcpg_fail(KMCPG_EUNSUPPORTED, "non-canonical index");
+  K1Args a{};
+  a.seqs = d_seqs;
+  a.offs = d_offs;
+  a.seqs2 = d_seqs2;
+  a.offs2 = d_offs2;
+  a.n_reads = n_reads;
+  a.k = I.k;
+  a.min_qlen = p.min_qlen;
+  a.scaled = I.scaled;
+  a.max_hash = I.scaled ? max_hash_for(I.scale) : ~0ULL;
+  a.mode = I.syncmer ? 2 : (I.minimizer ? 1 : 0);  // syncmer > minimizer > plain (:1052-1058)
+  a.w_or_s = I.syncmer ? I.syncmer_s : I.minimizer_w;
+  a.hashes = d_hashes;
+  a.scratch = d_scratch;
+  a.scratch2 = d_scratch ? d_scratch + scratch_half : nullptr;
+  a.nk_raw = d_nk_raw;
+  a.nk1 = d_nk1;
+  a.qlen = d_qlen;
+  // whole genomes (single-end, plain or FracMinHash k-mers): segments of a read on their own workgroups
+  const uint32_t segs = (max_read_len + (uint32_t)k1_segment_len() - 1) / (uint32_t)k1_segment_len();
+  if (a.mode == 0 && !d_seqs2 && segs > 1 && d_scratch && (uint64_t)n_reads * segs <= (1ull << 21)) {  // one workgroup of 1024 threads per segment, < 2^32 threads per launch
+    if (db->w_seg_cnt.ensure((size_t)n_reads * segs)) return kmcpg_fail(KMCPG_ENOMEM, "hipMalloc failed");
+    a.seg_cnt = db->w_seg_cnt.p;
+    a.segs_max = segs;
+  }
+  launch_k1(a, max_read_len, st);
+  uint64_t ub = max_read_len >= (uint32_t)I.k ? (uint64_t)(max_read_len - I.k + 1) : 0;
+  if (d_seqs2) ub *= 2;
+  *max_n_out = ub;
+  if (ub > (uint64_t)p.dedup_threshold) {
+    DedupArgs d{};
+    d.offs = d_offs;
+    d.offs2 = d_offs2;
+    d.n_reads = n_reads;
+    d.dedup_threshold = p.dedup_threshold;
+    d.min_matched = p.min_matched;
+    d.hashes = d_hashes;
+    d.scratch = d_scratch;
+    d.nk_raw = d_nk_raw;
+    d.nk_search = d_nk_search;
+    d.pre = a.mode != 0;
+    launch_dedup(d, ub, st);
+    if (ub > HUGE_MIN) {
+      // whole-genome queries: which ones they are is only known on the device -> one small read-back, then a device-wide
+      // sort + unique per such query
+      const int32_t thr = std::max<int32_t>((int32_t)HUGE_MIN, p.dedup_threshold);
+      uint32_t meta[2] = {0, 0};
+      if (db->w_long_list.ensure(n_reads + 1) || db->w_long_meta.ensure(2)) return kmcpg_fail(KMCPG_ENOMEM, "hipMalloc failed");
+      HIPCHK(hipMemsetAsync(db->w_long_meta.p, 0, 2 * sizeof(uint32_t), st));
+      launch_list_long(d_nk_raw, n_reads, thr, db->w_long_list.p, db->w_long_meta.p, st);
+      HIPCHK(hipMemcpyAsync(meta, db->w_long_meta.p, sizeof meta, hipMemcpyDeviceToHost, st));
+      HIPCHK(hipStreamSynchronize(st));
+      if (meta[0]) {
+        const size_t tb = huge_dedup_temp_bytes(meta[1]);
+        if (db->w_huge_info.ensure(3 * (size_t)meta[0] + 1) || db->w_huge_temp.ensure(tb + 64)) return kmcpg_fail(KMCPG_ENOMEM, "hipMalloc failed");
+        launch_gather_huge(db->w_long_list.p, meta[0], d_nk_raw, d_offs, d_offs2, db->w_huge_info.p, st);
+        std::vector<uint64_t> hinfo(3 * (size_t)meta[0]);
+        HIPCHK(hipMemcpyAsync(hinfo.data(), db->w_huge_info.p, hinfo.size() * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        int* d_num = (int*)db->w_huge_temp.p;  // first 64 bytes: the unique count
+        for (uint32_t i = 0; i < meta[0]; i++) {
+          const uint32_t r = (uint32_t)hinfo[3 * i], n = (uint32_t)hinfo[3 * i + 1];
+          const uint64_t koff = hinfo[3 * i + 2];
+          if (huge_dedup(d_hashes + koff, d_scratch + koff, n, d_num, db->w_huge_temp.p + 64, tb, d_nk_search, r, p.min_matched, st) != 0)
+            return kmcpg_fail(KMCPG_EDEVICE, "device-wide sort of a %u-k-mer query failed", n);
+        }
+      }
+    }
+  } else {
+    launch_nk_simple(d_nk_raw, d_nk_search, n_reads, p.min_matched, st);
+  }
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int kmcpg_kmers_device(kmcpg_db* db, const uint8_t* d_seqs, const uint64_t* d_offs, uint32_t n_reads, uint64_t total_bases,
+                                  uint32_t max_read_len, const kmcpg_params* params, uint64_t* d_hashes, uint64_t hashes_cap, uint64_t* d_koff,
+                                  int32_t* d_nk, void* stream) {
+  if (!db || !d_seqs || !d_offs || !d_hashes || !d_nk) return kmcpg_fail(KMCPG_EINVAL, "null argument");
+  if (hashes_cap < total_bases) return kmcpg_fail(KMCPG_EINVAL, "hashes_cap must be >= total_bases");
+  std::lock_guard<std::mutex> g(db->mu);
+  KMCPG_USE_DEVICE(db);
+  const kmcpg_params p = params ? *params : default_params();
+  hipStream_t st = (hipStream_t)stream;
+  if (db->w_scratch.ensure(2 * total_bases + 2) || db->w_nk_raw.ensure(n_reads + 1) || db->w_nk1.ensure(n_reads + 1)) return kmcpg_fail(KMCPG_ENOMEM, "hipMalloc failed");
+  DevBuf<int32_t> ql;
+  if (ql.ensure(n_reads + 1)) return kmcpg_fail(KMCPG_ENOMEM, "hipMalloc failed");
+  uint64_t maxn = 0;
+  int rc = run_kmers(db, d_seqs, d_offs, nullptr, nullptr, n_reads, max_read_len, p, d_hashes, db->w_scratch.p, total_bases + 1, db->w_nk_raw.p, db->w_nk1.p,
+                     d_nk, ql.p, st, &maxn);
+  if (rc == 0 && d_koff) HIPCHK(hipMemcpyAsync(d_koff, d_offs, (size_t)n_reads * sizeof(uint64_t), hipMemcpyDeviceToDevice, st));
+  hipError_t e = hipStreamSynchronize(st);
+  ql.release();
+  if (rc) return rc;
+  if (e != hipSuccess) return kmcpg_fail(KMCPG_EDEVICE, "k-mer kernel failed: %s", hipGetErrorString(e));
+  return 0;
+}
+
+extern "C" int kmcpg_query_device(kmcpg_db* db, const uint8_t* d_seqs, const uint64_t* d_offs, const uint8_t* d_seqs2, const uint64_t* d_offs2,
+                                  uint32_t n_reads, uint64_t total_bases, uint32_t max_read_len, const kmcpg_params* params, kmcpg_hit* d_hits,
+                                  uint64_t hit_cap, uint64_t* d_counters, int32_t* d_qkmers, int32_t* d_qlen, void* stream) {
+  if (!db || !d_seqs || !d_offs || !d_counters || !d_qkmers || !d_qlen || (!d_hits && hit_cap)) return kmcpg_fail(KMCPG_EINVAL, "null argument");
+  if ((d_seqs2 == nullptr) != (d_offs2 == nullptr)) return kmcpg_fail(KMCPG_EINVAL, "seqs2 and offs2 must be given together");
+  std::lock_guard<std::mutex> g(db->mu);
+  KMCPG_USE_DEVICE(db);
+  const kmcpg_params p = params ? *params : default_params();
+  if (p.min_matched < 1) return kmcpg_fail(KMCPG_EINVAL, "min_matched must be >= 1");  // getFlagPositiveInt (search.go:165)
+  hipStream_t st = (hipStream_t)stream;
+  if (db->w_hashes.ensure(total_bases + 1) || db->w_nk_raw.ensure(n_reads + 1) || db->w_nk1.ensure(n_reads + 1)) return kmcpg_fail(KMCPG_ENOMEM, "hipMalloc failed");
+  uint64_t ub = max_read_len >= (uint32_t)db->info.k ? (uint64_t)(max_read_len - db->info.k + 1) : 0;
+  if (d_seqs2) ub *= 2;
+  const bool window_sketch = db->info.syncmer || db->info.minimizer;
+  if ((ub > (uint64_t)p.dedup_threshold || window_sketch) && db->w_scratch.ensure(2 * total_bases + 2)) return kmcpg_fail(KMCPG_ENOMEM, "hipMalloc failed");
+  uint64_t maxn = 0;
+  if (db->profiling) {
+    for (auto& ev : db->ev)
+      if (!ev) HIPCHK(hipEventCreate(&ev));
+    HIPCHK(hipEventRecord(db->ev[0], st));
+  }
+  int rc = run_kmers(db, d_seqs, d_offs, d_seqs2, d_offs2, n_reads, max_read_len, p, db->w_hashes.p, db->w_scratch.p, total_bases + 1, db->w_nk_raw.p,
+                     db->w_nk1.p, d_qkmers, d_qlen, st, &maxn);
+  if (rc) return rc;
+  HIPCHK(hipMemsetAsync(d_counters, 0, sizeof(uint64_t), st));
+  if (db->profiling) HIPCHK(hipEventRecord(db->ev[1], st));
+  // long queries (whole genomes, -g) are split into chunks of k-mers so that they spread over the chip; short ones keep
+  // the one-wave-per-(query, slot) kernel.  Which queries are long is only known on the device: one small D2H read.
+  const char* sm_env = getenv("KMCPG_SPLIT_MIN");
+  const int32_t split_min = sm_env ? atoi(sm_env) : 2048;
+  uint32_t long_meta[2] = {0, 0};
+  if (split_min > 0 && maxn > (uint64_t)split_min) {
+    if (db->w_long_list.ensure(n_reads + 1) || db->w_long_meta.ensure(2)) return kmcpg_fail(KMCPG_ENOMEM, "hipMalloc failed");
+    HIPCHK(hipMemsetAsync(db->w_long_meta.p, 0, 2 * sizeof(uint32_t), st));
+    launch_list_long(d_qkmers, n_reads, split_min, db->w_long_list.p, db->w_long_meta.p, st);
+    HIPCHK(hipMemcpyAsync(long_meta, db->w_long_meta.p, sizeof long_meta, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+  }
+  uint32_t n_long = long_meta[0];
+  size_t total_slots = 0;
+  for (const auto& c : db->classes) total_slots += c.slots.size();
+  // splitting pays when the long queries alone would leave the chip idle (few (query, slot) pairs) or need more than 16
+  // counter planes; a batch of thousands of 10-kb reads already fills it and keeps the plain kernel (unless forced by env)
+  if (n_long && !sm_env && (uint64_t)n_long * total_slots > 16384 && long_meta[1] <= 65535) n_long = 0;
+  // largest NumKmers the plain kernel will meet: bounded by the read length, and exactly known once the long ones were listed
+  uint64_t max_short = maxn;
+  if (split_min > 0 && maxn > (uint64_t)split_min)
+    max_short = n_long ? (uint64_t)split_min : std::max<uint64_t>(long_meta[1], (uint64_t)split_min);
+  const int npl = max_short <= 255 ? 8 : (max_short <= 65535 ? 16 : (max_short <= 16777215 ? 24 : 0));
+  if (!npl) return kmcpg_fail(KMCPG_EUNSUPPORTED, "queries with more than 16777215 k-mers need KMCPG_SPLIT_MIN > 0");
+  K2Args a{};
+  a.blocks = db->d_blockdev;
+  a.n_reads = n_reads;
+  a.hashes = db->w_hashes.p;
+  a.offs = d_offs;
+  a.offs2 = d_offs2;
+  a.nk = d_qkmers;
+  a.min_qcov = p.min_qcov;
+  a.min_matched = p.min_matched;
+  a.num_hashes = db->info.num_hashes;
+  a.nt_loads = getenv("KMCPG_NT_LOADS") ? atoi(getenv("KMCPG_NT_LOADS")) : 1;
+  a.prune = getenv("KMCPG_PRUNE") ? atoi(getenv("KMCPG_PRUNE")) : 1;
+  a.split_min = n_long ? split_min : 0;
+  a.hits = d_hits;
+  a.hit_cap = hit_cap;
+  a.counter = (unsigned long long*)d_counters;
+  for (const auto& c : db->classes) {
+    a.slots = c.d_slots;
+    a.nslots = (uint32_t)c.slots.size();
+    if (launch_k2(a, c.lpr, npl, st) != 0) return kmcpg_fail(KMCPG_EINVAL, "batch too large for one launch: split it");
+  }
+  if (n_long) {
+    a.ncols_total = (uint32_t)db->info.n_cols;
+    // ~64 chunks for the largest query, 1024..8192 k-mers each (at most 8192: the chunk's counts fit 16 planes)
+    uint32_t chk = 1024;
+    while (chk < 8192 && (uint64_t)chk * 64 < long_meta[1]) chk <<= 1;
+    a.split_chk = chk;
+    a.split_chunks = (long_meta[1] + chk - 1) / chk;
+    // count arrays of at most ~2 GB at a time
+    const uint32_t group = (uint32_t)std::max<uint64_t>(1, (2ull << 30) / ((uint64_t)a.ncols_total * 4));
+    if (db->w_long_counts.ensure((size_t)std::min<uint32_t>(group, n_long) * a.ncols_total)) return kmcpg_fail(KMCPG_ENOMEM, "hipMalloc failed");
+    a.long_counts = db->w_long_counts.p;
+    for (uint32_t g0 = 0; g0 < n_long; g0 += group) {
+      a.long_list = db->w_long_list.p + g0;
+      a.n_long = std::min<uint32_t>(group, n_long - g0);
+      HIPCHK(hipMemsetAsync(a.long_counts, 0, (size_t)a.n_long * a.ncols_total * sizeof(uint32_t), st));
+      for (const auto& c : db->classes) {
+        a.slots = c.d_slots;
+        a.nslots = (uint32_t)c.slots.size();
+        if (launch_k2_split(a, c.lpr, st) != 0) return kmcpg_fail(KMCPG_EINVAL, "batch too large for one launch: split it");
+      }
+      launch_threshold_long(a, st);
+    }
+  }
+  if (db->profiling) {
+    HIPCHK(hipEventRecord(db->ev[2], st));
+    db->ev_valid = true;
+  }
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+extern "C" int kmcpg_set_profiling(kmcpg_db* db, int enable) {
+  if (!db) return kmcpg_fail(KMCPG_EINVAL, "null argument");
+  std::lock_guard<std::mutex> g(db->mu);
+  db->profiling = enable != 0;
+  db->ev_valid = false;
+  return 0;
+}
+
+extern "C" int kmcpg_last_timing(kmcpg_db* db, float* kmers_ms, float* cobs_ms) {
+  if (!db) return kmcpg_fail(KMCPG_EINVAL, "null argument");
+  std::lock_guard<std::mutex> g(db->mu);
+  if (!db->profiling || !db->ev_valid) return kmcpg_fail(KMCPG_EINVAL, "no profiled kmcpg_query_device call yet");
+  KMCPG_USE_DEVICE(db);
+  HIPCHK(hipEventSynchronize(db->ev[2]));
+  float a = 0, b = 0;
+  HIPCHK(hipEventElapsedTime(&a, db->ev[0], db->ev[1]));
+  HIPCHK(hipEventElapsedTime(&b, db->ev[1], db->ev[2]));
+  if (kmers_ms) *kmers_ms = a;
+  if (cobs_ms) *cobs_ms = b;
+  return 0;
+}
+
+extern "C" int kmcpg_plant_reads_device(kmcpg_db* db, const uint8_t* d_seqs, const uint64_t* d_offs, uint32_t n_reads, uint64_t total_bases,
+                                        uint32_t max_read_len, const uint32_t* d_cols, void* stream) {
+  if (!db || !d_seqs || !d_offs || !d_cols) return kmcpg_fail(KMCPG_EINVAL, "null argument");
+  std::lock_guard<std::mutex> g(db->mu);
+  KMCPG_USE_DEVICE(db);
+  hipStream_t st = (hipStream_t)stream;
+  if (db->w_hashes.ensure(total_bases + 1) || db->w_nk_raw.ensure(n_reads + 1) || db->w_nk1.ensure(n_reads + 1)) return kmcpg_fail(KMCPG_ENOMEM, "hipMalloc failed");
+  DevBuf<int32_t> tmp;
+  if (tmp.ensure(2 * (size_t)n_reads + 2)) return kmcpg_fail(KMCPG_ENOMEM, "hipMalloc failed");
+  kmcpg_params p = default_params();
+  p.min_qlen = 0;
+  p.min_matched = 1;
+  p.dedup_threshold = 0x7fffffff;  // plant every k-mer occurrence (idempotent)
+  uint64_t maxn = 0;
+  if ((db->info.syncmer || db->info.minimizer) && db->w_scratch.ensure(2 * total_bases + 2)) return kmcpg_fail(KMCPG_ENOMEM, "hipMalloc failed");
+  int rc = run_kmers(db, d_seqs, d_offs, nullptr, nullptr, n_reads, max_read_len, p, db->w_hashes.p, db->w_scratch.p, total_bases + 1, db->w_nk_raw.p,
+                     db->w_nk1.p, tmp.p, tmp.p + n_reads + 1, st, &maxn);
+  if (rc == 0)
+    launch_plant_reads(db->d_blockdev, (uint32_t)db->h_blockdev.size(), db->info.num_hashes, db->w_hashes.p, d_offs, db->w_nk_raw.p, d_cols, n_reads, st);
+  hipError_t e = hipStreamSynchronize(st);
+  tmp.release();
+  if (rc) return rc;
+  if (e != hipSuccess) return kmcpg_fail(KMCPG_EDEVICE, "plant kernel failed: %s", hipGetErrorString(e));
+  return 0;
+}
+
