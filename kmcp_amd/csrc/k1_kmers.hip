@@ -1,0 +1,650 @@
+// k1_kmers.hip — K1: ntHash canonical k-mer hashes of batched reads, FracMinHash filter, Closed-Syncmer and Minimizer
+// selection: one wave per short read (k1_kmers), one 1024-thread workgroup with LDS prefix arrays per long read
+// (k1_kmers_wg), one workgroup per 65536-position segment of a genome (k1_seg_hash / k1_seg_pack).  Replaces bio/sketches
+// NextHash / NextSyncmer / NextMinimizer behind generateKmers (kmcp/cmd/util-db-search.go:1037-1107).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+
+#include "common.hpp"
+#include "device_utils.hpp"
+#include "kernels.hpp"
+
+namespace kmcpg {
+
+// ------------------------------------------------------------------------------------------------
+// K1: k-mer generation.  ntHash of the k-mer at position i in closed form:
+//     fh(i) = XOR_j rol(F[i+j], k-1-j),   rh(i) = XOR_j rol(R[i+j], j)      (F = seed of the base, R = of its complement)
+// Every term is a rotation of a per-position value by an amount that depends on i+j only up to a common rotation, so with
+// the prefix XORs  P(n) = XOR_{m<n} ror(F[m], m)  and  Q(n) = XOR_{m<n} rol(R[m], m)
+//     fh(i) = rol(P(i+k) ^ P(i), k-1+i),   rh(i) = ror(Q(i+k) ^ Q(i), i)
+// i.e. one XOR scan over the bases gives the hashes of every k (and of the s-mers of a syncmer) for two look-ups each,
+// instead of k table look-ups per k-mer.  The scans run on DPP within a wave (row_shr 1/2/4/8, row_bcast 15/31).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t rolv(uint64_t x, int n) {
+  n &= 63;
+  return (x << n) | (x >> ((64 - n) & 63));
+}
+__device__ __forceinline__ uint64_t rorv(uint64_t x, int n) {
+  n &= 63;
+  return (x >> n) | (x << ((64 - n) & 63));
+}
+
+// inclusive XOR scan over the 64 lanes of a wave (all lanes must be active)
+__device__ __forceinline__ uint32_t wave_xor_scan32(uint32_t v) {
+  v ^= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);  // row_shr:1
+  v ^= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);  // row_shr:2
+  v ^= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);  // row_shr:4
+  v ^= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);  // row_shr:8: scan within rows of 16
+  v ^= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);  // row_bcast:15 into rows 1 and 3
+  v ^= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);  // row_bcast:31 into rows 2 and 3
+  return v;
+}
+__device__ __forceinline__ uint64_t wave_xor_scan(uint64_t v) {
+  const uint32_t lo = wave_xor_scan32((uint32_t)v), hi = wave_xor_scan32((uint32_t)(v >> 32));
+  return ((uint64_t)hi << 32) | lo;
+}
+__device__ __forceinline__ uint64_t wave_last(uint64_t v) {  // lane 63's value, uniform
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, 63), hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), 63);
+  return ((uint64_t)hi << 32) | lo;
+}
+
+// One wave per read: a tile is 64 consecutive bases, lane = base index & 63 (also its rotation amount).
+struct WTile {
+  uint64_t ip, iq;  // inclusive prefixes P(e+1), Q(e+1) at this lane's base e
+  uint64_t xp, xq;  // this base's own terms
+};
+constexpr int K1_SCAN_MAX_K = 65;  // a k-mer may reach into the next tile only
+
+__device__ __forceinline__ WTile wave_tile(const uint8_t* __restrict__ s, int len, int e0, const uint64_t* tab, uint64_t& cp, uint64_t& cq, int lane) {
+  const int e = e0 + lane;
+  uint64_t F = 0, R = 0;
+  if (e < len) {
+    const uint8_t b = s[e];
+    F = tab[b];
+    R = tab[b & 7];
+  }
+  WTile t;
+  t.xp = rorv(F, lane);
+  t.xq = rolv(R, lane);
+  t.ip = wave_xor_scan(t.xp) ^ cp;
+  t.iq = wave_xor_scan(t.xq) ^ cq;
+  cp = wave_last(t.ip);
+  cq = wave_last(t.iq);
+  return t;
+}
+
+// canonical hash of the kk-mer starting at this lane's base of tile c (n = the following tile); every lane must call it
+__device__ __forceinline__ uint64_t wave_hash(const WTile& c, const WTile& n, int kk, int lane) {
+  const int src = lane + kk - 1;  // the k-mer's last base
+  const uint64_t ec = __shfl(c.ip, src & 63), en = __shfl(n.ip, src & 63);
+  const uint64_t qc = __shfl(c.iq, src & 63), qn = __shfl(n.iq, src & 63);
+  const uint64_t dp = (src >= 64 ? en : ec) ^ c.ip ^ c.xp;
+  const uint64_t dq = (src >= 64 ? qn : qc) ^ c.iq ^ c.xq;
+  const uint64_t f = rolv(dp, kk - 1 + lane), r = rorv(dq, lane);
+  return f < r ? f : r;
+}
+
+__device__ __forceinline__ int hash_mate_scan(const uint8_t* __restrict__ s, int len, int k, const uint64_t* tab, bool scaled, uint64_t max_hash,
+                                              uint64_t* __restrict__ out, int cnt, int lane) {
+  const int npos = len - k + 1;
+  if (npos <= 0) return cnt;  // ErrShortSeq => no k-mers (util-db-search.go:1060-1062)
+  uint64_t cp = 0, cq = 0;
+  WTile cur = wave_tile(s, len, 0, tab, cp, cq, lane);
+  for (int base = 0; base < npos; base += 64) {
+    const WTile nxt = wave_tile(s, len, base + 64, tab, cp, cq, lane);
+    const uint64_t h = wave_hash(cur, nxt, k, lane);
+    const bool keep = base + lane < npos && h != 0 && (!scaled || h <= max_hash);  // :1097-1103
+    const uint64_t m = __ballot(keep);
+    if (keep) out[cnt + __popcll(m & ((1ULL << lane) - 1ULL))] = h;
+    cnt += __popcll(m);
+    cur = nxt;
+  }
+  return cnt;
+}
+
+// all canonical k1-mer (and, if out2, k2-mer) hashes of s, uncompacted (input of the window sketches)
+__device__ __forceinline__ void hash_positions_scan(const uint8_t* __restrict__ s, int len, int k1, uint64_t* __restrict__ out1, int k2,
+                                                    uint64_t* __restrict__ out2, const uint64_t* tab, int lane) {
+  const int n1 = len - k1 + 1, n2 = out2 ? len - k2 + 1 : 0;
+  const int nmax = n1 > n2 ? n1 : n2;
+  uint64_t cp = 0, cq = 0;
+  WTile cur = wave_tile(s, len, 0, tab, cp, cq, lane);
+  for (int base = 0; base < nmax; base += 64) {
+    const WTile nxt = wave_tile(s, len, base + 64, tab, cp, cq, lane);
+    const uint64_t h1 = wave_hash(cur, nxt, k1, lane);
+    if (base + lane < n1) out1[base + lane] = h1;
+    if (out2) {
+      const uint64_t h2 = wave_hash(cur, nxt, k2, lane);
+      if (base + lane < n2) out2[base + lane] = h2;
+    }
+    cur = nxt;
+  }
+}
+
+// Fallback for k > 65 (the closed form evaluated per k-mer); kept hashes are compacted in order with a wave ballot.
+__device__ __forceinline__ int hash_mate(const uint8_t* __restrict__ s, int len, int k, const uint64_t* tab, bool scaled,
+                                         uint64_t max_hash, uint64_t* __restrict__ out, int cnt, int lane) {
+  if (k <= K1_SCAN_MAX_K) return hash_mate_scan(s, len, k, tab, scaled, max_hash, out, cnt, lane);
+  const int npos = len - k + 1;
+  if (npos <= 0) return cnt;  // ErrShortSeq => no k-mers (util-db-search.go:1060-1062)
+  for (int base = 0; base < npos; base += 64) {
+    const int i = base + lane;
+    const bool v = i < npos;
+    uint64_t h = 0;
+    if (v) {
+      uint64_t f = 0, r = 0;
+      for (int j = 0; j < k; j++) {
+        f = rol1(f) ^ tab[s[i + j]];
+        r = rol1(r) ^ tab[s[i + k - 1 - j] & 7];
+      }
+      h = f < r ? f : r;
+    }
+    const bool keep = v && h != 0 && (!scaled || h <= max_hash);  // :1097-1103
+    const uint64_t m = __ballot(keep);
+    if (keep) out[cnt + __popcll(m & ((1ULL << lane) - 1ULL))] = h;
+    cnt += __popcll(m);
+  }
+  return cnt;
+}
+
+// all canonical kk-mer hashes of s, uncompacted (input of the window sketches)
+__device__ __forceinline__ void hash_positions(const uint8_t* __restrict__ s, int len, int kk, const uint64_t* tab, uint64_t* __restrict__ out,
+                                               int lane) {
+  const int npos = len - kk + 1;
+  for (int i = lane; i < npos; i += 64) {
+    uint64_t f = 0, r = 0;
+    for (int j = 0; j < kk; j++) {
+      f = rol1(f) ^ tab[s[i + j]];
+      r = rol1(r) ^ tab[s[i + kk - 1 - j] & 7];
+    }
+    out[i] = f < r ? f : r;
+  }
+}
+
+__device__ __forceinline__ int argmin_left(const uint64_t* __restrict__ h, int b, int n) {
+  int m = b;
+  uint64_t mv = h[b];
+  for (int i = b + 1; i < b + n; i++) {
+    const uint64_t v = h[i];
+    if (v < mv) {  // strict: the leftmost of equal values wins
+      mv = v;
+      m = i;
+    }
+  }
+  return m;
+}
+
+// Closed Syncmer as bio/sketches emits it (NextSyncmer, call site util-db-search.go:1053,1068; semantics pinned by
+// demo-searching/README.md:61-68): window of 2k-s-1 bases = 2(k-s) s-mers, m = leftmost minimal canonical s-mer;
+// emit the k-mer starting at m if m-w0 < k-s, else the k-mer ending at m+s.  One emission per window.
+__device__ __forceinline__ int syncmer_mate(const uint8_t* __restrict__ s, int len, int k, int sm, const uint64_t* tab, bool scaled,
+                                            uint64_t max_hash, uint64_t* hk, uint64_t* hs, uint64_t* __restrict__ out, int cnt, int lane) {
+  const int L = 2 * k - sm - 1;
+  if (sm < 1 || sm > k || len < L || len < k) return cnt;  // ErrShortSeq
+  if (k <= K1_SCAN_MAX_K) {
+    hash_positions_scan(s, len, k, hk, sm, hs, tab, lane);
+  } else {
+    hash_positions(s, len, k, tab, hk, lane);
+    hash_positions(s, len, sm, tab, hs, lane);
+  }
+  __threadfence_block();
+  const int wsz = 2 * (k - sm);
+  const int nw = wsz > 0 ? len - L + 1 : len - k + 1;  // s == k: every k-mer is its own window
+  for (int base = 0; base < nw; base += 64) {
+    const int w0 = base + lane;
+    const bool v = w0 < nw;
+    uint64_t h = 0;
+    if (v) {
+      int pos = w0;
+      if (wsz > 0) {
+        const int m = argmin_left(hs, w0, wsz);
+        pos = (m - w0 < k - sm) ? m : m + sm - k;
+      }
+      h = hk[pos];
+    }
+    const bool keep = v && h != 0 && (!scaled || h <= max_hash);
+    const uint64_t mk = __ballot(keep);
+    if (keep) out[cnt + __popcll(mk & ((1ULL << lane) - 1ULL))] = h;
+    cnt += __popcll(mk);
+  }
+  return cnt;
+}
+
+// Minimizer sketch (NextMinimizer, call site util-db-search.go:1055,1081): leftmost minimum of every window of w
+// k-mers, emitted when its position changes.  (Parity unpinned: the reference holds no golden for this mode.)
+__device__ __forceinline__ int minimizer_mate(const uint8_t* __restrict__ s, int len, int k, int w, const uint64_t* tab, bool scaled,
+                                              uint64_t max_hash, uint64_t* hk, uint64_t* __restrict__ out, int cnt, int lane) {
+  if (w < 1 || len < k + w - 1) return cnt;  // ErrShortSeq
+  if (k <= K1_SCAN_MAX_K) hash_positions_scan(s, len, k, hk, 0, nullptr, tab, lane);
+  else hash_positions(s, len, k, tab, hk, lane);
+  __threadfence_block();
+  const int nw = len - k + 1 - w + 1;
+  for (int base = 0; base < nw; base += 64) {
+    const int w0 = base + lane;
+    const bool v = w0 < nw;
+    int m = -1, pm = -2;
+    if (v) {
+      m = argmin_left(hk, w0, w);
+      pm = w0 > 0 ? argmin_left(hk, w0 - 1, w) : -2;
+    }
+    const uint64_t h = (v && m != pm) ? hk[m] : 0;
+    const bool keep = v && m != pm && h != 0 && (!scaled || h <= max_hash);
+    const uint64_t mk = __ballot(keep);
+    if (keep) out[cnt + __popcll(mk & ((1ULL << lane) - 1ULL))] = h;
+    cnt += __popcll(mk);
+  }
+  return cnt;
+}
+
+__device__ __forceinline__ int sketch_mate(const K1Args& a, const uint8_t* s, int len, const uint64_t* tab, uint64_t* tmp_k, uint64_t* tmp_s,
+                                           uint64_t* out, int cnt, int lane) {
+  if (a.mode == 2) return syncmer_mate(s, len, a.k, (int)a.w_or_s, tab, a.scaled != 0, a.max_hash, tmp_k, tmp_s, out, cnt, lane);
+  if (a.mode == 1) return minimizer_mate(s, len, a.k, (int)a.w_or_s, tab, a.scaled != 0, a.max_hash, tmp_k, out, cnt, lane);
+  return hash_mate(s, len, a.k, tab, a.scaled != 0, a.max_hash, out, cnt, lane);
+}
+
+__global__ void __launch_bounds__(256) k1_kmers(const K1Args a) {
+  __shared__ uint64_t tab[256];
+  tab[threadIdx.x] = seed_of(threadIdx.x);
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const uint32_t wave = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const uint32_t nwaves = gridDim.x * 4;
+  for (uint32_t r = wave; r < a.n_reads; r += nwaves) {
+    const uint64_t o1 = a.offs[r];
+    const int len1 = (int)(a.offs[r + 1] - o1);
+    uint64_t o2 = 0;
+    int len2 = 0;
+    const bool pe = a.offs2 != nullptr;
+    if (pe) {
+      o2 = a.offs2[r];
+      len2 = (int)(a.offs2[r + 1] - o2);
+    }
+    uint64_t* out = a.hashes + o1 + o2;
+    // skip short query: handleQuery :778-786
+    const bool skip = len1 < a.min_qlen && !(pe && len2 >= a.min_qlen);
+    int cnt = 0, cnt1 = 0;
+    if (!skip) {
+      uint64_t* tk = a.scratch ? a.scratch + o1 + o2 : nullptr;   // k-mer hashes of the mate being sketched
+      uint64_t* ts = a.scratch2 ? a.scratch2 + o1 + o2 : nullptr;  // its s-mer hashes (syncmer mode)
+      cnt = sketch_mate(a, a.seqs + o1, len1, tab, tk, ts, out, 0, lane);
+      cnt1 = cnt;
+      if (pe) {
+        __threadfence_block();
+        cnt = sketch_mate(a, a.seqs2 + o2, len2, tab, tk, ts, out, cnt, lane);
+      }
+    }
+    if (lane == 0) {
+      a.nk_raw[r] = cnt;
+      a.nk1[r] = cnt1;
+      a.qlen[r] = len1 + len2;
+    }
+  }
+}
+
+// ---- long queries (HiFi reads, -g whole genomes): one 1024-thread workgroup per read -------------------------
+constexpr int K1WG = 1024;
+
+// ordered compaction of one tile of K1WG candidates into out[cnt...]; returns the new (uniform) count
+__device__ __forceinline__ int wg_compact(bool keep, uint64_t h, uint64_t* __restrict__ out, int cnt, int* s_wave, int tid) {
+  const int lane = tid & 63, w = tid >> 6;
+  const uint64_t m = __ballot(keep);
+  if (lane == 0) s_wave[w] = __popcll(m);
+  __syncthreads();
+  int before = 0, total = 0;
+#pragma unroll
+  for (int i = 0; i < K1WG / 64; i++) {
+    const int c = s_wave[i];
+    if (i < w) before += c;
+    total += c;
+  }
+  if (keep) out[cnt + before + __popcll(m & ((1ULL << lane) - 1ULL))] = h;
+  __syncthreads();
+  return cnt + total;
+}
+
+__device__ __forceinline__ uint64_t hash_at(const uint8_t* __restrict__ s, int i, int kk, const uint64_t* tab) {
+  uint64_t f = 0, r = 0;
+  for (int j = 0; j < kk; j++) {
+    f = rol1(f) ^ tab[s[i + j]];
+    r = rol1(r) ^ tab[s[i + kk - 1 - j] & 7];
+  }
+  return f < r ? f : r;
+}
+
+__device__ __forceinline__ int wg_sketch_mate(const K1Args& a, const uint8_t* __restrict__ s, int len, const uint64_t* tab, uint64_t* hk, uint64_t* hs,
+                                              uint64_t* __restrict__ out, int cnt, int* s_wave, int tid) {
+  const int k = a.k;
+  const bool scaled = a.scaled != 0;
+  if (a.mode == 0) {
+    const int npos = len - k + 1;
+    if (npos <= 0) return cnt;
+    for (int base = 0; base < npos; base += K1WG) {
+      const int i = base + tid;
+      const bool v = i < npos;
+      const uint64_t h = v ? hash_at(s, i, k, tab) : 0;
+      cnt = wg_compact(v && h != 0 && (!scaled || h <= a.max_hash), h, out, cnt, s_wave, tid);
+    }
+    return cnt;
+  }
+  if (a.mode == 2) {  // closed syncmer, see syncmer_mate
+    const int sm = (int)a.w_or_s, L = 2 * k - sm - 1;
+    if (sm < 1 || sm > k || len < L || len < k) return cnt;
+    for (int i = tid; i < len - k + 1; i += K1WG) hk[i] = hash_at(s, i, k, tab);
+    for (int i = tid; i < len - sm + 1; i += K1WG) hs[i] = hash_at(s, i, sm, tab);
+    __threadfence_block();
+    __syncthreads();
+    const int wsz = 2 * (k - sm);
+    const int nw = wsz > 0 ? len - L + 1 : len - k + 1;
+    for (int base = 0; base < nw; base += K1WG) {
+      const int w0 = base + tid;
+      const bool v = w0 < nw;
+      uint64_t h = 0;
+      if (v) {
+        int pos = w0;
+        if (wsz > 0) {
+          const int m = argmin_left(hs, w0, wsz);
+          pos = (m - w0 < k - sm) ? m : m + sm - k;
+        }
+        h = hk[pos];
+      }
+      cnt = wg_compact(v && h != 0 && (!scaled || h <= a.max_hash), h, out, cnt, s_wave, tid);
+    }
+    __syncthreads();
+    return cnt;
+  }
+  // minimizer, see minimizer_mate
+  const int w = (int)a.w_or_s;
+  if (w < 1 || len < k + w - 1) return cnt;
+  for (int i = tid; i < len - k + 1; i += K1WG) hk[i] = hash_at(s, i, k, tab);
+  __threadfence_block();
+  __syncthreads();
+  const int nw = len - k + 1 - w + 1;
+  for (int base = 0; base < nw; base += K1WG) {
+    const int w0 = base + tid;
+    const bool v = w0 < nw;
+    int m = -1, pm = -2;
+    if (v) {
+      m = argmin_left(hk, w0, w);
+      pm = w0 > 0 ? argmin_left(hk, w0 - 1, w) : -2;
+    }
+    const uint64_t h = (v && m != pm) ? hk[m] : 0;
+    cnt = wg_compact(v && m != pm && h != 0 && (!scaled || h <= a.max_hash), h, out, cnt, s_wave, tid);
+  }
+  __syncthreads();
+  return cnt;
+}
+
+// LDS-tiled form of wg_sketch_mate: the prefix XORs P, Q (see the K1 header) of one tile — 1024 positions + halo — are
+// built in LDS by wave scans + a scan of the 64-base group totals, after which any k-mer or s-mer hash of the tile costs
+// four LDS reads; the window scans never go to global memory.  Usable while the halo fits (L = 2k-s-1 <= 512 for syncmers,
+// w < 512 for minimizers); otherwise the scratch-buffer version above is used.
+constexpr int K1H = 512;
+constexpr int K1CAP = 2 * K1WG;  // bases per tile: 1024 positions + a halo of at most 1024
+struct K1Lds {
+  uint64_t ip[K1CAP + 1];                   // ip[n] = P(n) = XOR_{m<n} ror(F[m], m) over the tile's bases, ip[0] = 0
+  uint64_t iq[K1CAP + 1];                   // iq[n] = Q(n)
+  uint64_t tp[K1CAP / 64], tq[K1CAP / 64];  // totals of the 64-base groups, then their exclusive prefixes
+  uint64_t hw[K1WG + K1H];                  // the hashes the windows scan: s-mers (syncmer) or k-mers (minimizer)
+};
+
+// builds L.ip / L.iq over the nb (<= K1CAP) bases at s; all K1WG threads call it; ends with a barrier
+__device__ __forceinline__ void wg_prefix(const uint8_t* __restrict__ s, int nb, const uint64_t* tab, K1Lds& L, int tid) {
+  const int lane = tid & 63;
+  const int rounds = nb > K1WG ? 2 : 1;
+  uint64_t ip[2] = {0, 0}, iq[2] = {0, 0};
+#pragma unroll
+  for (int r = 0; r < 2; r++) {
+    if (r < rounds) {
+      const int e = r * K1WG + tid;
+      uint64_t F = 0, R = 0;
+      if (e < nb) {
+        const uint8_t b = s[e];
+        F = tab[b];
+        R = tab[b & 7];
+      }
+      ip[r] = wave_xor_scan(rorv(F, lane));  // K1WG % 64 == 0: e & 63 == lane
+      iq[r] = wave_xor_scan(rolv(R, lane));
+      if (lane == 63) {
+        L.tp[e >> 6] = ip[r];
+        L.tq[e >> 6] = iq[r];
+      }
+    }
+  }
+  __syncthreads();
+  if (tid < 64) {  // one wave scans the group totals
+    const int ng = rounds * (K1WG / 64);
+    const uint64_t a = tid < ng ? L.tp[tid] : 0, b = tid < ng ? L.tq[tid] : 0;
+    const uint64_t sa = wave_xor_scan(a), sb = wave_xor_scan(b);
+    if (tid < ng) {
+      L.tp[tid] = sa ^ a;
+      L.tq[tid] = sb ^ b;
+    }
+    if (tid == 0) L.ip[0] = L.iq[0] = 0;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < 2; r++) {
+    if (r < rounds) {
+      const int e = r * K1WG + tid;
+      L.ip[e + 1] = ip[r] ^ L.tp[e >> 6];
+      L.iq[e + 1] = iq[r] ^ L.tq[e >> 6];
+    }
+  }
+  __syncthreads();
+}
+
+// canonical hash of the kk-mer at tile position i (i + kk <= nb of the last wg_prefix)
+__device__ __forceinline__ uint64_t lds_hash(const K1Lds& L, int i, int kk) {
+  const uint64_t f = rolv(L.ip[i + kk] ^ L.ip[i], kk - 1 + i), r = rorv(L.iq[i + kk] ^ L.iq[i], i);
+  return f < r ? f : r;
+}
+
+// positions per tile: with a small halo the tile shrinks so that positions + halo fit one scan round of K1WG bases
+__device__ __forceinline__ int wg_tile_step(int halo) { return halo <= K1WG / 2 ? K1WG - halo : K1WG; }
+
+__device__ __forceinline__ bool wg_lds_usable(const K1Args& a) {
+  if (a.k > 255) return false;
+  if (a.mode == 2) return 2 * a.k - (int)a.w_or_s - 1 <= K1H && (int)a.w_or_s >= 1 && (int)a.w_or_s <= a.k;
+  if (a.mode == 1) return (int)a.w_or_s >= 1 && (int)a.w_or_s + 1 < K1H;
+  return true;
+}
+
+__device__ __forceinline__ int wg_sketch_mate_lds(const K1Args& a, const uint8_t* __restrict__ s, int len, const uint64_t* tab, K1Lds& L,
+                                                  uint64_t* __restrict__ out, int cnt, int* s_wave, int tid) {
+  const int k = a.k;
+  const bool scaled = a.scaled != 0;
+  const int nk = len - k + 1;  // k-mer positions
+  if (nk <= 0) return cnt;
+  if (a.mode == 0) {
+    const int T = wg_tile_step(k - 1);
+    for (int p0 = 0; p0 < nk; p0 += T) {
+      wg_prefix(s + p0, min(len - p0, T + k - 1), tab, L, tid);
+      const bool v = tid < T && p0 + tid < nk;
+      const uint64_t h = v ? lds_hash(L, tid, k) : 0;
+      cnt = wg_compact(v && h != 0 && (!scaled || h <= a.max_hash), h, out, cnt, s_wave, tid);
+    }
+    return cnt;
+  }
+  if (a.mode == 2) {  // closed syncmer (see syncmer_mate)
+    const int sm = (int)a.w_or_s, Lw = 2 * k - sm - 1;
+    if (len < Lw) return cnt;
+    const int wsz = 2 * (k - sm);
+    const int nw = wsz > 0 ? len - Lw + 1 : nk;
+    const int ns = len - sm + 1;
+    const int T = wg_tile_step(Lw);
+    for (int p0 = 0; p0 < nw; p0 += T) {
+      wg_prefix(s + p0, min(len - p0, T + Lw), tab, L, tid);
+      const int nst = min(ns - p0, T + max(wsz - 1, 0));
+      for (int i = tid; i < nst; i += K1WG) L.hw[i] = lds_hash(L, i, sm);
+      __syncthreads();
+      const bool v = tid < T && p0 + tid < nw;
+      uint64_t h = 0;
+      if (v) {
+        int pos = tid;
+        if (wsz > 0) {
+          const int m = argmin_left(L.hw, tid, wsz);
+          pos = (m - tid < k - sm) ? m : m + sm - k;
+        }
+        h = lds_hash(L, pos, k);
+      }
+      cnt = wg_compact(v && h != 0 && (!scaled || h <= a.max_hash), h, out, cnt, s_wave, tid);
+    }
+    return cnt;
+  }
+  // minimizer (see minimizer_mate)
+  const int w = (int)a.w_or_s;
+  if (len < k + w - 1) return cnt;
+  const int nw = nk - w + 1;
+  const int T = wg_tile_step(w + k);
+  for (int p0 = 0; p0 < nw; p0 += T) {
+    const int b0 = p0 > 0 ? p0 - 1 : 0, off = p0 - b0;  // the window before the tile's first one is needed too
+    wg_prefix(s + b0, min(len - b0, T + w + k), tab, L, tid);
+    const int nkt = min(nk - b0, T + w);
+    for (int i = tid; i < nkt; i += K1WG) L.hw[i] = lds_hash(L, i, k);
+    __syncthreads();
+    const int w0 = p0 + tid;
+    const bool v = tid < T && w0 < nw;
+    int m = -1, pm = -2;
+    if (v) {
+      m = argmin_left(L.hw, off + tid, w);
+      pm = w0 > 0 ? argmin_left(L.hw, off + tid - 1, w) : -2;
+    }
+    const uint64_t h = (v && m != pm) ? L.hw[m] : 0;
+    cnt = wg_compact(v && m != pm && h != 0 && (!scaled || h <= a.max_hash), h, out, cnt, s_wave, tid);
+  }
+  return cnt;
+}
+
+__global__ void __launch_bounds__(K1WG) k1_kmers_wg(const K1Args a) {
+  __shared__ uint64_t tab[256];
+  __shared__ int s_wave[K1WG / 64];
+  __shared__ K1Lds lds;
+  const int tid = threadIdx.x;
+  if (tid < 256) tab[tid] = seed_of(tid);
+  __syncthreads();
+  const bool use_lds = wg_lds_usable(a);
+  for (uint32_t r = blockIdx.x; r < a.n_reads; r += gridDim.x) {
+    const uint64_t o1 = a.offs[r];
+    const int len1 = (int)(a.offs[r + 1] - o1);
+    uint64_t o2 = 0;
+    int len2 = 0;
+    const bool pe = a.offs2 != nullptr;
+    if (pe) {
+      o2 = a.offs2[r];
+      len2 = (int)(a.offs2[r + 1] - o2);
+    }
+    uint64_t* out = a.hashes + o1 + o2;
+    const bool skip = len1 < a.min_qlen && !(pe && len2 >= a.min_qlen);
+    int cnt = 0, cnt1 = 0;
+    if (!skip) {
+      uint64_t* tk = a.scratch ? a.scratch + o1 + o2 : nullptr;
+      uint64_t* ts = a.scratch2 ? a.scratch2 + o1 + o2 : nullptr;
+      cnt = use_lds ? wg_sketch_mate_lds(a, a.seqs + o1, len1, tab, lds, out, 0, s_wave, tid)
+                    : wg_sketch_mate(a, a.seqs + o1, len1, tab, tk, ts, out, 0, s_wave, tid);
+      cnt1 = cnt;
+      if (pe)
+        cnt = use_lds ? wg_sketch_mate_lds(a, a.seqs2 + o2, len2, tab, lds, out, cnt, s_wave, tid)
+                      : wg_sketch_mate(a, a.seqs2 + o2, len2, tab, tk, ts, out, cnt, s_wave, tid);
+    }
+    if (tid == 0) {
+      a.nk_raw[r] = cnt;
+      a.nk1[r] = cnt1;
+      a.qlen[r] = len1 + len2;
+    }
+  }
+}
+
+// ---- whole genomes (plain / FracMinHash k-mers): segments of K1SEG positions on their own workgroups ----------------
+// Pass 1 hashes a segment and compacts its kept hashes at scratch[offs[r] + seg*K1SEG ...]; pass 2 moves the segments of a
+// read together in order (destination = sum of the counts of the earlier segments).
+constexpr int K1SEG = 65536;
+
+__global__ void __launch_bounds__(K1WG) k1_seg_hash(const K1Args a) {
+  __shared__ uint64_t tab[256];
+  __shared__ int s_wave[K1WG / 64];
+  __shared__ K1Lds lds;
+  const int tid = threadIdx.x;
+  if (tid < 256) tab[tid] = seed_of(tid);
+  __syncthreads();
+  const uint32_t r = blockIdx.x / a.segs_max, seg = blockIdx.x % a.segs_max;
+  const uint64_t o1 = a.offs[r];
+  const int len = (int)(a.offs[r + 1] - o1);
+  const int npos = len - a.k + 1;
+  const int p_lo = (int)seg * K1SEG;
+  int cnt = 0;
+  if (len >= a.min_qlen && p_lo < npos) {  // (:778-786 gate; ErrShortSeq => no k-mers)
+    const uint8_t* __restrict__ s = a.seqs + o1;
+    uint64_t* __restrict__ out = a.scratch + o1 + p_lo;
+    const int p_hi = min(npos, p_lo + K1SEG);
+    const bool scaled = a.scaled != 0;
+    const int T = wg_tile_step(a.k - 1);
+    for (int p0 = p_lo; p0 < p_hi; p0 += T) {
+      wg_prefix(s + p0, min(len - p0, T + a.k - 1), tab, lds, tid);
+      const bool v = tid < T && p0 + tid < p_hi;
+      const uint64_t h = v ? lds_hash(lds, tid, a.k) : 0;
+      cnt = wg_compact(v && h != 0 && (!scaled || h <= a.max_hash), h, out, cnt, s_wave, tid);
+    }
+  }
+  if (tid == 0) a.seg_cnt[blockIdx.x] = cnt;
+}
+
+__global__ void __launch_bounds__(256) k1_seg_pack(const K1Args a) {
+  const uint32_t r = blockIdx.x / a.segs_max, seg = blockIdx.x % a.segs_max;
+  const uint64_t o1 = a.offs[r];
+  const int len = (int)(a.offs[r + 1] - o1);
+  const int npos = len - a.k + 1;
+  const int nsegs = npos > 0 ? (npos + K1SEG - 1) / K1SEG : 1;
+  if ((int)seg >= nsegs) return;
+  const int* __restrict__ sc = a.seg_cnt + (size_t)r * a.segs_max;
+  int dest = 0;
+  for (uint32_t t = 0; t < seg; t++) dest += sc[t];
+  const int cnt = sc[seg];
+  const uint64_t* __restrict__ src = a.scratch + o1 + (uint64_t)seg * K1SEG;
+  uint64_t* __restrict__ dst = a.hashes + o1 + dest;
+  for (int i = threadIdx.x; i < cnt; i += blockDim.x) dst[i] = src[i];
+  if ((int)seg == nsegs - 1 && threadIdx.x == 0) {
+    a.nk_raw[r] = dest + cnt;
+    a.nk1[r] = dest + cnt;
+    a.qlen[r] = len;
+  }
+}
+
+// NumKmers when no read of the batch can exceed the dedup threshold.
+__global__ void k_nk_simple(const int32_t* nk_raw, int32_t* nk_search, uint32_t n, int32_t min_matched) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) {
+    int v = nk_raw[i];
+    nk_search[i] = v >= min_matched ? v : 0;  // :854-869: too few k-mers => not searched
+  }
+}
+
+
+
+int k1_segment_len() { return K1SEG; }
+
+void launch_k1(const K1Args& a, uint32_t max_read_len, hipStream_t st) {
+  if (a.n_reads == 0) return;
+  if (a.seg_cnt && a.segs_max > 1) {  // whole genomes: one workgroup per 65536-position segment, then an ordered pack
+    const unsigned blocks = a.n_reads * a.segs_max;
+    hipLaunchKernelGGL(k1_seg_hash, dim3(blocks), dim3(K1WG), 0, st, a);
+    hipLaunchKernelGGL(k1_seg_pack, dim3(blocks), dim3(256), 0, st, a);
+    return;
+  }
+  if (max_read_len > 2048) {  // long queries: a whole workgroup per read
+    unsigned blocks = a.n_reads > 65536 ? 65536 : a.n_reads;
+    hipLaunchKernelGGL(k1_kmers_wg, dim3(blocks), dim3(K1WG), 0, st, a);
+    return;
+  }
+  unsigned blocks = (a.n_reads + 3) / 4;
+  if (blocks > 32768) blocks = 32768;
+  hipLaunchKernelGGL(k1_kmers, dim3(blocks), dim3(256), 0, st, a);
+}
+
+void launch_nk_simple(const int32_t* nk_raw, int32_t* nk_search, uint32_t n, int32_t min_matched, hipStream_t st) {
+  if (n == 0) return;
+  hipLaunchKernelGGL(k_nk_simple, dim3((n + 255) / 256), dim3(256), 0, st, nk_raw, nk_search, n, min_matched);
+}
+
+}  // namespace kmcpg

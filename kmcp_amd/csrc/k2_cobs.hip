@@ -1,0 +1,357 @@
+// k2_cobs.hip — K2: the COBS query: row = hash % NumSigs, gather rows, AND the h rows, per-column match counts in bit-sliced
+// counters, integer threshold, hit emission (kmcp/cmd/util-db-search.go:6611-7742); SPLIT form + k_threshold_long for long
+// queries.  The path is bitwise/integer and HBM-bound; there is no MFMA here by design.  wave = 64 lanes.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+
+#include "common.hpp"
+#include "device_utils.hpp"
+#include "kernels.hpp"
+
+namespace kmcpg {
+
+// ------------------------------------------------------------------------------------------------
+// K2: the COBS query.
+//
+// Work unit = (read, slot) with slot = (resident block, tile of LPR*16 bytes of its rows).  LPR lanes
+// serve one unit, so a wave carries G = 64/LPR units: LPR = 64 for wide rows (GTDB-scale, 1872 B),
+// 16 or 4 for narrow rows (a 312-column block has 39-byte rows).  Each lane owns 16 bytes = 128
+// columns of its unit's rows and keeps their match counts as NPL bit-sliced planes (vertical
+// counters): 8 rows are reduced with a carry-save adder tree (7 CSAs) and the carry word rippled into
+// the upper planes, ~4 VALU ops per loaded dword, which keeps the kernel HBM-bound.
+// Row indices of a chunk of CH k-mers are computed cooperatively (one exact fastmod per (k-mer,
+// block)) into a per-wave LDS table; k-mers past the end of a read map to the all-zero row appended to
+// each block, so the inner loop has no tail code.
+// ------------------------------------------------------------------------------------------------
+#define CSA(h, l, a_, b_, c_)              \
+  {                                        \
+    uint32_t u_ = (a_) ^ (b_);             \
+    h = ((a_) & (b_)) | (u_ & (c_));       \
+    l = u_ ^ (c_);                         \
+  }
+
+// 16 bytes of a row.  Index rows are read once and never reused: non-temporal loads keep them from displacing the
+// hash/offset lines in L2 (+2 % on the random-gather microbenchmark, profiles/).
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint4 load_row16(const uint8_t* p, int nt) {
+  const u32x4* q = reinterpret_cast<const u32x4*>(p);
+  const u32x4 v = nt ? __builtin_nontemporal_load(q) : *q;
+  return make_uint4(v.x, v.y, v.z, v.w);
+}
+
+template <int NPL>
+__device__ __forceinline__ void csa8(uint32_t (&pl)[NPL], uint32_t x0, uint32_t x1, uint32_t x2, uint32_t x3, uint32_t x4,
+                                     uint32_t x5, uint32_t x6, uint32_t x7) {
+  uint32_t ta, tb, fa, fb, e;
+  CSA(ta, pl[0], pl[0], x0, x1);
+  CSA(tb, pl[0], pl[0], x2, x3);
+  CSA(fa, pl[1], pl[1], ta, tb);
+  CSA(ta, pl[0], pl[0], x4, x5);
+  CSA(tb, pl[0], pl[0], x6, x7);
+  CSA(fb, pl[1], pl[1], ta, tb);
+  CSA(e, pl[2], pl[2], fa, fb);
+#pragma unroll
+  for (int p = 3; p < NPL; p++) {
+    uint32_t t = pl[p] & e;
+    pl[p] ^= e;
+    e = t;
+  }
+}
+
+// SPLIT = true is the long-query form: a unit is (long query, slot, chunk of a.split_chk <= 8192 k-mers); its counts are added to a
+// per-query u32 array with atomics and thresholded by k_threshold_long, so a whole genome spreads over the chip instead
+// of one wave per (query, slot).
+
+template <int LPR, int NPL, bool MULTI, bool SPLIT>
+__global__ void __launch_bounds__(256) k2_cobs(const K2Args a) {
+  constexpr int G = 64 / LPR;
+  constexpr int PAIRS = MULTI ? 256 : 1024;
+  constexpr int CH = (PAIRS / G) > 64 ? 64 : (PAIRS / G);
+  constexpr int NHMAX = MULTI ? 4 : 1;
+  static_assert(CH % 8 == 0, "chunk must be a multiple of the CSA group");
+  __shared__ uint32_t s_rows[4][NHMAX][G * CH];
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int g = lane / LPR, li = lane % LPR;
+  const uint64_t per_read = SPLIT ? (uint64_t)a.nslots * a.split_chunks : (uint64_t)a.nslots;
+  const uint64_t total_units = (SPLIT ? (uint64_t)a.n_long : (uint64_t)a.n_reads) * per_read;
+  const uint64_t u = a.unit_base + ((uint64_t)blockIdx.x * 4 + wave) * G + g;
+  const bool valid = u < total_units;
+  uint32_t r = 0, sidx = 0, li_long = 0;
+  int k0 = 0;
+  if (valid) {
+    if (SPLIT) {
+      li_long = (uint32_t)(u / per_read);
+      const uint32_t rem = (uint32_t)(u % per_read);
+      sidx = rem / a.split_chunks;
+      k0 = (int)(rem % a.split_chunks) * (int)a.split_chk;
+      r = a.long_list[li_long];
+    } else {
+      r = (uint32_t)(u / a.nslots);
+      sidx = (uint32_t)(u % a.nslots);
+    }
+  }
+  const Slot slot = a.slots[sidx];
+  const BlockDev* __restrict__ bd = a.blocks + slot.block;
+  int n = valid ? a.nk[r] : 0;
+  if (SPLIT) n = max(0, min(n - k0, (int)a.split_chk));
+  else if (a.split_min > 0 && n > a.split_min) n = 0;  // long queries are left to the SPLIT launch
+  int nmax = n;
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) nmax = max(nmax, __shfl_xor(nmax, off));
+  if (nmax == 0) return;
+
+  const uint32_t stride = bd->stride;
+  const uint32_t boff = (slot.tile * LPR + li) * 16u;
+  const bool active = n > 0 && boff < stride;
+  // integer threshold (:7468-7470): count >= minMatched && float64(count) > nHashes*queryCov
+  const double thr = __dmul_rn((double)n, a.min_qcov);
+  uint32_t cmin = (uint32_t)thr + 1u;  // smallest integer c with (double)c > thr  (thr >= 0)
+  if (cmin < (uint32_t)a.min_matched) cmin = (uint32_t)a.min_matched;
+  // Branch and bound: once count + (k-mers still to come) < cmin for every column of a 128-byte sector of the row, nothing
+  // in it can become a hit any more and its lanes stop loading.  Unrelated references are dead after ~80 % of a read's
+  // k-mers (Bloom density <= fpr), so the tail of the row traffic is never fetched; results are unchanged.
+  constexpr int GRP = LPR < 8 ? LPR : 8;  // lanes that share a sector
+  bool live = active;
+  const uint8_t* __restrict__ base = bd->rows + boff;
+  const uint64_t koff = a.offs[r] + (a.offs2 ? a.offs2[r] : 0) + (uint64_t)k0;
+  const int nh = MULTI ? a.num_hashes : 1;
+
+  uint32_t pl[4][NPL];
+#pragma unroll
+  for (int d = 0; d < 4; d++)
+#pragma unroll
+    for (int p = 0; p < NPL; p++) pl[d][p] = 0;
+
+  for (int c0 = 0; c0 < nmax; c0 += CH) {
+    // ---- row indices of this chunk: loc = h % NumSigs (:6811), multi-hash h_i = uint32(a + b*i) (util-hash.go:125-142)
+    for (int p = lane; p < G * CH; p += 64) {
+      const int q = p / CH, j = p % CH;
+      const int srcl = q * LPR;
+      const int nq = __shfl(n, srcl);
+      const uint64_t koq = __shfl((unsigned long long)koff, srcl);
+      const uint32_t bi = __shfl(slot.block, srcl);
+      const BlockDev* __restrict__ bq = a.blocks + bi;
+      const uint64_t ns = bq->num_sigs;
+      const uint64_t s16 = bq->stride >> 4;  // rows are addressed in 16-byte units: 32 bits reach 64 GB per block
+      const int kidx = c0 + j;
+      if (kidx < nq) {
+        const uint64_t h = a.hashes[koq + kidx];
+        if (!MULTI) {
+          s_rows[wave][0][p] = (uint32_t)(fastmod_u64(h, ns, bq->magic_hi, bq->magic_lo) * s16);
+        } else {
+          const uint32_t ha = (uint32_t)(h >> 32), hb = (uint32_t)h;
+          for (int i = 0; i < nh; i++)
+            s_rows[wave][i][p] = (uint32_t)(fastmod_u64((uint64_t)(uint32_t)(ha + hb * (uint32_t)i), ns, bq->magic_hi, bq->magic_lo) * s16);
+        }
+      } else {
+        for (int i = 0; i < nh; i++) s_rows[wave][i][p] = (uint32_t)(ns * s16);  // the appended all-zero row
+      }
+    }
+    wave_lds_fence();
+
+    const int cnt = min(CH, nmax - c0);
+    for (int j = 0; j < cnt; j += 8) {
+      uint4 x[8];
+#pragma unroll
+      for (int i = 0; i < 8; i++) {
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (live) {
+          const uint32_t row = s_rows[wave][0][g * CH + j + i];
+          v = load_row16(base + ((uint64_t)row << 4), a.nt_loads);
+          if (MULTI) {
+            for (int hh = 1; hh < nh; hh++) {  // AND of the h rows (pand.AndUnsafe, :6639-6646)
+              const uint32_t row2 = s_rows[wave][hh][g * CH + j + i];
+              const uint4 w = load_row16(base + ((uint64_t)row2 << 4), a.nt_loads);
+              v.x &= w.x; v.y &= w.y; v.z &= w.z; v.w &= w.w;
+            }
+          }
+        }
+        x[i] = v;
+      }
+      csa8<NPL>(pl[0], x[0].x, x[1].x, x[2].x, x[3].x, x[4].x, x[5].x, x[6].x, x[7].x);
+      csa8<NPL>(pl[1], x[0].y, x[1].y, x[2].y, x[3].y, x[4].y, x[5].y, x[6].y, x[7].y);
+      csa8<NPL>(pl[2], x[0].z, x[1].z, x[2].z, x[3].z, x[4].z, x[5].z, x[6].z, x[7].z);
+      csa8<NPL>(pl[3], x[0].w, x[1].w, x[2].w, x[3].w, x[4].w, x[5].w, x[6].w, x[7].w);
+      if (!SPLIT && a.prune) {
+        const int done = min(n, c0 + j + 8);
+        const int need = (int)cmin - (n - done);  // a column must already hold this many to stay in the race
+        bool lane_alive = live;
+        if (live && need > 0) {
+          uint32_t any = 0;
+          if (NPL >= 32 || ((uint32_t)need >> NPL) == 0) {
+#pragma unroll
+            for (int d = 0; d < 4; d++) {
+              uint32_t ge = 0xffffffffu;
+#pragma unroll
+              for (int p = 0; p < NPL; p++) ge = (((uint32_t)need >> p) & 1u) ? (ge & pl[d][p]) : (ge | pl[d][p]);
+              any |= ge;
+            }
+          }
+          lane_alive = any != 0;
+        }
+        const uint64_t alive = __ballot(lane_alive);
+        live = live && ((alive >> (lane & ~(GRP - 1))) & ((1ULL << GRP) - 1ULL)) != 0;
+        if (alive == 0) break;  // the whole wave is done with these rows
+      }
+    }
+    wave_lds_fence();
+    if (!SPLIT && a.prune && __ballot(live) == 0) break;
+  }
+
+  if (!live) return;
+  if (SPLIT) {
+    // partial counts of this chunk -> the query's count array (consecutive lanes hit consecutive words)
+    uint32_t* __restrict__ acc = a.long_counts + (uint64_t)li_long * a.ncols_total + bd->col_base;
+#pragma unroll
+    for (int d = 0; d < 4; d++) {
+      for (int q = 0; q < 32; q++) {
+        uint32_t count = 0;
+#pragma unroll
+        for (int p = 0; p < NPL; p++) count |= ((pl[d][p] >> q) & 1u) << p;
+        const uint32_t col = (boff + (uint32_t)d * 4u + (uint32_t)(q >> 3)) * 8u + (7u - (uint32_t)(q & 7));
+        if (count && col < bd->ncols) atomicAdd(acc + col, count);
+      }
+    }
+    return;
+  }
+  if (NPL < 32 && (cmin >> NPL) != 0) return;  // unreachable count
+#pragma unroll
+  for (int d = 0; d < 4; d++) {
+    uint32_t ge = 0xffffffffu;  // bit-sliced (count >= cmin), LSB to MSB
+#pragma unroll
+    for (int p = 0; p < NPL; p++) ge = ((cmin >> p) & 1u) ? (ge & pl[d][p]) : (ge | pl[d][p]);
+    while (ge) {
+      const int q = __ffs(ge) - 1;
+      ge &= ge - 1;
+      uint32_t count = 0;
+#pragma unroll
+      for (int p = 0; p < NPL; p++) count |= ((pl[d][p] >> q) & 1u) << p;
+      // byte (q>>3) of this dword, bit (q&7): bit 7 = first column of the byte (index.go:1157)
+      const uint32_t col = (boff + (uint32_t)d * 4u + (uint32_t)(q >> 3)) * 8u + (7u - (uint32_t)(q & 7));
+      if (col < bd->ncols) {
+        const unsigned long long idx = atomicAdd(a.counter, 1ULL);
+        if (idx < a.hit_cap) {
+          kmcpg_hit hit;
+          hit.read = r;
+          hit.col = bd->col_base + col;
+          hit.count = count;
+          a.hits[idx] = hit;
+        }
+      }
+    }
+  }
+}
+
+constexpr uint64_t K2_MAX_BLOCKS = 1ull << 23;  // x 256 threads = 2^31
+
+template <int LPR, int NPL>
+static void launch_k2_t(const K2Args& a, bool multi, hipStream_t st) {
+  constexpr int G = 64 / LPR;
+  const uint64_t units = (uint64_t)a.n_reads * a.nslots;
+  const uint64_t waves = (units + G - 1) / G;
+  const uint64_t blocks = (waves + 3) / 4;
+  K2Args b = a;
+  for (uint64_t b0 = 0; b0 < blocks; b0 += K2_MAX_BLOCKS) {  // a launch holds fewer than 2^32 threads
+    const unsigned nb = (unsigned)std::min<uint64_t>(K2_MAX_BLOCKS, blocks - b0);
+    b.unit_base = b0 * 4 * G;
+    if (multi)
+      hipLaunchKernelGGL((k2_cobs<LPR, NPL, true, false>), dim3(nb), dim3(256), 0, st, b);
+    else
+      hipLaunchKernelGGL((k2_cobs<LPR, NPL, false, false>), dim3(nb), dim3(256), 0, st, b);
+  }
+}
+
+template <int LPR>
+static int launch_k2_l(const K2Args& a, int npl, bool multi, hipStream_t st) {
+  switch (npl) {
+    case 8: launch_k2_t<LPR, 8>(a, multi, st); return 0;
+    case 16: launch_k2_t<LPR, 16>(a, multi, st); return 0;
+    case 24: launch_k2_t<LPR, 24>(a, multi, st); return 0;
+    default: return -1;
+  }
+}
+
+int launch_k2(const K2Args& a, int lpr, int npl, hipStream_t st) {
+  const bool multi = a.num_hashes > 1;
+  switch (lpr) {
+    case 4: return launch_k2_l<4>(a, npl, multi, st);
+    case 16: return launch_k2_l<16>(a, npl, multi, st);
+    case 64: return launch_k2_l<64>(a, npl, multi, st);
+    default: return -1;
+  }
+}
+
+template <int LPR>
+static void launch_k2_split_t(const K2Args& a, bool multi, hipStream_t st) {
+  constexpr int G = 64 / LPR;
+  const uint64_t units = (uint64_t)a.n_long * a.nslots * a.split_chunks;
+  const uint64_t blocks = ((units + G - 1) / G + 3) / 4;
+  K2Args b = a;
+  for (uint64_t b0 = 0; b0 < blocks; b0 += K2_MAX_BLOCKS) {
+    const unsigned nb = (unsigned)std::min<uint64_t>(K2_MAX_BLOCKS, blocks - b0);
+    b.unit_base = b0 * 4 * G;
+    if (multi)
+      hipLaunchKernelGGL((k2_cobs<LPR, 16, true, true>), dim3(nb), dim3(256), 0, st, b);
+    else
+      hipLaunchKernelGGL((k2_cobs<LPR, 16, false, true>), dim3(nb), dim3(256), 0, st, b);
+  }
+}
+
+int launch_k2_split(const K2Args& a, int lpr, hipStream_t st) {
+  const bool multi = a.num_hashes > 1;
+  switch (lpr) {
+    case 4: launch_k2_split_t<4>(a, multi, st); return 0;
+    case 16: launch_k2_split_t<16>(a, multi, st); return 0;
+    case 64: launch_k2_split_t<64>(a, multi, st); return 0;
+    default: return -1;
+  }
+}
+
+// queries with more than split_min k-mers: meta[0] = how many, meta[1] = their largest NumKmers
+__global__ void k_list_long(const int32_t* __restrict__ nk, uint32_t n_reads, int32_t split_min, uint32_t* __restrict__ list, uint32_t* __restrict__ meta) {
+  const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r < n_reads && nk[r] > split_min) {
+    list[atomicAdd(&meta[0], 1u)] = r;
+    atomicMax(&meta[1], (uint32_t)nk[r]);
+  }
+}
+
+void launch_list_long(const int32_t* nk, uint32_t n_reads, int32_t split_min, uint32_t* list, uint32_t* meta, hipStream_t st) {
+  if (n_reads == 0) return;
+  hipLaunchKernelGGL(k_list_long, dim3((n_reads + 255) / 256), dim3(256), 0, st, nk, n_reads, split_min, list, meta);
+}
+
+// threshold over the accumulated counts of the long queries (same integer rule as the k2_cobs epilogue)
+__global__ void k_threshold_long(const K2Args a) {
+  const uint64_t total = (uint64_t)a.n_long * a.ncols_total;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (uint64_t)gridDim.x * blockDim.x) {
+    const uint32_t c = a.long_counts[i];
+    if (c == 0) continue;
+    const uint32_t li = (uint32_t)(i / a.ncols_total), col = (uint32_t)(i % a.ncols_total);
+    const uint32_t r = a.long_list[li];
+    const double thr = __dmul_rn((double)a.nk[r], a.min_qcov);
+    uint32_t cmin = (uint32_t)thr + 1u;
+    if (cmin < (uint32_t)a.min_matched) cmin = (uint32_t)a.min_matched;
+    if (c >= cmin) {
+      const unsigned long long idx = atomicAdd(a.counter, 1ULL);
+      if (idx < a.hit_cap) {
+        kmcpg_hit hit;
+        hit.read = r;
+        hit.col = col;
+        hit.count = c;
+        a.hits[idx] = hit;
+      }
+    }
+  }
+}
+
+void launch_threshold_long(const K2Args& a, hipStream_t st) {
+  const uint64_t total = (uint64_t)a.n_long * a.ncols_total;
+  if (total == 0) return;
+  unsigned blocks = (unsigned)((total + 255) / 256 > 65536 ? 65536 : (total + 255) / 256);
+  hipLaunchKernelGGL(k_threshold_long, dim3(blocks), dim3(256), 0, st, a);
+}
+
+}  // namespace kmcpg

@@ -1,4 +1,4 @@
-// kernels.hpp — host-callable launchers of the HIP kernels in kernels.hip.
+// kernels.hpp — host-callable launchers of the HIP kernels in k1_kmers.hip, k1_dedup.hip, k2_cobs.hip, support.hip and sort_huge.hip.
 #pragma once
 #include <hip/hip_runtime.h>
 

@@ -1,6 +1,6 @@
 // sort_huge.hip — sort + unique (handleQuery, kmcp/cmd/util-db-search.go:874-908) for queries with more than 65 536 k-mers
 // (whole genomes under -g): a device-wide radix sort and an adjacent-unique pass from hipCUB/rocPRIM.  The per-read
-// workgroup kernels in kernels.hip cover everything smaller; this file exists so that one 5-M-k-mer query does not run on a
+// workgroup kernels in k1_dedup.hip cover everything smaller; this file exists so that one 5-M-k-mer query does not run on a
 // single workgroup.
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>

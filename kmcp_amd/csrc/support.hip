@@ -1,0 +1,200 @@
+// support.hip — not on the query path: load-time layout (k_repack), parity helpers (k_gather_rows, k_plant*), the synthetic
+// index of bench.py (k_synth_fill) and the `kmcp index` scatter (k_build_scatter, index.go:1107-1309).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+
+#include "common.hpp"
+#include "device_utils.hpp"
+#include "kernels.hpp"
+
+namespace kmcpg {
+
+// ------------------------------------------------------------------------------------------------
+// layout: on-disk rows (NumRowBytes, unpadded — serialization.go:140,379) -> HBM rows (stride)
+// ------------------------------------------------------------------------------------------------
+__global__ void k_repack(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, uint64_t n_rows, uint32_t row_bytes,
+                         uint32_t stride) {
+  const uint32_t wpr = stride / 4;  // dwords per dst row
+  const uint64_t total = n_rows * wpr;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (uint64_t)gridDim.x * blockDim.x) {
+    const uint64_t row = i / wpr;
+    const uint32_t b0 = (uint32_t)(i % wpr) * 4;
+    uint32_t v = 0;
+    const uint8_t* s = src + row * row_bytes;
+#pragma unroll
+    for (int t = 0; t < 4; t++)
+      if (b0 + t < row_bytes) v |= (uint32_t)s[b0 + t] << (8 * t);
+    reinterpret_cast<uint32_t*>(dst + row * stride)[b0 / 4] = v;
+  }
+}
+
+void launch_repack(const uint8_t* src, uint8_t* dst, uint64_t n_rows, uint32_t row_bytes, uint32_t stride, hipStream_t st) {
+  if (n_rows == 0) return;
+  uint64_t total = n_rows * (stride / 4);
+  unsigned blocks = (unsigned)((total + 255) / 256 > 65536 ? 65536 : (total + 255) / 256);
+  hipLaunchKernelGGL(k_repack, dim3(blocks), dim3(256), 0, st, src, dst, n_rows, row_bytes, stride);
+}
+
+__global__ void k_gather_rows(const uint8_t* __restrict__ rows, uint32_t stride, uint32_t row_bytes, const uint64_t* __restrict__ idx,
+                              uint64_t n, uint8_t* __restrict__ out) {
+  const uint64_t total = n * row_bytes;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (uint64_t)gridDim.x * blockDim.x) {
+    const uint64_t r = i / row_bytes;
+    const uint32_t b = (uint32_t)(i % row_bytes);
+    out[i] = rows[idx[r] * stride + b];
+  }
+}
+
+void launch_gather_rows(const uint8_t* rows, uint32_t stride, uint32_t row_bytes, const uint64_t* idx, uint64_t n, uint8_t* out,
+                        hipStream_t st) {
+  if (n == 0) return;
+  uint64_t total = n * row_bytes;
+  unsigned blocks = (unsigned)((total + 255) / 256 > 65536 ? 65536 : (total + 255) / 256);
+  hipLaunchKernelGGL(k_gather_rows, dim3(blocks), dim3(256), 0, st, rows, stride, row_bytes, idx, n, out);
+}
+
+// ------------------------------------------------------------------------------------------------
+// synthetic index (bench / full-size parity only): i.i.d. Bernoulli bits from a counter-based generator
+// ------------------------------------------------------------------------------------------------
+__host__ __device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
+  x += 0x9e3779b97f4a7c15ULL;
+  x = (x ^ (x >> 30)) * 0xbf58476d1ce4e5b9ULL;
+  x = (x ^ (x >> 27)) * 0x94d049bb133111ebULL;
+  return x ^ (x >> 31);
+}
+
+// 64 Bernoulli(p8/256) bits for counter c
+__device__ __forceinline__ uint64_t bernoulli64(uint64_t key, uint64_t c, uint32_t p8) {
+  uint64_t acc = 0;
+#pragma unroll
+  for (int i = 0; i < 8; i++) {  // LSB of p8 first
+    const uint64_t rnd = splitmix64(key ^ (c * 8 + i) * 0xd6e8feb86659fd93ULL);
+    acc = ((p8 >> i) & 1u) ? (acc | rnd) : (acc & rnd);
+  }
+  return acc;
+}
+
+__global__ void k_synth_fill(uint8_t* __restrict__ rows, uint64_t n_rows, uint32_t stride, uint32_t ncols, uint64_t key, uint32_t p8) {
+  const uint32_t qpr = stride / 8;  // qwords per row
+  const uint64_t total = n_rows * qpr;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (uint64_t)gridDim.x * blockDim.x) {
+    const uint64_t row = i / qpr;
+    const uint32_t qw = (uint32_t)(i % qpr);
+    uint64_t v = bernoulli64(key, i, p8);
+    // zero the bits of columns >= ncols (padding columns never match: :7466 scans them but count is 0)
+    const uint32_t col0 = qw * 64;
+    if (col0 >= ncols) v = 0;
+    else if (col0 + 64 > ncols) {
+      uint64_t m = 0;
+      for (uint32_t c = col0; c < ncols; c++) {
+        const uint32_t byte = (c - col0) >> 3, bit = 7 - ((c - col0) & 7);
+        m |= 1ULL << (byte * 8 + bit);
+      }
+      v &= m;
+    }
+    reinterpret_cast<uint64_t*>(rows + row * stride)[qw] = v;
+  }
+}
+
+void launch_synth_fill(uint8_t* rows, uint64_t n_rows, uint32_t stride, uint32_t ncols, uint64_t key, uint32_t p8, hipStream_t st) {
+  uint64_t total = n_rows * (stride / 8);
+  unsigned blocks = (unsigned)((total + 255) / 256 > 262144 ? 262144 : (total + 255) / 256);
+  hipLaunchKernelGGL(k_synth_fill, dim3(blocks), dim3(256), 0, st, rows, n_rows, stride, ncols, key, p8);
+}
+
+// sigs[h % NumSigs] |= 1 << (7 - col%8)  (index.go:1157) for a list of hashes
+__global__ void k_plant(BlockDev bd, uint32_t col, int num_hashes, const uint64_t* __restrict__ hashes, uint64_t n) {
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+    const uint64_t h = hashes[i];
+    const uint32_t ha = (uint32_t)(h >> 32), hb = (uint32_t)h;
+    for (int t = 0; t < num_hashes; t++) {
+      const uint64_t hv = num_hashes == 1 ? h : (uint64_t)(uint32_t)(ha + hb * (uint32_t)t);
+      const uint64_t row = fastmod_u64(hv, bd.num_sigs, bd.magic_hi, bd.magic_lo);
+      const uint64_t byte = row * bd.stride + (col >> 3);
+      uint32_t* w = reinterpret_cast<uint32_t*>(const_cast<uint8_t*>(bd.rows) + (byte & ~3ULL));
+      atomicOr(w, (uint32_t)(1u << (7 - (col & 7))) << (8 * (byte & 3)));
+    }
+  }
+}
+
+void launch_plant(const BlockDev& bd, uint32_t col, int num_hashes, const uint64_t* hashes, uint64_t n, hipStream_t st) {
+  if (n == 0) return;
+  unsigned blocks = (unsigned)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256);
+  hipLaunchKernelGGL(k_plant, dim3(blocks), dim3(256), 0, st, bd, col, num_hashes, hashes, n);
+}
+
+// plant every k-mer of read r into global column cols[r] (bench / full-size parity only)
+__global__ void __launch_bounds__(256) k_plant_reads(const BlockDev* __restrict__ blocks, uint32_t nblocks, int num_hashes,
+                                                     const uint64_t* __restrict__ hashes, const uint64_t* __restrict__ offs,
+                                                     const int32_t* __restrict__ nk, const uint32_t* __restrict__ cols, uint32_t n_reads) {
+  const int lane = threadIdx.x & 63;
+  const uint32_t wave = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const uint32_t nwaves = gridDim.x * 4;
+  for (uint32_t r = wave; r < n_reads; r += nwaves) {
+    const uint32_t cg = cols[r];
+    if (cg == 0xffffffffu) continue;
+    uint32_t bi = nblocks;
+    for (uint32_t b = 0; b < nblocks; b++)
+      if (cg >= blocks[b].col_base && cg < blocks[b].col_base + blocks[b].ncols) bi = b;
+    if (bi == nblocks) continue;  // column lives on another shard
+    const BlockDev bd = blocks[bi];
+    const uint32_t col = cg - bd.col_base;
+    const int n = nk[r];
+    for (int j = lane; j < n; j += 64) {
+      const uint64_t h = hashes[offs[r] + j];
+      const uint32_t ha = (uint32_t)(h >> 32), hb = (uint32_t)h;
+      for (int t = 0; t < num_hashes; t++) {
+        const uint64_t hv = num_hashes == 1 ? h : (uint64_t)(uint32_t)(ha + hb * (uint32_t)t);
+        const uint64_t row = fastmod_u64(hv, bd.num_sigs, bd.magic_hi, bd.magic_lo);
+        const uint64_t byte = row * bd.stride + (col >> 3);
+        uint32_t* w = reinterpret_cast<uint32_t*>(const_cast<uint8_t*>(bd.rows) + (byte & ~3ULL));
+        atomicOr(w, (uint32_t)(1u << (7 - (col & 7))) << (8 * (byte & 3)));
+      }
+    }
+  }
+}
+
+void launch_plant_reads(const BlockDev* blocks, uint32_t nblocks, int num_hashes, const uint64_t* hashes, const uint64_t* offs,
+                        const int32_t* nk, const uint32_t* cols, uint32_t n_reads, hipStream_t st) {
+  if (n_reads == 0 || nblocks == 0) return;
+  unsigned nb = (n_reads + 3) / 4;
+  if (nb > 32768) nb = 32768;
+  hipLaunchKernelGGL(k_plant_reads, dim3(nb), dim3(256), 0, st, blocks, nblocks, num_hashes, hashes, offs, nk, cols, n_reads);
+}
+
+}  // namespace kmcpg
+
+namespace kmcpg {
+
+// index building: sigs[h_i % NumSigs][col] = 1 for every hash of every column of one block (index.go:1107-1309).
+// hashes = the block's columns back to back, col_off[c] = first hash of column c (n_cols+1 entries); the matrix is row-major
+// with the on-disk row width (no padding), bit 7 - col%8 of byte col/8 (index.go:1157).
+__global__ void k_build_scatter(uint8_t* __restrict__ sigs, uint64_t num_sigs, uint64_t mh, uint64_t ml, uint32_t row_bytes, int num_hashes,
+                                const uint64_t* __restrict__ hashes, const uint64_t* __restrict__ col_off, uint32_t col0, uint32_t n_cols, uint64_t n) {
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+    uint32_t lo = 0, hi = n_cols;  // column of hash i: last c with col_off[c] <= i
+    while (hi - lo > 1) {
+      const uint32_t mid = (lo + hi) >> 1;
+      if (col_off[mid] <= i) lo = mid; else hi = mid;
+    }
+    const uint32_t col = col0 + lo;
+    const uint64_t h = hashes[i];
+    const uint32_t ha = (uint32_t)(h >> 32), hb = (uint32_t)h;
+    for (int t = 0; t < num_hashes; t++) {
+      const uint64_t hv = num_hashes == 1 ? h : (uint64_t)(uint32_t)(ha + hb * (uint32_t)t);
+      const uint64_t byte = fastmod_u64(hv, num_sigs, mh, ml) * row_bytes + (col >> 3);
+      uint32_t* w = reinterpret_cast<uint32_t*>(sigs + (byte & ~3ULL));
+      atomicOr(w, (uint32_t)(1u << (7 - (col & 7))) << (8 * (byte & 3)));
+    }
+  }
+}
+
+void launch_build_scatter(uint8_t* sigs, uint64_t num_sigs, uint64_t mh, uint64_t ml, uint32_t row_bytes, int num_hashes, const uint64_t* hashes,
+                          const uint64_t* col_off, uint32_t col0, uint32_t n_cols, uint64_t n, hipStream_t st) {
+  if (n == 0) return;
+  unsigned blocks = (unsigned)((n + 255) / 256 > 65536 ? 65536 : (n + 255) / 256);
+  hipLaunchKernelGGL(k_build_scatter, dim3(blocks), dim3(256), 0, st, sigs, num_sigs, mh, ml, row_bytes, num_hashes, hashes, col_off, col0, n_cols, n);
+}
+
+}  // namespace kmcpg
