@@ -31,7 +31,168 @@ struct FastxRec {
   size_t seq_len = 0;
 };
 
-// Block-buffered FASTA/FASTQ reader (plain files through read(2), gzip through zlib).  A record whose sequence sits on one
+// BGZF (block gzip: bgzip / htslib output — gzip members of at most 64 KB that carry their compressed size in a "BC" extra
+// field) inflated by several threads: one thread walks the block headers and cuts the file into tasks of ~4 MB, workers
+// inflate the blocks of a task independently (every block's output size is in its trailer, so the offsets are known up
+// front) and check CRC32/ISIZE, the consumer takes the tasks back in file order.  Plain gzip has no such structure and stays
+// on the single inflate thread of FastxReader.
+class BgzfInflater {
+ public:
+  static bool detect(int fd) {
+    unsigned char h[18];
+    if (pread(fd, h, 18, 0) != 18) return false;
+    return h[0] == 0x1f && h[1] == 0x8b && h[2] == 8 && (h[3] & 4) && h[12] == 'B' && h[13] == 'C' && h[14] == 2 && h[15] == 0;
+  }
+  BgzfInflater(int fd, const std::string& path, int workers) : path_(path) {
+    f_ = fdopen(fd, "rb");
+    if (!f_) die("%s: %s", path.c_str(), strerror(errno));
+    setvbuf(f_, nullptr, _IOFBF, 1 << 20);
+    walker_ = std::thread([this] { walk(); });
+    for (int i = 0; i < std::max(1, workers); i++) pool_.emplace_back([this] { work(); });
+  }
+  ~BgzfInflater() {
+    {
+      std::lock_guard<std::mutex> l(m_);
+      stop_ = true;
+      cv_.notify_all();
+    }
+    walker_.join();
+    for (auto& t : pool_) t.join();
+    fclose(f_);
+  }
+  // up to `room` inflated bytes in file order; 0 at the end of the file
+  size_t read(char* dst, size_t room) {
+    if (!cur_ || cur_pos_ == cur_->out.size()) {
+      std::unique_lock<std::mutex> l(m_);
+      for (;;) {
+        cur_.reset();
+        cv_.wait(l, [&] { return !err_.empty() || (!order_.empty() && order_.front()->done) || (order_.empty() && walked_); });
+        if (!err_.empty()) die("%s: %s", path_.c_str(), err_.c_str());
+        if (order_.empty()) return 0;
+        cur_ = std::move(order_.front());
+        order_.pop_front();
+        cv_.notify_all();  // room for the walker
+        cur_pos_ = 0;
+        if (!cur_->out.empty()) break;  // (a task of empty blocks, e.g. the EOF marker alone)
+      }
+    }
+    const size_t n = std::min(room, cur_->out.size() - cur_pos_);
+    memcpy(dst, cur_->out.data() + cur_pos_, n);
+    cur_pos_ += n;
+    return n;
+  }
+
+ private:
+  struct Block {
+    size_t coff, clen, ooff;  // deflate bytes in Task::comp, output offset
+    uint32_t crc, isize;
+  };
+  struct Task {
+    std::vector<unsigned char> comp;
+    std::vector<Block> blocks;
+    std::vector<char> out;
+    bool done = false;
+  };
+  void fail(const std::string& e) {
+    std::lock_guard<std::mutex> l(m_);
+    if (err_.empty()) err_ = e;
+    walked_ = true;
+    cv_.notify_all();
+  }
+  void walk() {
+    for (;;) {
+      std::shared_ptr<Task> t(new Task());
+      size_t out_total = 0;
+      while (t->comp.size() < (4u << 20) && t->blocks.size() < 512) {
+        unsigned char h[12];
+        const size_t got = fread(h, 1, 12, f_);
+        if (got == 0) break;  // end of file at a block boundary
+        if (got != 12 || h[0] != 0x1f || h[1] != 0x8b || h[2] != 8 || !(h[3] & 4)) return fail("corrupt BGZF block header");
+        const size_t xlen = h[10] | ((size_t)h[11] << 8);
+        unsigned char extra[65536];
+        if (fread(extra, 1, xlen, f_) != xlen) return fail("truncated BGZF block");
+        long bsize = -1;
+        for (size_t p = 0; p + 4 <= xlen;) {
+          const size_t sl = extra[p + 2] | ((size_t)extra[p + 3] << 8);
+          if (extra[p] == 'B' && extra[p + 1] == 'C' && sl == 2 && p + 6 <= xlen) bsize = (long)(extra[p + 4] | ((size_t)extra[p + 5] << 8));
+          p += 4 + sl;
+        }
+        const long rest = bsize + 1 - 12 - (long)xlen;  // deflate data + CRC32 + ISIZE
+        if (bsize < 0 || rest < 8) return fail("corrupt BGZF block header");
+        const size_t at = t->comp.size();
+        t->comp.resize(at + (size_t)rest);
+        if (fread(t->comp.data() + at, 1, (size_t)rest, f_) != (size_t)rest) return fail("truncated BGZF block");
+        const unsigned char* tr = t->comp.data() + at + rest - 8;
+        Block b;
+        b.coff = at;
+        b.clen = (size_t)rest - 8;
+        b.crc = tr[0] | (tr[1] << 8) | (tr[2] << 16) | ((uint32_t)tr[3] << 24);
+        b.isize = tr[4] | (tr[5] << 8) | (tr[6] << 16) | ((uint32_t)tr[7] << 24);
+        if (b.isize > 65536) return fail("corrupt BGZF block (ISIZE > 64 KB)");
+        b.ooff = out_total;
+        out_total += b.isize;
+        t->blocks.push_back(b);
+      }
+      if (t->blocks.empty()) break;
+      t->out.resize(out_total);
+      std::unique_lock<std::mutex> l(m_);
+      cv_.wait(l, [&] { return stop_ || order_.size() < 12; });
+      if (stop_) return;
+      order_.push_back(t);
+      todo_.push_back(t);
+      cv_.notify_all();
+    }
+    std::lock_guard<std::mutex> l(m_);
+    walked_ = true;
+    cv_.notify_all();
+  }
+  void work() {
+    z_stream z;
+    memset(&z, 0, sizeof z);
+    if (inflateInit2(&z, -15) != Z_OK) return fail("zlib initialisation failed");
+    for (;;) {
+      std::shared_ptr<Task> t;
+      {
+        std::unique_lock<std::mutex> l(m_);
+        cv_.wait(l, [&] { return stop_ || !todo_.empty() || walked_; });
+        if (stop_ || (todo_.empty() && walked_)) break;
+        if (todo_.empty()) continue;
+        t = std::move(todo_.front());
+        todo_.pop_front();
+      }
+      for (const Block& b : t->blocks) {
+        inflateReset(&z);
+        z.next_in = t->comp.data() + b.coff;
+        z.avail_in = (uInt)b.clen;
+        z.next_out = (Bytef*)t->out.data() + b.ooff;
+        z.avail_out = b.isize;
+        const int rc = inflate(&z, Z_FINISH);
+        if (rc != Z_STREAM_END || z.avail_out != 0 || crc32(crc32(0L, Z_NULL, 0), (const Bytef*)t->out.data() + b.ooff, b.isize) != b.crc) {
+          inflateEnd(&z);
+          return fail("corrupt BGZF block (inflate / CRC32 mismatch)");
+        }
+      }
+      std::vector<unsigned char>().swap(t->comp);
+      std::lock_guard<std::mutex> l(m_);
+      t->done = true;
+      cv_.notify_all();
+    }
+    inflateEnd(&z);
+  }
+  std::string path_;
+  FILE* f_ = nullptr;
+  std::thread walker_;
+  std::vector<std::thread> pool_;
+  std::mutex m_;
+  std::condition_variable cv_;
+  std::deque<std::shared_ptr<Task>> order_, todo_;
+  std::shared_ptr<Task> cur_;
+  size_t cur_pos_ = 0;
+  bool walked_ = false, stop_ = false;
+  std::string err_;
+};
+
+// Block-buffered FASTA/FASTQ reader (plain files through read(2), gzip through zlib, BGZF through BgzfInflater).  A record whose sequence sits on one
 // line — every FASTQ in practice — is handed out as pointers into the block buffer: no per-record allocation or copy; wrapped
 // sequences (FASTA) are joined in a scratch string.  ID = header up to the first blank (fastx: `record.ID`).
 class FastxReader {
@@ -55,7 +216,12 @@ class FastxReader {
       if (got >= 6 && memcmp(magic, "\xfd" "7zXZ\0", 6) == 0) die("%s: xz input is not supported (decompress it: xz -dc file | kmcp-search ... -)", path.c_str());
       if (got >= 4 && memcmp(magic, "\x28\xb5\x2f\xfd", 4) == 0) die("%s: zstd input is not supported (zstd -dc file | kmcp-search ... -)", path.c_str());
       if (got >= 3 && memcmp(magic, "BZh", 3) == 0) die("%s: bzip2 input is not supported (bzip2 -dc file | kmcp-search ... -)", path.c_str());
-      if (got < 0 || (got >= 2 && magic[0] == 0x1f && magic[1] == 0x8b)) {  // gzip, or not seekable (a pipe): let zlib look
+      if (got >= 6 && BgzfInflater::detect(fd_)) {  // block gzip: several inflate threads
+        int w = (int)std::min(8u, std::max(2u, std::thread::hardware_concurrency() / 4));
+        if (const char* e = getenv("KMCP_BGZF_THREADS")) w = std::max(1, atoi(e));
+        bgzf_.reset(new BgzfInflater(fd_, path, w));
+        fd_ = -1;  // owned by the inflater now
+      } else if (got < 0 || (got >= 2 && magic[0] == 0x1f && magic[1] == 0x8b)) {  // gzip, or not seekable (a pipe): let zlib look
         gz_ = gzdopen(fd_, "rb");
         if (!gz_) die("%s: %s", path.c_str(), strerror(errno));
         fd_ = -1;  // owned by zlib now
@@ -203,7 +369,8 @@ class FastxReader {
       if (end_ == buf_.size()) buf_.resize(buf_.size() * 2);  // a record longer than the buffer (a genome on one line)
       const size_t room = std::min<size_t>(buf_.size() - end_, 1u << 30);
       ssize_t got;
-      if (gz_) got = (ssize_t)take_inflated(&buf_[end_], room);
+      if (bgzf_) got = (ssize_t)bgzf_->read(&buf_[end_], room);
+      else if (gz_) got = (ssize_t)take_inflated(&buf_[end_], room);
       else
         do got = read(fd_, &buf_[end_], room);
         while (got < 0 && errno == EINTR);
@@ -236,6 +403,7 @@ class FastxReader {
   };
   gzFile gz_ = nullptr;
   int fd_ = -1;
+  std::unique_ptr<BgzfInflater> bgzf_;
   std::thread inflater_;
   std::mutex im_;
   std::condition_variable icv_;

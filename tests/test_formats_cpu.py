@@ -242,6 +242,17 @@ def test_cli_reader_against_python_reader(tmp_path):
         g.build()
     rng = np.random.default_rng(21)
 
+    def bgzf(data, block):
+        import struct
+        import zlib
+        blocks = [data[i:i + block] for i in range(0, len(data), block)] + [b""]  # + the EOF marker block
+        o = bytearray()
+        for b in blocks:
+            c = zlib.compressobj(6, zlib.DEFLATED, -15)
+            d = c.compress(b) + c.flush()
+            o += b"\x1f\x8b\x08\x04\0\0\0\0\0\xff\x06\0BC\x02\0" + struct.pack("<H", len(d) + 25) + d + struct.pack("<II", zlib.crc32(b), len(b))
+        return bytes(o)
+
     def fnv(recs):
         h = 1469598103934665603
         for i, s in recs:
@@ -249,7 +260,7 @@ def test_cli_reader_against_python_reader(tmp_path):
                 h = ((h ^ b) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
         return h
 
-    for it in range(120):
+    for it in range(160):
         fastq = rng.random() < 0.6
         nl = b"\r\n" if rng.random() < 0.3 else b"\n"
         out = bytearray()
@@ -274,14 +285,18 @@ def test_cli_reader_against_python_reader(tmp_path):
             while out and out[-1:] in (b"\n", b"\r"):
                 out = out[:-1]
         p = str(tmp_path / ("f%d.%s" % (it, "fq" if fastq else "fa")))
-        if rng.random() < 0.2:
+        u = rng.random()
+        if u < 0.2:
             p += ".gz"
             with gzip.open(p, "wb") as fh:
                 fh.write(bytes(out))
+        elif u < 0.4:  # BGZF (bgzip/htslib): inflated by several threads in kmcp-search, read as multi-member gzip by Python
+            p += ".gz"
+            open(p, "wb").write(bgzf(bytes(out), int(rng.choice([1, 37, 1000, 65280]))))
         else:
             open(p, "wb").write(bytes(out))
         want = list(read_fastx(p))
-        env = dict(os.environ, KMCP_READER_BUF=str(int(rng.choice([16, 17, 31, 64, 100, 257, 4096, 1 << 20]))))
+        env = dict(os.environ, KMCP_READER_BUF=str(int(rng.choice([16, 17, 31, 64, 100, 257, 4096, 1 << 20]))), KMCP_BGZF_THREADS="3")
         r = subprocess.run([cli, "--parse-only", p], capture_output=True, text=True, env=env, timeout=60)
         assert r.returncode == 0, (p, r.stderr)
         got = dict(x.split("=") for x in r.stdout.strip().split("\t")[1:])
