@@ -465,3 +465,35 @@ def test_more_shards_than_blocks(G, oracle_lib, tmp_path):
             assert int(qk.sum().item()) > 0  # k-mers are generated on every shard
             total += c
     assert total > 200
+
+
+def test_hit_buffer_overflow_is_retried(G, oracle_lib, tmp_path):
+    """-t just above the Bloom density: half of all columns pass the threshold by chance, hundreds of hits per read — far more
+    than the first hit buffer of kmcpg_search_batch (8 per read); the call must notice the overflow, rerun with room for every
+    hit and still agree with the oracle; the same for a caller-sized buffer of kmcpg_query_device (count reported, no write
+    past the capacity)."""
+    import torch
+    O = oracle_lib
+    genomes = synth.random_genomes(600, 3000, seed=95)
+    db_dir = synth.make_db(tmp_path, genomes, k=21, fpr=0.3, block_size=600)
+    reads = synth.sample_reads(genomes, 150, 150, seed=96, frac_random=0.5)
+    kw = dict(min_qcov=0.31, max_fpr=1.0, min_matched=1)
+    n, res = _run(G, O, db_dir, reads, oracle_kw=kw, gpu_kw=kw)
+    total = int(res.offs[-1])
+    assert n == total > 50 * len(reads)  # every match compared; way beyond 8 hits per read
+    # device-level: capacity 100, guard words behind it stay untouched, the counter reports the real number
+    dev = torch.device("cuda:0")
+    seqs, offs = G["lib"].pack_reads(reads)
+    t_seqs = torch.from_numpy(seqs).to(dev)
+    t_offs = torch.from_numpy(offs.view(np.int64)).to(dev)
+    with G["Database"].open(db_dir, device=0) as db:
+        hits = torch.full((200, 3), -7, dtype=torch.int32, device=dev)
+        cnt = torch.zeros(2, dtype=torch.int64, device=dev)
+        qk = torch.zeros(len(reads), dtype=torch.int32, device=dev)
+        ql = torch.zeros(len(reads), dtype=torch.int32, device=dev)
+        db.query_device(t_seqs.data_ptr(), t_offs.data_ptr(), len(reads), len(seqs), 150, hits.data_ptr(), 100, cnt.data_ptr(), qk.data_ptr(),
+                        ql.data_ptr(), params=G["default_params"](**kw))
+        torch.cuda.synchronize()
+        assert int(cnt[0].item()) >= total  # hits before the float64 filters of the host half
+        h = hits.cpu().numpy()
+        assert (h[100:] == -7).all() and (h[:100, 2] > 0).all()
