@@ -80,7 +80,7 @@ bool match_less(const kmcpg_match& x, const kmcpg_match& y, int sort_by) {
 
 extern "C" int kmcpg_finalize(const kmcpg_db* db, const kmcpg_hit* hits, uint64_t n_hits, const int32_t* qkmers, const int32_t* qlen, uint32_t n_reads,
                               const kmcpg_params* params, kmcpg_result* out) {
-  if (!db || !out || (!hits && n_hits) || !qkmers || !qlen) return kmcpg_fail(KMCPG_EINVAL, "null argument");
+  if (!db || !out || (!hits && n_hits) || (n_reads && (!qkmers || !qlen))) return kmcpg_fail(KMCPG_EINVAL, "null argument");
   const kmcpg_params p = params ? *params : default_params();
   std::unique_ptr<ResultOwner, OwnerReturn> o(take_owner());
   o->qlen.assign(qlen, qlen + n_reads);

@@ -497,3 +497,36 @@ def test_hit_buffer_overflow_is_retried(G, oracle_lib, tmp_path):
         assert int(cnt[0].item()) >= total  # hits before the float64 filters of the host half
         h = hits.cpu().numpy()
         assert (h[100:] == -7).all() and (h[:100, 2] > 0).all()
+
+
+def test_degenerate_batches(G, oracle_lib, tmp_path):
+    """Zero reads, only empty reads, an empty mate, no hit buffer at all (hit_cap 0: count only)."""
+    import torch
+    O = oracle_lib
+    genomes = synth.random_genomes(8, 4000, seed=97)
+    db_dir = synth.make_db(tmp_path, genomes, k=21, threads=2)
+    dev = torch.device("cuda:0")
+    with G["Database"].open(db_dir, device=0) as db:
+        res = db.search([], params=G["default_params"]())
+        assert len(res) == 0 and len(res.matches) == 0
+        res = db.search([b"", b"", b""], params=G["default_params"]())
+        assert list(res.qlen) == [0, 0, 0] and len(res.matches) == 0
+        r1 = [genomes[0][:150], b"", genomes[1][100:250]]
+        r2 = [b"", genomes[2][:150], genomes[1][300:450]]
+        odb = O.OracleDB(db_dir)
+        try:
+            res = db.search(r1, r2, params=G["default_params"](try_se=1))
+            assert synth.assert_parity(odb, res, r1, r2, O.default_params(try_se=1, fpr_buf_size=499)) >= 2
+        finally:
+            odb.close()
+        reads = synth.sample_reads(genomes, 64, 150, seed=98, frac_random=0.0)
+        seqs, offs = G["lib"].pack_reads(reads)
+        t_seqs = torch.from_numpy(seqs).to(dev)
+        t_offs = torch.from_numpy(offs.view(np.int64)).to(dev)
+        cnt = torch.zeros(2, dtype=torch.int64, device=dev)
+        qk = torch.zeros(64, dtype=torch.int32, device=dev)
+        ql = torch.zeros(64, dtype=torch.int32, device=dev)
+        db.query_device(t_seqs.data_ptr(), t_offs.data_ptr(), 64, len(seqs), 150, None, 0, cnt.data_ptr(), qk.data_ptr(), ql.data_ptr(),
+                        params=G["default_params"]())
+        torch.cuda.synchronize()
+        assert int(cnt[0].item()) >= 64 and int(qk.min().item()) == 130
