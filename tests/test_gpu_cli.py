@@ -234,3 +234,38 @@ def test_cli_reader_torture(oracle_lib, tmp_path):
     want, trailer = oracle_tsv(O, odb, ids, reads)
     compare(run_cli(["-d", db_root, fq], str(tmp_path / "fq.tsv")), want, trailer)
     odb.close()
+
+
+def test_cli_empty_and_ragged_inputs(oracle_lib, tmp_path):
+    """An empty file, a file without any record, paired files of different lengths (the shorter one ends the run, search.go:818-826),
+    -g on an empty file: no crash, header + trailer as the reference prints them (0 queries: 'NaN%')."""
+    O = oracle_lib
+    genomes = synth.random_genomes(4, 3000, seed=99)
+    db_dir = synth.make_db(tmp_path / "db", genomes, k=21, threads=2)
+    db_root = os.path.dirname(db_dir)
+    empty = str(tmp_path / "empty.fq")
+    open(empty, "w").close()
+    blank = str(tmp_path / "blank.fa")
+    open(blank, "w").write("\n\n\n")
+    for args in ([empty], [blank], ["-g", empty], [empty, blank]):
+        got = run_cli(["-d", db_root] + args, str(tmp_path / "e.tsv"))
+        assert got == [HEADER, "# input queries: 0", "# matched queries: 0", "# matched percentage: NaN%", ""], (args, got)
+    r1 = synth.sample_reads(genomes, 30, 150, seed=100, frac_random=0.0)
+    r2 = synth.sample_reads(genomes, 30, 150, seed=101, frac_random=0.0)
+    ids = [f"p{i}" for i in range(30)]
+    write_fastq(str(tmp_path / "a.fq"), ids, r1)
+    write_fastq(str(tmp_path / "b.fq"), ids[:17], r2[:17])
+    odb = O.OracleDB(db_dir)
+    want, trailer = oracle_tsv(O, odb, ids[:17], r1[:17], r2[:17], params=O.default_params(fpr_buf_size=499))
+    odb.close()
+    compare(run_cli(["-d", db_root, "-1", str(tmp_path / "a.fq"), "-2", str(tmp_path / "b.fq")], str(tmp_path / "pe.tsv")), want, trailer)
+    compare(run_cli(["-d", db_root, "-1", str(tmp_path / "b.fq"), "-2", str(tmp_path / "a.fq")], str(tmp_path / "pe2.tsv")),
+            *oracle_tsv_swapped(O, db_dir, ids[:17], r2[:17], r1[:17]))
+
+
+def oracle_tsv_swapped(O, db_dir, ids, a, b):
+    odb = O.OracleDB(db_dir)
+    try:
+        return oracle_tsv(O, odb, ids, a, b, params=O.default_params(fpr_buf_size=499))
+    finally:
+        odb.close()
