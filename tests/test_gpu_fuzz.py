@@ -103,11 +103,20 @@ def test_random_long_queries(oracle_lib, tmp_path, seed):
     t = max(float(rng.choice([0.55, 0.3, 0.8])), fpr + 0.05)
     flags = dict(min_qcov=t, min_matched=int(rng.choice([1, 10])), dedup_threshold=int(rng.choice([256, 0, 1 << 30])), sort_by=int(rng.integers(0, 3)),
                  max_fpr=float(rng.choice([0.01, 1.0])))
+    # every fourth draw is paired: long (or short, or empty) mates go through the second-mate code of the workgroup kernels
+    reads2 = None
+    if seed % 4 == 3:
+        reads2 = []
+        for r in reads:
+            L2 = int(min(glen - 1, rng.choice([0, 150, 3000, 9000])))
+            reads2.append(synth.sample_reads(genomes, 1, L2, sub_rate=0.01, seed=int(rng.integers(1 << 30)), frac_random=0.3)[0] if L2 else b"")
+        flags["try_se"] = int(rng.random() < 0.5)
+    oflags = dict(flags, fpr_buf_size=499) if reads2 is not None else flags
     odb = O.OracleDB(db_dir)
     try:
         with Database.open(db_dir, device=0) as db:
-            res = db.search(reads, None, params=default_params(**flags))
+            res = db.search(reads, reads2, params=default_params(**flags))
         # (a few draws — large scale, high -t — legitimately have no matching read on either side)
-        synth.assert_parity(odb, res, reads, None, O.default_params(**flags))
+        synth.assert_parity(odb, res, reads, reads2, O.default_params(**oflags))
     finally:
         odb.close()
