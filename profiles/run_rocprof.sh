@@ -27,3 +27,5 @@ ls -la $OUT | head -40
 run gtdb_pmc_sq --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU GRBM_GUI_ACTIVE --kernel-trace -d $OUT/_prof_gtdb_pmc_sq -o gtdb_pmc_sq -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-secondary
 run gtdb_pmc_l2 --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum --kernel-trace -d $OUT/_prof_gtdb_pmc_l2 -o gtdb_pmc_l2 -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-secondary
 ls $OUT | head -60
+# the one-block form of the 10k-chunk index (bench.py --workload config1_wide)
+run config1_wide_pmc --pmc FETCH_SIZE --kernel-trace -d $OUT/_prof_config1_wide_pmc -o config1_wide_pmc -- python $R/bench.py --workload config1_wide --steps 2 --warmup 1 --no-cpu-baseline
