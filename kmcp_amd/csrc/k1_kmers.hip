@@ -165,6 +165,7 @@ __device__ __forceinline__ void hash_positions(const uint8_t* __restrict__ s, in
 __device__ __forceinline__ int argmin_left(const uint64_t* __restrict__ h, int b, int n) {
   int m = b;
   uint64_t mv = h[b];
+#pragma unroll 4
   for (int i = b + 1; i < b + n; i++) {
     const uint64_t v = h[i];
     if (v < mv) {  // strict: the leftmost of equal values wins
