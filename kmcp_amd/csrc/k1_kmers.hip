@@ -238,13 +238,15 @@ __device__ __forceinline__ int minimizer_mate(const uint8_t* __restrict__ s, int
   return cnt;
 }
 
-__device__ __forceinline__ int sketch_mate(const K1Args& a, const uint8_t* s, int len, const uint64_t* tab, uint64_t* tmp_k, uint64_t* tmp_s,
+__device__ __forceinline__ int sketch_mate(const K1Args& a, int mode, const uint8_t* s, int len, const uint64_t* tab, uint64_t* tmp_k, uint64_t* tmp_s,
                                            uint64_t* out, int cnt, int lane) {
-  if (a.mode == 2) return syncmer_mate(s, len, a.k, (int)a.w_or_s, tab, a.scaled != 0, a.max_hash, tmp_k, tmp_s, out, cnt, lane);
-  if (a.mode == 1) return minimizer_mate(s, len, a.k, (int)a.w_or_s, tab, a.scaled != 0, a.max_hash, tmp_k, out, cnt, lane);
+  if (mode == 2) return syncmer_mate(s, len, a.k, (int)a.w_or_s, tab, a.scaled != 0, a.max_hash, tmp_k, tmp_s, out, cnt, lane);
+  if (mode == 1) return minimizer_mate(s, len, a.k, (int)a.w_or_s, tab, a.scaled != 0, a.max_hash, tmp_k, out, cnt, lane);
   return hash_mate(s, len, a.k, tab, a.scaled != 0, a.max_hash, out, cnt, lane);
 }
 
+// one kernel per sketch mode: the plain/FracMinHash form (every short-read search) does not carry the window sketches' registers
+template <int MODE>
 __global__ void __launch_bounds__(256) k1_kmers(const K1Args a) {
   __shared__ uint64_t tab[256];
   tab[threadIdx.x] = seed_of(threadIdx.x);
@@ -269,11 +271,11 @@ __global__ void __launch_bounds__(256) k1_kmers(const K1Args a) {
     if (!skip) {
       uint64_t* tk = a.scratch ? a.scratch + o1 + o2 : nullptr;   // k-mer hashes of the mate being sketched
       uint64_t* ts = a.scratch2 ? a.scratch2 + o1 + o2 : nullptr;  // its s-mer hashes (syncmer mode)
-      cnt = sketch_mate(a, a.seqs + o1, len1, tab, tk, ts, out, 0, lane);
+      cnt = sketch_mate(a, MODE, a.seqs + o1, len1, tab, tk, ts, out, 0, lane);
       cnt1 = cnt;
       if (pe) {
         __threadfence_block();
-        cnt = sketch_mate(a, a.seqs2 + o2, len2, tab, tk, ts, out, cnt, lane);
+        cnt = sketch_mate(a, MODE, a.seqs2 + o2, len2, tab, tk, ts, out, cnt, lane);
       }
     }
     if (lane == 0) {
@@ -314,11 +316,11 @@ __device__ __forceinline__ uint64_t hash_at(const uint8_t* __restrict__ s, int i
   return f < r ? f : r;
 }
 
-__device__ __forceinline__ int wg_sketch_mate(const K1Args& a, const uint8_t* __restrict__ s, int len, const uint64_t* tab, uint64_t* hk, uint64_t* hs,
-                                              uint64_t* __restrict__ out, int cnt, int* s_wave, int tid) {
+__device__ __forceinline__ int wg_sketch_mate(const K1Args& a, int mode, const uint8_t* __restrict__ s, int len, const uint64_t* tab, uint64_t* hk,
+                                              uint64_t* hs, uint64_t* __restrict__ out, int cnt, int* s_wave, int tid) {
   const int k = a.k;
   const bool scaled = a.scaled != 0;
-  if (a.mode == 0) {
+  if (mode == 0) {
     const int npos = len - k + 1;
     if (npos <= 0) return cnt;
     for (int base = 0; base < npos; base += K1WG) {
@@ -329,7 +331,7 @@ __device__ __forceinline__ int wg_sketch_mate(const K1Args& a, const uint8_t* __
     }
     return cnt;
   }
-  if (a.mode == 2) {  // closed syncmer, see syncmer_mate
+  if (mode == 2) {  // closed syncmer, see syncmer_mate
     const int sm = (int)a.w_or_s, L = 2 * k - sm - 1;
     if (sm < 1 || sm > k || len < L || len < k) return cnt;
     for (int i = tid; i < len - k + 1; i += K1WG) hk[i] = hash_at(s, i, k, tab);
@@ -445,20 +447,20 @@ __device__ __forceinline__ uint64_t lds_hash(const K1Lds& L, int i, int kk) {
 // positions per tile: with a small halo the tile shrinks so that positions + halo fit one scan round of K1WG bases
 __device__ __forceinline__ int wg_tile_step(int halo) { return halo <= K1WG / 2 ? K1WG - halo : K1WG; }
 
-__device__ __forceinline__ bool wg_lds_usable(const K1Args& a) {
+__host__ __device__ __forceinline__ bool wg_lds_usable(const K1Args& a) {
   if (a.k > 255) return false;
   if (a.mode == 2) return 2 * a.k - (int)a.w_or_s - 1 <= K1H && (int)a.w_or_s >= 1 && (int)a.w_or_s <= a.k;
   if (a.mode == 1) return (int)a.w_or_s >= 1 && (int)a.w_or_s + 1 < K1H;
   return true;
 }
 
-__device__ __forceinline__ int wg_sketch_mate_lds(const K1Args& a, const uint8_t* __restrict__ s, int len, const uint64_t* tab, K1Lds& L,
+__device__ __forceinline__ int wg_sketch_mate_lds(const K1Args& a, int mode, const uint8_t* __restrict__ s, int len, const uint64_t* tab, K1Lds& L,
                                                   uint64_t* __restrict__ out, int cnt, int* s_wave, int tid) {
   const int k = a.k;
   const bool scaled = a.scaled != 0;
   const int nk = len - k + 1;  // k-mer positions
   if (nk <= 0) return cnt;
-  if (a.mode == 0) {
+  if (mode == 0) {
     const int T = wg_tile_step(k - 1);
     for (int p0 = 0; p0 < nk; p0 += T) {
       wg_prefix(s + p0, min(len - p0, T + k - 1), tab, L, tid);
@@ -468,7 +470,7 @@ __device__ __forceinline__ int wg_sketch_mate_lds(const K1Args& a, const uint8_t
     }
     return cnt;
   }
-  if (a.mode == 2) {  // closed syncmer (see syncmer_mate)
+  if (mode == 2) {  // closed syncmer (see syncmer_mate)
     const int sm = (int)a.w_or_s, Lw = 2 * k - sm - 1;
     if (len < Lw) return cnt;
     const int wsz = 2 * (k - sm);
@@ -518,14 +520,9 @@ __device__ __forceinline__ int wg_sketch_mate_lds(const K1Args& a, const uint8_t
   return cnt;
 }
 
-__global__ void __launch_bounds__(K1WG) k1_kmers_wg(const K1Args a) {
-  __shared__ uint64_t tab[256];
-  __shared__ int s_wave[K1WG / 64];
-  __shared__ K1Lds lds;
-  const int tid = threadIdx.x;
-  if (tid < 256) tab[tid] = seed_of(tid);
-  __syncthreads();
-  const bool use_lds = wg_lds_usable(a);
+// the per-read loop of the workgroup kernels; LDS = the tile form with prefix arrays in LDS, else the scratch-buffer form
+template <bool LDS>
+__device__ __forceinline__ void wg_reads(const K1Args& a, int mode, const uint64_t* tab, int* s_wave, K1Lds* lds, int tid) {
   for (uint32_t r = blockIdx.x; r < a.n_reads; r += gridDim.x) {
     const uint64_t o1 = a.offs[r];
     const int len1 = (int)(a.offs[r + 1] - o1);
@@ -540,14 +537,17 @@ __global__ void __launch_bounds__(K1WG) k1_kmers_wg(const K1Args a) {
     const bool skip = len1 < a.min_qlen && !(pe && len2 >= a.min_qlen);
     int cnt = 0, cnt1 = 0;
     if (!skip) {
-      uint64_t* tk = a.scratch ? a.scratch + o1 + o2 : nullptr;
-      uint64_t* ts = a.scratch2 ? a.scratch2 + o1 + o2 : nullptr;
-      cnt = use_lds ? wg_sketch_mate_lds(a, a.seqs + o1, len1, tab, lds, out, 0, s_wave, tid)
-                    : wg_sketch_mate(a, a.seqs + o1, len1, tab, tk, ts, out, 0, s_wave, tid);
-      cnt1 = cnt;
-      if (pe)
-        cnt = use_lds ? wg_sketch_mate_lds(a, a.seqs2 + o2, len2, tab, lds, out, cnt, s_wave, tid)
-                      : wg_sketch_mate(a, a.seqs2 + o2, len2, tab, tk, ts, out, cnt, s_wave, tid);
+      if (LDS) {
+        cnt = wg_sketch_mate_lds(a, mode, a.seqs + o1, len1, tab, *lds, out, 0, s_wave, tid);
+        cnt1 = cnt;
+        if (pe) cnt = wg_sketch_mate_lds(a, mode, a.seqs2 + o2, len2, tab, *lds, out, cnt, s_wave, tid);
+      } else {
+        uint64_t* tk = a.scratch ? a.scratch + o1 + o2 : nullptr;
+        uint64_t* ts = a.scratch2 ? a.scratch2 + o1 + o2 : nullptr;
+        cnt = wg_sketch_mate(a, mode, a.seqs + o1, len1, tab, tk, ts, out, 0, s_wave, tid);
+        cnt1 = cnt;
+        if (pe) cnt = wg_sketch_mate(a, mode, a.seqs2 + o2, len2, tab, tk, ts, out, cnt, s_wave, tid);
+      }
     }
     if (tid == 0) {
       a.nk_raw[r] = cnt;
@@ -555,6 +555,28 @@ __global__ void __launch_bounds__(K1WG) k1_kmers_wg(const K1Args a) {
       a.qlen[r] = len1 + len2;
     }
   }
+}
+
+// One kernel per sketch mode (the other modes' code and registers stay out of it); 64 VGPRs => two workgroups per CU.
+template <int MODE>
+__global__ void __launch_bounds__(K1WG, 8) k1_kmers_wg(const K1Args a) {
+  __shared__ uint64_t tab[256];
+  __shared__ int s_wave[K1WG / 64];
+  __shared__ K1Lds lds;
+  const int tid = threadIdx.x;
+  if (tid < 256) tab[tid] = seed_of(tid);
+  __syncthreads();
+  wg_reads<true>(a, MODE, tab, s_wave, &lds, tid);
+}
+
+// halo too large for the LDS tiles (2k-s-1 > 512, w >= 511, k > 255): window scans over scratch arrays in global memory
+__global__ void __launch_bounds__(K1WG) k1_kmers_wg_global(const K1Args a) {
+  __shared__ uint64_t tab[256];
+  __shared__ int s_wave[K1WG / 64];
+  const int tid = threadIdx.x;
+  if (tid < 256) tab[tid] = seed_of(tid);
+  __syncthreads();
+  wg_reads<false>(a, a.mode, tab, s_wave, nullptr, tid);
 }
 
 // ---- whole genomes (plain / FracMinHash k-mers): segments of K1SEG positions on their own workgroups ----------------
@@ -635,12 +657,17 @@ void launch_k1(const K1Args& a, uint32_t max_read_len, hipStream_t st) {
   }
   if (max_read_len > 2048) {  // long queries: a whole workgroup per read
     unsigned blocks = a.n_reads > 65536 ? 65536 : a.n_reads;
-    hipLaunchKernelGGL(k1_kmers_wg, dim3(blocks), dim3(K1WG), 0, st, a);
+    if (!wg_lds_usable(a)) hipLaunchKernelGGL(k1_kmers_wg_global, dim3(blocks), dim3(K1WG), 0, st, a);
+    else if (a.mode == 2) hipLaunchKernelGGL(k1_kmers_wg<2>, dim3(blocks), dim3(K1WG), 0, st, a);
+    else if (a.mode == 1) hipLaunchKernelGGL(k1_kmers_wg<1>, dim3(blocks), dim3(K1WG), 0, st, a);
+    else hipLaunchKernelGGL(k1_kmers_wg<0>, dim3(blocks), dim3(K1WG), 0, st, a);
     return;
   }
   unsigned blocks = (a.n_reads + 3) / 4;
   if (blocks > 32768) blocks = 32768;
-  hipLaunchKernelGGL(k1_kmers, dim3(blocks), dim3(256), 0, st, a);
+  if (a.mode == 2) hipLaunchKernelGGL(k1_kmers<2>, dim3(blocks), dim3(256), 0, st, a);
+  else if (a.mode == 1) hipLaunchKernelGGL(k1_kmers<1>, dim3(blocks), dim3(256), 0, st, a);
+  else hipLaunchKernelGGL(k1_kmers<0>, dim3(blocks), dim3(256), 0, st, a);
 }
 
 void launch_nk_simple(const int32_t* nk_raw, int32_t* nk_search, uint32_t n, int32_t min_matched, hipStream_t st) {

@@ -317,6 +317,8 @@ def test_k1_all_forms_across_k(G, oracle_lib, k):
     long_ = [genomes[0][:n] for n in (2049, 3000, 1024 + k - 1, 1024 + k, 2 * 1024 + k - 1, 5000)] + short[:5]
     huge = [genomes[1][:140000], genomes[0][:65536 + k - 1], genomes[0][:65536 + k], genomes[1][:70000]]
     modes = [dict(), dict(scale=5), dict(syncmer_s=max(1, k // 2)), dict(minimizer_w=5)]
+    if k == 21:
+        modes.append(dict(minimizer_w=600))  # halo too large for the LDS tiles: the scratch-buffer form of the workgroup kernel
     for kw in modes:
         spec = lib.SynthSpec(k=k, num_hashes=1, fpr=0.3, n_blocks=1, cols_per_block=8, num_sigs=1000, kmers_per_col=10, seed=1,
                              scale=kw.get("scale", 1), syncmer_s=kw.get("syncmer_s", 0), minimizer_w=kw.get("minimizer_w", 0))
