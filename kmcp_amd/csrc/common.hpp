@@ -77,6 +77,7 @@ struct K2Args {
   int32_t nt_loads;      // non-temporal row loads
   int32_t prune;         // stop loading sectors whose columns can no longer reach the threshold
   int32_t split_min;     // >0: queries with more k-mers are handled by the SPLIT launch
+  int32_t slot_major;    // unit order: 1 = slot-major (unit u -> slot u / n_reads, read u % n_reads), 0 = read-major
   // long-query (SPLIT) form
   const uint32_t* long_list;  // indices of the long queries
   uint32_t n_long;

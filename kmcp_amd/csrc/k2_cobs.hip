@@ -88,8 +88,13 @@ __global__ void __launch_bounds__(256) k2_cobs(const K2Args a) {
       k0 = (int)(rem % a.split_chunks) * (int)a.split_chk;
       r = a.long_list[li_long];
     } else {
-      r = (uint32_t)(u / a.nslots);
-      sidx = (uint32_t)(u % a.nslots);
+      if (a.slot_major) {  // all waves in flight work on one (block, tile) slice of the index at a time
+        sidx = (uint32_t)(u / a.n_reads);
+        r = (uint32_t)(u % a.n_reads);
+      } else {
+        r = (uint32_t)(u / a.nslots);
+        sidx = (uint32_t)(u % a.nslots);
+      }
     }
   }
   const Slot slot = a.slots[sidx];

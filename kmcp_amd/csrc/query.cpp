@@ -207,6 +207,9 @@ extern "C" int kmcpg_query_device(kmcpg_db* db, const uint8_t* d_seqs, const uin
   a.nt_loads = getenv("KMCPG_NT_LOADS") ? atoi(getenv("KMCPG_NT_LOADS")) : 1;
   a.prune = getenv("KMCPG_PRUNE") ? atoi(getenv("KMCPG_PRUNE")) : 1;
   a.split_min = n_long ? split_min : 0;
+  // slot-major unit order: the waves in flight share one (block, tile) slice of the index, so the address range they gather
+  // from is ~1/64 of the index (GTDB scale: 575 -> 510 ms per 524 k reads; profiles/r02_order_exp.txt)
+  a.slot_major = getenv("KMCPG_SLOT_MAJOR") ? atoi(getenv("KMCPG_SLOT_MAJOR")) : 1;
   a.hits = d_hits;
   a.hit_cap = hit_cap;
   a.counter = (unsigned long long*)d_counters;
