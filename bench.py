@@ -36,7 +36,8 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.2-6.3 
 
 WORKLOADS = {
     # GTDB r202 k=21 x10 chunks: 58.03 GB in 32 blocks (docs/database-time-and-mem-v2021.12.md:20-36)
-    "gtdb": dict(k=21, num_hashes=1, fpr=0.3, n_blocks=32, cols_per_block=14976, num_sigs=968700, kmers_per_col=345510,
+    # every block has its own NumSigs, as in a real database (blocks hold genomes of ascending size): 967 708 + 64 i rows
+    "gtdb": dict(k=21, num_hashes=1, fpr=0.3, n_blocks=32, cols_per_block=14976, num_sigs=967708, sigs_step=64, kmers_per_col=345510,
                  batch_reads=524288, kernel="k2_cobs<64,8,false>",
                  name="gtdb-scale synthetic: 32 blocks x 14976 cols x 968700 sigs (58.03 GB), 150bp k=21"),
     # 10 k chunks, `kmcp index -j 32`: 32 blocks x 312 columns, 39-byte rows (BASELINE.json configs[1])
@@ -102,7 +103,8 @@ def run_workload(name, ctx, steps, warmup, batch_reads=0, cpu_baseline=True, cpu
     wl = dict(WORKLOADS[name])
     B = batch_reads or wl["batch_reads"]
     spec = lib.SynthSpec(k=wl["k"], num_hashes=wl["num_hashes"], fpr=wl["fpr"], n_blocks=wl["n_blocks"],
-                         cols_per_block=wl["cols_per_block"], num_sigs=wl["num_sigs"], kmers_per_col=wl["kmers_per_col"], seed=42)
+                         cols_per_block=wl["cols_per_block"], num_sigs=wl["num_sigs"], kmers_per_col=wl["kmers_per_col"], seed=42,
+                         sigs_step=wl.get("sigs_step", 0))
     free_b, _ = torch.cuda.mem_get_info(dev)
     need = wl["n_blocks"] * wl["num_sigs"] * ((wl["cols_per_block"] + 7) // 8 + 64) / world
     if need > 0.9 * free_b:

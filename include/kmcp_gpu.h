@@ -162,7 +162,8 @@ typedef struct {
   uint32_t scale;       /* 0/1 = all k-mers; >1 = FracMinHash database (`scaled: true`, `scale`) */
   uint32_t syncmer_s;   /* >0 = Closed-Syncmer database */
   uint32_t minimizer_w; /* >0 = Minimizer database */
-  uint32_t reserved;
+  uint32_t sigs_step;   /* block i has num_sigs + i*sigs_step rows.  Real databases have a different NumSigs in (almost) every
+                           block; blocks with equal NumSigs are laid side by side in HBM and served by one gather */
 } kmcpg_synth_spec;
 /* Builds a synthetic database directly in HBM: every bit i.i.d. Bernoulli(density) from a
  * counter-based generator keyed by (seed, block, row, word).  Column names are "syn<global col>". */

@@ -6,22 +6,36 @@
 
 namespace kmcpg {
 
-// Device-side description of one resident .uniki block (index/serialization.go:66-82 Header,
-// re-laid-out: rows padded to `stride` bytes, one all-zero row appended at index num_sigs).
+// Device-side description of resident index rows (index/serialization.go:66-82 Header, re-laid-out: rows padded to `stride`
+// bytes, one all-zero row appended at index num_sigs).  Two arrays of these live on the device:
+//  - one entry per resident .uniki block (used by the planting / read-back helpers): `rows` points at the block's first byte
+//    inside its group's rows, ncols/col_base are the block's own;
+//  - one entry per GROUP (used by K2): resident blocks with the same NumSigs are laid side by side in one row — a k-mer's row
+//    index h % NumSigs is the same in all of them, so one wide gather serves them all (the on-disk format is untouched).
+//    row_bytes is the sum of the members' NumRowBytes; segs[seg0 .. seg0+nsegs) map a byte of the row back to columns.
 struct BlockDev {
   const uint8_t* rows;  // device pointer, (num_sigs + 1) * stride bytes
   uint64_t num_sigs;    // Header.NumSigs: modulus of the row address (util-db-search.go:6811)
   uint64_t magic_hi;    // M = floor((2^128-1)/num_sigs)+1, exact 64-bit fastmod (replaces fastdiv, :6611)
   uint64_t magic_lo;
   uint32_t stride;      // bytes per row in HBM (multiple of 16)
-  uint32_t row_bytes;   // Header.NumRowBytes = (ncols+7)/8
+  uint32_t row_bytes;   // Header.NumRowBytes = (ncols+7)/8 (group: sum over the members)
   uint32_t ncols;
-  uint32_t col_base;    // global column id of column 0
+  uint32_t col_base;    // global column id of column 0 (group: of the first member)
+  uint32_t seg0, nsegs; // group entries: its members in the segment table
+};
+
+// One member block of a group: bytes [byte_start, byte_end) of the group's row hold its columns, MSB of a byte first
+// (index.go:1157); the last byte may carry padding bits (always zero).
+struct Seg {
+  uint32_t byte_start, byte_end;
+  uint32_t col_base;  // global column id of the member's column 0
+  uint32_t ncols;
 };
 
 // One unit of COBS work per read: (local block, tile of LPR*16 bytes of the row).
 struct Slot {
-  uint32_t block;  // index into the BlockDev array
+  uint32_t block;  // index into the group array
   uint32_t tile;
 };
 
@@ -63,7 +77,8 @@ struct DedupArgs {
 };
 
 struct K2Args {
-  const BlockDev* blocks;
+  const BlockDev* blocks;  // groups
+  const Seg* segs;
   const Slot* slots;
   uint32_t nslots;
   uint32_t n_reads;

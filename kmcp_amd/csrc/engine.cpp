@@ -85,10 +85,62 @@ void assign_shards(kmcpg_db* db) {
   }
 }
 
+// Resident blocks with the same NumSigs go side by side into one group (a k-mer has the same row index in all of them), as
+// long as the group's rows stay addressable in 16-byte units with 32 bits.  KMCPG_FUSE=0 keeps every block on its own.
+void form_groups(kmcpg_db* db) {
+  const bool fuse = !(getenv("KMCPG_FUSE") && atoi(getenv("KMCPG_FUSE")) == 0);
+  db->groups.clear();
+  for (size_t i = 0; i < db->blocks.size(); i++) {
+    BlockMeta& b = db->blocks[i];
+    b.group = -1;
+    if (!b.local) continue;
+    int gi = -1;
+    if (fuse)
+      for (size_t g = 0; g < db->groups.size(); g++) {
+        const Group& G = db->groups[g];
+        if (G.num_sigs != b.h.num_sigs) continue;
+        const uint64_t st = device_stride(G.row_bytes + b.h.row_bytes);
+        if ((G.num_sigs + 1) * (st >> 4) <= 0xffffffffULL) gi = (int)g;
+      }
+    if (gi < 0) {
+      db->groups.push_back(Group{});
+      gi = (int)db->groups.size() - 1;
+      db->groups[(size_t)gi].num_sigs = b.h.num_sigs;
+    }
+    Group& G = db->groups[(size_t)gi];
+    b.group = gi;
+    b.byte_off = G.row_bytes;
+    G.row_bytes += b.h.row_bytes;
+    G.members.push_back((int)i);
+  }
+  for (auto& G : db->groups) {
+    G.stride = device_stride(G.row_bytes);
+    for (int m : G.members) db->blocks[(size_t)m].stride = G.stride;
+  }
+}
+
+// rows of every group: zero-filled (row padding, the all-zero row at index NumSigs, the target of the OR-ing repack)
+int alloc_groups(kmcpg_db* db) {
+  for (auto& G : db->groups) {
+    // the kernel addresses rows in 16-byte units with 32 bits
+    if ((G.num_sigs + 1) * (uint64_t)(G.stride >> 4) > 0xffffffffULL)
+      return kmcpg_fail(KMCPG_EUNSUPPORTED, "%s: block larger than 64 GB in HBM (NumSigs %llu x %u B)", db->blocks[(size_t)G.members[0]].path.c_str(),
+                        (unsigned long long)G.num_sigs, G.stride);
+    const uint64_t bytes = (G.num_sigs + 1) * (uint64_t)G.stride;
+    HIPCHK(hipMalloc((void**)&G.d_rows, bytes));
+    HIPCHK(hipMemsetAsync(G.d_rows, 0, bytes, nullptr));
+    for (int m : G.members) db->blocks[(size_t)m].d_rows = G.d_rows + db->blocks[(size_t)m].byte_off;
+  }
+  HIPCHK(hipDeviceSynchronize());
+  return 0;
+}
+
 int finish_open(kmcpg_db* db) {
-  // BlockDev table + slot classes
+  // per-block and per-group device tables + slot classes
   db->local.clear();
   db->h_blockdev.clear();
+  db->h_groupdev.clear();
+  db->h_segs.clear();
   db->classes.clear();
   db->info.n_blocks_local = 0;
   db->info.matrix_bytes_local = 0;
@@ -110,7 +162,8 @@ int finish_open(kmcpg_db* db) {
     db->info.n_blocks_local++;
     db->info.matrix_bytes_local += b.h.num_sigs * (uint64_t)b.h.row_bytes;
     db->info.row_bytes_sum_local += b.h.row_bytes;
-    const int lpr = lpr_for_stride(b.stride);
+  }
+  auto add_slot = [&](int lpr, uint32_t group, uint32_t byte0) {
     SlotClass* cls = nullptr;
     for (auto& c : db->classes)
       if (c.lpr == lpr) cls = &c;
@@ -119,13 +172,37 @@ int finish_open(kmcpg_db* db) {
       cls = &db->classes.back();
       cls->lpr = lpr;
     }
-    const uint32_t tile_bytes = (uint32_t)lpr * 16u;
-    const uint32_t tiles = (b.stride + tile_bytes - 1) / tile_bytes;
-    for (uint32_t t = 0; t < tiles; t++) cls->slots.push_back(Slot{(uint32_t)b.local_idx, t});
+    cls->slots.push_back(Slot{group, byte0 / ((uint32_t)lpr * 16u)});
+  };
+  for (size_t g = 0; g < db->groups.size(); g++) {
+    const Group& G = db->groups[g];
+    BlockDev gd{};
+    gd.rows = G.d_rows;
+    gd.num_sigs = G.num_sigs;
+    magic_for(G.num_sigs, &gd.magic_hi, &gd.magic_lo);
+    gd.stride = G.stride;
+    gd.row_bytes = G.row_bytes;
+    gd.col_base = db->blocks[(size_t)G.members[0]].col_base;
+    gd.seg0 = (uint32_t)db->h_segs.size();
+    gd.nsegs = (uint32_t)G.members.size();
+    for (int m : G.members) {
+      const BlockMeta& b = db->blocks[(size_t)m];
+      db->h_segs.push_back(Seg{b.byte_off, b.byte_off + b.h.row_bytes, b.col_base, (uint32_t)b.h.names.size()});
+      gd.ncols += (uint32_t)b.h.names.size();
+    }
+    db->h_groupdev.push_back(gd);
+    // whole 1-KB tiles go to full waves (64 lanes x 16 B); what is left of the row to the narrowest lane group that covers it
+    const uint32_t full = G.stride / 1024u, rem = G.stride % 1024u;
+    for (uint32_t t = 0; t < full; t++) add_slot(64, (uint32_t)g, t * 1024u);
+    if (rem) add_slot(lpr_for_stride(rem), (uint32_t)g, full * 1024u);
   }
   if (db->opts.device >= 0 && !db->h_blockdev.empty()) {
     HIPCHK(hipMalloc((void**)&db->d_blockdev, db->h_blockdev.size() * sizeof(BlockDev)));
     HIPCHK(hipMemcpy(db->d_blockdev, db->h_blockdev.data(), db->h_blockdev.size() * sizeof(BlockDev), hipMemcpyHostToDevice));
+    HIPCHK(hipMalloc((void**)&db->d_groupdev, db->h_groupdev.size() * sizeof(BlockDev)));
+    HIPCHK(hipMemcpy(db->d_groupdev, db->h_groupdev.data(), db->h_groupdev.size() * sizeof(BlockDev), hipMemcpyHostToDevice));
+    HIPCHK(hipMalloc((void**)&db->d_segs, db->h_segs.size() * sizeof(Seg)));
+    HIPCHK(hipMemcpy(db->d_segs, db->h_segs.data(), db->h_segs.size() * sizeof(Seg), hipMemcpyHostToDevice));
   }
   for (auto& c : db->classes) {
     if (db->opts.device < 0) break;
@@ -155,12 +232,6 @@ int upload_blocks(kmcpg_db* db) {
     if (!b.local) continue;
     const uint64_t ns = b.h.num_sigs;
     const uint32_t rb = b.h.row_bytes;
-    b.stride = device_stride(rb);
-    // the kernel addresses rows in 16-byte units with 32 bits
-    if ((ns + 1) * (uint64_t)(b.stride >> 4) > 0xffffffffULL)
-      return kmcpg_fail(KMCPG_EUNSUPPORTED, "%s: block larger than 64 GB in HBM (NumSigs %llu x %u B)", b.path.c_str(), (unsigned long long)ns, b.stride);
-    HIPCHK(hipMalloc((void**)&b.d_rows, (ns + 1) * (uint64_t)b.stride));
-    HIPCHK(hipMemset(b.d_rows + ns * b.stride, 0, b.stride));  // the all-zero row
     const uint64_t chunk_rows = std::max<uint64_t>(1, kChunkBytes / rb);
     for (uint64_t r0 = 0; r0 < ns; r0 += chunk_rows) {
       chunks.push_back(UploadChunk{&b, r0, std::min(chunk_rows, ns - r0)});
@@ -229,7 +300,7 @@ int upload_blocks(kmcpg_db* db) {
         set_err(KMCPG_EDEVICE, "uploading " + c.b->path + ": " + hipGetErrorString(he));
         break;
       }
-      launch_repack(d_tmp, c.b->d_rows + c.r0 * c.b->stride, c.nr, rb, c.b->stride, st);
+      launch_repack(d_tmp, db->groups[(size_t)c.b->group].d_rows + c.r0 * c.b->stride, c.nr, rb, c.b->stride, c.b->byte_off, st);
     }
     if (st) {
       he = hipStreamSynchronize(st);
@@ -317,12 +388,12 @@ extern "C" int kmcpg_open(const char* db_dir, const kmcpg_opts* opts, kmcpg_db**
   I.n_cols = base;
   if (I.num_hashes < 1 || I.num_hashes > 4) return kmcpg_fail(KMCPG_EUNSUPPORTED, "hashes=%d (kmcp index allows 1..4)", I.num_hashes);
   assign_shards(db.get());
+  form_groups(db.get());
   if (!meta_only) {
+    rc = alloc_groups(db.get());
+    if (rc) return rc;
     rc = upload_blocks(db.get());
     if (rc) return rc;
-  } else {
-    for (auto& b : db->blocks)
-      if (b.local) b.stride = device_stride(b.h.row_bytes);
   }
   rc = finish_open(db.get());
   if (rc) return rc;
@@ -362,7 +433,7 @@ extern "C" int kmcpg_open_synthetic(const kmcpg_synth_spec* s, const kmcpg_opts*
     b.h.canonical = true;
     b.h.compact = true;
     b.h.num_hashes = s->num_hashes;
-    b.h.num_sigs = s->num_sigs;
+    b.h.num_sigs = s->num_sigs + (uint64_t)i * s->sigs_step;
     b.h.row_bytes = (s->cols_per_block + 7) / 8;
     for (uint32_t c = 0; c < s->cols_per_block; c++) {
       snprintf(name, sizeof name, "syn%u", base + c);
@@ -380,18 +451,17 @@ extern "C" int kmcpg_open_synthetic(const kmcpg_synth_spec* s, const kmcpg_opts*
   I.n_cols = base;
   assign_shards(db.get());
   // density of one Bloom filter holding kmers_per_col of num_sigs slots with h hashes, at 8-bit resolution
-  const double dens = 1.0 - exp(-(double)s->num_hashes * (double)s->kmers_per_col / (double)s->num_sigs);
-  uint32_t p8 = (uint32_t)llround(dens * 256.0);
-  if (p8 > 255) p8 = 255;
+  form_groups(db.get());
+  rc = alloc_groups(db.get());
+  if (rc) return rc;
   for (size_t i = 0; i < db->blocks.size(); i++) {
     BlockMeta& b = db->blocks[i];
     if (!b.local) continue;
-    b.stride = device_stride(b.h.row_bytes);
-    if ((b.h.num_sigs + 1) * (uint64_t)(b.stride >> 4) > 0xffffffffULL) return kmcpg_fail(KMCPG_EUNSUPPORTED, "synthetic block larger than 64 GB");
-    HIPCHK(hipMalloc((void**)&b.d_rows, (b.h.num_sigs + 1) * (uint64_t)b.stride));
-    HIPCHK(hipMemset(b.d_rows + b.h.num_sigs * b.stride, 0, b.stride));
-    launch_synth_fill(b.d_rows, b.h.num_sigs, b.stride, (uint32_t)b.h.names.size(), s->seed * 0x9e3779b97f4a7c15ULL + i * 0x632be59bd9b4e019ULL + 1, p8,
-                      nullptr);
+    const double dens = 1.0 - exp(-(double)s->num_hashes * (double)s->kmers_per_col / (double)b.h.num_sigs);
+    uint32_t p8 = (uint32_t)llround(dens * 256.0);
+    if (p8 > 255) p8 = 255;
+    launch_synth_fill(b.d_rows, b.h.num_sigs, b.stride, device_stride(b.h.row_bytes), (uint32_t)b.h.names.size(),
+                      s->seed * 0x9e3779b97f4a7c15ULL + i * 0x632be59bd9b4e019ULL + 1, p8, nullptr);
   }
   HIPCHK(hipDeviceSynchronize());
   rc = finish_open(db.get());
@@ -405,9 +475,11 @@ extern "C" int kmcpg_close(kmcpg_db* db) {
   for (kmcpg_db* sh : db->shards) kmcpg_close(sh);
   db->shards.clear();
   if (db->opts.device >= 0) (void)hipSetDevice(db->opts.device);
-  for (auto& b : db->blocks)
-    if (b.d_rows) (void)hipFree(b.d_rows);
+  for (auto& G : db->groups)
+    if (G.d_rows) (void)hipFree(G.d_rows);
   if (db->d_blockdev) (void)hipFree(db->d_blockdev);
+  if (db->d_groupdev) (void)hipFree(db->d_groupdev);
+  if (db->d_segs) (void)hipFree(db->d_segs);
   for (auto& c : db->classes)
     if (c.d_slots) (void)hipFree(c.d_slots);
   db->w_hashes.release();

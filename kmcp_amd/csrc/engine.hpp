@@ -39,8 +39,18 @@ struct BlockMeta {
   uint32_t col_base = 0;
   bool local = false;
   int local_idx = -1;
-  uint32_t stride = 0;
+  uint32_t stride = 0;          // row pitch of the group the block lives in
+  uint8_t* d_rows = nullptr;    // first byte of the block inside its group's rows (not an allocation of its own)
+  int group = -1;
+  uint32_t byte_off = 0;        // offset of the block's bytes inside the group's row
+};
+
+// Resident blocks with the same NumSigs share one set of rows (common.hpp BlockDev): the allocation belongs to the group.
+struct Group {
   uint8_t* d_rows = nullptr;
+  uint64_t num_sigs = 0;
+  uint32_t stride = 0, row_bytes = 0;
+  std::vector<int> members;  // global block indices, in __db.yml `files` order
 };
 
 struct SlotClass {
@@ -77,8 +87,13 @@ struct kmcpg_db {
   kmcpg_info info{};
   std::vector<kmcpg::BlockMeta> blocks;
   std::vector<int> local;  // global indices of resident blocks, in kmcpg::BlockDev order
-  std::vector<kmcpg::BlockDev> h_blockdev;
+  std::vector<kmcpg::BlockDev> h_blockdev;  // per resident block (planting / read-back helpers)
   kmcpg::BlockDev* d_blockdev = nullptr;
+  std::vector<kmcpg::Group> groups;
+  std::vector<kmcpg::BlockDev> h_groupdev;  // per group: what K2 gathers from
+  kmcpg::BlockDev* d_groupdev = nullptr;
+  std::vector<kmcpg::Seg> h_segs;
+  kmcpg::Seg* d_segs = nullptr;
   std::vector<kmcpg::SlotClass> classes;
   std::vector<uint32_t> col_block;  // global column -> block index
   std::unique_ptr<kmcpg::QueryFpr> fpr;

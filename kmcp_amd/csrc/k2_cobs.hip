@@ -59,6 +59,19 @@ __device__ __forceinline__ void csa8(uint32_t (&pl)[NPL], uint32_t x0, uint32_t 
   }
 }
 
+// byte `byte` of a group's row, bit `bit` (7 = first column of the byte, index.go:1157) -> global column; false for padding
+__device__ __forceinline__ bool group_col(const Seg* __restrict__ segs, const BlockDev* __restrict__ bd, uint32_t byte, uint32_t bit, uint32_t* col) {
+  const Seg* s = segs + bd->seg0;
+  for (uint32_t i = 0; i < bd->nsegs; i++, s++) {
+    if (byte < s->byte_end) {
+      const uint32_t c = (byte - s->byte_start) * 8u + (7u - bit);
+      *col = s->col_base + c;
+      return byte >= s->byte_start && c < s->ncols;
+    }
+  }
+  return false;
+}
+
 // SPLIT = true is the long-query form: a unit is (long query, slot, chunk of a.split_chk <= 8192 k-mers); its counts are added to a
 // per-query u32 array with atomics and thresholded by k_threshold_long, so a whole genome spreads over the chip instead
 // of one wave per (query, slot).
@@ -208,15 +221,15 @@ __global__ void __launch_bounds__(256) k2_cobs(const K2Args a) {
   if (!live) return;
   if (SPLIT) {
     // partial counts of this chunk -> the query's count array (consecutive lanes hit consecutive words)
-    uint32_t* __restrict__ acc = a.long_counts + (uint64_t)li_long * a.ncols_total + bd->col_base;
+    uint32_t* __restrict__ acc = a.long_counts + (uint64_t)li_long * a.ncols_total;
 #pragma unroll
     for (int d = 0; d < 4; d++) {
       for (int q = 0; q < 32; q++) {
         uint32_t count = 0;
 #pragma unroll
         for (int p = 0; p < NPL; p++) count |= ((pl[d][p] >> q) & 1u) << p;
-        const uint32_t col = (boff + (uint32_t)d * 4u + (uint32_t)(q >> 3)) * 8u + (7u - (uint32_t)(q & 7));
-        if (count && col < bd->ncols) atomicAdd(acc + col, count);
+        uint32_t col;
+        if (count && group_col(a.segs, bd, boff + (uint32_t)d * 4u + (uint32_t)(q >> 3), (uint32_t)(q & 7), &col)) atomicAdd(acc + col, count);
       }
     }
     return;
@@ -234,13 +247,13 @@ __global__ void __launch_bounds__(256) k2_cobs(const K2Args a) {
 #pragma unroll
       for (int p = 0; p < NPL; p++) count |= ((pl[d][p] >> q) & 1u) << p;
       // byte (q>>3) of this dword, bit (q&7): bit 7 = first column of the byte (index.go:1157)
-      const uint32_t col = (boff + (uint32_t)d * 4u + (uint32_t)(q >> 3)) * 8u + (7u - (uint32_t)(q & 7));
-      if (col < bd->ncols) {
+      uint32_t col;
+      if (group_col(a.segs, bd, boff + (uint32_t)d * 4u + (uint32_t)(q >> 3), (uint32_t)(q & 7), &col)) {
         const unsigned long long idx = atomicAdd(a.counter, 1ULL);
         if (idx < a.hit_cap) {
           kmcpg_hit hit;
           hit.read = r;
-          hit.col = bd->col_base + col;
+          hit.col = col;
           hit.count = count;
           a.hits[idx] = hit;
         }

@@ -195,7 +195,8 @@ extern "C" int kmcpg_query_device(kmcpg_db* db, const uint8_t* d_seqs, const uin
   const int npl = max_short <= 255 ? 8 : (max_short <= 65535 ? 16 : (max_short <= 16777215 ? 24 : 0));
   if (!npl) return kmcpg_fail(KMCPG_EUNSUPPORTED, "queries with more than 16777215 k-mers need KMCPG_SPLIT_MIN > 0");
   K2Args a{};
-  a.blocks = db->d_blockdev;
+  a.blocks = db->d_groupdev;
+  a.segs = db->d_segs;
   a.n_reads = n_reads;
   a.hashes = db->w_hashes.p;
   a.offs = d_offs;

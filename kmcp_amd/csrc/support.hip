@@ -13,27 +13,34 @@ namespace kmcpg {
 // ------------------------------------------------------------------------------------------------
 // layout: on-disk rows (NumRowBytes, unpadded — serialization.go:140,379) -> HBM rows (stride)
 // ------------------------------------------------------------------------------------------------
+// dst = the group's rows (zero-filled beforehand); this block's bytes land at [byte_off, byte_off + row_bytes) of every row.
+// Interior dwords are stored, the (at most two) dwords a block shares with its neighbours in the group are OR-ed in.
 __global__ void k_repack(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, uint64_t n_rows, uint32_t row_bytes,
-                         uint32_t stride) {
-  const uint32_t wpr = stride / 4;  // dwords per dst row
+                         uint32_t stride, uint32_t byte_off) {
+  const uint32_t w0 = byte_off / 4, w1 = (byte_off + row_bytes + 3) / 4;  // dst dwords touched per row
+  const uint32_t wpr = w1 - w0;
   const uint64_t total = n_rows * wpr;
   for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (uint64_t)gridDim.x * blockDim.x) {
     const uint64_t row = i / wpr;
-    const uint32_t b0 = (uint32_t)(i % wpr) * 4;
-    uint32_t v = 0;
+    const uint32_t w = w0 + (uint32_t)(i % wpr);
     const uint8_t* s = src + row * row_bytes;
+    uint32_t v = 0;
 #pragma unroll
-    for (int t = 0; t < 4; t++)
-      if (b0 + t < row_bytes) v |= (uint32_t)s[b0 + t] << (8 * t);
-    reinterpret_cast<uint32_t*>(dst + row * stride)[b0 / 4] = v;
+    for (int t = 0; t < 4; t++) {
+      const uint32_t b = w * 4 + t;  // byte of the dst row
+      if (b >= byte_off && b < byte_off + row_bytes) v |= (uint32_t)s[b - byte_off] << (8 * t);
+    }
+    uint32_t* d = reinterpret_cast<uint32_t*>(dst + row * stride) + w;
+    if (w * 4 >= byte_off && w * 4 + 4 <= byte_off + row_bytes) *d = v;
+    else if (v) atomicOr(d, v);
   }
 }
 
-void launch_repack(const uint8_t* src, uint8_t* dst, uint64_t n_rows, uint32_t row_bytes, uint32_t stride, hipStream_t st) {
+void launch_repack(const uint8_t* src, uint8_t* dst, uint64_t n_rows, uint32_t row_bytes, uint32_t stride, uint32_t byte_off, hipStream_t st) {
   if (n_rows == 0) return;
-  uint64_t total = n_rows * (stride / 4);
+  uint64_t total = n_rows * ((byte_off + row_bytes + 3) / 4 - byte_off / 4);
   unsigned blocks = (unsigned)((total + 255) / 256 > 65536 ? 65536 : (total + 255) / 256);
-  hipLaunchKernelGGL(k_repack, dim3(blocks), dim3(256), 0, st, src, dst, n_rows, row_bytes, stride);
+  hipLaunchKernelGGL(k_repack, dim3(blocks), dim3(256), 0, st, src, dst, n_rows, row_bytes, stride, byte_off);
 }
 
 __global__ void k_gather_rows(const uint8_t* __restrict__ rows, uint32_t stride, uint32_t row_bytes, const uint64_t* __restrict__ idx,
@@ -75,17 +82,22 @@ __device__ __forceinline__ uint64_t bernoulli64(uint64_t key, uint64_t c, uint32
   return acc;
 }
 
-__global__ void k_synth_fill(uint8_t* __restrict__ rows, uint64_t n_rows, uint32_t stride, uint32_t ncols, uint64_t key, uint32_t p8) {
-  const uint32_t qpr = stride / 8;  // qwords per row
-  const uint64_t total = n_rows * qpr;
+// `rows` = the block's first byte inside its group's rows (row pitch `stride`); the bits depend on (key, row, qword of the block's
+// own padded row) only, so a block holds the same bits however it is grouped with others.  own_stride = the block's row
+// padded as if it stood alone.
+__global__ void k_synth_fill(uint8_t* __restrict__ rows, uint64_t n_rows, uint32_t stride, uint32_t own_stride, uint32_t ncols, uint64_t key, uint32_t p8) {
+  const uint32_t qpr = own_stride / 8;  // qwords per row of the block
+  const uint32_t row_bytes = (ncols + 7) / 8;
+  const uint32_t qused = (row_bytes + 7) / 8;
+  const uint64_t total = n_rows * qused;
+  const bool aligned = ((uintptr_t)rows & 7) == 0 && (stride & 7) == 0;
   for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (uint64_t)gridDim.x * blockDim.x) {
-    const uint64_t row = i / qpr;
-    const uint32_t qw = (uint32_t)(i % qpr);
-    uint64_t v = bernoulli64(key, i, p8);
+    const uint64_t row = i / qused;
+    const uint32_t qw = (uint32_t)(i % qused);
+    uint64_t v = bernoulli64(key, row * qpr + qw, p8);
     // zero the bits of columns >= ncols (padding columns never match: :7466 scans them but count is 0)
     const uint32_t col0 = qw * 64;
-    if (col0 >= ncols) v = 0;
-    else if (col0 + 64 > ncols) {
+    if (col0 + 64 > ncols) {
       uint64_t m = 0;
       for (uint32_t c = col0; c < ncols; c++) {
         const uint32_t byte = (c - col0) >> 3, bit = 7 - ((c - col0) & 7);
@@ -93,14 +105,17 @@ __global__ void k_synth_fill(uint8_t* __restrict__ rows, uint64_t n_rows, uint32
       }
       v &= m;
     }
-    reinterpret_cast<uint64_t*>(rows + row * stride)[qw] = v;
+    uint8_t* d = rows + row * stride + (uint64_t)qw * 8;
+    if (aligned && qw * 8 + 8 <= row_bytes) *reinterpret_cast<uint64_t*>(d) = v;
+    else
+      for (uint32_t t = 0; t < 8 && qw * 8 + t < row_bytes; t++) d[t] = (uint8_t)(v >> (8 * t));
   }
 }
 
-void launch_synth_fill(uint8_t* rows, uint64_t n_rows, uint32_t stride, uint32_t ncols, uint64_t key, uint32_t p8, hipStream_t st) {
-  uint64_t total = n_rows * (stride / 8);
+void launch_synth_fill(uint8_t* rows, uint64_t n_rows, uint32_t stride, uint32_t own_stride, uint32_t ncols, uint64_t key, uint32_t p8, hipStream_t st) {
+  uint64_t total = n_rows * (((ncols + 7) / 8 + 7) / 8);
   unsigned blocks = (unsigned)((total + 255) / 256 > 262144 ? 262144 : (total + 255) / 256);
-  hipLaunchKernelGGL(k_synth_fill, dim3(blocks), dim3(256), 0, st, rows, n_rows, stride, ncols, key, p8);
+  hipLaunchKernelGGL(k_synth_fill, dim3(blocks), dim3(256), 0, st, rows, n_rows, stride, own_stride, ncols, key, p8);
 }
 
 // sigs[h % NumSigs] |= 1 << (7 - col%8)  (index.go:1157) for a list of hashes
@@ -111,9 +126,9 @@ __global__ void k_plant(BlockDev bd, uint32_t col, int num_hashes, const uint64_
     for (int t = 0; t < num_hashes; t++) {
       const uint64_t hv = num_hashes == 1 ? h : (uint64_t)(uint32_t)(ha + hb * (uint32_t)t);
       const uint64_t row = fastmod_u64(hv, bd.num_sigs, bd.magic_hi, bd.magic_lo);
-      const uint64_t byte = row * bd.stride + (col >> 3);
-      uint32_t* w = reinterpret_cast<uint32_t*>(const_cast<uint8_t*>(bd.rows) + (byte & ~3ULL));
-      atomicOr(w, (uint32_t)(1u << (7 - (col & 7))) << (8 * (byte & 3)));
+      // bd.rows is the block's first byte inside its group's row: any alignment
+      const uintptr_t byte = (uintptr_t)bd.rows + row * bd.stride + (col >> 3);
+      atomicOr(reinterpret_cast<uint32_t*>(byte & ~(uintptr_t)3), (uint32_t)(1u << (7 - (col & 7))) << (8 * (byte & 3)));
     }
   }
 }
@@ -147,9 +162,8 @@ __global__ void __launch_bounds__(256) k_plant_reads(const BlockDev* __restrict_
       for (int t = 0; t < num_hashes; t++) {
         const uint64_t hv = num_hashes == 1 ? h : (uint64_t)(uint32_t)(ha + hb * (uint32_t)t);
         const uint64_t row = fastmod_u64(hv, bd.num_sigs, bd.magic_hi, bd.magic_lo);
-        const uint64_t byte = row * bd.stride + (col >> 3);
-        uint32_t* w = reinterpret_cast<uint32_t*>(const_cast<uint8_t*>(bd.rows) + (byte & ~3ULL));
-        atomicOr(w, (uint32_t)(1u << (7 - (col & 7))) << (8 * (byte & 3)));
+        const uintptr_t byte = (uintptr_t)bd.rows + row * bd.stride + (col >> 3);
+        atomicOr(reinterpret_cast<uint32_t*>(byte & ~(uintptr_t)3), (uint32_t)(1u << (7 - (col & 7))) << (8 * (byte & 3)));
       }
     }
   }

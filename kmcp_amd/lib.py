@@ -60,7 +60,7 @@ class Result(C.Structure):
 class SynthSpec(C.Structure):
     _fields_ = [("k", C.c_int32), ("num_hashes", C.c_int32), ("fpr", C.c_double), ("n_blocks", C.c_uint32),
                 ("cols_per_block", C.c_uint32), ("num_sigs", C.c_uint64), ("kmers_per_col", C.c_uint64), ("seed", C.c_uint64),
-                ("scale", C.c_uint32), ("syncmer_s", C.c_uint32), ("minimizer_w", C.c_uint32), ("reserved", C.c_uint32)]
+                ("scale", C.c_uint32), ("syncmer_s", C.c_uint32), ("minimizer_w", C.c_uint32), ("sigs_step", C.c_uint32)]
 
 
 class BuildCfg(C.Structure):
