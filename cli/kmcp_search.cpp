@@ -756,11 +756,11 @@ int main(int argc, char** argv) {
           const uint64_t qidx = b->first_idx + i;
           const uint64_t m0 = r.match_offs[i], m1 = r.match_offs[i + 1];
           if (m0 == m1) {
-            if (o.keep_unmatched) F.unmatched(buf, b->id(i), r.qlen[i], r.qkmers[i], r.k, qidx);
+            if (o.keep_unmatched) F.unmatched(buf, b->id(i), r.qlen[i], r.qkmers[i], r.ksize[i], qidx);
             continue;
           }
           part_matched[(size_t)pi]++;
-          for (uint64_t j = m0; j < m1; j++) F.row(buf, b->id(i), r.qlen[i], r.qkmers[i], m1 - m0, target[r.matches[j].col], r.matches[j], r.k, qidx);
+          for (uint64_t j = m0; j < m1; j++) F.row(buf, b->id(i), r.qlen[i], r.qkmers[i], m1 - m0, target[r.matches[j].col], r.matches[j], r.ksize[i], qidx);
         }
         if (out.gz()) buf = gzip_member(buf);
       };

@@ -10,7 +10,8 @@
  * available from kmcpg_last_error() (thread-local).  No exception or abort crosses the ABI.  Input
  * buffers are borrowed for the duration of the call only; buffers returned inside kmcpg_result are
  * owned by the library and released by kmcpg_result_free().  A kmcpg_db may be used from several OS
- * threads; calls on one handle are serialised internally.
+ * threads: the enqueueing of GPU work on one handle is serialised internally, and consecutive kmcpg_query_device calls
+ * on different streams are ordered by an event (they share the handle's k-mer workspace), so they never overlap on the GPU.
  */
 #ifndef KMCP_GPU_H
 #define KMCP_GPU_H
@@ -29,6 +30,7 @@ extern "C" {
 #define KMCPG_EDEVICE (-4)  /* HIP error, no GPU */
 #define KMCPG_ENOMEM (-5)
 #define KMCPG_EUNSUPPORTED (-6)
+#define KMCPG_EBUSY (-7)    /* kmcpg_submit: every lane of the handle is in flight */
 
 typedef struct kmcpg_db kmcpg_db;
 
@@ -76,6 +78,9 @@ typedef struct {
   int32_t do_not_sort;     /* -S */
   int32_t top_n_scores;    /* -n/--keep-top-scores */
   int32_t fpr_buf_size;    /* 249 single-end / 499 paired-end (search.go:250-255); 0 = pick */
+  int32_t k;               /* 0 = the database's k-mer sizes, largest first, smaller ones for queries that matched nothing
+                              (util-db-search.go:764, :1016-1022); > 0 = this size only (must be one of the database's) */
+  int32_t reserved;
 } kmcpg_params;
 
 /* One (read, reference chunk) pair that passed the integer thresholds on the GPU:
@@ -102,6 +107,8 @@ typedef struct {
   int32_t k;
   int32_t* qlen;         /* [n_reads] QueryLen (read1+read2 for paired-end; the searched mate after --try-se) */
   int32_t* qkmers;       /* [n_reads] NumKmers (0 when the query was not searched) */
+  int32_t* ksize;        /* [n_reads] QueryResult.K: the k-mer size the query was last searched with (differs from `k` only in
+                            databases with several k-mer sizes) */
   uint64_t* match_offs;  /* [n_reads+1] */
   kmcpg_match* matches;  /* [match_offs[n_reads]] sorted as handleQuerySingleDB does (:273-282) */
   void* owner;           /* internal */
@@ -128,6 +135,19 @@ int kmcpg_col_info(const kmcpg_db* db, uint32_t col, const char** name, uint32_t
 int kmcpg_search_batch(kmcpg_db* db, const uint8_t* seqs, const uint64_t* offs, const uint8_t* seqs2,
                        const uint64_t* offs2, uint32_t n_reads, const kmcpg_params* params, kmcpg_result* out);
 void kmcpg_result_free(kmcpg_result* r);
+
+/* -- the same pipeline, asynchronous: the reference keeps 30 x threads queries in flight (util-db-search.go:243, :347-351);
+ *    here a few BATCHES are.  kmcpg_submit copies the batch into pinned staging (the caller's buffers are free again when it
+ *    returns), enqueues H2D copy, kernels and D2H copy on the handle's private stream and returns.  It never blocks: with all
+ *    lanes (KMCPG_INFLIGHT, default 4) in flight it fails with KMCPG_EBUSY and the caller waits for one of its tickets first
+ *    (kmcpg_search_batch waits for a lane instead, so a thread must not call it while it holds every lane itself).  kmcpg_wait blocks until that batch's GPU work is done and runs the host half
+ *    (float64 thresholds, FPR, sorting; --try-se / smaller-k retries) on the calling thread while later batches occupy the GPU.
+ *    Tickets may be waited for in any order and from any thread; kmcpg_wait consumes the ticket, also when it fails.
+ *    kmcpg_search_batch(...) == kmcpg_submit(...) + kmcpg_wait(...). */
+typedef struct kmcpg_ticket kmcpg_ticket;
+int kmcpg_submit(kmcpg_db* db, const uint8_t* seqs, const uint64_t* offs, const uint8_t* seqs2, const uint64_t* offs2,
+                 uint32_t n_reads, const kmcpg_params* params, kmcpg_ticket** out);
+int kmcpg_wait(kmcpg_ticket* ticket, kmcpg_result* out);
 
 /* -- the GPU half only (k-mer generation + COBS query on the local blocks), device-resident in and
  *    out: generateKmers (util-db-search.go:1037-1107) + dedup (:874-908) + the UnikIndex workers

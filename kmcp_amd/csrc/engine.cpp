@@ -358,7 +358,12 @@ extern "C" int kmcpg_open(const char* db_dir, const kmcpg_opts* opts, kmcpg_db**
   DbYml y;
   std::string e = read_db_yml(dir + "/__db.yml", &y);
   if (!e.empty()) return kmcpg_fail(e.find("open") != std::string::npos ? KMCPG_EIO : KMCPG_EFORMAT, "%s", e.c_str());
-  int k = y.ks.empty() ? y.k : *std::max_element(y.ks.begin(), y.ks.end());
+  // a database may hold several k-mer sizes (`ks`); queries start with the largest and fall back to smaller ones
+  // (util-db-search.go:752-758, :1016-1022); the .uniki headers carry the largest (:690)
+  db->ks_desc = y.ks.empty() ? std::vector<int>{y.k} : y.ks;
+  std::sort(db->ks_desc.begin(), db->ks_desc.end(), [](int a, int b) { return a > b; });
+  db->ks_desc.erase(std::unique(db->ks_desc.begin(), db->ks_desc.end()), db->ks_desc.end());
+  int k = db->ks_desc[0];
   kmcpg_info& I = db->info;
   I.k = k;
   I.canonical = y.canonical;
@@ -422,6 +427,7 @@ extern "C" int kmcpg_open_synthetic(const kmcpg_synth_spec* s, const kmcpg_opts*
   I.minimizer = s->minimizer_w > 0;
   I.minimizer_w = s->minimizer_w;
   I.fpr = s->fpr;
+  db->ks_desc.assign(1, s->k);
   uint32_t base = 0;
   char name[64];
   for (uint32_t i = 0; i < s->n_blocks; i++) {
@@ -492,14 +498,8 @@ extern "C" int kmcpg_close(kmcpg_db* db) {
   db->w_long_counts.release();
   db->w_huge_info.release();
   db->w_huge_temp.release();
-  db->s_seqs.release();
-  db->s_seqs2.release();
-  db->s_offs.release();
-  db->s_offs2.release();
-  db->s_counter.release();
-  db->s_hits.release();
-  db->s_qk.release();
-  db->s_ql.release();
+  kmcpg::async_release(db);
+  if (db->ws_ev) (void)hipEventDestroy(db->ws_ev);
   for (auto& ev : db->ev)
     if (ev) (void)hipEventDestroy(ev);
   delete db;

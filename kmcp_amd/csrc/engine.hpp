@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <condition_variable>
 #include <memory>
 #include <mutex>
 #include <string>
@@ -82,6 +83,11 @@ struct DevBuf {
 
 }  // namespace kmcpg
 
+namespace kmcpg {
+struct AsyncState;
+void async_release(kmcpg_db* db);  // host.cpp
+}  // namespace kmcpg
+
 struct kmcpg_db {
   kmcpg_opts opts{};
   kmcpg_info info{};
@@ -97,20 +103,18 @@ struct kmcpg_db {
   std::vector<kmcpg::SlotClass> classes;
   std::vector<uint32_t> col_block;  // global column -> block index
   std::unique_ptr<kmcpg::QueryFpr> fpr;
-  std::mutex mu;      // guards the device workspace of one GPU-half call
-  std::mutex api_mu;  // serialises the GPU halves of kmcpg_search_batch callers (they share the staging buffers); the host
-                      // half (kmcpg_finalize) runs outside it, so two callers overlap one's finalize with the other's kernels
+  std::mutex mu;      // serialises the enqueueing of GPU-half calls (their kernels share the workspace below, in stream order;
+                      // calls on different streams are ordered by ws_ev)
+  hipEvent_t ws_ev = nullptr;  // recorded at the end of every kmcpg_query_device: the next call's stream waits for it
+  bool ws_ev_valid = false;
+  std::vector<int> ks_desc;    // k-mer sizes of the database, descending (`ks` of __db.yml; one entry for most databases)
+  kmcpg::AsyncState* async = nullptr;  // lanes + stream of kmcpg_submit/kmcpg_wait (host.cpp), created on first use
   // workspace of kmcpg_query_device
   kmcpg::DevBuf<uint64_t> w_hashes, w_scratch;
   kmcpg::DevBuf<int32_t> w_nk_raw, w_nk1, w_seg_cnt;
   kmcpg::DevBuf<uint32_t> w_long_list, w_long_meta, w_long_counts;  // long-query (split) path
   kmcpg::DevBuf<uint64_t> w_huge_info;                             // whole-genome queries: (read, n, offset)
   kmcpg::DevBuf<uint8_t> w_huge_temp;                              // hipCUB temporary storage
-  // workspace of kmcpg_search_batch
-  kmcpg::DevBuf<uint8_t> s_seqs, s_seqs2;
-  kmcpg::DevBuf<uint64_t> s_offs, s_offs2, s_counter;
-  kmcpg::DevBuf<kmcpg_hit> s_hits;
-  kmcpg::DevBuf<int32_t> s_qk, s_ql;
   bool synthetic = false;
   // in-process multi-GPU front handle (kmcpg_open_devices): metadata only itself, one resident shard handle per device
   std::vector<kmcpg_db*> shards;
@@ -150,7 +154,7 @@ struct NoInitAlloc : std::allocator<T> {
 typedef std::vector<kmcpg_match, NoInitAlloc<kmcpg_match>> MatchVec;
 
 struct ResultOwner {
-  std::vector<int32_t> qlen, qkmers;
+  std::vector<int32_t> qlen, qkmers, ksize;
   std::vector<uint64_t> offs;
   MatchVec matches;
 };

@@ -49,7 +49,7 @@ ResultOwner* take_owner() {
 }
 
 void give_owner(ResultOwner* o) {
-  const size_t bytes = o->matches.capacity() * sizeof(kmcpg_match) + (o->qlen.capacity() + o->qkmers.capacity()) * 4 + o->offs.capacity() * 8;
+  const size_t bytes = o->matches.capacity() * sizeof(kmcpg_match) + (o->qlen.capacity() + o->qkmers.capacity() + o->ksize.capacity()) * 4 + o->offs.capacity() * 8;
   {
     std::lock_guard<std::mutex> g(g_owner_mu);
     if (g_owner_pool.size() < 4 && bytes <= (1ull << 30)) {
@@ -85,6 +85,8 @@ extern "C" int kmcpg_finalize(const kmcpg_db* db, const kmcpg_hit* hits, uint64_
   std::unique_ptr<ResultOwner, OwnerReturn> o(take_owner());
   o->qlen.assign(qlen, qlen + n_reads);
   o->qkmers.assign(qkmers, qkmers + n_reads);
+  const int k_used = p.k > 0 ? p.k : db->info.k;
+  o->ksize.assign(n_reads, k_used);
   // scratch of this thread, kept between calls (a caller thread finalizes batch after batch)
   static thread_local std::vector<uint64_t> start, cur, per_read;
   static thread_local std::vector<kmcpg_hit, NoInitAlloc<kmcpg_hit>> sorted;
@@ -205,9 +207,10 @@ extern "C" int kmcpg_finalize(const kmcpg_db* db, const kmcpg_hit* hits, uint64_
   o->offs[0] = 0;
   for (uint32_t r = 0; r < n_reads; r++) o->offs[r + 1] = o->offs[r] + per_read[r];
   out->n_reads = n_reads;
-  out->k = db->info.k;
+  out->k = k_used;
   out->qlen = o->qlen.data();
   out->qkmers = o->qkmers.data();
+  out->ksize = o->ksize.data();
   out->match_offs = o->offs.data();
   out->matches = o->matches.data();
   out->owner = o.release();

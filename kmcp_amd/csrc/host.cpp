@@ -12,6 +12,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <condition_variable>
 #include <memory>
 #include <mutex>
 #include <string>
@@ -28,89 +29,466 @@
 using namespace kmcpg;
 
 // ------------------------------------------------------------------------------------------------
-// whole pipeline on host buffers
+// whole pipeline on host buffers: kmcpg_submit / kmcpg_wait, kmcpg_search_batch = submit + wait
+//
+// A handle owns a private non-blocking stream and a few LANES; a lane is the staging of one batch in flight (pinned host
+// input and output buffers, device input and output buffers, a completion event).  kmcpg_submit copies the caller's batch
+// into a free lane, enqueues H2D + K1 + K2 + D2H on the stream and returns; kmcpg_wait waits for the lane's event and runs
+// the host half (float64 thresholds, FPR, sort) on the calling thread, so the GPU works on the next batches meanwhile.
+// The number of lanes bounds the batches in flight the way the reference's token channel bounds its queries
+// (util-db-search.go:243, :347-351).  Retries (--try-se, smaller k of a multi-k database) are rare, small and synchronous;
+// they run on a lane of their own so that they never wait for a lane another waiter holds.
 // ------------------------------------------------------------------------------------------------
-namespace {
+namespace kmcpg {
 
-struct RawBatch {
-  std::vector<kmcpg_hit> hits;
-  std::vector<int32_t> qk, ql;
+template <typename T>
+struct PinBuf {
+  T* p = nullptr;
+  size_t cap = 0;
+  int ensure(size_t n) {
+    if (n <= cap) return 0;
+    if (p) (void)hipHostFree(p);
+    p = nullptr;
+    cap = 0;
+    const size_t want = n + n / 8 + 64;
+    if (hipHostMalloc((void**)&p, want * sizeof(T), hipHostMallocPortable) != hipSuccess) return -1;
+    cap = want;
+    return 0;
+  }
+  void release() {
+    if (p) (void)hipHostFree(p);
+    p = nullptr;
+    cap = 0;
+  }
 };
 
-int run_raw(kmcpg_db* db, const uint8_t* seqs, const uint64_t* offs, const uint8_t* seqs2, const uint64_t* offs2, uint32_t n, const kmcpg_params& p,
-            RawBatch* rb) {
-  rb->hits.clear();
-  rb->qk.assign(n, 0);
-  rb->ql.assign(n, 0);
-  if (n == 0) return 0;
-  const uint64_t tb1 = offs[n] - offs[0], tb2 = seqs2 ? offs2[n] - offs2[0] : 0;
-  if (offs[0] != 0 || (seqs2 && offs2[0] != 0)) return kmcpg_fail(KMCPG_EINVAL, "offs[0] must be 0");
+struct Lane {
+  PinBuf<uint8_t> h_seqs, h_seqs2;
+  PinBuf<uint64_t> h_offs, h_offs2, h_cnt;
+  PinBuf<int32_t> h_qk, h_ql;
+  PinBuf<kmcpg_hit> h_hits;
+  DevBuf<uint8_t> d_seqs, d_seqs2;
+  DevBuf<uint64_t> d_offs, d_offs2, d_cnt;
+  DevBuf<int32_t> d_qk, d_ql;
+  DevBuf<kmcpg_hit> d_hits;
+  hipEvent_t done = nullptr;
+  uint32_t n = 0;
+  bool paired = false;
+  uint64_t tb1 = 0, tb2 = 0;
   uint32_t maxlen = 0;
-  for (uint32_t i = 0; i < n; i++) {
-    uint64_t l = offs[i + 1] - offs[i];
-    if (seqs2) l = std::max<uint64_t>(l, offs2[i + 1] - offs2[i]);
-    if (l > 0x7fffffffULL) return kmcpg_fail(KMCPG_EUNSUPPORTED, "query longer than 2^31-1 bases");
-    maxlen = std::max<uint32_t>(maxlen, (uint32_t)l);
+  uint64_t copied = 0;  // hits already on their way to h_hits when `done` fires
+  bool busy = false;
+  void release() {
+    h_seqs.release(); h_seqs2.release(); h_offs.release(); h_offs2.release(); h_cnt.release(); h_qk.release(); h_ql.release(); h_hits.release();
+    d_seqs.release(); d_seqs2.release(); d_offs.release(); d_offs2.release(); d_cnt.release(); d_qk.release(); d_ql.release(); d_hits.release();
+    if (done) (void)hipEventDestroy(done);
+    done = nullptr;
   }
-  {
-    std::lock_guard<std::mutex> g(db->mu);
-    KMCPG_USE_DEVICE(db);
-    if (db->s_seqs.ensure(tb1 + 16) || db->s_offs.ensure(n + 1) || db->s_counter.ensure(2) || db->s_qk.ensure(n) || db->s_ql.ensure(n))
-      return kmcpg_fail(KMCPG_ENOMEM, "hipMalloc failed");
-    if (seqs2 && (db->s_seqs2.ensure(tb2 + 16) || db->s_offs2.ensure(n + 1))) return kmcpg_fail(KMCPG_ENOMEM, "hipMalloc failed");
-    HIPCHK(hipMemcpy(db->s_seqs.p, seqs, tb1, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(db->s_offs.p, offs, (size_t)(n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice));
-    if (seqs2) {
-      HIPCHK(hipMemcpy(db->s_seqs2.p, seqs2, tb2, hipMemcpyHostToDevice));
-      HIPCHK(hipMemcpy(db->s_offs2.p, offs2, (size_t)(n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice));
-    }
-  }
-  uint64_t cap = std::max<uint64_t>(db->s_hits.cap, (uint64_t)n * 8 + 1024);
-  for (int attempt = 0; attempt < 3; attempt++) {
-    {
-      std::lock_guard<std::mutex> g(db->mu);
-      if (db->s_hits.ensure(cap)) return kmcpg_fail(KMCPG_ENOMEM, "hipMalloc failed");
-    }
-    int rc = kmcpg_query_device(db, db->s_seqs.p, db->s_offs.p, seqs2 ? db->s_seqs2.p : nullptr, seqs2 ? db->s_offs2.p : nullptr, n, tb1 + tb2, maxlen, &p,
-                                db->s_hits.p, db->s_hits.cap, db->s_counter.p, db->s_qk.p, db->s_ql.p, nullptr);
-    if (rc) return rc;
-    uint64_t cnt = 0;
-    HIPCHK(hipMemcpy(&cnt, db->s_counter.p, sizeof cnt, hipMemcpyDeviceToHost));  // synchronises the default stream
-    if (cnt <= db->s_hits.cap) {
-      rb->hits.resize(cnt);
-      if (cnt) HIPCHK(hipMemcpy(rb->hits.data(), db->s_hits.p, cnt * sizeof(kmcpg_hit), hipMemcpyDeviceToHost));
-      HIPCHK(hipMemcpy(rb->qk.data(), db->s_qk.p, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost));
-      HIPCHK(hipMemcpy(rb->ql.data(), db->s_ql.p, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost));
-      return 0;
-    }
-    cap = cnt + cnt / 4;  // buffer was too small: rerun with room for every hit
-  }
-  return kmcpg_fail(KMCPG_ENOMEM, "hit buffer overflow");
+};
+
+struct AsyncState {
+  hipStream_t stream = nullptr;
+  std::vector<std::unique_ptr<Lane>> lanes;
+  size_t max_lanes = 4;
+  std::mutex mu;
+  std::condition_variable cv;
+  Lane retry;
+  std::mutex retry_mu;
+};
+
+void async_release(kmcpg_db* db) {
+  if (!db->async) return;
+  if (db->opts.device >= 0) (void)hipSetDevice(db->opts.device);
+  if (db->async->stream) (void)hipStreamSynchronize(db->async->stream);
+  for (auto& l : db->async->lanes) l->release();
+  db->async->retry.release();
+  if (db->async->stream) (void)hipStreamDestroy(db->async->stream);
+  delete db->async;
+  db->async = nullptr;
 }
 
-// all resident shards of a multi-device handle search the batch concurrently (one host thread per GPU); the hit lists are
-// concatenated exactly as the reference concatenates the replies of its per-block workers (:946-964)
-int run_raw_any(kmcpg_db* db, const uint8_t* seqs, const uint64_t* offs, const uint8_t* seqs2, const uint64_t* offs2, uint32_t n, const kmcpg_params& p,
-                RawBatch* rb) {
-  if (db->shards.empty()) return run_raw(db, seqs, offs, seqs2, offs2, n, p, rb);
-  const size_t S = db->shards.size();
-  std::vector<RawBatch> parts(S);
-  std::vector<int> rcs(S, 0);
-  std::vector<std::string> errs(S);
-  std::vector<std::thread> th;
-  for (size_t i = 0; i < S; i++)
-    th.emplace_back([&, i] {
-      rcs[i] = run_raw(db->shards[i], seqs, offs, seqs2, offs2, n, p, &parts[i]);
-      if (rcs[i]) errs[i] = kmcpg_err_ref();  // thread-local message of the worker
-    });
-  for (auto& t : th) t.join();
-  for (size_t i = 0; i < S; i++)
-    if (rcs[i]) return kmcpg_fail(rcs[i], "device %d: %s", db->shards[i]->opts.device, errs[i].c_str());
-  rb->qk = parts[0].qk;  // every shard generates the same k-mers
-  rb->ql = parts[0].ql;
-  rb->hits.clear();
-  for (auto& pt : parts) rb->hits.insert(rb->hits.end(), pt.hits.begin(), pt.hits.end());
+}  // namespace kmcpg
+
+// one batch in flight; single-device handles have one part, kmcpg_open_devices handles one part per GPU
+struct kmcpg_ticket {
+  kmcpg_db* db = nullptr;
+  struct Part {
+    kmcpg_db* shard;
+    Lane* lane;
+    bool retry;
+  };
+  std::vector<Part> parts;
+  uint32_t n = 0;
+  bool paired = false;
+  kmcpg_params p{};
+};
+
+namespace {
+
+int async_state(kmcpg_db* db, AsyncState** out) {
+  static std::mutex init_mu;
+  std::lock_guard<std::mutex> g(init_mu);
+  if (!db->async) {
+    std::unique_ptr<AsyncState> a(new AsyncState());
+    HIPCHK(hipSetDevice(db->opts.device));
+    HIPCHK(hipStreamCreateWithFlags(&a->stream, hipStreamNonBlocking));
+    if (const char* e = getenv("KMCPG_INFLIGHT")) a->max_lanes = (size_t)std::max(1, std::min(atoi(e), 16));
+    db->async = a.release();
+  }
+  *out = db->async;
   return 0;
+}
+
+// block = false: nullptr when every lane is in flight (kmcpg_submit never blocks: a caller that submits from one thread
+// would otherwise wait for itself); block = true: wait for a lane (kmcpg_search_batch: whoever holds a lane through it gives
+// it back without needing another one)
+Lane* acquire_lane(AsyncState* A, bool retry, bool block) {
+  if (retry) {
+    A->retry_mu.lock();
+    return &A->retry;
+  }
+  std::unique_lock<std::mutex> g(A->mu);
+  for (;;) {
+    for (auto& l : A->lanes)
+      if (!l->busy) {
+        l->busy = true;
+        return l.get();
+      }
+    if (A->lanes.size() < A->max_lanes) {
+      A->lanes.emplace_back(new Lane());
+      A->lanes.back()->busy = true;
+      return A->lanes.back().get();
+    }
+    if (!block) return nullptr;
+    A->cv.wait(g);
+  }
+}
+
+void release_lane(AsyncState* A, Lane* l, bool retry) {
+  if (retry) {
+    A->retry_mu.unlock();
+    return;
+  }
+  {
+    std::lock_guard<std::mutex> g(A->mu);
+    l->busy = false;
+  }
+  A->cv.notify_one();
+}
+
+void par_memcpy(void* dst, const void* src, size_t n) {
+  const size_t kMin = 8u << 20;
+  if (n < 2 * kMin) {
+    memcpy(dst, src, n);
+    return;
+  }
+  const size_t T = std::min<size_t>(4, n / kMin);
+  std::vector<std::thread> th;
+  for (size_t t = 1; t < T; t++) th.emplace_back([=] { memcpy((char*)dst + n * t / T, (const char*)src + n * t / T, n * (t + 1) / T - n * t / T); });
+  memcpy(dst, src, n / T);
+  for (auto& t : th) t.join();
+}
+
+// caller's batch -> the lane's pinned buffers (the caller may reuse its buffers as soon as kmcpg_submit returns)
+int stage(Lane* L, const uint8_t* seqs, const uint64_t* offs, const uint8_t* seqs2, const uint64_t* offs2, uint32_t n) {
+  L->n = n;
+  L->paired = seqs2 != nullptr;
+  L->tb1 = L->tb2 = 0;
+  L->maxlen = 0;
+  L->copied = 0;
+  if (n == 0) return 0;
+  if (offs[0] != 0 || (seqs2 && offs2[0] != 0)) return kmcpg_fail(KMCPG_EINVAL, "offs[0] must be 0");
+  uint64_t maxlen = 0;
+  for (uint32_t i = 0; i < n; i++) {
+    if (offs[i + 1] < offs[i] || (seqs2 && offs2[i + 1] < offs2[i])) return kmcpg_fail(KMCPG_EINVAL, "offsets must not decrease (read %u)", i);
+    maxlen = std::max(maxlen, offs[i + 1] - offs[i]);
+    if (seqs2) maxlen = std::max(maxlen, offs2[i + 1] - offs2[i]);
+  }
+  if (maxlen > 0x7fffffffULL) return kmcpg_fail(KMCPG_EUNSUPPORTED, "query longer than 2^31-1 bases");
+  L->maxlen = (uint32_t)maxlen;
+  L->tb1 = offs[n];
+  L->tb2 = seqs2 ? offs2[n] : 0;
+  if (L->h_seqs.ensure(L->tb1 + 16) || L->h_offs.ensure((size_t)n + 1) || (seqs2 && (L->h_seqs2.ensure(L->tb2 + 16) || L->h_offs2.ensure((size_t)n + 1))))
+    return kmcpg_fail(KMCPG_ENOMEM, "hipHostMalloc failed");
+  par_memcpy(L->h_seqs.p, seqs, L->tb1);
+  par_memcpy(L->h_offs.p, offs, ((size_t)n + 1) * sizeof(uint64_t));
+  if (seqs2) {
+    par_memcpy(L->h_seqs2.p, seqs2, L->tb2);
+    par_memcpy(L->h_offs2.p, offs2, ((size_t)n + 1) * sizeof(uint64_t));
+  }
+  return 0;
+}
+
+int enqueue_query(kmcpg_db* db, AsyncState* A, Lane* L, const kmcpg_params& p) {
+  hipStream_t st = A->stream;
+  int rc = kmcpg_query_device(db, L->d_seqs.p, L->d_offs.p, L->paired ? L->d_seqs2.p : nullptr, L->paired ? L->d_offs2.p : nullptr, L->n, L->tb1 + L->tb2,
+                              L->maxlen, &p, L->d_hits.p, L->d_hits.cap, L->d_cnt.p, L->d_qk.p, L->d_ql.p, st);
+  if (rc) return rc;
+  HIPCHK(hipMemcpyAsync(L->h_cnt.p, L->d_cnt.p, 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+  return 0;
+}
+
+// H2D + K1 + K2 + D2H of one staged lane on the handle's stream; returns without waiting
+int enqueue(kmcpg_db* db, AsyncState* A, Lane* L, const kmcpg_params& p) {
+  KMCPG_USE_DEVICE(db);
+  if (!L->done) HIPCHK(hipEventCreateWithFlags(&L->done, hipEventDisableTiming));
+  const uint32_t n = L->n;
+  if (n == 0) return 0;
+  hipStream_t st = A->stream;
+  const uint64_t cap = std::max<uint64_t>(L->d_hits.cap, (uint64_t)n * 8 + 1024);
+  const uint64_t first = std::min<uint64_t>(cap, (uint64_t)n * 2 + 1024);  // ~1 hit per read is typical: the rest is fetched in kmcpg_wait if needed
+  if (L->d_seqs.ensure(L->tb1 + 16) || L->d_offs.ensure((size_t)n + 1) || L->d_cnt.ensure(2) || L->d_qk.ensure(n) || L->d_ql.ensure(n) || L->d_hits.ensure(cap) ||
+      (L->paired && (L->d_seqs2.ensure(L->tb2 + 16) || L->d_offs2.ensure((size_t)n + 1))))
+    return kmcpg_fail(KMCPG_ENOMEM, "hipMalloc failed");
+  if (L->h_cnt.ensure(2) || L->h_qk.ensure(n) || L->h_ql.ensure(n) || L->h_hits.ensure(first)) return kmcpg_fail(KMCPG_ENOMEM, "hipHostMalloc failed");
+  if (L->tb1) HIPCHK(hipMemcpyAsync(L->d_seqs.p, L->h_seqs.p, L->tb1, hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemcpyAsync(L->d_offs.p, L->h_offs.p, ((size_t)n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, st));
+  if (L->paired) {
+    if (L->tb2) HIPCHK(hipMemcpyAsync(L->d_seqs2.p, L->h_seqs2.p, L->tb2, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(L->d_offs2.p, L->h_offs2.p, ((size_t)n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, st));
+  }
+  int rc = enqueue_query(db, A, L, p);
+  if (rc) return rc;
+  HIPCHK(hipMemcpyAsync(L->h_qk.p, L->d_qk.p, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+  HIPCHK(hipMemcpyAsync(L->h_ql.p, L->d_ql.p, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+  L->copied = std::min<uint64_t>(first, L->d_hits.cap);
+  HIPCHK(hipMemcpyAsync(L->h_hits.p, L->d_hits.p, L->copied * sizeof(kmcpg_hit), hipMemcpyDeviceToHost, st));
+  HIPCHK(hipEventRecord(L->done, st));
+  return 0;
+}
+
+// waits for the lane; afterwards h_hits[0..*n_hits), h_qk, h_ql are complete
+int collect(kmcpg_db* db, AsyncState* A, Lane* L, const kmcpg_params& p, uint64_t* n_hits) {
+  *n_hits = 0;
+  if (L->n == 0) return 0;
+  KMCPG_USE_DEVICE(db);
+  HIPCHK(hipEventSynchronize(L->done));
+  uint64_t cnt = L->h_cnt.p[0];
+  for (int attempt = 0; cnt > L->d_hits.cap; attempt++) {  // the hit buffer was too small: rerun with room for every hit
+    if (attempt == 2) return kmcpg_fail(KMCPG_ENOMEM, "hit buffer overflow");
+    HIPCHK(hipStreamSynchronize(A->stream));
+    if (L->d_hits.ensure(cnt + cnt / 4)) return kmcpg_fail(KMCPG_ENOMEM, "hipMalloc failed");
+    int rc = enqueue_query(db, A, L, p);
+    if (rc) return rc;
+    HIPCHK(hipStreamSynchronize(A->stream));
+    cnt = L->h_cnt.p[0];
+    L->copied = 0;
+  }
+  // the k-mer count the counter planes were sized for (the longest read) bounds every query's NumKmers
+  const uint64_t bound = (uint64_t)L->maxlen * (L->paired ? 2 : 1);
+  if (L->h_cnt.p[1] > bound) return kmcpg_fail(KMCPG_EDEVICE, "internal: a query reported %llu k-mers, more than its length allows", (unsigned long long)L->h_cnt.p[1]);
+  if (cnt > L->copied) {
+    if (cnt > L->h_hits.cap) {
+      if (L->h_hits.ensure(cnt)) return kmcpg_fail(KMCPG_ENOMEM, "hipHostMalloc failed");
+      L->copied = 0;
+    }
+    HIPCHK(hipMemcpyAsync(L->h_hits.p + L->copied, L->d_hits.p + L->copied, (cnt - L->copied) * sizeof(kmcpg_hit), hipMemcpyDeviceToHost, A->stream));
+    HIPCHK(hipStreamSynchronize(A->stream));  // behind whatever later batches enqueued meanwhile: rare, bounded by the lanes
+    L->copied = cnt;
+  }
+  *n_hits = cnt;
+  return 0;
+}
+
+void drop_ticket(kmcpg_ticket* t, bool failed = false) {
+  for (auto& pt : t->parts) {
+    if (pt.shard->opts.device >= 0) (void)hipSetDevice(pt.shard->opts.device);
+    // the lane must be idle before someone else stages into it
+    if (failed && pt.shard->async && pt.shard->async->stream) (void)hipStreamSynchronize(pt.shard->async->stream);
+    else if (pt.lane->done && pt.lane->n) (void)hipEventSynchronize(pt.lane->done);
+    release_lane(pt.shard->async, pt.lane, pt.retry);
+  }
+  delete t;
+}
+
+int submit_impl(kmcpg_db* db, const uint8_t* seqs, const uint64_t* offs, const uint8_t* seqs2, const uint64_t* offs2, uint32_t n, const kmcpg_params& p, bool retry,
+                bool block, kmcpg_ticket** out) {
+  std::unique_ptr<kmcpg_ticket> t(new kmcpg_ticket());
+  t->db = db;
+  t->n = n;
+  t->paired = seqs2 != nullptr;
+  t->p = p;
+  std::vector<kmcpg_db*> targets = db->shards.empty() ? std::vector<kmcpg_db*>{db} : db->shards;
+  for (kmcpg_db* sh : targets) {
+    AsyncState* A = nullptr;
+    int rc = async_state(sh, &A);
+    if (rc) {
+      drop_ticket(t.release(), true);
+      return rc;
+    }
+    Lane* lane = acquire_lane(A, retry, block);
+    if (!lane) {
+      drop_ticket(t.release());
+      return kmcpg_fail(KMCPG_EBUSY, "all %zu lanes of this handle are in flight: kmcpg_wait for a ticket first (KMCPG_INFLIGHT)", A->max_lanes);
+    }
+    t->parts.push_back({sh, lane, retry});
+  }
+  // every GPU gets the whole batch (150 B per read; cheaper than moving k-mer hashes between GPUs)
+  std::vector<int> rcs(t->parts.size(), 0);
+  std::vector<std::string> errs(t->parts.size());
+  auto one = [&](size_t i) {
+    auto& pt = t->parts[i];
+    rcs[i] = stage(pt.lane, seqs, offs, seqs2, offs2, n);
+    if (rcs[i] == 0) rcs[i] = enqueue(pt.shard, pt.shard->async, pt.lane, p);
+    if (rcs[i]) errs[i] = kmcpg_err_ref();
+  };
+  if (t->parts.size() == 1) one(0);
+  else {
+    std::vector<std::thread> th;
+    for (size_t i = 0; i < t->parts.size(); i++) th.emplace_back(one, i);
+    for (auto& x : th) x.join();
+  }
+  for (size_t i = 0; i < rcs.size(); i++)
+    if (rcs[i]) {
+      const int rc = rcs[i];
+      const std::string msg = t->parts.size() > 1 ? "device " + std::to_string(t->parts[i].shard->opts.device) + ": " + errs[i] : errs[i];
+      drop_ticket(t.release(), true);
+      return kmcpg_fail(rc, "%s", msg.c_str());
+    }
+  *out = t.release();
+  return 0;
+}
+
+// raw results of a ticket -> finalized matches (host half).  The hit lists of the parts are concatenated exactly as the
+// reference concatenates the replies of its per-block workers (:946-964).
+int finish_raw(kmcpg_ticket* t, kmcpg_result* out) {
+  const kmcpg_hit* hits = nullptr;
+  uint64_t n_hits = 0;
+  static thread_local std::vector<kmcpg_hit, NoInitAlloc<kmcpg_hit>> merged;
+  if (t->parts.size() == 1) {
+    auto& pt = t->parts[0];
+    int rc = collect(pt.shard, pt.shard->async, pt.lane, t->p, &n_hits);
+    if (rc) return rc;
+    hits = pt.lane->h_hits.p;
+  } else {
+    merged.clear();
+    for (auto& pt : t->parts) {
+      uint64_t c = 0;
+      int rc = collect(pt.shard, pt.shard->async, pt.lane, t->p, &c);
+      if (rc) return kmcpg_fail(rc, "device %d: %s", pt.shard->opts.device, std::string(kmcpg_err_ref()).c_str());
+      merged.insert(merged.end(), pt.lane->h_hits.p, pt.lane->h_hits.p + c);
+    }
+    hits = merged.data();
+    n_hits = merged.size();
+  }
+  Lane* L0 = t->parts[0].lane;  // every shard generates the same k-mers
+  return kmcpg_finalize(t->db, hits, n_hits, t->n ? L0->h_qk.p : nullptr, t->n ? L0->h_ql.p : nullptr, t->n, &t->p, out);
+}
+
+// a small synchronous search on the retry lane(s): the sub-batches of --try-se and of the smaller k of multi-k databases
+int search_sync(kmcpg_db* db, const uint8_t* seqs, const uint64_t* offs, const uint8_t* seqs2, const uint64_t* offs2, uint32_t n, const kmcpg_params& p,
+                kmcpg_result* out) {
+  kmcpg_ticket* t = nullptr;
+  int rc = submit_impl(db, seqs, offs, seqs2, offs2, n, p, true, true, &t);
+  if (rc) return rc;
+  rc = finish_raw(t, out);
+  const std::string keep = rc ? kmcpg_err_ref() : std::string();
+  drop_ticket(t, rc != 0);
+  if (rc) kmcpg_err_ref() = keep;
+  return rc;
+}
+
+// What the reference does with a query that was searched but matched nothing (handleQuery, util-db-search.go:763-1025):
+// with --try-se the k-mers of read 1, then of read 2 are searched on their own (:831-850, :1001-1014; the length gate is not
+// applied again); if the database holds several k-mer sizes the whole procedure is repeated with the next smaller k
+// (:764, :1016-1022).  A query with fewer than MinMatched k-mers at any step is final (:854-869).
+int retry_unmatched(kmcpg_ticket* t, kmcpg_result* out) {
+  kmcpg_db* db = t->db;
+  const kmcpg_params& p = t->p;
+  const uint32_t n = t->n;
+  std::vector<int> ks = db->ks_desc;  // descending
+  if (p.k > 0) ks.assign(1, p.k);     // an explicit k: no walk over the database's sizes
+  const bool try_se = p.try_se && t->paired;
+  if (n == 0 || (!try_se && ks.size() < 2)) return 0;
+  ResultOwner* o = (ResultOwner*)out->owner;
+  Lane* L = t->parts[0].lane;  // the batch as staged
+  const uint8_t* S[2] = {L->h_seqs.p, t->paired ? L->h_seqs2.p : nullptr};
+  const uint64_t* O[2] = {L->h_offs.p, t->paired ? L->h_offs2.p : nullptr};
+  std::vector<char> final_(n, 0);
+  std::vector<uint32_t> todo;
+  std::vector<uint8_t> sub[2];
+  std::vector<uint64_t> so[2];
+  // splices the result of a sub-batch (queries `todo`) into the batch result
+  auto splice = [&](const kmcpg_result& r2, bool whole_query, int k) {
+    std::vector<uint64_t> noffs((size_t)n + 1, 0);
+    MatchVec nm;
+    size_t ti = 0;
+    for (uint32_t r = 0; r < n; r++) {
+      if (ti < todo.size() && todo[ti] == r) {
+        o->qlen[r] = r2.qlen[ti];
+        o->ksize[r] = k;
+        if (r2.qkmers[ti] > 0) o->qkmers[r] = r2.qkmers[ti];
+        else {
+          final_[r] = 1;  // fewer than MinMatched k-mers: the reference returns here (:854-869)
+          if (whole_query) o->qkmers[r] = 0;  // a fresh QueryResult: NumKmers never set (this build reports 0)
+        }
+        if (r2.match_offs[ti + 1] > r2.match_offs[ti]) final_[r] = 1;
+        nm.insert(nm.end(), r2.matches + r2.match_offs[ti], r2.matches + r2.match_offs[ti + 1]);
+        ti++;
+      } else {
+        nm.insert(nm.end(), o->matches.begin() + (ptrdiff_t)o->offs[r], o->matches.begin() + (ptrdiff_t)o->offs[r + 1]);
+      }
+      noffs[r + 1] = nm.size();
+    }
+    o->matches.swap(nm);
+    o->offs.swap(noffs);
+  };
+  // after the first pass: matched, or never searched (too short / fewer than MinMatched k-mers) => final
+  for (uint32_t r = 0; r < n; r++) final_[r] = (o->offs[r + 1] > o->offs[r]) || o->qkmers[r] <= 0;
+  int rc = 0;
+  for (size_t ik = 0; ik < ks.size() && rc == 0; ik++) {
+    if (ik > 0) {  // the whole query again with the next smaller k
+      todo.clear();
+      for (uint32_t r = 0; r < n; r++)
+        if (!final_[r]) todo.push_back(r);
+      if (todo.empty()) break;
+      for (int m = 0; m < 2; m++) {
+        sub[m].clear();
+        so[m].assign(1, 0);
+        if (!S[m]) continue;
+        for (uint32_t r : todo) {
+          sub[m].insert(sub[m].end(), S[m] + O[m][r], S[m] + O[m][r + 1]);
+          so[m].push_back(sub[m].size());
+        }
+      }
+      kmcpg_params q = p;
+      q.k = ks[ik];
+      q.try_se = 0;
+      kmcpg_result r2;
+      rc = search_sync(db, sub[0].data(), so[0].data(), S[1] ? sub[1].data() : nullptr, S[1] ? so[1].data() : nullptr, (uint32_t)todo.size(), q, &r2);
+      if (rc) break;
+      splice(r2, true, ks[ik]);
+      kmcpg_result_free(&r2);
+    }
+    if (!try_se) continue;
+    for (int mate = 0; mate < 2 && rc == 0; mate++) {
+      todo.clear();
+      for (uint32_t r = 0; r < n; r++)
+        if (!final_[r]) todo.push_back(r);
+      if (todo.empty()) break;
+      sub[0].clear();
+      so[0].assign(1, 0);
+      for (uint32_t r : todo) {
+        sub[0].insert(sub[0].end(), S[mate] + O[mate][r], S[mate] + O[mate][r + 1]);
+        so[0].push_back(sub[0].size());
+      }
+      kmcpg_params q = p;
+      q.k = ks[ik];
+      q.min_qlen = 0;  // the length gate was applied once, before k-mer generation
+      q.try_se = 0;
+      kmcpg_result r2;
+      rc = search_sync(db, sub[0].data(), so[0].data(), nullptr, nullptr, (uint32_t)todo.size(), q, &r2);
+      if (rc) break;
+      splice(r2, false, ks[ik]);
+      kmcpg_result_free(&r2);
+    }
+  }
+  out->qlen = o->qlen.data();
+  out->qkmers = o->qkmers.data();
+  out->ksize = o->ksize.data();
+  out->matches = o->matches.data();
+  out->match_offs = o->offs.data();
+  return rc;
 }
 
 }  // namespace
@@ -144,84 +522,47 @@ extern "C" int kmcpg_open_devices(const char* db_dir, const int32_t* devices, in
   return 0;
 }
 
-extern "C" int kmcpg_search_batch(kmcpg_db* db, const uint8_t* seqs, const uint64_t* offs, const uint8_t* seqs2, const uint64_t* offs2, uint32_t n_reads,
-                                  const kmcpg_params* params, kmcpg_result* out) {
+static int submit_checked(kmcpg_db* db, const uint8_t* seqs, const uint64_t* offs, const uint8_t* seqs2, const uint64_t* offs2, uint32_t n_reads,
+                          const kmcpg_params* params, bool block, kmcpg_ticket** out) {
   if (!db || !out || (n_reads && (!seqs || !offs))) return kmcpg_fail(KMCPG_EINVAL, "null argument");
+  *out = nullptr;
   if ((seqs2 == nullptr) != (offs2 == nullptr)) return kmcpg_fail(KMCPG_EINVAL, "seqs2 and offs2 must be given together");
   if (db->opts.shard_count != 1)
-    return kmcpg_fail(KMCPG_EINVAL, "kmcpg_search_batch needs the whole database: open it on one GPU or with kmcpg_open_devices; use kmcpg_query_device + kmcpg_finalize per shard");
-  kmcpg_params p = params ? *params : default_params();
-  memset(out, 0, sizeof *out);
-  RawBatch rb;
-  int rc;
-  {
-    std::lock_guard<std::mutex> api_guard(db->api_mu);
-    rc = run_raw_any(db, seqs, offs, seqs2, offs2, n_reads, p, &rb);
-  }
-  if (rc) return rc;
-  rc = kmcpg_finalize(db, rb.hits.data(), rb.hits.size(), rb.qk.data(), rb.ql.data(), n_reads, &p, out);
-  if (rc) return rc;
-  if (!(p.try_se && seqs2)) return 0;
+    return kmcpg_fail(KMCPG_EINVAL, "kmcpg_submit/kmcpg_search_batch need the whole database: open it on one GPU or with kmcpg_open_devices; use kmcpg_query_device + kmcpg_finalize per shard");
+  if (db->shards.empty() && db->opts.device < 0) return kmcpg_fail(KMCPG_EDEVICE, "metadata-only handle (device -1): no GPU work possible");
+  const kmcpg_params p = params ? *params : default_params();
+  if (p.min_matched < 1) return kmcpg_fail(KMCPG_EINVAL, "min_matched must be >= 1");
+  return submit_impl(db, seqs, offs, seqs2, offs2, n_reads, p, false, block, out);
+}
 
-  // --try-se (:831-850, :1001-1014): paired-end queries without a match are searched again with read 1, then read 2.
-  // The retries skip the length gate (it is applied once, before k-mer generation) and reuse the mates' own k-mers.
-  ResultOwner* o = (ResultOwner*)out->owner;
-  for (int mate = 0; mate < 2; mate++) {
-    std::vector<uint32_t> todo;
-    for (uint32_t r = 0; r < n_reads; r++)
-      if (o->offs[r + 1] == o->offs[r] && o->qkmers[r] > 0) todo.push_back(r);  // searched (>= MinMatched k-mers) but nothing found
-    if (todo.empty()) break;
-    const uint8_t* S = mate == 0 ? seqs : seqs2;
-    const uint64_t* O = mate == 0 ? offs : offs2;
-    std::vector<uint8_t> sub;
-    std::vector<uint64_t> so(1, 0);
-    for (uint32_t r : todo) {
-      sub.insert(sub.end(), S + O[r], S + O[r + 1]);
-      so.push_back(sub.size());
-    }
-    kmcpg_params q = p;
-    q.min_qlen = 0;
-    q.try_se = 0;
-    RawBatch rb2;
-    {
-      std::lock_guard<std::mutex> api_guard(db->api_mu);
-      rc = run_raw_any(db, sub.data(), so.data(), nullptr, nullptr, (uint32_t)todo.size(), q, &rb2);
-    }
-    if (rc) return rc;
-    kmcpg_result r2;
-    rc = kmcpg_finalize(db, rb2.hits.data(), rb2.hits.size(), rb2.qk.data(), rb2.ql.data(), (uint32_t)todo.size(), &q, &r2);
-    if (rc) return rc;
-    // splice the retried queries back in
-    std::vector<uint64_t> noffs((size_t)n_reads + 1, 0);
-    MatchVec nm;
-    size_t t = 0;
-    std::vector<char> stop(n_reads, 0);
-    for (uint32_t r = 0; r < n_reads; r++) {
-      if (t < todo.size() && todo[t] == r) {
-        o->qlen[r] = r2.qlen[t];
-        if (r2.qkmers[t] > 0) o->qkmers[r] = r2.qkmers[t];
-        else stop[r] = 1;  // fewer than MinMatched k-mers in this mate: the reference returns here (:854-869)
-        nm.insert(nm.end(), r2.matches + r2.match_offs[t], r2.matches + r2.match_offs[t + 1]);
-        t++;
-      } else {
-        nm.insert(nm.end(), o->matches.begin() + (ptrdiff_t)o->offs[r], o->matches.begin() + (ptrdiff_t)o->offs[r + 1]);
-      }
-      noffs[r + 1] = nm.size();
-    }
-    kmcpg_result_free(&r2);
-    o->matches.swap(nm);
-    o->offs.swap(noffs);
-    if (mate == 0)
-      for (uint32_t r = 0; r < n_reads; r++)
-        if (stop[r]) o->qkmers[r] = -o->qkmers[r] - 1;  // park: not retried with read 2
-    out->matches = o->matches.data();
-    out->match_offs = o->offs.data();
+extern "C" int kmcpg_submit(kmcpg_db* db, const uint8_t* seqs, const uint64_t* offs, const uint8_t* seqs2, const uint64_t* offs2, uint32_t n_reads,
+                            const kmcpg_params* params, kmcpg_ticket** out) {
+  return submit_checked(db, seqs, offs, seqs2, offs2, n_reads, params, false, out);
+}
+
+extern "C" int kmcpg_wait(kmcpg_ticket* t, kmcpg_result* out) {
+  if (!t || !out) {
+    if (t) drop_ticket(t);
+    return kmcpg_fail(KMCPG_EINVAL, "null argument");
   }
-  for (uint32_t r = 0; r < n_reads; r++)
-    if (o->qkmers[r] < 0) o->qkmers[r] = -(o->qkmers[r] + 1);
-  out->qlen = o->qlen.data();
-  out->qkmers = o->qkmers.data();
-  return 0;
+  memset(out, 0, sizeof *out);
+  int rc = finish_raw(t, out);
+  if (rc == 0) rc = retry_unmatched(t, out);
+  const std::string keep = rc ? kmcpg_err_ref() : std::string();
+  if (rc) kmcpg_result_free(out);
+  drop_ticket(t, rc != 0);
+  if (rc) kmcpg_err_ref() = keep;
+  return rc;
+}
+
+extern "C" int kmcpg_search_batch(kmcpg_db* db, const uint8_t* seqs, const uint64_t* offs, const uint8_t* seqs2, const uint64_t* offs2, uint32_t n_reads,
+                                  const kmcpg_params* params, kmcpg_result* out) {
+  if (!out) return kmcpg_fail(KMCPG_EINVAL, "null argument");
+  memset(out, 0, sizeof *out);
+  kmcpg_ticket* t = nullptr;
+  int rc = submit_checked(db, seqs, offs, seqs2, offs2, n_reads, params, true, &t);
+  if (rc) return rc;
+  return kmcpg_wait(t, out);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -341,6 +341,21 @@ void launch_list_long(const int32_t* nk, uint32_t n_reads, int32_t split_min, ui
   hipLaunchKernelGGL(k_list_long, dim3((n_reads + 255) / 256), dim3(256), 0, st, nk, n_reads, split_min, list, meta);
 }
 
+// largest NumKmers of the batch (callers compare it with what the stated read length allows)
+__global__ void k_max_nk(const int32_t* __restrict__ nk, uint32_t n_reads, unsigned long long* __restrict__ out) {
+  int m = 0;
+  for (uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; r < n_reads; r += gridDim.x * blockDim.x) m = max(m, nk[r]);
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) m = max(m, __shfl_xor(m, off));
+  if ((threadIdx.x & 63) == 0 && m > 0) atomicMax(out, (unsigned long long)m);
+}
+
+void launch_max_nk(const int32_t* nk, uint32_t n_reads, unsigned long long* out, hipStream_t st) {
+  if (n_reads == 0) return;
+  const unsigned blocks = std::min<unsigned>(1024, (n_reads + 255) / 256);
+  hipLaunchKernelGGL(k_max_nk, dim3(blocks), dim3(256), 0, st, nk, n_reads, out);
+}
+
 // threshold over the accumulated counts of the long queries (same integer rule as the k2_cobs epilogue)
 __global__ void k_threshold_long(const K2Args a) {
   const uint64_t total = (uint64_t)a.n_long * a.ncols_total;

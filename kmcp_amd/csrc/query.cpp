@@ -51,7 +51,7 @@ int run_kmers(kmcpg_db* db, const uint8_t* d_seqs, const uint64_t* d_offs, const
   a.seqs2 = d_seqs2;
   a.offs2 = d_offs2;
   a.n_reads = n_reads;
-  a.k = I.k;
+  a.k = p.k > 0 ? p.k : I.k;
   a.min_qlen = p.min_qlen;
   a.scaled = I.scaled;
   a.max_hash = I.scaled ? max_hash_for(I.scale) : ~0ULL;
@@ -71,7 +71,7 @@ int run_kmers(kmcpg_db* db, const uint8_t* d_seqs, const uint64_t* d_offs, const
     a.segs_max = segs;
   }
   launch_k1(a, max_read_len, st);
-  uint64_t ub = max_read_len >= (uint32_t)I.k ? (uint64_t)(max_read_len - I.k + 1) : 0;
+  uint64_t ub = max_read_len >= (uint32_t)a.k ? (uint64_t)(max_read_len - a.k + 1) : 0;
   if (d_seqs2) ub *= 2;
   *max_n_out = ub;
   if (ub > (uint64_t)p.dedup_threshold) {
@@ -119,6 +119,20 @@ int run_kmers(kmcpg_db* db, const uint8_t* d_seqs, const uint64_t* d_offs, const
   return 0;
 }
 
+// The k-mer workspace (w_hashes, w_scratch, ...) is shared by every GPU-half call on a handle; calls are enqueued under
+// db->mu, and a call on another stream than its predecessor's waits for the predecessor's last kernel.
+int ws_begin(kmcpg_db* db, hipStream_t st) {
+  if (!db->ws_ev) HIPCHK(hipEventCreateWithFlags(&db->ws_ev, hipEventDisableTiming));
+  if (db->ws_ev_valid) HIPCHK(hipStreamWaitEvent(st, db->ws_ev, 0));
+  return 0;
+}
+
+int ws_end(kmcpg_db* db, hipStream_t st) {
+  HIPCHK(hipEventRecord(db->ws_ev, st));
+  db->ws_ev_valid = true;
+  return 0;
+}
+
 }  // namespace
 
 extern "C" int kmcpg_kmers_device(kmcpg_db* db, const uint8_t* d_seqs, const uint64_t* d_offs, uint32_t n_reads, uint64_t total_bases,
@@ -130,6 +144,7 @@ extern "C" int kmcpg_kmers_device(kmcpg_db* db, const uint8_t* d_seqs, const uin
   KMCPG_USE_DEVICE(db);
   const kmcpg_params p = params ? *params : default_params();
   hipStream_t st = (hipStream_t)stream;
+  if (int rc0 = ws_begin(db, st)) return rc0;
   if (db->w_scratch.ensure(2 * total_bases + 2) || db->w_nk_raw.ensure(n_reads + 1) || db->w_nk1.ensure(n_reads + 1)) return kmcpg_fail(KMCPG_ENOMEM, "hipMalloc failed");
   DevBuf<int32_t> ql;
   if (ql.ensure(n_reads + 1)) return kmcpg_fail(KMCPG_ENOMEM, "hipMalloc failed");
@@ -153,9 +168,13 @@ extern "C" int kmcpg_query_device(kmcpg_db* db, const uint8_t* d_seqs, const uin
   KMCPG_USE_DEVICE(db);
   const kmcpg_params p = params ? *params : default_params();
   if (p.min_matched < 1) return kmcpg_fail(KMCPG_EINVAL, "min_matched must be >= 1");  // getFlagPositiveInt (search.go:165)
+  if (p.k > 0 && std::find(db->ks_desc.begin(), db->ks_desc.end(), p.k) == db->ks_desc.end())
+    return kmcpg_fail(KMCPG_EINVAL, "k=%d is not a k-mer size of this database", p.k);
+  const int k_used = p.k > 0 ? p.k : db->info.k;
   hipStream_t st = (hipStream_t)stream;
+  if (int rc0 = ws_begin(db, st)) return rc0;
   if (db->w_hashes.ensure(total_bases + 1) || db->w_nk_raw.ensure(n_reads + 1) || db->w_nk1.ensure(n_reads + 1)) return kmcpg_fail(KMCPG_ENOMEM, "hipMalloc failed");
-  uint64_t ub = max_read_len >= (uint32_t)db->info.k ? (uint64_t)(max_read_len - db->info.k + 1) : 0;
+  uint64_t ub = max_read_len >= (uint32_t)k_used ? (uint64_t)(max_read_len - k_used + 1) : 0;
   if (d_seqs2) ub *= 2;
   const bool window_sketch = db->info.syncmer || db->info.minimizer;
   if ((ub > (uint64_t)p.dedup_threshold || window_sketch) && db->w_scratch.ensure(2 * total_bases + 2)) return kmcpg_fail(KMCPG_ENOMEM, "hipMalloc failed");
@@ -168,7 +187,8 @@ extern "C" int kmcpg_query_device(kmcpg_db* db, const uint8_t* d_seqs, const uin
   int rc = run_kmers(db, d_seqs, d_offs, d_seqs2, d_offs2, n_reads, max_read_len, p, db->w_hashes.p, db->w_scratch.p, total_bases + 1, db->w_nk_raw.p,
                      db->w_nk1.p, d_qkmers, d_qlen, st, &maxn);
   if (rc) return rc;
-  HIPCHK(hipMemsetAsync(d_counters, 0, sizeof(uint64_t), st));
+  HIPCHK(hipMemsetAsync(d_counters, 0, 2 * sizeof(uint64_t), st));
+  launch_max_nk(d_qkmers, n_reads, (unsigned long long*)d_counters + 1, st);
   if (db->profiling) HIPCHK(hipEventRecord(db->ev[1], st));
   // long queries (whole genomes, -g) are split into chunks of k-mers so that they spread over the chip; short ones keep
   // the one-wave-per-(query, slot) kernel.  Which queries are long is only known on the device: one small D2H read.
@@ -246,6 +266,7 @@ extern "C" int kmcpg_query_device(kmcpg_db* db, const uint8_t* d_seqs, const uin
     HIPCHK(hipEventRecord(db->ev[2], st));
     db->ev_valid = true;
   }
+  if (int rc1 = ws_end(db, st)) return rc1;
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -278,6 +299,7 @@ extern "C" int kmcpg_plant_reads_device(kmcpg_db* db, const uint8_t* d_seqs, con
   std::lock_guard<std::mutex> g(db->mu);
   KMCPG_USE_DEVICE(db);
   hipStream_t st = (hipStream_t)stream;
+  if (int rc0 = ws_begin(db, st)) return rc0;
   if (db->w_hashes.ensure(total_bases + 1) || db->w_nk_raw.ensure(n_reads + 1) || db->w_nk1.ensure(n_reads + 1)) return kmcpg_fail(KMCPG_ENOMEM, "hipMalloc failed");
   DevBuf<int32_t> tmp;
   if (tmp.ensure(2 * (size_t)n_reads + 2)) return kmcpg_fail(KMCPG_ENOMEM, "hipMalloc failed");

@@ -15,7 +15,7 @@ EXPORTS = [
     "kmcpg_open", "kmcpg_close", "kmcpg_last_error", "kmcpg_db_info", "kmcpg_col_info", "kmcpg_search_batch",
     "kmcpg_result_free", "kmcpg_query_device", "kmcpg_finalize", "kmcpg_open_synthetic", "kmcpg_plant",
     "kmcpg_read_rows", "kmcpg_block_info", "kmcpg_kmers_device", "kmcpg_plant_reads_device", "kmcpg_set_profiling",
-    "kmcpg_last_timing", "kmcpg_open_devices", "kmcpg_build_db",
+    "kmcpg_last_timing", "kmcpg_open_devices", "kmcpg_build_db", "kmcpg_submit", "kmcpg_wait",
 ]
 
 
@@ -40,7 +40,8 @@ class Info(C.Structure):
 class Params(C.Structure):
     _fields_ = [("min_qlen", C.c_int32), ("min_matched", C.c_int32), ("min_qcov", C.c_double), ("min_tcov", C.c_double),
                 ("max_fpr", C.c_double), ("dedup_threshold", C.c_int32), ("try_se", C.c_int32), ("sort_by", C.c_int32),
-                ("do_not_sort", C.c_int32), ("top_n_scores", C.c_int32), ("fpr_buf_size", C.c_int32)]
+                ("do_not_sort", C.c_int32), ("top_n_scores", C.c_int32), ("fpr_buf_size", C.c_int32), ("k", C.c_int32),
+                ("reserved", C.c_int32)]
 
 
 class Hit(C.Structure):
@@ -54,7 +55,7 @@ class Match(C.Structure):
 
 class Result(C.Structure):
     _fields_ = [("n_reads", C.c_uint32), ("k", C.c_int32), ("qlen", C.POINTER(C.c_int32)), ("qkmers", C.POINTER(C.c_int32)),
-                ("match_offs", C.POINTER(C.c_uint64)), ("matches", C.POINTER(Match)), ("owner", C.c_void_p)]
+                ("ksize", C.POINTER(C.c_int32)), ("match_offs", C.POINTER(C.c_uint64)), ("matches", C.POINTER(Match)), ("owner", C.c_void_p)]
 
 
 class SynthSpec(C.Structure):
@@ -86,7 +87,7 @@ assert HIT_DTYPE.itemsize == C.sizeof(Hit) and MATCH_DTYPE.itemsize == C.sizeof(
 def default_params(**kw):
     """Defaults of `kmcp search` (kmcp/cmd/search.go:1052-1102)."""
     p = Params(min_qlen=30, min_matched=10, min_qcov=0.55, min_tcov=0.0, max_fpr=0.01, dedup_threshold=256, try_se=0,
-               sort_by=0, do_not_sort=0, top_n_scores=0, fpr_buf_size=0)
+               sort_by=0, do_not_sort=0, top_n_scores=0, fpr_buf_size=0, k=0, reserved=0)
     for k, v in kw.items():
         if not hasattr(p, k):
             raise AttributeError(k)
@@ -126,6 +127,8 @@ def load():
     L.kmcpg_search_batch.argtypes = [vp, vp, vp, vp, vp, C.c_uint32, C.POINTER(Params), C.POINTER(Result)]
     L.kmcpg_result_free.argtypes = [C.POINTER(Result)]
     L.kmcpg_result_free.restype = None
+    L.kmcpg_submit.argtypes = [vp, vp, vp, vp, vp, C.c_uint32, C.POINTER(Params), C.POINTER(vp)]
+    L.kmcpg_wait.argtypes = [vp, C.POINTER(Result)]
     L.kmcpg_query_device.argtypes = [vp, vp, vp, vp, vp, C.c_uint32, C.c_uint64, C.c_uint32, C.POINTER(Params), vp,
                                      C.c_uint64, vp, vp, vp, vp]
     L.kmcpg_finalize.argtypes = [vp, vp, C.c_uint64, vp, vp, C.c_uint32, C.POINTER(Params), C.POINTER(Result)]
@@ -174,8 +177,8 @@ def build_db(out_dir, columns, k=21, num_hashes=1, fpr=0.3, threads=32, block_si
 class BatchResult:
     """QueryResult for a batch (numpy copies of kmcpg_result)."""
 
-    def __init__(self, qlen, qkmers, offs, matches, k):
-        self.qlen, self.qkmers, self.offs, self.matches, self.k = qlen, qkmers, offs, matches, k
+    def __init__(self, qlen, qkmers, offs, matches, k, ksize=None):
+        self.qlen, self.qkmers, self.offs, self.matches, self.k, self.ksize = qlen, qkmers, offs, matches, k, ksize
 
     def __len__(self):
         return len(self.qlen)
@@ -195,7 +198,8 @@ def _copy_result(r):
         matches = np.frombuffer(buf, dtype=MATCH_DTYPE).copy()
     else:
         matches = np.zeros(0, dtype=MATCH_DTYPE)
-    out = BatchResult(qlen, qk, offs, matches, r.k)
+    ks = np.ctypeslib.as_array(r.ksize, shape=(n,)).copy() if n else np.zeros(0, np.int32)
+    out = BatchResult(qlen, qk, offs, matches, r.k, ks)
     load().kmcpg_result_free(C.byref(r))
     return out
 
@@ -270,6 +274,25 @@ class Database:
         _check(load().kmcpg_search_batch(self._h, seqs.ctypes.data, offs.ctypes.data,
                                          seqs2.ctypes.data if seqs2 is not None else None,
                                          offs2.ctypes.data if offs2 is not None else None, n, C.byref(p), C.byref(r)))
+        return _copy_result(r)
+
+    def submit(self, seqs, offs, seqs2=None, offs2=None, params=None):
+        """kmcpg_submit: returns a ticket; the arrays may be reused at once."""
+        p = params or default_params()
+        t = C.c_void_p()
+        n = len(offs) - 1
+        _check(load().kmcpg_submit(self._h, seqs.ctypes.data, offs.ctypes.data, seqs2.ctypes.data if seqs2 is not None else None,
+                                   offs2.ctypes.data if offs2 is not None else None, n, C.byref(p), C.byref(t)))
+        return t
+
+    def wait(self, ticket, count_only=False):
+        """kmcpg_wait: the finalized matches of a submitted batch (or just their number)."""
+        r = Result()
+        _check(load().kmcpg_wait(ticket, C.byref(r)))
+        if count_only:
+            m = int(r.match_offs[r.n_reads])
+            load().kmcpg_result_free(C.byref(r))
+            return m
         return _copy_result(r)
 
     def search_packed_count(self, seqs, offs, params=None):

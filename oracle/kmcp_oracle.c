@@ -336,6 +336,8 @@ typedef struct {
 
 struct ko_db {
   ko_sketch_cfg cfg;
+  int ks[16];   /* k-mer sizes of the database, descending (util-db-search.go:752-758); cfg.k = ks[0] */
+  int nks;
   int num_hashes;
   double fpr;
   int nblocks;
@@ -608,7 +610,7 @@ ko_db* ko_db_open(const char* db_dir) {
     if (s[0] == '-') {
       char* v = trim(s + 1);
       if (in_files) { files = (char**)realloc(files, (size_t)(nfiles + 1) * sizeof(char*)); files[nfiles++] = strdup(v); }
-      else if (in_ks) { int kk = atoi(v); if (kk > ks_max) ks_max = kk; }
+      else if (in_ks) { int kk = atoi(v); if (kk > ks_max) ks_max = kk; if (db->nks < 16) db->ks[db->nks++] = kk; }
       continue;
     }
     char* colon = strchr(s, ':');
@@ -619,7 +621,7 @@ ko_db* ko_db_open(const char* db_dir) {
     in_files = !strcmp(key, "files");
     in_ks = !strcmp(key, "ks");
     if (in_ks && *val == '[') { /* flow style: ks: [21] */
-      for (char* q = val + 1; *q; q++) if (*q >= '0' && *q <= '9') { int kk = atoi(q); if (kk > ks_max) ks_max = kk; while (*q >= '0' && *q <= '9') q++; if (!*q) break; }
+      for (char* q = val + 1; *q; q++) if (*q >= '0' && *q <= '9') { int kk = atoi(q); if (kk > ks_max) ks_max = kk; if (db->nks < 16) db->ks[db->nks++] = kk; while (*q >= '0' && *q <= '9') q++; if (!*q) break; }
     }
     if (!strcmp(key, "version")) version = atoi(val);
     else if (!strcmp(key, "k")) db->cfg.k = atoi(val);
@@ -634,7 +636,9 @@ ko_db* ko_db_open(const char* db_dir) {
     else if (!strcmp(key, "fpr")) db->fpr = strtod(val, NULL);
   }
   fclose(f);
-  if (ks_max > 0) db->cfg.k = ks_max; /* single k in practice; handleQuery walks ks descending */
+  if (ks_max > 0) db->cfg.k = ks_max; /* handleQuery walks ks descending (:752-758, :764) */
+  if (db->nks == 0) db->ks[db->nks++] = db->cfg.k; /* util-db-info.go:124-126 */
+  for (int i = 0; i < db->nks; i++) for (int j = i + 1; j < db->nks; j++) if (db->ks[j] > db->ks[i]) { int t = db->ks[i]; db->ks[i] = db->ks[j]; db->ks[j] = t; }
   if (version != 4) { snprintf(g_err, sizeof g_err, "kmcp/index: version mismatch"); free(db); return NULL; }
   if (nfiles == 0) { snprintf(g_err, sizeof g_err, "no index files"); free(db); return NULL; }
   db->nblocks = nfiles;
@@ -663,6 +667,8 @@ ko_db* ko_db_create_mem(const ko_sketch_cfg* cfg, int num_hashes, double fpr, in
   db->num_hashes = num_hashes;
   db->fpr = fpr;
   db->nblocks = nblocks;
+  db->ks[0] = cfg->k;
+  db->nks = 1;
   db->blocks = (ko_block*)calloc((size_t)nblocks, sizeof(ko_block));
   for (int i = 0; i < nblocks; i++) {
     ko_block* b = &db->blocks[i];
@@ -828,40 +834,55 @@ static int search_kmers(ko_db* db, uint64_t* kmers, size_t nk, const ko_search_p
   return 0;
 }
 
-/* handleQuery, util-db-search.go:763-1025 (+ --try-se retry :831-850,:1001-1014) and the post-processing of
- * handleQuerySingleDB :260-345 (sort, --keep-top-scores). */
-int ko_search(ko_db* db, const uint8_t* seq1, size_t len1, const uint8_t* seq2, size_t len2, const ko_search_params* p,
-              ko_result* out) {
-  memset(out, 0, sizeof *out);
-  out->k = db->cfg.k;
+/* one pass of the `for _ik, k := range ks` body (:764-1023).  Returns 1 when the result is final (matched, or one of the
+ * early returns), 0 when nothing matched and the caller may try the next smaller k. */
+static int search_one_k(ko_db* db, const ko_sketch_cfg* cfg, const uint8_t* seq1, size_t len1, const uint8_t* seq2, size_t len2,
+                        const ko_search_params* p, ko_result* out, int* found_out) {
+  *found_out = 0;
+  memset(out, 0, sizeof *out); /* a fresh QueryResult per k (:765); NumKmers of the pooled object is stale: the oracle says 0 */
+  out->k = cfg->k;
   out->nmatches = -1;
   out->qlen = (int32_t)len1 + (seq2 ? (int32_t)len2 : 0);
   int try_se = p->try_se && seq2 != NULL;
   if ((int)len1 < p->min_qlen) { /* :778-786 */
-    if (!(seq2 && (int)len2 >= p->min_qlen)) { out->qkmers = 0; return 0; }
+    if (!(seq2 && (int)len2 >= p->min_qlen)) { out->qkmers = 0; return 1; }
   }
   uint64_t* kmers = (uint64_t*)malloc((len1 + (seq2 ? len2 : 0) + 1) * sizeof(uint64_t));
-  size_t n1 = ko_generate_kmers(seq1, len1, &db->cfg, kmers);
+  size_t n1 = ko_generate_kmers(seq1, len1, cfg, kmers);
   size_t n = n1;
-  if (seq2) n += ko_generate_kmers(seq2, len2, &db->cfg, kmers + n1);
+  if (seq2) n += ko_generate_kmers(seq2, len2, cfg, kmers + n1);
+  if ((int)n < p->min_matched) { free(kmers); return 1; } /* :854-869: final, also for the smaller k */
   uint64_t* copy = NULL;
   if (try_se) { copy = (uint64_t*)malloc((n + 1) * sizeof(uint64_t)); memcpy(copy, kmers, n * sizeof(uint64_t)); }
   int found = search_kmers(db, kmers, n, p, out);
-  if (!found && try_se && (int)n >= p->min_matched) {
-    /* note: when len(kmers) < MinMatched the reference returns before any retry (:854-869) */
+  if (!found && try_se) {
     out->qlen = (int32_t)len1; /* tries == 1: read1 */
     memcpy(kmers, copy, n1 * sizeof(uint64_t));
-    if ((int)n1 < p->min_matched) { free(kmers); free(copy); return 0; }
+    if ((int)n1 < p->min_matched) { free(kmers); free(copy); return 1; }
     found = search_kmers(db, kmers, n1, p, out);
     if (!found) {
       out->qlen = (int32_t)len2; /* tries == 2: read2 */
       memcpy(kmers, copy + n1, (n - n1) * sizeof(uint64_t));
-      if ((int)(n - n1) < p->min_matched) { free(kmers); free(copy); return 0; }
+      if ((int)(n - n1) < p->min_matched) { free(kmers); free(copy); return 1; }
       found = search_kmers(db, kmers, n - n1, p, out);
     }
   }
   free(kmers);
   free(copy);
+  *found_out = found;
+  return found;
+}
+
+/* handleQuery, util-db-search.go:763-1025 (+ --try-se retry :831-850,:1001-1014; smaller k of a multi-k database :764,
+ * :1016-1022) and the post-processing of handleQuerySingleDB :260-345 (sort, --keep-top-scores). */
+int ko_search(ko_db* db, const uint8_t* seq1, size_t len1, const uint8_t* seq2, size_t len2, const ko_search_params* p,
+              ko_result* out) {
+  int found = 0;
+  for (int ik = 0; ik < db->nks; ik++) {
+    ko_sketch_cfg cfg = db->cfg;
+    cfg.k = db->ks[ik];
+    if (search_one_k(db, &cfg, seq1, len1, seq2, len2, p, out, &found)) break;
+  }
   if (found) {
     if (out->nmatches > 1 && !p->do_not_sort) { g_sort_by = p->sort_by; qsort(out->matches, (size_t)out->nmatches, sizeof(ko_match), cmp_match); }
     if (p->top_n_scores > 0 && !p->do_not_sort) { /* :285-311 */

@@ -31,7 +31,7 @@ def test_struct_layouts_match_header(L):
     assert C.sizeof(L.Hit) == 12
     assert C.sizeof(L.Match) == 56
     assert C.sizeof(L.Opts) == 16
-    assert C.sizeof(L.Params) == 56
+    assert C.sizeof(L.Params) == 64
     assert C.sizeof(L.SynthSpec) == 64
 
 
