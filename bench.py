@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """bench.py — reads/s searched (150 bp, k=21) against a GTDB-scale COBS index on MI355X.
 
-One "step" = one pass of the hot path (K1 ntHash k-mer generation + K2 COBS query + hit hand-over) over
-one batch of synthetic 150-bp reads that is already resident in HBM.
+One "step" = one pass of the hot path over one batch of synthetic 150-bp reads that is already resident in HBM: K1 ntHash
+k-mer generation + K2 COBS query on the GPU, hit hand-over, and the host half (float64 thresholds, FPR, sort) that turns
+the hit tuples into finalized matches in host memory; the host half of step i overlaps the kernels of step i+1.
 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--workload gtdb|config1] [--batch-reads B]
 
@@ -41,8 +42,9 @@ WORKLOADS = {
                  batch_reads=524288, kernel="k2_cobs<64,8,false>",
                  name="gtdb-scale synthetic: 32 blocks x 14976 cols x 968700 sigs (58.03 GB), 150bp k=21"),
     # 10 k chunks, `kmcp index -j 32`: 32 blocks x 312 columns, 39-byte rows (BASELINE.json configs[1])
+    # (equal-length chunks => the same NumSigs in every block: libkmcpgpu lays them side by side, one 1248-byte gather per k-mer)
     "config1": dict(k=21, num_hashes=1, fpr=0.3, n_blocks=32, cols_per_block=312, num_sigs=1121470, kmers_per_col=400000,
-                    batch_reads=1048576, kernel="k2_cobs<4,8,false>",
+                    batch_reads=1048576, kernel="k2_cobs<64,8,false> + k2_cobs<16,8,false> (grouped) / k2_cobs<4,8,false> (KMCPG_FUSE=0)",
                     name="10k-chunk synthetic: 32 blocks x 312 cols x 1121470 sigs (1.4 GB), 150bp k=21"),
     # the same 9 984 columns indexed as ONE block (`kmcp index -b 9984`): 130 gathers of 1 248 B per read instead of 4 160 of 39 B
     "config1_wide": dict(k=21, num_hashes=1, fpr=0.3, n_blocks=1, cols_per_block=9984, num_sigs=1121470, kmers_per_col=400000,
@@ -94,8 +96,34 @@ class Ctx:
     pass
 
 
-def run_workload(name, ctx, steps, warmup, batch_reads=0, cpu_baseline=True, cpu_target_s=8.0, cpu_sample_reads=0):
-    """Builds the synthetic index of workload `name` in HBM, times `steps` steps, returns the result dict (rank 0)."""
+def host_memory_available():
+    """Bytes of host RAM this process may still take (cgroup limit honoured)."""
+    import psutil
+    avail = psutil.virtual_memory().available
+    for f in ("/sys/fs/cgroup/memory.max", "/sys/fs/cgroup/memory/memory.limit_in_bytes"):
+        try:
+            v = open(f).read().strip()
+            if v != "max":
+                used = 0
+                for u in ("/sys/fs/cgroup/memory.current", "/sys/fs/cgroup/memory/memory.usage_in_bytes"):
+                    try:
+                        used = int(open(u).read())
+                        break
+                    except Exception:
+                        pass
+                avail = min(avail, int(v) - used)
+            break
+        except Exception:
+            continue
+    return avail
+
+
+def run_workload(name, ctx, steps, warmup, batch_reads=0, cpu_baseline=True, cpu_target_s=8.0, cpu_sample_reads=0, extras=True):
+    """Builds the synthetic index of workload `name` in HBM, times `steps` steps, returns the result dict (rank 0).
+
+    One step = reads resident in HBM -> K1 + K2 on this rank's blocks -> hit lists to rank 0 (RCCL when N > 1) -> D2H ->
+    kmcpg_finalize on the host (float64 thresholds, FPR, sort): finalized matches in host memory.  The host half of step i runs
+    while the GPU works on step i+1 (it is inside the timed region for every one of the K steps)."""
     from kmcp_amd import Database, default_params, lib
     from kmcp_amd.dist import gather_hits
 
@@ -129,54 +157,116 @@ def run_workload(name, ctx, steps, warmup, batch_reads=0, cpu_baseline=True, cpu
     setup_s = time.time() - t0
 
     cap = 4 * B + 4096
-    d_hits = torch.empty((cap, 3), dtype=torch.int32, device=dev)
-    d_cnt = torch.zeros(2, dtype=torch.int64, device=dev)
-    d_qk = torch.zeros(B, dtype=torch.int32, device=dev)
-    d_ql = torch.zeros(B, dtype=torch.int32, device=dev)
-    h_hits = torch.empty((cap * world, 3), dtype=torch.int32).pin_memory()
-    stream = torch.cuda.current_stream(dev).cuda_stream
+    main = torch.cuda.current_stream(dev)
+    side = torch.cuda.Stream(dev)  # D2H of a finished step while the next step's kernels run on `main`
+    stream = main.cuda_stream
 
-    def step(i):
-        """K1+K2 on this rank's blocks, hit lists to rank 0 (RCCL), hit tuples to host memory. Returns #hits on rank 0.
-        Holds collectives: every rank must call it the same number of times."""
+    class Buf:  # device outputs of one step in flight + their pinned host copies
+        def __init__(self):
+            self.d_hits = torch.empty((cap, 3), dtype=torch.int32, device=dev)
+            self.d_cnt = torch.zeros(2, dtype=torch.int64, device=dev)
+            self.d_qk = torch.zeros(B, dtype=torch.int32, device=dev)
+            self.d_ql = torch.zeros(B, dtype=torch.int32, device=dev)
+            self.h_cnt = torch.zeros(2, dtype=torch.int64).pin_memory()
+            self.h_hits = torch.empty((cap * world, 3), dtype=torch.int32).pin_memory()
+            self.h_qk = torch.empty(B, dtype=torch.int32).pin_memory()
+            self.h_ql = torch.empty(B, dtype=torch.int32).pin_memory()
+            self.kernels_done = torch.cuda.Event()
+            self.copied = torch.cuda.Event()
+            self.used = False
+
+    bufs = [Buf(), Buf()] if world == 1 else [Buf()]
+
+    def gpu_half(i, bf):
+        """Enqueues K1+K2 of batch i on this rank's blocks (nothing waits here)."""
         reads, offs, _ = batches[i % n_batches]
-        db.query_device(reads.data_ptr(), offs.data_ptr(), B, B * READ_LEN, READ_LEN, d_hits.data_ptr(), cap, d_cnt.data_ptr(),
-                        d_qk.data_ptr(), d_ql.data_ptr(), params=params, stream=stream)
+        if bf.used:
+            main.wait_event(bf.copied)  # the previous step that used these buffers has left them
+        db.query_device(reads.data_ptr(), offs.data_ptr(), B, B * READ_LEN, READ_LEN, bf.d_hits.data_ptr(), cap, bf.d_cnt.data_ptr(),
+                        bf.d_qk.data_ptr(), bf.d_ql.data_ptr(), params=params, stream=stream)
+        bf.h_cnt.copy_(bf.d_cnt, non_blocking=True)
+        bf.kernels_done.record(main)
+        bf.used = True
+
+    def exchange(bf):
+        """Waits for the step's kernels; hit lists to rank 0 (RCCL when N > 1) and on their way to pinned host memory
+        (`copied` fires when the host may read).  Returns #hits on rank 0.  Holds collectives when N > 1."""
         if world == 1:
-            n = int(d_cnt[0].item())
+            bf.kernels_done.synchronize()
+            n = int(bf.h_cnt[0])
             assert n <= cap, "hit buffer overflow"
-            h_hits[:n].copy_(d_hits[:n], non_blocking=True)
-            torch.cuda.current_stream(dev).synchronize()
+            side.wait_event(bf.kernels_done)
+            with torch.cuda.stream(side):
+                bf.h_hits[:n].copy_(bf.d_hits[:n], non_blocking=True)
+                bf.h_qk.copy_(bf.d_qk, non_blocking=True)
+                bf.h_ql.copy_(bf.d_ql, non_blocking=True)
+                bf.copied.record(side)
             return n
-        parts = gather_hits(d_hits, d_cnt[:1], dst=0)  # RCCL: all_gather(counts) + gather(hit buffers) over xGMI
+        parts = gather_hits(bf.d_hits, bf.d_cnt[:1], dst=0)  # RCCL: all_gather(counts) + gather(hit buffers) over xGMI
+        n = 0
+        if rank == 0:
+            for part in parts:
+                c = part.shape[0]
+                bf.h_hits[n:n + c].copy_(part, non_blocking=True)
+                n += c
+            bf.h_qk.copy_(bf.d_qk, non_blocking=True)
+            bf.h_ql.copy_(bf.d_ql, non_blocking=True)
+        bf.copied.record(main)
+        return n
+
+    def host_half(bf, n):
+        """kmcpg_finalize on rank 0: float64 thresholds, FPR, Match values, sort -> finalized matches in host memory."""
         if rank != 0:
-            torch.cuda.current_stream(dev).synchronize()
             return 0
-        pos = 0
-        for part in parts:
-            c = part.shape[0]
-            h_hits[pos:pos + c].copy_(part, non_blocking=True)
-            pos += c
-        torch.cuda.current_stream(dev).synchronize()
-        return pos
+        bf.copied.synchronize()
+        return db.finalize_count(bf.h_hits[:n].numpy(), bf.h_qk.numpy(), bf.h_ql.numpy(), params=params)
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for i in range(warmup):
-        step(i)
+    def run_steps(first, count, with_host=True, times=None):
+        """`count` steps starting at batch `first`.  N = 1: two steps in flight (the kernels of step i+1 are enqueued before
+        step i's hits are fetched and finalized).  N > 1: the collective keeps the steps in order; the host half of step i still
+        runs while the kernels of step i+1 do.  Returns (#hits, #matches) on rank 0."""
+        hits = matches = 0
+        pending = None  # (buffers, #hits) of the step whose host half is still to run
+        if world == 1:
+            gpu_half(first, bufs[0])
+            for j in range(count):
+                bf = bufs[j % 2]
+                if j + 1 < count:
+                    gpu_half(first + j + 1, bufs[(j + 1) % 2])
+                n = exchange(bf)
+                hits += n
+                if with_host:
+                    matches += host_half(bf, n)
+                if times is not None:
+                    times.append(db.last_timing(age=1 if j + 1 < count else 0))
+            return hits, matches
+        for j in range(count):
+            gpu_half(first + j, bufs[0])
+            if pending is not None and with_host:
+                matches += host_half(*pending)
+            n = exchange(bufs[0])
+            hits += n
+            pending = (bufs[0], n)
+            if times is not None:
+                times.append(db.last_timing())
+        if pending is not None and with_host:
+            matches += host_half(*pending)
+        return hits, matches
+
+    run_steps(0, warmup)
     barrier()
-    k2_ms, k1_ms, n_hits_total = [], [], 0
+    times = []
     t_start = time.perf_counter()
-    for i in range(steps):
-        n_hits_total += step(warmup + i)
-        a, b = db.last_timing()
-        k1_ms.append(a)
-        k2_ms.append(b)
+    n_hits_total, n_matches_total = run_steps(warmup, steps, times=times)
     barrier()
     elapsed = time.perf_counter() - t_start
+    k1_ms = [t_[0] for t_ in times]
+    k2_ms = [t_[1] for t_ in times]
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if ctx.same_gpu else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -185,12 +275,12 @@ def run_workload(name, ctx, steps, warmup, batch_reads=0, cpu_baseline=True, cpu
     # ---- roofline of the dominant kernel (k2_cobs) on this rank: algorithmic bytes per launch:
     #      sum over reads of kept k-mers x sum over local blocks of numHashes x NumRowBytes, + qLen, + 12 B per hit
     last = (warmup + steps - 1) % n_batches
-    qk = d_qk.cpu().numpy().astype(np.int64)
+    qk = bufs[(steps - 1) % len(bufs)].d_qk.cpu().numpy().astype(np.int64)
     kmers_per_launch = int(qk.sum())
     alg_bytes = kmers_per_launch * int(info.row_bytes_sum_local) * int(info.num_hashes) + B * READ_LEN + 12 * (n_hits_total // max(1, steps))
     k2_avg_ms = float(np.mean(k2_ms))
     achieved = alg_bytes / (k2_avg_ms * 1e-3) / 1e9
-    traffic = None
+    traffic, traffic_src = None, None
     tfile = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tfile):
         try:
@@ -198,6 +288,7 @@ def run_workload(name, ctx, steps, warmup, batch_reads=0, cpu_baseline=True, cpu
             key = f"{name}:{B}:{world}"
             if key in tj:
                 traffic = tj[key]["hbm_bytes_per_launch"]
+                traffic_src = tj[key].get("source")
         except Exception:
             traffic = None
 
@@ -214,84 +305,162 @@ def run_workload(name, ctx, steps, warmup, batch_reads=0, cpu_baseline=True, cpu
         "vs_baseline": None,
         "dtype": "u32 bitwise (bit-sliced counters), u64 hashes",
         "data": "synthetic",
+        "value_definition": "reads resident in HBM -> finalized (target, mKmers, qCov, tCov, jacc, FPR) tuples in host memory; the host half "
+                            "of a step overlaps the next step's kernels; see host_boundary for reads starting in host memory",
         "config": {"workload": wl["name"], "batch_reads": B, "read_len": READ_LEN, "k": wl["k"], "num_hashes": wl["num_hashes"],
                    "index_bytes": int(info.matrix_bytes), "index_bytes_this_rank": int(info.matrix_bytes_local),
                    "blocks": int(info.n_blocks), "columns": n_cols, "parallelism": f"block-shard x{world}",
                    "search_flags": "-t 0.55 -c 10 -m 30 -f 0.01 -u 256"},
         "roofline": {"bound": "hbm", "kernel": wl["kernel"], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes_per_launch": alg_bytes,
-                     "kernel_ms": k2_avg_ms, "kmers_kernel_ms": float(np.mean(k1_ms))},
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                     "wire_gbps": (traffic / (k2_avg_ms * 1e-3) / 1e9) if traffic else None,
+                     "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": k2_avg_ms, "kmers_kernel_ms": float(np.mean(k1_ms))},
         "hits_per_step": n_hits_total / max(1, steps),
+        "matches_per_step": n_matches_total / max(1, steps),
         "setup_s": setup_s,
     }
 
     # ---- sanity on the last batch: planted reads must come back with their column (the step holds collectives: every
     #      rank takes part, rank 0 evaluates the merged hit list)
-    n_last = step(last)
+    gpu_half(last, bufs[0])
+    n_last = exchange(bufs[0])
+    torch.cuda.synchronize()
     hh = None
     if rank == 0:
-        hh = h_hits[:n_last].numpy().astype(np.int64)
+        hh = bufs[0].h_hits[:n_last].numpy().astype(np.int64)
         cols_last = batches[last][2].cpu().numpy().astype(np.int64)
         got = set(zip(hh[:, 0].tolist(), hh[:, 1].tolist()))
         planted = np.nonzero(cols_last >= 0)[0]
         out["planted_recall"] = sum((int(r), int(cols_last[r])) in got for r in planted[:20000]) / max(1, min(len(planted), 20000))
 
-    # ---- the drop-in boundary with host buffers (PCIe-inclusive; reported beside `value`, never as `value`): one batch through
-    #      kmcpg_search_batch — reads in host memory in; H2D, K1, K2, D2H of the hits, float64 thresholds, FPR, sort; matches out
-    if rank == 0 and world == 1:
-        reads_hb = batches[last][0].cpu().numpy()
-        offs_hb = batches[last][1].cpu().numpy().astype(np.uint64)
-        db.search_packed_count(reads_hb, offs_hb, params=params)  # first call sizes the staging buffers
+    if extras:
+        # ---- the kernel alone and the data-independent variant: no host half; then sector pruning switched off (every row byte
+        #      of every k-mer is fetched whatever the index holds: the pruning gain depends on the data, this number does not)
+        def kernel_only(nsteps, env=None):
+            old = {}
+            for k_, v_ in (env or {}).items():
+                old[k_] = os.environ.get(k_)
+                os.environ[k_] = v_
+            try:
+                tms = []
+                barrier()
+                t1 = time.perf_counter()
+                run_steps(0, nsteps, with_host=False, times=tms)
+                barrier()
+                dt = time.perf_counter() - t1
+                ms = [t_[1] for t_ in tms]
+            finally:
+                for k_, v_ in old.items():
+                    if v_ is None:
+                        os.environ.pop(k_, None)
+                    else:
+                        os.environ[k_] = v_
+            return dt / nsteps, float(np.mean(ms))
+        per_step, _ = kernel_only(max(2, min(steps, 4)))
+        out["device_only"] = {"value": B / per_step, "unit": "reads/s", "ms_per_step": per_step * 1e3,
+                              "note": "reads in HBM -> raw (read, column, count) hit tuples in host memory, no host half (round 1's `value`)"}
+        _, k2_np = kernel_only(2, {"KMCPG_PRUNE": "0"})
+        out["roofline"]["kernel_ms_prune_off"] = k2_np
+        out["roofline"]["achieved_prune_off"] = alg_bytes / (k2_np * 1e-3) / 1e9
+        out["roofline"]["frac_prune_off"] = out["roofline"]["achieved_prune_off"] / HBM_PEAK_GBS
+
+    # ---- the drop-in boundary with host buffers (PCIe-inclusive; reported beside `value`, never as `value`): batches through
+    #      kmcpg_submit / kmcpg_wait — reads in host memory in; H2D, K1, K2, D2H of the hits, float64 thresholds, FPR, sort;
+    #      finalized matches in host memory out — three batches in flight, and one batch alone through kmcpg_search_batch
+    if rank == 0 and world == 1 and extras:
+        hb = [(b_[0].cpu().numpy(), b_[1].cpu().numpy().astype(np.uint64)) for b_ in batches]
+        db.search_packed_count(hb[0][0], hb[0][1], params=params)  # first calls size the staging buffers
+        tk = [db.submit(*hb[i % len(hb)], params=params) for i in range(3)]
+        for t_ in tk:
+            db.wait(t_, count_only=True)
         t1 = time.perf_counter()
-        n_matches = db.search_packed_count(reads_hb, offs_hb, params=params)  # the C call alone, result freed, nothing copied to numpy
-        dt = time.perf_counter() - t1
-        out["host_boundary"] = {"value": B / dt, "unit": "reads/s", "ms_per_batch": dt * 1e3, "matches": n_matches,
-                                "note": "kmcpg_search_batch: host buffers in, finalized matches out (PCIe + host finalize included)"}
-        del reads_hb, offs_hb
+        n_matches = db.search_packed_count(hb[0][0], hb[0][1], params=params)  # the C call alone, result freed, nothing copied to numpy
+        single = time.perf_counter() - t1
+        import threading
+        NB = max(8, 2 * steps)
+        HT = 2  # host threads, each keeping two batches in flight (the C++ CLI runs two searcher threads the same way)
+
+        def pump(t_):
+            tk = []
+            for i in range(t_, NB, HT):
+                if len(tk) == 2:
+                    db.wait(tk.pop(0), count_only=True)
+                tk.append(db.submit(*hb[i % len(hb)], params=params))
+            while tk:
+                db.wait(tk.pop(0), count_only=True)
+
+        th = [threading.Thread(target=pump, args=(t_,)) for t_ in range(HT)]
+        t1 = time.perf_counter()
+        [x.start() for x in th]
+        [x.join() for x in th]
+        dt = (time.perf_counter() - t1) / NB
+        out["host_boundary"] = {"value": B / dt, "unit": "reads/s", "ms_per_batch": dt * 1e3, "batches": NB, "host_threads": HT, "in_flight": 2 * HT,
+                                "single_batch_ms": single * 1e3, "single_batch_reads_per_s": B / single, "matches": n_matches,
+                                "note": "kmcpg_submit/kmcpg_wait: host buffers in, finalized matches out (staging copy, PCIe both ways and "
+                                        "the host half included); single_batch = one kmcpg_search_batch call with nothing overlapped"}
+        del hb
 
     # ---- CPU baseline: the oracle (C restatement of the reference algorithm), timed on this box's host cores on a bounded
-    #      sample: the first S blocks copied back from HBM and the first R reads of the last batch.
+    #      sample: ALL blocks copied back from HBM (when host memory allows) x the first R reads of the last batch.
     if rank == 0 and world == 1 and cpu_baseline:
+        import shutil
         from oracle import oracle as O
-        S = 2 if name == "gtdb" else wl["n_blocks"]  # gtdb: 2 of the 32 blocks x the whole batch is ~10 s on 16 threads
+        index_bytes = int(info.matrix_bytes)
+        avail = host_memory_available()
+        S = wl["n_blocks"] if index_bytes * 1.15 + (8 << 30) < avail else max(1, min(wl["n_blocks"], int((avail - (8 << 30)) * 0.8 / (index_bytes / wl["n_blocks"]))))
+        t1 = time.perf_counter()
         blocks = []
         for b in range(S):
             bi = db.block_info(b)
             rows = np.empty((bi["num_sigs"], bi["row_bytes"]), dtype=np.uint8)
-            chunk = 65536
+            chunk = 262144
             for r0 in range(0, bi["num_sigs"], chunk):
-                idx = np.arange(r0, min(bi["num_sigs"], r0 + chunk), dtype=np.uint64)
-                rows[r0:r0 + len(idx)] = db.read_rows(b, idx)
+                db.read_row_range(b, r0, rows[r0:r0 + chunk])
             blocks.append((bi["num_sigs"], bi["n_cols"], bi["col_base"], rows))
+        copy_s = time.perf_counter() - t1
         odb = O.OracleDB.from_memory(O.sketch_cfg(k=wl["k"]), wl["num_hashes"], wl["fpr"], blocks, wl["kmers_per_col"])
         threads = effective_cpus()
         reads_h = batches[last][0].cpu().numpy()
         offs_h = batches[last][1].cpu().numpy().astype(np.uint64)
-        R = cpu_sample_reads or 256
-        tcpu = 0.0
-        while True:  # grow the sample until it is several seconds of CPU work
-            t1 = time.perf_counter()
-            oqk, ohits = odb.search_batch(reads_h[:R * READ_LEN], offs_h[:R + 1], O.default_params(), threads=threads)
-            tcpu = time.perf_counter() - t1
-            if cpu_sample_reads or tcpu >= cpu_target_s or R >= B:
-                break
-            R = min(B, int(R * max(2.0, 1.5 * cpu_target_s / max(tcpu, 1e-3))))
+
+        def timed(refshape, target_s):
+            R = cpu_sample_reads or 256
+            while True:  # grow the sample until it is several seconds of CPU work
+                t2 = time.perf_counter()
+                oqk, ohits = odb.search_batch(reads_h[:R * READ_LEN], offs_h[:R + 1], O.default_params(), threads=threads, refshape=refshape)
+                tcpu = time.perf_counter() - t2
+                if cpu_sample_reads or tcpu >= target_s or R >= B:
+                    return R, tcpu, oqk, ohits
+                R = min(B, int(R * max(2.0, 1.5 * target_s / max(tcpu, 1e-3))))
+
+        R, tcpu, oqk, ohits = timed(False, cpu_target_s)
         # same-run parity on the sample: GPU hits of these reads restricted to the sampled blocks == oracle hits
         hi_col = blocks[-1][2] + blocks[-1][1]
         g = hh[(hh[:, 0] < R) & (hh[:, 1] < hi_col)]
         g = g[np.lexsort((g[:, 1], g[:, 0]))]
         parity = bool(np.array_equal(g, ohits.astype(np.int64))) and bool(np.array_equal(oqk[:R], qk[:R]))
         frac_blocks = S / wl["n_blocks"]
-        out["cpu_baseline"] = {"value": R / tcpu * frac_blocks, "unit": "reads/s", "cores": threads, "kind": "port",
-                               "sample": f"{R} reads x {S} of {wl['n_blocks']} blocks in {tcpu:.2f} s on {threads} threads "
-                                         f"(oracle ko_search_batch, index rows copied back from HBM); value scaled by {frac_blocks:.4f} "
-                                         "to the whole index", "parity_on_sample": parity, "sample_hits": int(len(ohits))}
+        R2, tcpu2, oqk2, ohits2 = timed(True, cpu_target_s)
+        same = bool(np.array_equal(ohits2, ohits[ohits[:, 0] < R2])) if R2 <= R else bool(np.array_equal(ohits2[ohits2[:, 0] < R], ohits))
+        out["cpu_baseline"] = {
+            "value": R / tcpu * frac_blocks, "unit": "reads/s", "cores": threads, "kind": "port",
+            "sample": f"{R} reads x {S} of {wl['n_blocks']} blocks ({sum(b_[3].nbytes for b_ in blocks)/1e9:.1f} GB of index rows copied back from HBM "
+                      f"in {copy_s:.1f} s) in {tcpu:.2f} s on {threads} threads: oracle ko_search_batch (OpenMP over reads, LUT vertical counters)"
+                      + ("" if S == wl["n_blocks"] else f"; host memory holds only {S} blocks: value scaled by {frac_blocks:.4f}"),
+            "parity_on_sample": parity, "sample_hits": int(len(ohits)),
+            "reference_shaped": {"value": R2 / tcpu2 * frac_blocks, "unit": "reads/s", "cores": threads,
+                                 "sample": f"{R2} reads x {S} blocks in {tcpu2:.2f} s: one worker per block, 64 buffered rows, byte transposition + "
+                                           "Count8 per column byte (util-db-search.go:6811-6972, :213-219), AVX2 movemask Count8",
+                                 "same_hits_as_port": same},
+            "reference_binary": {"kmcp": shutil.which("kmcp"), "go": shutil.which("go"),
+                                 "note": "BASELINE.md 3.1 probe: the Go reference is timed instead when a kmcp binary is on PATH (none in this image)"},
+        }
         odb.close()
         del blocks
         assert parity, "GPU hits differ from the CPU oracle on the sample"
 
     db.close()
-    del d_hits, batches
+    del bufs, batches
     torch.cuda.empty_cache()
     return out
 
@@ -306,6 +475,7 @@ def main():
     ap.add_argument("--cpu-sample-reads", type=int, default=0, help="0 = size the CPU sample to several seconds of CPU work")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the configs[1] numbers that ride along at N=1")
+    ap.add_argument("--no-extras", action="store_true", help="timed steps only (profiling runs: no pruning-off / host-boundary launches in the trace)")
     args = ap.parse_args()
 
     ctx = Ctx()
@@ -331,14 +501,18 @@ def main():
             dist.init_process_group("nccl", device_id=ctx.dev)
 
     out = run_workload(args.workload, ctx, args.steps, args.warmup, args.batch_reads, cpu_baseline=not args.no_cpu_baseline,
-                       cpu_sample_reads=args.cpu_sample_reads)
+                       cpu_sample_reads=args.cpu_sample_reads, extras=not args.no_extras)
     if ctx.world == 1 and args.workload == "gtdb" and not args.no_secondary and not args.batch_reads:
-        sec = run_workload("config1", ctx, min(args.steps, 3), 1, cpu_baseline=not args.no_cpu_baseline, cpu_target_s=3.0)
-        keys = ("value", "unit", "ms_per_step", "config", "roofline", "planted_recall", "host_boundary", "cpu_baseline")
+        sec = run_workload("config1", ctx, min(args.steps, 5), 1, cpu_baseline=not args.no_cpu_baseline, cpu_target_s=3.0)
+        keys = ("value", "unit", "ms_per_step", "config", "roofline", "planted_recall", "device_only", "host_boundary", "cpu_baseline")
         out["secondary"] = {"config1": {k: sec[k] for k in keys if k in sec}}
-        # the same columns indexed as one wide block: what the block layout (`kmcp index -b`) is worth on this hardware
-        wide = run_workload("config1_wide", ctx, min(args.steps, 3), 1, cpu_baseline=False)
-        out["secondary"]["config1_wide"] = {k: wide[k] for k in keys if k in wide}
+        # the same index with every block on its own (what a database with a different NumSigs per block gets): KMCPG_FUSE=0
+        os.environ["KMCPG_FUSE"] = "0"
+        try:
+            unf = run_workload("config1", ctx, min(args.steps, 3), 1, cpu_baseline=False)
+        finally:
+            os.environ.pop("KMCPG_FUSE", None)
+        out["secondary"]["config1_ungrouped"] = {k: unf[k] for k in keys if k in unf}
     if ctx.rank == 0:
         print(json.dumps(out))
     if ctx.world > 1:

@@ -198,8 +198,13 @@ int kmcpg_plant_reads_device(kmcpg_db* db, const uint8_t* d_seqs, const uint64_t
  * kmcpg_last_timing waits for the last call to finish; times are milliseconds. */
 int kmcpg_set_profiling(kmcpg_db* db, int enable);
 int kmcpg_last_timing(kmcpg_db* db, float* kmers_ms, float* cobs_ms);
+/* The same for an earlier call: age 0 = the last one, 1 = the one before ... (the last 4 are kept), so that a caller with
+ * several batches in flight can read the times of a finished one without waiting for the newest. */
+int kmcpg_timing_at(kmcpg_db* db, uint32_t age, float* kmers_ms, float* cobs_ms);
 /* Copies rows (on-disk width NumRowBytes each) of a local block back to the host. */
 int kmcpg_read_rows(kmcpg_db* db, uint32_t block, const uint64_t* row_idx, uint64_t n_rows, uint8_t* out);
+/* The same for rows first_row .. first_row + n_rows - 1 (bench: the index goes back to the host for the CPU baseline). */
+int kmcpg_read_row_range(kmcpg_db* db, uint32_t block, uint64_t first_row, uint64_t n_rows, uint8_t* out);
 /* Geometry of block b (global index): NumSigs, columns, NumRowBytes, device row stride, is-local. */
 int kmcpg_block_info(const kmcpg_db* db, uint32_t block, uint64_t* num_sigs, uint32_t* n_cols, uint32_t* row_bytes,
                      uint32_t* dev_stride, int32_t* is_local, uint32_t* col_base);

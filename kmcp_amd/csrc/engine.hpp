@@ -102,6 +102,8 @@ struct kmcpg_db {
   kmcpg::Seg* d_segs = nullptr;
   std::vector<kmcpg::SlotClass> classes;
   std::vector<uint32_t> col_block;  // global column -> block index
+  std::vector<uint64_t> col_size, col_gsize;  // Header.Sizes / GSizes per global column (flat copies for the host half)
+  std::vector<uint32_t> col_tidx;             // Header.Indices
   std::unique_ptr<kmcpg::QueryFpr> fpr;
   std::mutex mu;      // serialises the enqueueing of GPU-half calls (their kernels share the workspace below, in stream order;
                       // calls on different streams are ordered by ws_ev)
@@ -120,8 +122,8 @@ struct kmcpg_db {
   std::vector<kmcpg_db*> shards;
   // optional HIP-event timing of the last kmcpg_query_device call
   bool profiling = false;
-  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
-  bool ev_valid = false;
+  hipEvent_t ev[12] = {};   // ring of 4 calls x (start, k-mers done, COBS done)
+  uint64_t ev_calls = 0;    // profiled calls so far
 };
 
 

@@ -11,6 +11,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <memory>
 #include <mutex>
 #include <string>
@@ -82,99 +83,176 @@ extern "C" int kmcpg_finalize(const kmcpg_db* db, const kmcpg_hit* hits, uint64_
                               const kmcpg_params* params, kmcpg_result* out) {
   if (!db || !out || (!hits && n_hits) || (n_reads && (!qkmers || !qlen))) return kmcpg_fail(KMCPG_EINVAL, "null argument");
   const kmcpg_params p = params ? *params : default_params();
+  const bool timing = getenv("KMCPG_FIN_TIMING") != nullptr;
+  auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  double t_0 = now(), t_1 = 0, t_2 = 0, t_3 = 0, t_4 = 0;
   std::unique_ptr<ResultOwner, OwnerReturn> o(take_owner());
   o->qlen.assign(qlen, qlen + n_reads);
   o->qkmers.assign(qkmers, qkmers + n_reads);
   const int k_used = p.k > 0 ? p.k : db->info.k;
   o->ksize.assign(n_reads, k_used);
-  // scratch of this thread, kept between calls (a caller thread finalizes batch after batch)
-  static thread_local std::vector<uint64_t> start, cur, per_read;
-  static thread_local std::vector<kmcpg_hit, NoInitAlloc<kmcpg_hit>> sorted;
-  // bucket hits by read (counting sort), then order each bucket by column
-  start.assign((size_t)n_reads + 1, 0);
-  for (uint64_t i = 0; i < n_hits; i++) {
-    if (hits[i].read >= n_reads) return kmcpg_fail(KMCPG_EINVAL, "hit %llu names read %u of %u", (unsigned long long)i, hits[i].read, n_reads);
-    if (hits[i].col >= db->col_block.size()) return kmcpg_fail(KMCPG_EINVAL, "hit names column %u of %zu", hits[i].col, db->col_block.size());
-    start[hits[i].read + 1]++;
+  // Reads are independent, so the batch is cut into W contiguous ranges of reads, one per worker thread:
+  //  A. every worker takes a slice of the hit list (it arrives in no particular order) and counts its hits per range;
+  //  B. ... and scatters them into the ranges' areas of `parted`;
+  //  C. worker w owns range w: counting sort of its hits by read, float64 thresholds, Match values, sort per read.  A hit
+  //     yields at most one match, so the worker writes its matches straight into the result array from the position of its
+  //     range's first hit on; the gaps the filters leave are closed afterwards.
+  static thread_local std::vector<kmcpg_hit, NoInitAlloc<kmcpg_hit>> parted;
+  static thread_local std::vector<uint64_t> per_read;
+  int W = (int)std::max<uint64_t>(1, std::min<uint64_t>(8, n_hits / 32768));
+  if ((uint64_t)W > n_reads) W = n_reads ? (int)n_reads : 1;
+  if (const char* e = getenv("KMCPG_FINALIZE_THREADS")) W = std::max(1, std::min(atoi(e), 64));
+  if ((uint64_t)W > std::max<uint32_t>(1, n_reads)) W = (int)std::max<uint32_t>(1, n_reads);
+  const uint32_t per_range = n_reads ? (n_reads + (uint32_t)W - 1) / (uint32_t)W : 1;
+  auto range_lo = [&](int w) { return (uint32_t)std::min<uint64_t>((uint64_t)w * per_range, n_reads); };
+  const size_t n_cols = db->col_block.size();
+  parted.resize(n_hits);
+  per_read.assign((size_t)n_reads, 0);
+  // thread_local objects are per thread: the workers get at this thread's buffers through plain pointers
+  kmcpg_hit* const parted_p = parted.data();
+  o->matches.resize(n_hits);
+  std::vector<uint64_t> cnt((size_t)W * W, 0);  // cnt[slice a][range b]
+  std::atomic<int> bad{0};
+  auto run = [&](auto&& fn) {
+    if (W == 1) {
+      fn(0);
+      return;
+    }
+    std::vector<std::thread> th;
+    for (int w = 1; w < W; w++) th.emplace_back(fn, w);
+    fn(0);
+    for (auto& t : th) t.join();
+  };
+  auto slice = [&](int a, uint64_t* lo, uint64_t* hi) {
+    *lo = n_hits * (uint64_t)a / (uint64_t)W;
+    *hi = n_hits * (uint64_t)(a + 1) / (uint64_t)W;
+  };
+  run([&](int a) {
+    uint64_t lo, hi;
+    slice(a, &lo, &hi);
+    uint64_t* c = cnt.data() + (size_t)a * W;
+    for (uint64_t i = lo; i < hi; i++) {
+      if (hits[i].read >= n_reads || hits[i].col >= n_cols) {
+        bad.store(1);
+        return;
+      }
+      c[hits[i].read / per_range]++;
+    }
+  });
+  if (bad.load()) {
+    for (uint64_t i = 0; i < n_hits; i++) {
+      if (hits[i].read >= n_reads) return kmcpg_fail(KMCPG_EINVAL, "hit %llu names read %u of %u", (unsigned long long)i, hits[i].read, n_reads);
+      if (hits[i].col >= n_cols) return kmcpg_fail(KMCPG_EINVAL, "hit names column %u of %zu", hits[i].col, n_cols);
+    }
   }
-  for (uint32_t r = 0; r < n_reads; r++) start[r + 1] += start[r];
-  sorted.resize(n_hits);
-  cur.assign(start.begin(), start.end() - 1);
-  for (uint64_t i = 0; i < n_hits; i++) sorted[cur[hits[i].read]++] = hits[i];
+  std::vector<uint64_t> range_start((size_t)W + 1, 0), pos((size_t)W * W, 0);
+  for (int b2 = 0; b2 < W; b2++) {
+    uint64_t p0 = range_start[(size_t)b2];
+    for (int a = 0; a < W; a++) {
+      pos[(size_t)a * W + b2] = p0;
+      p0 += cnt[(size_t)a * W + b2];
+    }
+    range_start[(size_t)b2 + 1] = p0;
+  }
+  run([&](int a) {
+    uint64_t lo, hi;
+    slice(a, &lo, &hi);
+    uint64_t* q = pos.data() + (size_t)a * W;
+    kmcpg_hit* dst = parted_p;
+    for (uint64_t i = lo; i < hi; i++) dst[q[hits[i].read / per_range]++] = hits[i];
+  });
+  t_1 = now();
   // FPR rows of the NumKmers values present (a handful for short reads), fetched once so that the workers below never lock
   QueryFpr* F = db->fpr.get();
   std::unordered_map<int, const std::vector<double>*> fpr_rows;
-  int last_n = -1;  // reads of one batch mostly share their NumKmers: skip the map for runs of the same value
-  for (uint32_t r = 0; r < n_reads; r++) {
-    const int n = qkmers[r];
-    if (n == last_n || n <= 0 || n > QueryFpr::kCachedMaxN || start[r + 1] == start[r]) continue;
-    last_n = n;
-    if (!fpr_rows.count(n)) fpr_rows.emplace(n, F->ensure_row(n));
+  {
+    std::vector<char> seen((size_t)QueryFpr::kCachedMaxN + 1, 0);
+    const kmcpg_hit* ph = parted_p;
+    for (uint64_t i = 0; i < n_hits; i++) {  // only queries with hits need a row
+      const int n = qkmers[ph[i].read];
+      if (n <= 0 || n > QueryFpr::kCachedMaxN || seen[(size_t)n]) continue;
+      seen[(size_t)n] = 1;
+      fpr_rows.emplace(n, F->ensure_row(n));
+    }
   }
-  // Reads are independent: contiguous ranges of reads per worker thread.  A hit yields at most one match, so worker w writes
-  // its matches straight into the result array from position start[lo_w] on; the ranges are closed up afterwards.
-  const int workers = (int)std::max<uint64_t>(1, std::min<uint64_t>(8, n_hits / 32768));
-  o->matches.resize(n_hits);
+  t_2 = now();
   kmcpg_match* const mbase = o->matches.data();
-  per_read.assign((size_t)n_reads, 0);
   uint64_t* const per_read_p = per_read.data();
-  const uint64_t* const start_p = start.data();
-  const kmcpg_hit* const sorted_p = sorted.data();
-  std::vector<uint64_t> wcount((size_t)workers, 0);
-  auto work = [&, mbase, per_read_p, start_p, sorted_p](int w) {
-    const uint32_t lo = (uint32_t)((uint64_t)n_reads * w / workers), hi = (uint32_t)((uint64_t)n_reads * (w + 1) / workers);
-    uint64_t pos = start_p[lo];
+  std::vector<uint64_t> wcount((size_t)W, 0);
+  const uint64_t* const col_size = db->col_size.data();
+  const uint64_t* const col_gsize = db->col_gsize.data();
+  const uint32_t* const col_tidx = db->col_tidx.data();
+  run([&](int w) {
+    const uint32_t lo = range_lo(w), hi = range_lo(w + 1);
+    const uint64_t h0 = range_start[(size_t)w], h1 = range_start[(size_t)w + 1];
+    if (hi <= lo) return;
+    // counting sort of the range's hits by read
+    static thread_local std::vector<uint64_t> start;
+    static thread_local std::vector<kmcpg_hit, NoInitAlloc<kmcpg_hit>> sorted;
+    start.assign((size_t)(hi - lo) + 1, 0);
+    const kmcpg_hit* ph = parted_p;
+    for (uint64_t i = h0; i < h1; i++) start[(size_t)(ph[i].read - lo) + 1]++;
+    for (uint32_t r = 0; r < hi - lo; r++) start[(size_t)r + 1] += start[r];
+    sorted.resize(h1 - h0);
+    {
+      static thread_local std::vector<uint64_t> cur;
+      cur.assign(start.begin(), start.end() - 1);
+      for (uint64_t i = h0; i < h1; i++) sorted[cur[ph[i].read - lo]++] = ph[i];
+    }
+    const uint64_t* const start_p = start.data();
+    const kmcpg_hit* const sorted_p = sorted.data();
+    uint64_t pos2 = h0;
     int row_n = -1;
     const std::vector<double>* row_of_n = nullptr;
     for (uint32_t r = lo; r < hi; r++) {
-      const uint64_t first = pos;
+      const uint64_t s0 = start_p[r - lo], s1 = start_p[r - lo + 1];
+      if (s0 == s1) continue;
+      const uint64_t first = pos2;
       const int n = qkmers[r];
       const double nh = (double)n;
       const double thr = nh * p.min_qcov;
       const std::vector<double>* row = nullptr;
-      if (start_p[r + 1] > start_p[r] && n > 0 && n <= QueryFpr::kCachedMaxN) {
+      if (n > 0 && n <= QueryFpr::kCachedMaxN) {
         if (n != row_n) {
           row_n = n;
           row_of_n = fpr_rows.find(n)->second;
         }
         row = row_of_n;
       }
-      for (uint64_t i = start_p[r]; i < start_p[r + 1]; i++) {
+      for (uint64_t i = s0; i < s1; i++) {
         const kmcpg_hit& h = sorted_p[i];
         const int count = (int)h.count;
         if (count < p.min_matched) continue;
         const double c = (double)count;
         if (!(c > thr)) continue;
-        const BlockMeta& b = db->blocks[db->col_block[h.col]];
-        const uint32_t ci = h.col - b.col_base;
-        const double nt = (double)b.h.sizes[ci];
+        const double nt = (double)col_size[h.col];
         const double T = c / nt;
         if (!(T >= p.min_tcov)) continue;
         const double fpr = row ? (*row)[(size_t)std::min(count, n)] : F->get(n, count);
         if (!(fpr <= p.max_fpr)) continue;
         kmcpg_match m{};
         m.col = h.col;
-        m.target_idx = b.h.indices[ci];
-        m.gsize = b.h.gsizes[ci];
+        m.target_idx = col_tidx[h.col];
+        m.gsize = col_gsize[h.col];
         m.mkmers = count;
         m.fpr = fpr;
         m.qcov = c / nh;
         m.tcov = T;
         m.jacc = c / (nh + nt - c);
-        mbase[pos++] = m;
+        mbase[pos2++] = m;
       }
-      uint64_t cnt = pos - first;
-      if (cnt > 1 && !p.do_not_sort) {
+      uint64_t cnt2 = pos2 - first;
+      if (cnt2 > 1 && !p.do_not_sort) {
         const int sb = p.sort_by;
-        std::sort(mbase + first, mbase + pos, [sb](const kmcpg_match& x, const kmcpg_match& y) { return match_less(x, y, sb); });
-      } else if (cnt > 1) {
-        std::sort(mbase + first, mbase + pos, [](const kmcpg_match& x, const kmcpg_match& y) { return x.col < y.col; });
+        std::sort(mbase + first, mbase + pos2, [sb](const kmcpg_match& x, const kmcpg_match& y) { return match_less(x, y, sb); });
+      } else if (cnt2 > 1) {
+        std::sort(mbase + first, mbase + pos2, [](const kmcpg_match& x, const kmcpg_match& y) { return x.col < y.col; });
       }
-      if (cnt > 0 && p.top_n_scores > 0 && !p.do_not_sort) {  // --keep-top-scores (:285-311), including its [:i+1]
+      if (cnt2 > 0 && p.top_n_scores > 0 && !p.do_not_sort) {  // --keep-top-scores (:285-311), including its [:i+1]
         int nn = 0;
         uint64_t i = 0;
         double pscore = 1024;
-        for (; i < cnt; i++) {
+        for (; i < cnt2; i++) {
           const kmcpg_match& m = mbase[first + i];
           const double score = p.sort_by == 1 ? m.tcov : (p.sort_by == 2 ? m.jacc : m.qcov);
           if (score < pscore) {
@@ -183,29 +261,25 @@ extern "C" int kmcpg_finalize(const kmcpg_db* db, const kmcpg_hit* hits, uint64_
             pscore = score;
           }
         }
-        if (i >= cnt) i = cnt - 1;
-        pos = first + i + 1;
+        if (i >= cnt2) i = cnt2 - 1;
+        pos2 = first + i + 1;
       }
-      per_read_p[r] = pos - first;
+      per_read_p[r] = pos2 - first;
     }
-    wcount[(size_t)w] = pos - start_p[lo];
-  };
-  if (workers == 1) work(0);
-  else {
-    std::vector<std::thread> th;
-    for (int w = 0; w < workers; w++) th.emplace_back(work, w);
-    for (auto& t : th) t.join();
-  }
+    wcount[(size_t)w] = pos2 - h0;
+  });
+  t_3 = now();
   uint64_t total = 0;
-  for (int w = 0; w < workers; w++) {  // close the gaps the filters left between the workers' ranges
-    const uint32_t lo = (uint32_t)((uint64_t)n_reads * w / workers);
-    if (start[lo] != total && wcount[(size_t)w]) memmove(mbase + total, mbase + start[lo], wcount[(size_t)w] * sizeof(kmcpg_match));
+  for (int w = 0; w < W; w++) {  // close the gaps the filters left between the workers' ranges
+    if (range_start[(size_t)w] != total && wcount[(size_t)w]) memmove(mbase + total, mbase + range_start[(size_t)w], wcount[(size_t)w] * sizeof(kmcpg_match));
     total += wcount[(size_t)w];
   }
   o->matches.resize(total);
   o->offs.resize((size_t)n_reads + 1);
   o->offs[0] = 0;
   for (uint32_t r = 0; r < n_reads; r++) o->offs[r + 1] = o->offs[r] + per_read[r];
+  t_4 = now();
+  if (timing) fprintf(stderr, "finalize: bucket %.2f fprrows %.2f workers %.2f close %.2f ms\n", t_1 - t_0, t_2 - t_1, t_3 - t_2, t_4 - t_3);
   out->n_reads = n_reads;
   out->k = k_used;
   out->qlen = o->qlen.data();

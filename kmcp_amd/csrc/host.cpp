@@ -575,12 +575,15 @@ extern "C" int kmcpg_plant(kmcpg_db* db, uint32_t col, const uint64_t* hashes, u
   if (!b.local || n == 0) return 0;
   std::lock_guard<std::mutex> g(db->mu);
   KMCPG_USE_DEVICE(db);
-  uint64_t* d = nullptr;
-  HIPCHK(hipMalloc((void**)&d, n * sizeof(uint64_t)));
-  HIPCHK(hipMemcpy(d, hashes, n * sizeof(uint64_t), hipMemcpyHostToDevice));
-  launch_plant(db->h_blockdev[(size_t)b.local_idx], col - b.col_base, db->info.num_hashes, d, n, nullptr);
-  HIPCHK(hipDeviceSynchronize());
-  HIPCHK(hipFree(d));
+  DevBuf<uint64_t> d;  // released on every path
+  if (d.ensure(n)) return kmcpg_fail(KMCPG_ENOMEM, "hipMalloc failed");
+  hipError_t e = hipMemcpy(d.p, hashes, n * sizeof(uint64_t), hipMemcpyHostToDevice);
+  if (e == hipSuccess) {
+    launch_plant(db->h_blockdev[(size_t)b.local_idx], col - b.col_base, db->info.num_hashes, d.p, n, nullptr);
+    e = hipDeviceSynchronize();
+  }
+  d.release();
+  if (e != hipSuccess) return kmcpg_fail(KMCPG_EDEVICE, "planting: %s", hipGetErrorString(e));
   return 0;
 }
 
@@ -593,14 +596,47 @@ extern "C" int kmcpg_read_rows(kmcpg_db* db, uint32_t block, const uint64_t* row
   if (n_rows == 0) return 0;
   std::lock_guard<std::mutex> g(db->mu);
   KMCPG_USE_DEVICE(db);
-  uint64_t* d_idx = nullptr;
+  DevBuf<uint64_t> d_idx;  // released on every path
+  DevBuf<uint8_t> d_out;
+  if (d_idx.ensure(n_rows) || d_out.ensure(n_rows * b.h.row_bytes)) {
+    d_idx.release();
+    d_out.release();
+    return kmcpg_fail(KMCPG_ENOMEM, "hipMalloc failed");
+  }
+  hipError_t e = hipMemcpy(d_idx.p, row_idx, n_rows * sizeof(uint64_t), hipMemcpyHostToDevice);
+  if (e == hipSuccess) {
+    launch_gather_rows(b.d_rows, b.stride, b.h.row_bytes, d_idx.p, 0, n_rows, d_out.p, nullptr);
+    e = hipMemcpy(out, d_out.p, n_rows * b.h.row_bytes, hipMemcpyDeviceToHost);
+  }
+  d_idx.release();
+  d_out.release();
+  if (e != hipSuccess) return kmcpg_fail(KMCPG_EDEVICE, "reading rows back: %s", hipGetErrorString(e));
+  return 0;
+}
+
+extern "C" int kmcpg_read_row_range(kmcpg_db* db, uint32_t block, uint64_t first_row, uint64_t n_rows, uint8_t* out) {
+  if (!db || block >= db->blocks.size() || (!out && n_rows)) return kmcpg_fail(KMCPG_EINVAL, "bad argument");
+  const BlockMeta& b = db->blocks[block];
+  if (!b.local) return kmcpg_fail(KMCPG_EINVAL, "block %u is not resident on this rank", block);
+  if (first_row > b.h.num_sigs || n_rows > b.h.num_sigs - first_row) return kmcpg_fail(KMCPG_EINVAL, "row out of range");
+  if (n_rows == 0) return 0;
+  std::lock_guard<std::mutex> g(db->mu);
+  KMCPG_USE_DEVICE(db);
+  if (b.h.row_bytes >= 512) {  // wide rows: one strided copy
+    HIPCHK(hipMemcpy2D(out, b.h.row_bytes, b.d_rows + first_row * b.stride, b.stride, b.h.row_bytes, n_rows, hipMemcpyDeviceToHost));
+    return 0;
+  }
+  // narrow rows (a 2-D copy would move them one by one): packed on the device first
+  const uint64_t chunk = std::max<uint64_t>(1, (64ull << 20) / b.h.row_bytes);
   uint8_t* d_out = nullptr;
-  HIPCHK(hipMalloc((void**)&d_idx, n_rows * sizeof(uint64_t)));
-  HIPCHK(hipMalloc((void**)&d_out, n_rows * b.h.row_bytes));
-  HIPCHK(hipMemcpy(d_idx, row_idx, n_rows * sizeof(uint64_t), hipMemcpyHostToDevice));
-  launch_gather_rows(b.d_rows, b.stride, b.h.row_bytes, d_idx, n_rows, d_out, nullptr);
-  HIPCHK(hipMemcpy(out, d_out, n_rows * b.h.row_bytes, hipMemcpyDeviceToHost));
-  HIPCHK(hipFree(d_idx));
-  HIPCHK(hipFree(d_out));
+  HIPCHK(hipMalloc((void**)&d_out, std::min(chunk, n_rows) * b.h.row_bytes));
+  hipError_t e = hipSuccess;
+  for (uint64_t r0 = 0; r0 < n_rows && e == hipSuccess; r0 += chunk) {
+    const uint64_t nr = std::min(chunk, n_rows - r0);
+    launch_gather_rows(b.d_rows, b.stride, b.h.row_bytes, nullptr, first_row + r0, nr, d_out, nullptr);
+    e = hipMemcpy(out + r0 * b.h.row_bytes, d_out, nr * b.h.row_bytes, hipMemcpyDeviceToHost);
+  }
+  (void)hipFree(d_out);
+  if (e != hipSuccess) return kmcpg_fail(KMCPG_EDEVICE, "reading rows back: %s", hipGetErrorString(e));
   return 0;
 }

@@ -18,7 +18,7 @@ void launch_list_long(const int32_t* nk, uint32_t n_reads, int32_t split_min, ui
 void launch_threshold_long(const K2Args& a, hipStream_t st);
 void launch_max_nk(const int32_t* nk, uint32_t n_reads, unsigned long long* out, hipStream_t st);
 void launch_repack(const uint8_t* src, uint8_t* dst, uint64_t n_rows, uint32_t row_bytes, uint32_t stride, uint32_t byte_off, hipStream_t st);
-void launch_gather_rows(const uint8_t* rows, uint32_t stride, uint32_t row_bytes, const uint64_t* idx, uint64_t n, uint8_t* out,
+void launch_gather_rows(const uint8_t* rows, uint32_t stride, uint32_t row_bytes, const uint64_t* idx, uint64_t first, uint64_t n, uint8_t* out,
                         hipStream_t st);
 void launch_synth_fill(uint8_t* rows, uint64_t n_rows, uint32_t stride, uint32_t own_stride, uint32_t ncols, uint64_t key, uint32_t p8, hipStream_t st);
 void launch_plant(const BlockDev& bd, uint32_t col, int num_hashes, const uint64_t* hashes, uint64_t n, hipStream_t st);

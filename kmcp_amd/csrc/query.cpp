@@ -179,17 +179,18 @@ extern "C" int kmcpg_query_device(kmcpg_db* db, const uint8_t* d_seqs, const uin
   const bool window_sketch = db->info.syncmer || db->info.minimizer;
   if ((ub > (uint64_t)p.dedup_threshold || window_sketch) && db->w_scratch.ensure(2 * total_bases + 2)) return kmcpg_fail(KMCPG_ENOMEM, "hipMalloc failed");
   uint64_t maxn = 0;
+  hipEvent_t* pev = db->ev + 3 * (db->ev_calls % 4);
   if (db->profiling) {
     for (auto& ev : db->ev)
       if (!ev) HIPCHK(hipEventCreate(&ev));
-    HIPCHK(hipEventRecord(db->ev[0], st));
+    HIPCHK(hipEventRecord(pev[0], st));
   }
   int rc = run_kmers(db, d_seqs, d_offs, d_seqs2, d_offs2, n_reads, max_read_len, p, db->w_hashes.p, db->w_scratch.p, total_bases + 1, db->w_nk_raw.p,
                      db->w_nk1.p, d_qkmers, d_qlen, st, &maxn);
   if (rc) return rc;
   HIPCHK(hipMemsetAsync(d_counters, 0, 2 * sizeof(uint64_t), st));
   launch_max_nk(d_qkmers, n_reads, (unsigned long long*)d_counters + 1, st);
-  if (db->profiling) HIPCHK(hipEventRecord(db->ev[1], st));
+  if (db->profiling) HIPCHK(hipEventRecord(pev[1], st));
   // long queries (whole genomes, -g) are split into chunks of k-mers so that they spread over the chip; short ones keep
   // the one-wave-per-(query, slot) kernel.  Which queries are long is only known on the device: one small D2H read.
   const char* sm_env = getenv("KMCPG_SPLIT_MIN");
@@ -263,8 +264,8 @@ extern "C" int kmcpg_query_device(kmcpg_db* db, const uint8_t* d_seqs, const uin
     }
   }
   if (db->profiling) {
-    HIPCHK(hipEventRecord(db->ev[2], st));
-    db->ev_valid = true;
+    HIPCHK(hipEventRecord(pev[2], st));
+    db->ev_calls++;
   }
   if (int rc1 = ws_end(db, st)) return rc1;
   HIPCHK(hipGetLastError());
@@ -275,23 +276,26 @@ extern "C" int kmcpg_set_profiling(kmcpg_db* db, int enable) {
   if (!db) return kmcpg_fail(KMCPG_EINVAL, "null argument");
   std::lock_guard<std::mutex> g(db->mu);
   db->profiling = enable != 0;
-  db->ev_valid = false;
+  db->ev_calls = 0;
   return 0;
 }
 
-extern "C" int kmcpg_last_timing(kmcpg_db* db, float* kmers_ms, float* cobs_ms) {
+extern "C" int kmcpg_timing_at(kmcpg_db* db, uint32_t age, float* kmers_ms, float* cobs_ms) {
   if (!db) return kmcpg_fail(KMCPG_EINVAL, "null argument");
   std::lock_guard<std::mutex> g(db->mu);
-  if (!db->profiling || !db->ev_valid) return kmcpg_fail(KMCPG_EINVAL, "no profiled kmcpg_query_device call yet");
+  if (!db->profiling || age >= 4 || db->ev_calls <= age) return kmcpg_fail(KMCPG_EINVAL, "no profiled kmcpg_query_device call of that age (the last 4 are kept)");
   KMCPG_USE_DEVICE(db);
-  HIPCHK(hipEventSynchronize(db->ev[2]));
+  hipEvent_t* pev = db->ev + 3 * ((db->ev_calls - 1 - age) % 4);
+  HIPCHK(hipEventSynchronize(pev[2]));
   float a = 0, b = 0;
-  HIPCHK(hipEventElapsedTime(&a, db->ev[0], db->ev[1]));
-  HIPCHK(hipEventElapsedTime(&b, db->ev[1], db->ev[2]));
+  HIPCHK(hipEventElapsedTime(&a, pev[0], pev[1]));
+  HIPCHK(hipEventElapsedTime(&b, pev[1], pev[2]));
   if (kmers_ms) *kmers_ms = a;
   if (cobs_ms) *cobs_ms = b;
   return 0;
 }
+
+extern "C" int kmcpg_last_timing(kmcpg_db* db, float* kmers_ms, float* cobs_ms) { return kmcpg_timing_at(db, 0, kmers_ms, cobs_ms); }
 
 extern "C" int kmcpg_plant_reads_device(kmcpg_db* db, const uint8_t* d_seqs, const uint64_t* d_offs, uint32_t n_reads, uint64_t total_bases,
                                         uint32_t max_read_len, const uint32_t* d_cols, void* stream) {

@@ -43,22 +43,23 @@ void launch_repack(const uint8_t* src, uint8_t* dst, uint64_t n_rows, uint32_t r
   hipLaunchKernelGGL(k_repack, dim3(blocks), dim3(256), 0, st, src, dst, n_rows, row_bytes, stride, byte_off);
 }
 
-__global__ void k_gather_rows(const uint8_t* __restrict__ rows, uint32_t stride, uint32_t row_bytes, const uint64_t* __restrict__ idx,
+// rows idx[0..n) — or first .. first+n-1 when idx is null — of a block, packed at the on-disk width
+__global__ void k_gather_rows(const uint8_t* __restrict__ rows, uint32_t stride, uint32_t row_bytes, const uint64_t* __restrict__ idx, uint64_t first,
                               uint64_t n, uint8_t* __restrict__ out) {
   const uint64_t total = n * row_bytes;
   for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (uint64_t)gridDim.x * blockDim.x) {
     const uint64_t r = i / row_bytes;
     const uint32_t b = (uint32_t)(i % row_bytes);
-    out[i] = rows[idx[r] * stride + b];
+    out[i] = rows[(idx ? idx[r] : first + r) * stride + b];
   }
 }
 
-void launch_gather_rows(const uint8_t* rows, uint32_t stride, uint32_t row_bytes, const uint64_t* idx, uint64_t n, uint8_t* out,
+void launch_gather_rows(const uint8_t* rows, uint32_t stride, uint32_t row_bytes, const uint64_t* idx, uint64_t first, uint64_t n, uint8_t* out,
                         hipStream_t st) {
   if (n == 0) return;
   uint64_t total = n * row_bytes;
   unsigned blocks = (unsigned)((total + 255) / 256 > 65536 ? 65536 : (total + 255) / 256);
-  hipLaunchKernelGGL(k_gather_rows, dim3(blocks), dim3(256), 0, st, rows, stride, row_bytes, idx, n, out);
+  hipLaunchKernelGGL(k_gather_rows, dim3(blocks), dim3(256), 0, st, rows, stride, row_bytes, idx, first, n, out);
 }
 
 // ------------------------------------------------------------------------------------------------

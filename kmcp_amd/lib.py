@@ -15,7 +15,7 @@ EXPORTS = [
     "kmcpg_open", "kmcpg_close", "kmcpg_last_error", "kmcpg_db_info", "kmcpg_col_info", "kmcpg_search_batch",
     "kmcpg_result_free", "kmcpg_query_device", "kmcpg_finalize", "kmcpg_open_synthetic", "kmcpg_plant",
     "kmcpg_read_rows", "kmcpg_block_info", "kmcpg_kmers_device", "kmcpg_plant_reads_device", "kmcpg_set_profiling",
-    "kmcpg_last_timing", "kmcpg_open_devices", "kmcpg_build_db", "kmcpg_submit", "kmcpg_wait",
+    "kmcpg_last_timing", "kmcpg_open_devices", "kmcpg_build_db", "kmcpg_submit", "kmcpg_wait", "kmcpg_read_row_range", "kmcpg_timing_at",
 ]
 
 
@@ -134,11 +134,13 @@ def load():
     L.kmcpg_finalize.argtypes = [vp, vp, C.c_uint64, vp, vp, C.c_uint32, C.POINTER(Params), C.POINTER(Result)]
     L.kmcpg_plant.argtypes = [vp, C.c_uint32, vp, C.c_uint64]
     L.kmcpg_read_rows.argtypes = [vp, C.c_uint32, vp, C.c_uint64, vp]
+    L.kmcpg_read_row_range.argtypes = [vp, C.c_uint32, C.c_uint64, C.c_uint64, vp]
     L.kmcpg_kmers_device.argtypes = [vp, vp, vp, C.c_uint32, C.c_uint64, C.c_uint32, C.POINTER(Params), vp, C.c_uint64,
                                      vp, vp, vp]
     L.kmcpg_plant_reads_device.argtypes = [vp, vp, vp, C.c_uint32, C.c_uint64, C.c_uint32, vp, vp]
     L.kmcpg_set_profiling.argtypes = [vp, C.c_int]
     L.kmcpg_last_timing.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    L.kmcpg_timing_at.argtypes = [vp, C.c_uint32, C.POINTER(C.c_float), C.POINTER(C.c_float)]
     L.kmcpg_build_db.argtypes = [C.c_char_p, C.POINTER(BuildCfg), C.POINTER(BuildCol), C.c_uint32, C.c_int32]
     _lib = L
     return L
@@ -329,7 +331,23 @@ class Database:
                                      len(qkmers), C.byref(p), C.byref(r)))
         return _copy_result(r)
 
+    def finalize_count(self, hits_u32, qkmers, qlen, params=None):
+        """kmcpg_finalize on raw buffers (hits: C-contiguous int32/uint32 [n, 3]); returns the number of matches, copies nothing."""
+        p = params or default_params()
+        assert hits_u32.flags["C_CONTIGUOUS"] and hits_u32.dtype.itemsize == 4 and qkmers.dtype == np.int32 and qlen.dtype == np.int32
+        r = Result()
+        n = len(qkmers)
+        _check(load().kmcpg_finalize(self._h, hits_u32.ctypes.data, hits_u32.shape[0], qkmers.ctypes.data, qlen.ctypes.data, n, C.byref(p), C.byref(r)))
+        m = int(r.match_offs[n]) if n else 0
+        load().kmcpg_result_free(C.byref(r))
+        return m
+
     # ---- bench / parity support -----------------------------------------------------------------------
+    def read_row_range(self, block, first_row, out):
+        """rows first_row .. first_row+len(out)-1 of a resident block into `out` (uint8 [n, NumRowBytes], C-contiguous)."""
+        assert out.flags["C_CONTIGUOUS"] and out.dtype == np.uint8
+        _check(load().kmcpg_read_row_range(self._h, block, first_row, out.shape[0], out.ctypes.data))
+
     def plant(self, col, hashes):
         hashes = np.ascontiguousarray(hashes, dtype=np.uint64)
         _check(load().kmcpg_plant(self._h, col, hashes.ctypes.data, len(hashes)))
@@ -340,10 +358,10 @@ class Database:
     def set_profiling(self, on=True):
         _check(load().kmcpg_set_profiling(self._h, int(on)))
 
-    def last_timing(self):
-        """(k-mer kernels ms, COBS kernel ms) of the last query_device call."""
+    def last_timing(self, age=0):
+        """(k-mer kernels ms, COBS kernel ms) of the last query_device call (age 1: the one before, ... up to 3)."""
         a, b = C.c_float(), C.c_float()
-        _check(load().kmcpg_last_timing(self._h, C.byref(a), C.byref(b)))
+        _check(load().kmcpg_timing_at(self._h, age, C.byref(a), C.byref(b)))
         return a.value, b.value
 
     def read_rows(self, block, row_idx):

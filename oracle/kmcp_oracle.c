@@ -1004,3 +1004,105 @@ int64_t ko_search_batch(ko_db* db, const uint8_t* seqs, const uint64_t* offs, ui
   (void)overflow;
   return nh;
 }
+
+
+/* ================================================================================================
+ * The reference's own loop shape for the bench's second cpu_baseline leg ("reference-shaped port"):
+ *  - one worker per index file, each handling every query against its block (NewUnikIndex's `fn`, util-db-search.go:1296-1320,
+ *    :7735-7756; with threads <= #blocks extraWorkers (:213-219) is 0), the query goroutines only generate k-mers (:793-919);
+ *  - rows are not copied: 64 row pointers are buffered (PosPopCountBufSize, :1164, :6811-6819), then for every byte i of the row
+ *    the 64 bytes buffs[j][i] are gathered into buf (the transposition the author calls the bottleneck, :1158-1163, :6823-6966)
+ *    and pospop.Count8(&counts[i], buf) adds the per-bit-position popcounts (:6968); the tail of < 64 rows goes through the same
+ *    code with a shorter buf (countKmerss[bufIdx], :1448-6539, :7408);
+ *  - counts are [NumRowBytes][8]int, reset by copy() per query (:6616); the threshold scan reads _counts[7]..[0] (:7466-7704).
+ * pospop v1.2.3 is AVX2 assembly; Count8 here is the same movemask formulation with intrinsics (scalar fallback).
+ * Single-hash, single-end databases only (the bench workload); results equal ko_search_batch's.
+ * ============================================================================================== */
+#if defined(__AVX2__)
+#include <immintrin.h>
+#endif
+static inline void count8(int64_t* counts /*[8]*/, const uint8_t* buf, int n) {
+  /* counts[b] += number of bytes of buf with bit b set (pospop.Count8: counts[0] is the LSB position) */
+  int i = 0;
+#if defined(__AVX2__)
+  for (; i + 32 <= n; i += 32) {
+    __m256i v = _mm256_loadu_si256((const __m256i*)(buf + i));
+    for (int b = 7; b >= 0; b--) {
+      counts[b] += __builtin_popcount((unsigned)_mm256_movemask_epi8(v));
+      v = _mm256_add_epi8(v, v);
+    }
+  }
+#endif
+  for (; i < n; i++) {
+    uint8_t v = buf[i];
+    for (int b = 0; b < 8; b++) counts[b] += (v >> b) & 1;
+  }
+}
+
+int64_t ko_search_batch_refshape(ko_db* db, const uint8_t* seqs, const uint64_t* offs, uint32_t n_reads, const ko_search_params* p,
+                                 int threads, int32_t* qkmers, uint32_t* hits_out, int64_t hits_cap) {
+  if (!g_seed_ready) seed_init();
+  if (db->num_hashes != 1) { snprintf(g_err, sizeof g_err, "ko_search_batch_refshape: single-hash databases only"); return -1; }
+#ifdef _OPENMP
+  if (threads > 0) omp_set_num_threads(threads);
+#endif
+  /* query goroutines: k-mers of every read (:793-919) */
+  uint64_t* kmers = (uint64_t*)malloc((size_t)(offs[n_reads] + 1) * sizeof(uint64_t));
+#pragma omp parallel for schedule(dynamic, 64)
+  for (uint32_t r = 0; r < n_reads; r++) {
+    size_t len = (size_t)(offs[r + 1] - offs[r]);
+    qkmers[r] = 0;
+    if ((int)len < p->min_qlen) continue;
+    size_t n = ko_generate_kmers(seqs + offs[r], len, &db->cfg, kmers + offs[r]);
+    if ((int)n < p->min_matched) continue;
+    if ((int)n > p->dedup_threshold) n = ko_sort_unique(kmers + offs[r], n);
+    qkmers[r] = (int32_t)n;
+  }
+  int64_t nh = 0;
+  /* index workers: one per block */
+#pragma omp parallel for schedule(dynamic, 1)
+  for (int bi = 0; bi < db->nblocks; bi++) {
+    const ko_block* b = &db->blocks[bi];
+    const uint8_t* sigs = b->file + b->offset0;
+    const uint32_t rb = b->row_bytes;
+    int64_t (*counts)[8] = (int64_t(*)[8])malloc((size_t)rb * sizeof(int64_t[8]));
+    const uint8_t* buffs[64];
+    uint8_t buf[64];
+    for (uint32_t r = 0; r < n_reads; r++) {
+      const int n = qkmers[r];
+      if (n <= 0) continue;
+      const uint64_t* km = kmers + offs[r];
+      memset(counts, 0, (size_t)rb * sizeof(int64_t[8])); /* copy(counts, counts0), :6616 */
+      int bufidx = 0;
+      for (int i = 0; i < n; i++) {
+        buffs[bufidx++] = sigs + (size_t)(km[i] % b->num_sigs) * rb; /* :6811-6816 */
+        if (bufidx == 64 || i == n - 1) {
+          for (uint32_t c = 0; c < rb; c++) { /* every column byte of the matrix, :6823 */
+            for (int j = 0; j < bufidx; j++) buf[j] = buffs[j][c];
+            count8(counts[c], buf, bufidx);
+          }
+          bufidx = 0;
+        }
+      }
+      const double nhf = (double)n, thr = nhf * p->min_qcov;
+      for (uint32_t c8 = 0; c8 < rb; c8++) {
+        for (int j = 0; j < 8; j++) { /* column 8i+j reads _counts[7-j], :7466-7704 */
+          const uint32_t c = c8 * 8 + (uint32_t)j;
+          const int count = (int)counts[c8][7 - j];
+          if (c >= b->ncols || count < p->min_matched) continue;
+          const double cf = (double)count;
+          if (!(cf > thr)) continue;
+          if (!(cf / (double)b->sizes[c] >= p->min_tcov)) continue;
+          if (!(ko_query_fpr(n, count, db->fpr) <= p->max_fpr)) continue;
+          int64_t slot;
+#pragma omp atomic capture
+          slot = nh++;
+          if (slot < hits_cap) { hits_out[3 * slot] = r; hits_out[3 * slot + 1] = b->col_base + c; hits_out[3 * slot + 2] = (uint32_t)count; }
+        }
+      }
+    }
+    free(counts);
+  }
+  free(kmers);
+  return nh;
+}

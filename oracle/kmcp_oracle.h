@@ -161,6 +161,12 @@ int64_t ko_search_batch(ko_db* db, const uint8_t* seqs, const uint64_t* offs, ui
                         const ko_search_params* p, int threads, int32_t* qkmers, uint32_t* hits_out,
                         int64_t hits_cap);
 
+/* the same batch through the reference's own loop shape: one worker per block, 64 buffered row pointers, byte transposition +
+ * Count8 per column byte (util-db-search.go:6811-6972, :213-219).  Single-hash databases. */
+int64_t ko_search_batch_refshape(ko_db* db, const uint8_t* seqs, const uint64_t* offs, uint32_t n_reads,
+                                 const ko_search_params* p, int threads, int32_t* qkmers, uint32_t* hits_out,
+                                 int64_t hits_cap);
+
 /* TSV line formatting exactly as search.go:517-575 (FormatFloat 'f',4 / 'e',4) */
 int ko_format_match(char* buf, size_t cap, const char* query_id, const ko_result* r, const ko_match* m,
                     uint64_t query_idx);

@@ -125,6 +125,8 @@ def lib():
     L.ko_search_batch.restype = C.c_int64
     L.ko_search_batch.argtypes = [C.c_void_p, C.c_void_p, u64p, C.c_uint32, C.POINTER(SearchParams), C.c_int,
                                   C.POINTER(C.c_int32), C.POINTER(C.c_uint32), C.c_int64]
+    L.ko_search_batch_refshape.restype = C.c_int64
+    L.ko_search_batch_refshape.argtypes = L.ko_search_batch.argtypes
     L.ko_format_match.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p, C.POINTER(Result), C.POINTER(Match), C.c_uint64]
     L.ko_set_seed_mode.argtypes = [C.c_int]
     _ = u8p
@@ -248,8 +250,9 @@ class OracleDB:
         lib().ko_result_free(C.byref(r))
         return res
 
-    def search_batch(self, seqs: np.ndarray, offs: np.ndarray, params=None, threads=0):
-        """Threaded single-end batch (cpu_baseline).  Returns (qkmers[n], hits[m,3] sorted by (read,col))."""
+    def search_batch(self, seqs: np.ndarray, offs: np.ndarray, params=None, threads=0, refshape=False):
+        """Threaded single-end batch (cpu_baseline).  Returns (qkmers[n], hits[m,3] sorted by (read,col)).
+        refshape: the reference's own loop shape (one worker per block, 64-row byte transposition + Count8)."""
         p = params or default_params()
         seqs = np.ascontiguousarray(seqs, dtype=np.uint8)
         offs = np.ascontiguousarray(offs, dtype=np.uint64)
@@ -258,7 +261,8 @@ class OracleDB:
         cap = max(1024, 64 * n)
         while True:
             hits = np.zeros((cap, 3), dtype=np.uint32)
-            m = lib().ko_search_batch(self.h, seqs.ctypes.data, _u64p(offs), n, C.byref(p), threads,
+            fn = lib().ko_search_batch_refshape if refshape else lib().ko_search_batch
+            m = fn(self.h, seqs.ctypes.data, _u64p(offs), n, C.byref(p), threads,
                                       qk.ctypes.data_as(C.POINTER(C.c_int32)),
                                       hits.ctypes.data_as(C.POINTER(C.c_uint32)), cap)
             if m <= cap:
