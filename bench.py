@@ -238,12 +238,17 @@ def run_workload(name, ctx, steps, warmup, batch_reads=0, cpu_baseline=True, cpu
                 bf = bufs[j % 2]
                 if j + 1 < count:
                     gpu_half(first + j + 1, bufs[(j + 1) % 2])
+                ta = time.perf_counter()
                 n = exchange(bf)
+                tb = time.perf_counter()
                 hits += n
                 if with_host:
                     matches += host_half(bf, n)
+                tc = time.perf_counter()
                 if times is not None:
                     times.append(db.last_timing(age=1 if j + 1 < count else 0))
+                if os.environ.get("KMCP_BENCH_TRACE"):
+                    print(f"step {j}: exchange {1e3*(tb-ta):.2f} ms, host half {1e3*(tc-tb):.2f} ms, timing {1e3*(time.perf_counter()-tc):.2f} ms", file=sys.stderr)
             return hits, matches
         for j in range(count):
             gpu_half(first + j, bufs[0])
@@ -285,7 +290,7 @@ def run_workload(name, ctx, steps, warmup, batch_reads=0, cpu_baseline=True, cpu
     if os.path.exists(tfile):
         try:
             tj = json.load(open(tfile))
-            key = f"{name}:{B}:{world}"
+            key = f"{name}{'_ungrouped' if os.environ.get('KMCPG_FUSE') == '0' else ''}:{B}:{world}"
             if key in tj:
                 traffic = tj[key]["hbm_bytes_per_launch"]
                 traffic_src = tj[key].get("source")
