@@ -1,0 +1,89 @@
+"""The N > 1 code paths, executed where only one GPU is visible: two ranks share GPU 0 (each holds its shard of the blocks),
+the exchange runs over gloo because RCCL refuses two ranks on one device.  When the box shows two or more GPUs the same
+launches run one rank per GPU over nccl (= RCCL over xGMI), the path the driver's scaling bench takes.
+
+  * bench.py --gpus 2 at the headline (GTDB-scale) shape: the merged hit list of two half-index ranks is the one-rank hit list;
+  * kmcp_amd.dist.ShardedSearcher's overflow loop (all-reduce of the largest per-rank hit count, rerun with room for every hit)
+    through python -m kmcp_amd.dist_search, against the oracle's TSV."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+from tests import synth
+from tests.test_gpu_cli import compare, oracle_tsv, write_fastq
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _env(same_gpu_var):
+    import torch
+    env = dict(os.environ, PYTHONPATH=ROOT, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    multi = torch.cuda.device_count() >= 2
+    if not multi:
+        env[same_gpu_var] = "1"
+    return env, multi
+
+
+def _launch(n, port, args, env):
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1", "--master-port", str(port)] + args
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
+    return r
+
+
+def _bench_line(stdout):
+    lines = [ln for ln in stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_two_ranks_equal_one_rank():
+    import torch
+    free_b, _ = torch.cuda.mem_get_info(0)
+    if free_b < 140e9:
+        pytest.skip("needs 140 GB of free HBM (58 GB index once for the one-rank run, once split over the two ranks)")
+    env, multi = _env("KMCP_BENCH_SAME_GPU")
+    args = ["--steps", "2", "--warmup", "1", "--batch-reads", "16384", "--no-cpu-baseline", "--no-secondary"]
+    one = subprocess.run([sys.executable, "bench.py", "--gpus", "1"] + args, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert one.returncode == 0, one.stderr[-3000:]
+    j1 = _bench_line(one.stdout)
+    j2 = _bench_line(_launch(2, 29741, ["bench.py", "--gpus", "2"] + args, env).stdout)
+    assert j1["n_gpus"] == 1 and j2["n_gpus"] == 2 and j2["scaling"] == "strong"
+    assert j2["config"]["parallelism"] == "block-shard x2"
+    assert j2["config"]["index_bytes"] == j1["config"]["index_bytes"]
+    assert abs(j2["config"]["index_bytes_this_rank"] * 2 - j1["config"]["index_bytes"]) < 0.02 * j1["config"]["index_bytes"]
+    # the union of the two ranks' hit lists, gathered on rank 0 and finalized there, is the one-rank result
+    assert j2["hits_per_step"] == j1["hits_per_step"] > 10000
+    assert j2["matches_per_step"] == j1["matches_per_step"] > 10000
+    assert j2["planted_recall"] == j1["planted_recall"] > 0.99
+    assert j2["roofline"]["algorithmic_bytes_per_launch"] * 2 == pytest.approx(j1["roofline"]["algorithmic_bytes_per_launch"], rel=0.02)
+    assert j2["value"] > 0 and "host_boundary" not in j2  # per-rank extras ride along only at N = 1
+    assert ("nccl" if multi else "gloo")  # which exchange ran is decided by the GPUs visible; both go through gather_hits
+
+
+def test_sharded_searcher_overflow_loop(oracle_lib, tmp_path):
+    """Hundreds of chance hits per read: the per-rank hit buffers (8 per read) overflow on every rank; the ranks agree on the
+    largest count with an all-reduce and rerun (kmcp_amd/dist.py)."""
+    O = oracle_lib
+    genomes = synth.random_genomes(400, 3000, seed=195)
+    db_dir = synth.make_db(tmp_path / "db", genomes, k=21, fpr=0.3, block_size=104)  # 4 blocks: two per rank
+    reads = synth.sample_reads(genomes, 120, 150, seed=196, frac_random=0.5)
+    ids = [f"q{i}" for i in range(len(reads))]
+    fq = str(tmp_path / "reads.fq")
+    write_fastq(fq, ids, reads)
+    odb = O.OracleDB(db_dir)
+    p = O.default_params(min_qcov=0.31, max_fpr=1.0, min_matched=1)
+    want, trailer = oracle_tsv(O, odb, ids, reads, params=p)
+    odb.close()
+    assert len(want) > 50 * len(reads)
+    env, _ = _env("KMCP_DIST_SAME_GPU")
+    out = str(tmp_path / "o.tsv")
+    _launch(2, 29743, ["-m", "kmcp_amd.dist_search", "-d", os.path.dirname(db_dir), fq, "-o", out, "-t", "0.31", "-f", "1", "-c", "1"], env)
+    compare(open(out).read().split("\n"), want, trailer)
