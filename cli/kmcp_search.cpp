@@ -269,6 +269,58 @@ class Queue {
   bool closed_ = false;
 };
 
+// The records of one single-end input file as batches of about `batch_reads` queries, in file order.  Plain four-line FASTQ
+// files are cut and parsed by several threads (ParallelFastq: every chunk becomes a batch without another copy); everything
+// else — gzip, BGZF, FASTA, wrapped FASTQ, pipes — goes through the single-threaded FastxReader.  Returns the number of records.
+template <class Emit>
+static uint64_t read_single_end(const std::string& file, size_t batch_reads, size_t max_bases, Emit&& emit) {
+  uint64_t n = 0;
+  std::unique_ptr<Batch> b(new Batch());
+  auto flush = [&] {
+    if (b->size() == 0) return;
+    n += b->size();
+    emit(std::move(b));
+    b.reset(new Batch());
+  };
+  auto add = [&](const FastxRec& r) {
+    b->id_buf.insert(b->id_buf.end(), r.id, r.id + r.id_len);
+    b->id_offs.push_back(b->id_buf.size());
+    b->seqs.insert(b->seqs.end(), (const uint8_t*)r.seq, (const uint8_t*)r.seq + r.seq_len);
+    b->offs.push_back(b->seqs.size());
+    if (b->size() >= batch_reads || b->seqs.size() >= max_bases) flush();
+  };
+  uint64_t resume = 0;
+  bool serial = true;
+  if (ParallelFastq::eligible(file)) {
+    int w = (int)std::min(8u, std::max(2u, std::thread::hardware_concurrency() / 2));
+    if (const char* e = getenv("KMCP_READER_THREADS")) w = std::max(1, atoi(e));
+    ParallelFastq pf(file, batch_reads, w);
+    serial = false;
+    while (std::unique_ptr<FastqChunk> c = pf.next()) {
+      if (!c->strict) {  // not four-line FASTQ from here on: the general reader takes over at the chunk's first byte
+        resume = c->file_off;
+        serial = true;
+        break;
+      }
+      if (c->size() == 0) continue;
+      std::unique_ptr<Batch> cb(new Batch());
+      cb->id_buf.swap(c->id_buf);
+      cb->id_offs.swap(c->id_offs);
+      cb->seqs.swap(c->seqs);
+      cb->offs.swap(c->offs);
+      n += cb->size();
+      emit(std::move(cb));
+    }
+  }
+  if (serial) {
+    FastxReader r(file, resume);
+    FastxRec rec;
+    while (r.next(&rec)) add(rec);
+    flush();
+  }
+  return n;
+}
+
 // one complete gzip member holding `in` (deflate level 6 as compress/gzip's default in the reference's outStream)
 static std::string gzip_member(const std::string& in) {
   z_stream z;
@@ -410,24 +462,52 @@ int main(int argc, char** argv) {
   const bool verbose = !o.quiet;
   const auto t_start = std::chrono::steady_clock::now();
   if (o.parse_only) {  // reader check, no database and no GPU: one summary line per input file
+    // checksum = sum over records i (0-based, in file order) of fnv1a("id\tseq\n") * (2 i + 1) mod 2^64: order-sensitive, yet
+    // every batch can be summed on its own thread
     for (const auto& file : o.files) {
-      FastxReader r(file);
-      FastxRec rec;
-      uint64_t n = 0, bases = 0, id_bytes = 0, sum = 1469598103934665603ULL;  // FNV-1a over "id\tseq\n"
-      auto mix = [&](const char* p, size_t len) {
-        for (size_t i = 0; i < len; i++) sum = (sum ^ (uint8_t)p[i]) * 1099511628211ULL;
-      };
-      while (r.next(&rec)) {
-        n++;
-        bases += rec.seq_len;
-        id_bytes += rec.id_len;
-        mix(rec.id, rec.id_len);
-        mix("\t", 1);
-        mix(rec.seq, rec.seq_len);
-        mix("\n", 1);
-      }
+      const auto t0 = std::chrono::steady_clock::now();
+      Queue<std::unique_ptr<Batch>> q(8);
+      std::mutex mu;
+      uint64_t n = 0, bases = 0, id_bytes = 0, sum = 0;
+      std::vector<std::thread> th;
+      for (int t = 0; t < 4; t++)
+        th.emplace_back([&] {
+          std::unique_ptr<Batch> b;
+          uint64_t my_sum = 0, my_bases = 0, my_ids = 0, my_n = 0;
+          while (q.pop(&b)) {
+            for (size_t i = 0; i < b->size(); i++) {
+              uint64_t h = 1469598103934665603ULL;
+              auto mix = [&](const char* p, size_t len) {
+                for (size_t j = 0; j < len; j++) h = (h ^ (uint8_t)p[j]) * 1099511628211ULL;
+              };
+              mix(b->id_buf.data() + b->id_offs[i], (size_t)(b->id_offs[i + 1] - b->id_offs[i]));
+              mix("\t", 1);
+              mix((const char*)b->seqs.data() + b->offs[i], (size_t)(b->offs[i + 1] - b->offs[i]));
+              mix("\n", 1);
+              my_sum += h * (2 * (b->first_idx + i) + 1);
+            }
+            my_n += b->size();
+            my_bases += b->seqs.size();
+            my_ids += b->id_buf.size();
+          }
+          std::lock_guard<std::mutex> g(mu);
+          sum += my_sum;
+          n += my_n;
+          bases += my_bases;
+          id_bytes += my_ids;
+        });
+      uint64_t idx = 0;
+      read_single_end(file, (size_t)o.batch, 64u << 20, [&](std::unique_ptr<Batch> b) {
+        b->first_idx = idx;
+        idx += b->size();
+        q.push(std::move(b));
+      });
+      q.close();
+      for (auto& t : th) t.join();
+      const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
       printf("%s\trecords=%llu\tbases=%llu\tid_bytes=%llu\tfnv1a=%016llx\n", file.c_str(), (unsigned long long)n, (unsigned long long)bases,
              (unsigned long long)id_bytes, (unsigned long long)sum);
+      if (!o.quiet) fprintf(stderr, "%s: %.3f s, %.2f M records/s\n", file.c_str(), dt, n / dt / 1e6);
     }
     return 0;
   }
@@ -660,8 +740,8 @@ int main(int argc, char** argv) {
       const std::string nnn((size_t)std::max(0, dbi.k - 1), 'N');
       for (const auto& file : files) {
         if (verbose) info("reading sequence file: %s", file.c_str());
-        FastxReader r(file);
         if (o.whole_file) {  // search.go:885-935
+          FastxReader r(file);
           std::string qid, whole;
           bool first = true;
           while (r.next(&id1, &s1)) {
@@ -678,10 +758,15 @@ int main(int argc, char** argv) {
           add(qid, whole, nullptr);
           continue;
         }
-        const uint64_t id0 = id;
-        FastxRec rec;
-        while (r.next(&rec)) add(std::string_view(rec.id, rec.id_len), std::string_view(rec.seq, rec.seq_len), nullptr);
-        if (id0 == id) warn("no valid sequences in file: %s", file.c_str());
+        flush();  // batches do not span input files on this path
+        const uint64_t got = read_single_end(file, (size_t)o.batch, max_bases, [&](std::unique_ptr<Batch> nb) {
+          nb->paired = false;
+          nb->first_idx = id;
+          id += nb->size();
+          b = std::move(nb);
+          flush();
+        });
+        if (got == 0) warn("no valid sequences in file: %s", file.c_str());
       }
     }
     flush();

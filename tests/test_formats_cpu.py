@@ -228,6 +228,17 @@ def test_mutated_headers_never_hang_or_crash(small_db, tmp_path):
     assert refused > 200 and refused + opened == 400
 
 
+def _reader_checksum(recs):
+    """kmcp-search --parse-only: sum over records i of fnv1a("id\\tseq\\n") * (2 i + 1) mod 2^64."""
+    total = 0
+    for idx, (i, s) in enumerate(recs):
+        h = 1469598103934665603
+        for b in i + b"\t" + s + b"\n":
+            h = ((h ^ b) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+        total = (total + h * (2 * idx + 1)) & 0xFFFFFFFFFFFFFFFF
+    return total
+
+
 def test_cli_reader_against_python_reader(tmp_path):
     """`kmcp-search --parse-only` (the CLI's block-buffered FASTA/Q reader alone: no database, no GPU) vs the independent Python
     reader of kmcp_amd.dist_search on random inputs — FASTA/FASTQ, wrapped or not, CRLF, blank lines, empty records, quality
@@ -253,12 +264,7 @@ def test_cli_reader_against_python_reader(tmp_path):
             o += b"\x1f\x8b\x08\x04\0\0\0\0\0\xff\x06\0BC\x02\0" + struct.pack("<H", len(d) + 25) + d + struct.pack("<II", zlib.crc32(b), len(b))
         return bytes(o)
 
-    def fnv(recs):
-        h = 1469598103934665603
-        for i, s in recs:
-            for b in i + b"\t" + s + b"\n":
-                h = ((h ^ b) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
-        return h
+    fnv = _reader_checksum
 
     for it in range(160):
         fastq = rng.random() < 0.6
@@ -302,3 +308,75 @@ def test_cli_reader_against_python_reader(tmp_path):
         got = dict(x.split("=") for x in r.stdout.strip().split("\t")[1:])
         assert got == dict(records=str(len(want)), bases=str(sum(len(s) for _, s in want)), id_bytes=str(sum(len(i) for i, _ in want)),
                            fnv1a="%016x" % fnv(want)), (p, env["KMCP_READER_BUF"])
+
+
+def test_parallel_fastq_reader(tmp_path):
+    """Plain four-line FASTQ is cut at record boundaries and parsed by several threads (cli/fastx_reader.hpp ParallelFastq).
+    Chunks of 64 bytes .. 64 KB put the cuts everywhere; quality lines start with '@' and '+' (they must never pass for a
+    header), CRLF, blank lines between records, no final newline, empty reads; files that stop being four-line half-way
+    (wrapped sequences, a FASTA record) are handed to the general reader at the chunk where that shows.  Always the
+    records of the independent Python reader, in order."""
+    import subprocess
+    from kmcp_amd.dist_search import read_fastx
+    cli = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "kmcp_amd", "kmcp-search")
+    if not os.path.exists(cli):
+        import __graft_entry__ as g
+        g.build()
+    rng = np.random.default_rng(77)
+    qual = np.frombuffer(b"@+I#5>", dtype=np.uint8)
+    for it in range(120):
+        nl = b"\r\n" if rng.random() < 0.25 else b"\n"
+        out = bytearray()
+        nrec = int(rng.integers(1, 400))
+        break_at = int(rng.integers(0, nrec)) if rng.random() < 0.35 else -1
+        for r in range(nrec):
+            L = int(rng.choice([0, 1, 30, 150, 150, 150, 151, 300]))
+            s = bytes(rng.choice(np.frombuffer(b"ACGTNacgt", dtype=np.uint8), L))
+            q = bytes(rng.choice(qual, L))
+            name = b"r%d" % r + (b" some text" if rng.random() < 0.5 else b"") + (b"\tmore" if rng.random() < 0.1 else b"")
+            if r == break_at:
+                kind = int(rng.integers(0, 2))
+                if kind == 0 and L > 10:  # a wrapped record
+                    out += b"@" + name + nl + s[:7] + nl + s[7:] + nl + b"+" + nl + q[:5] + nl + q[5:] + nl
+                    continue
+                if kind == 1:  # a FASTA record in the middle
+                    out += b">" + name + nl + s + nl
+                    continue
+            out += b"@" + name + nl + s + nl + b"+" + (name if rng.random() < 0.3 else b"") + nl + q + nl
+            if rng.random() < 0.05:
+                out += nl
+        if rng.random() < 0.3:
+            while out and out[-1:] in (b"\n", b"\r"):
+                out = out[:-1]
+        p = str(tmp_path / ("p%d.fq" % it))
+        open(p, "wb").write(bytes(out))
+        want = list(read_fastx(p))
+        env = dict(os.environ, KMCP_PARALLEL_MIN_BYTES="1", KMCP_READER_CHUNK=str(int(rng.choice([64, 100, 333, 1000, 4096, 65536]))),
+                   KMCP_READER_THREADS=str(int(rng.integers(1, 5))), KMCP_READER_BUF=str(int(rng.choice([64, 4096, 1 << 20]))))
+        r = subprocess.run([cli, "--parse-only", "-q", "--gpu-batch", str(int(rng.choice([1, 7, 100, 100000]))), p], capture_output=True, text=True, env=env,
+                           timeout=60)
+        assert r.returncode == 0, (p, r.stderr)
+        got = dict(x.split("=") for x in r.stdout.strip().split("\t")[1:])
+        assert got == dict(records=str(len(want)), bases=str(sum(len(s) for _, s in want)), id_bytes=str(sum(len(i) for i, _ in want)),
+                           fnv1a="%016x" % _reader_checksum(want)), (p, env["KMCP_READER_CHUNK"], break_at)
+
+
+def test_truncated_gzip_is_an_error(tmp_path):
+    """A .fastq.gz cut short (or with a damaged tail) must not produce a well-formed result for the part that could be read:
+    the reference's gzip reader aborts with 'unexpected EOF'."""
+    import gzip
+    import subprocess
+    cli = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "kmcp_amd", "kmcp-search")
+    rng = np.random.default_rng(5)
+    recs = b"".join(b"@r%d\n" % i + bytes(rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), 150)) + b"\n+\n" + b"I" * 150 + b"\n" for i in range(3000))
+    good = str(tmp_path / "good.fq.gz")
+    with gzip.open(good, "wb") as fh:
+        fh.write(recs)
+    data = open(good, "rb").read()
+    r = subprocess.run([cli, "--parse-only", "-q", good], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0 and "records=3000" in r.stdout
+    for name, blob in (("cut", data[:len(data) // 2]), ("crc", data[:-8] + bytes(8)), ("tail", data[:-3])):
+        p = str(tmp_path / (name + ".fq.gz"))
+        open(p, "wb").write(blob)
+        r = subprocess.run([cli, "--parse-only", "-q", p], capture_output=True, text=True, timeout=60)
+        assert r.returncode != 0 and "records=" not in r.stdout, (name, r.stdout, r.stderr)

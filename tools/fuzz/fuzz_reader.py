@@ -7,11 +7,13 @@ N = int(sys.argv[2])
 rng = np.random.default_rng(int(sys.argv[3]) if len(sys.argv) > 3 else 0)
 d = 'scratch/fuzzfmt/rd'; os.makedirs(d, exist_ok=True)
 def fnv(recs):
-    h = 1469598103934665603
-    for i, s in recs:
+    total = 0
+    for idx, (i, s) in enumerate(recs):
+        h = 1469598103934665603
         for b in i + b"\t" + s + b"\n":
             h = ((h ^ b) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
-    return h
+        total = (total + h * (2 * idx + 1)) & 0xFFFFFFFFFFFFFFFF
+    return total
 def rand_seq(n):
     return bytes(rng.choice(np.frombuffer(b"ACGTNacgt", dtype=np.uint8), n))
 bad = 0
