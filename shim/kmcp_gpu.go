@@ -8,8 +8,9 @@
 // so search.go (reader loop :793-1000, ordered writer :448-588, :733-781) is untouched.
 //
 // NOTE: there is no Go toolchain in the build container of this repository, so this file is delivered as source
-// and has not been compiled there; the C ABI it binds (include/kmcp_gpu.h) is exercised by the C++ CLI and the
-// Python tests.
+// and has not been compiled there.  The exact sequence of C calls it makes — malloc'd CSR buffers, kmcpg_submit,
+// kmcpg_wait from other threads, kmcpg_result_free, the error fetch on the failing thread — is replayed from several
+// threads by tests/shim_replay.c (tests/test_gpu_shim_replay.py), which is compiled and run with every GPU test run.
 package cmd
 
 /*
@@ -22,23 +23,49 @@ import "C"
 
 import (
 	"fmt"
+	"runtime"
+	"sync"
 	"unsafe"
 )
 
 // GPUBatchSize is the number of queries handed to the GPU per call.
 const GPUBatchSize = 1 << 17
 
+// GPUInFlight bounds the batches between kmcpg_submit and kmcpg_wait (the library has KMCPG_INFLIGHT = 4 lanes; the
+// reference bounds its in-flight queries the same way with a token channel, util-db-search.go:243, :347-351).
+const GPUInFlight = 3
+
 // GPUDB wraps a kmcpg_db handle (one per database directory, i.e. per <db>/R001).
 type GPUDB struct {
-	h    *C.kmcpg_db
-	Info C.kmcpg_info
+	h     *C.kmcpg_db
+	Info  C.kmcpg_info
+	names []string // Header.Names of every column, fetched once: no cgo call per match later
 }
 
-func gpuErr(rc C.int) error {
-	if rc == 0 {
-		return nil
+// gpuCall runs one C call and, if it fails, fetches the library's thread-local message on the SAME OS thread (the Go
+// scheduler may otherwise move the goroutine between the two cgo calls).
+func gpuCall(f func() C.int) error {
+	runtime.LockOSThread()
+	defer runtime.UnlockOSThread()
+	if rc := f(); rc != 0 {
+		return fmt.Errorf("kmcp-gpu: %s (code %d)", C.GoString(C.kmcpg_last_error()), int(rc))
 	}
-	return fmt.Errorf("kmcp-gpu: %s (code %d)", C.GoString(C.kmcpg_last_error()), int(rc))
+	return nil
+}
+
+func (db *GPUDB) finishOpen() error {
+	if err := gpuCall(func() C.int { return C.kmcpg_db_info(db.h, &db.Info) }); err != nil {
+		return err
+	}
+	db.names = make([]string, int(db.Info.n_cols))
+	for c := range db.names {
+		var name *C.char
+		if err := gpuCall(func() C.int { return C.kmcpg_col_info(db.h, C.uint32_t(c), &name, nil, nil, nil) }); err != nil {
+			return err
+		}
+		db.names[c] = C.GoString(name)
+	}
+	return nil
 }
 
 // OpenGPUDB replaces NewUnikIndexDB (util-db-search.go:648-743): parses __db.yml and the .uniki headers and
@@ -48,32 +75,37 @@ func OpenGPUDB(path string, device int) (*GPUDB, error) {
 	defer C.free(unsafe.Pointer(cpath))
 	opts := C.kmcpg_opts{device: C.int32_t(device), shard_rank: 0, shard_count: 1}
 	db := &GPUDB{}
-	if err := gpuErr(C.kmcpg_open(cpath, &opts, &db.h)); err != nil {
+	if err := gpuCall(func() C.int { return C.kmcpg_open(cpath, &opts, &db.h) }); err != nil {
 		return nil, err
 	}
-	if err := gpuErr(C.kmcpg_db_info(db.h, &db.Info)); err != nil {
+	if err := db.finishOpen(); err != nil {
+		db.Close()
 		return nil, err
 	}
 	return db, nil
 }
 
 // OpenGPUDBDevices is OpenGPUDB over several GPUs of the node: the index blocks are partitioned over `devices` and every
-// SearchBatch call fans out to all of them (one host thread per GPU inside the library).
+// batch fans out to all of them (one host thread per GPU inside the library).
 func OpenGPUDBDevices(path string, devices []int32) (*GPUDB, error) {
 	cpath := C.CString(path)
 	defer C.free(unsafe.Pointer(cpath))
+	cdev := (*C.int32_t)(C.malloc(C.size_t(4 * len(devices)))) // no Go pointer handed to C
+	defer C.free(unsafe.Pointer(cdev))
+	copy(unsafe.Slice((*int32)(unsafe.Pointer(cdev)), len(devices)), devices)
 	db := &GPUDB{}
-	if err := gpuErr(C.kmcpg_open_devices(cpath, (*C.int32_t)(unsafe.Pointer(&devices[0])), C.int32_t(len(devices)), &db.h)); err != nil {
+	if err := gpuCall(func() C.int { return C.kmcpg_open_devices(cpath, cdev, C.int32_t(len(devices)), &db.h) }); err != nil {
 		return nil, err
 	}
-	if err := gpuErr(C.kmcpg_db_info(db.h, &db.Info)); err != nil {
+	if err := db.finishOpen(); err != nil {
+		db.Close()
 		return nil, err
 	}
 	return db, nil
 }
 
 // Close replaces UnikIndexDB.Close (util-db-search.go:1119-1150).
-func (db *GPUDB) Close() error { return gpuErr(C.kmcpg_close(db.h)) }
+func (db *GPUDB) Close() error { return gpuCall(func() C.int { return C.kmcpg_close(db.h) }) }
 
 func gpuParams(opt SearchOptions) C.kmcpg_params {
 	sortBy := 0
@@ -95,18 +127,22 @@ func gpuParams(opt SearchOptions) C.kmcpg_params {
 		dedup_threshold: C.int32_t(opt.DeduplicateThreshold), try_se: b2i(opt.TrySingleEnd),
 		sort_by: C.int32_t(sortBy), do_not_sort: b2i(opt.DoNotSort), top_n_scores: C.int32_t(opt.TopNScores),
 		fpr_buf_size: C.int32_t(opt.FPRBufSize),
+		// k = 0: the library walks the database's k-mer sizes, largest first, as handleQuery does (:764, :1016-1022)
 	}
 }
 
-// SearchBatch runs handleQuery's work for a batch of queries and converts the CSR result into the
-// engine's own QueryResult/Match structs (util-db-search.go:60-93).  Everything C returns is copied
-// before kmcpg_result_free, so no C pointer outlives the call and no Go pointer is retained by C.
-func (db *GPUDB) SearchBatch(queries []*Query, opt SearchOptions, dbID int) ([]*QueryResult, error) {
+// gpuBatch is one batch between Submit and Wait.
+type gpuBatch struct {
+	queries []*Query
+	ticket  *C.kmcpg_ticket
+}
+
+// Submit packs the pooled Querys into two CSR buffers in C memory (no Go pointer is retained by C), hands them to
+// kmcpg_submit — which copies them into pinned staging and enqueues the GPU work — and frees them again.
+// kmcpg_submit never blocks; it fails with KMCPG_EBUSY when all lanes are taken, which RunGPUEngine's tokens rule out.
+func (db *GPUDB) Submit(queries []*Query, opt SearchOptions) (*gpuBatch, error) {
 	n := len(queries)
-	if n == 0 {
-		return nil, nil
-	}
-	paired := queries[0].Seq2 != nil
+	paired := n > 0 && queries[0].Seq2 != nil
 	pack := func(get func(q *Query) []byte) (unsafe.Pointer, unsafe.Pointer, func()) {
 		total := 0
 		for _, q := range queries {
@@ -133,33 +169,47 @@ func (db *GPUDB) SearchBatch(queries []*Query, opt SearchOptions, dbID int) ([]*
 		defer free2()
 	}
 	params := gpuParams(opt)
+	b := &gpuBatch{queries: queries}
+	err := gpuCall(func() C.int {
+		return C.kmcpg_submit(db.h, (*C.uint8_t)(s1), (*C.uint64_t)(o1), (*C.uint8_t)(s2), (*C.uint64_t)(o2), C.uint32_t(n), &params, &b.ticket)
+	})
+	if err != nil {
+		return nil, err
+	}
+	return b, nil
+}
+
+// Wait blocks until the batch's GPU work is done, lets the library run the host half (float64 thresholds, FPR, sort,
+// --try-se / smaller-k retries) on this thread, and converts the CSR result into the engine's own QueryResult/Match
+// structs (util-db-search.go:60-93).  Everything C returns is copied before kmcpg_result_free.
+func (db *GPUDB) Wait(b *gpuBatch, dbID int) ([]*QueryResult, error) {
 	var res C.kmcpg_result
-	rc := C.kmcpg_search_batch(db.h, (*C.uint8_t)(s1), (*C.uint64_t)(o1), (*C.uint8_t)(s2), (*C.uint64_t)(o2),
-		C.uint32_t(n), &params, &res)
-	if err := gpuErr(rc); err != nil {
+	if err := gpuCall(func() C.int { return C.kmcpg_wait(b.ticket, &res) }); err != nil { // the ticket is consumed either way
 		return nil, err
 	}
 	defer C.kmcpg_result_free(&res)
-
+	n := len(b.queries)
+	out := make([]*QueryResult, n)
+	if n == 0 {
+		return out, nil
+	}
 	qlen := unsafe.Slice((*int32)(unsafe.Pointer(res.qlen)), n)
 	qk := unsafe.Slice((*int32)(unsafe.Pointer(res.qkmers)), n)
+	ks := unsafe.Slice((*int32)(unsafe.Pointer(res.ksize)), n)
 	offs := unsafe.Slice((*uint64)(unsafe.Pointer(res.match_offs)), n+1)
 	var ms []C.kmcpg_match
 	if offs[n] > 0 {
 		ms = unsafe.Slice(res.matches, int(offs[n]))
 	}
-	out := make([]*QueryResult, n)
-	for i, q := range queries {
+	for i, q := range b.queries {
 		r := poolQueryResult.Get().(*QueryResult)
 		r.QueryIdx, r.QueryID, r.QueryLen = q.Idx, q.ID, int(qlen[i])
-		r.DBId, r.K, r.NumKmers, r.Matches = dbID, int(res.k), int(qk[i]), nil
+		r.DBId, r.K, r.NumKmers, r.Matches = dbID, int(ks[i]), int(qk[i]), nil
 		if offs[i+1] > offs[i] {
 			matches := poolMatches.Get().(*[]*Match)
 			for _, m := range ms[offs[i]:offs[i+1]] {
-				var name *C.char
-				C.kmcpg_col_info(db.h, m.col, &name, nil, nil, nil)
 				*matches = append(*matches, &Match{
-					Target: []string{C.GoString(name)}, TargetIdx: []uint32{uint32(m.target_idx)},
+					Target: []string{db.names[int(m.col)]}, TargetIdx: []uint32{uint32(m.target_idx)},
 					GenomeSize: []uint64{uint64(m.gsize)}, NumKmers: int(m.mkmers), FPR: float64(m.fpr),
 					QCov: float64(m.qcov), TCov: float64(m.tcov), JaccardIndex: float64(m.jacc),
 				})
@@ -171,32 +221,59 @@ func (db *GPUDB) SearchBatch(queries []*Query, opt SearchOptions, dbID int) ([]*
 	return out, nil
 }
 
+// SearchBatch = Submit + Wait (one batch, nothing overlapped).
+func (db *GPUDB) SearchBatch(queries []*Query, opt SearchOptions, dbID int) ([]*QueryResult, error) {
+	b, err := db.Submit(queries, opt)
+	if err != nil {
+		return nil, err
+	}
+	return db.Wait(b, dbID)
+}
+
 // RunGPUEngine is the batcher that takes the place of the goroutine started in
-// NewUnikIndexDBSearchEngine (util-db-search.go:239-352): it drains sg.InCh into batches, searches them on the
-// GPU and re-emits the QueryResults into sg.OutCh.  search.go's reorder goroutine (:733-781) restores input order.
+// NewUnikIndexDBSearchEngine (util-db-search.go:239-352).  One goroutine drains sg.InCh into batches and submits them
+// (packing batch i+1 while the GPU works on batch i); two goroutines wait for tickets, convert the results and re-emit
+// the QueryResults into sg.OutCh (conversion of batch i while batch i+1 is on the GPU).  search.go's reorder goroutine
+// (:733-781) restores input order, so batches may finish in any order.
 func RunGPUEngine(sg *UnikIndexDBSearchEngine, db *GPUDB) {
+	inflight := make(chan *gpuBatch, GPUInFlight)
+	tokens := make(chan struct{}, GPUInFlight) // one per batch between Submit and the end of Wait: never more than the library's lanes
+	var wg sync.WaitGroup
+	for w := 0; w < 2; w++ {
+		wg.Add(1)
+		go func() {
+			defer wg.Done()
+			for b := range inflight {
+				results, err := db.Wait(b, 0)
+				<-tokens
+				checkError(err) // fatal, as every error on the reference's search path (util-cli.go:35-40)
+				for i, r := range results {
+					if r.Matches != nil && len(sg.Options.NameMap) > 0 { // name mapping, util-db-search.go:317-332
+						for _, m := range *r.Matches {
+							if t, ok := sg.Options.NameMap[m.Target[0]]; ok {
+								m.Target[0] = t
+							}
+						}
+					}
+					sg.OutCh <- r
+					q := b.queries[i]
+					poolSeq.Put(q.Seq)
+					if q.Seq2 != nil {
+						poolSeq.Put(q.Seq2)
+					}
+					poolQuery.Put(q)
+				}
+			}
+		}()
+	}
 	go func() {
 		batch := make([]*Query, 0, GPUBatchSize)
 		flush := func() {
-			results, err := db.SearchBatch(batch, sg.Options, 0)
-			checkError(err) // fatal, as every error on the reference's search path (util-cli.go:35-40)
-			for i, r := range results {
-				if r.Matches != nil && len(sg.Options.NameMap) > 0 { // name mapping, util-db-search.go:317-332
-					for _, m := range *r.Matches {
-						if t, ok := sg.Options.NameMap[m.Target[0]]; ok {
-							m.Target[0] = t
-						}
-					}
-				}
-				sg.OutCh <- r
-				q := batch[i]
-				poolSeq.Put(q.Seq)
-				if q.Seq2 != nil {
-					poolSeq.Put(q.Seq2)
-				}
-				poolQuery.Put(q)
-			}
-			batch = batch[:0]
+			tokens <- struct{}{} // blocks while GPUInFlight batches are in flight: kmcpg_submit never sees all lanes taken
+			b, err := db.Submit(batch, sg.Options)
+			checkError(err)
+			inflight <- b
+			batch = make([]*Query, 0, GPUBatchSize)
 		}
 		for q := range sg.InCh {
 			batch = append(batch, q)
@@ -207,6 +284,8 @@ func RunGPUEngine(sg *UnikIndexDBSearchEngine, db *GPUDB) {
 		if len(batch) > 0 {
 			flush()
 		}
+		close(inflight)
+		wg.Wait()
 		sg.done <- 1
 	}()
 }

@@ -169,3 +169,67 @@ def test_merge_three_inputs_with_ties(tmp_path):
             row("r5", 5, "A", "0.6000", 2), row("r5", 5, "F", "0.6000", 2), row("r9", 9, "F", "1.0000", 1)]
     assert got == [HEADER] + want + ["# input queries: 10", "# matched queries: 4", "# matched percentage: 40.0000%", ""]
     assert want == merge_restated([f1, f2, f3], [10, 10, 10])[0]
+
+
+def test_merge_equals_search_of_the_joint_database(oracle_lib, tmp_path):
+    """An expectation that does not come from reading merge.go: a database whose index files are the files of database A
+    followed by the files of database B answers every query with A's rows and B's rows together (blocks are independent:
+    util-db-search.go:939-964 concatenates their replies).  So `kmcp search` on the joint database == `kmcp merge` of the
+    searches on A and on B: the same set of rows per query with `hits` = their number, rows in non-increasing printed score,
+    the same `# input queries` / `# matched queries` trailer.  (The order among rows whose scores print alike may differ:
+    search sorts on the exact value, merge on the four printed decimals — merge.go re-parses the column.)"""
+    import shutil
+    O = oracle_lib
+    genomes = synth.random_genomes(18, 9000, seed=160)
+    for i in range(9):  # relatives in the other half: queries with rows from both databases
+        g = bytearray(genomes[i])
+        for p in range(0, len(g), 83):
+            g[p] = ord("A") if g[p] != ord("A") else ord("C")
+        genomes[9 + i] = bytes(g)
+    reads = synth.sample_reads(genomes, 700, 150, sub_rate=0.01, seed=161, frac_random=0.15)
+    ids = [f"q{i}" for i in range(len(reads))]
+    dirs = [synth.make_db(tmp_path / f"db{h}", genomes[lo:hi], k=21, n_chunks=2, overlap=150, threads=3, names=[f"g{i:05d}" for i in range(lo, hi)])
+            for h, (lo, hi) in enumerate([(0, 9), (9, 18)])]
+    joint = tmp_path / "joint" / "R001"
+    os.makedirs(joint)
+    files = []
+    for d in dirs:
+        for f in sorted(x for x in os.listdir(d) if x.endswith(".uniki")):
+            name = "_block%03d.uniki" % (len(files) + 1)
+            shutil.copy(os.path.join(d, f), joint / name)
+            files.append(name)
+    yml = open(os.path.join(dirs[0], "__db.yml")).read()
+    yml = yml[:yml.index("files:")] + "files:\n" + "".join(f"- {f}\n" for f in files)
+    (joint / "__db.yml").write_text(yml)
+    p = O.default_params(min_qcov=0.4)
+    tsvs = []
+    for d in dirs + [str(joint)]:
+        odb = O.OracleDB(d)
+        tsvs.append(oracle_tsv(O, odb, ids, reads, params=p))
+        odb.close()
+    assert len(tsvs[2][0]) == len(tsvs[0][0]) + len(tsvs[1][0]) > 900
+    a, b = str(tmp_path / "a.tsv"), str(tmp_path / "b.tsv")
+    write_tsv(a, *tsvs[0])
+    write_tsv(b, *tsvs[1])
+    for sort_by, col, key in (("qcov", 11, 0), ("tcov", 12, 1), ("jacc", 13, 2)):
+        ps = O.default_params(min_qcov=0.4, sort_by=key)
+        odb = O.OracleDB(str(joint))
+        want_rows, want_trailer = oracle_tsv(O, odb, ids, reads, params=ps)
+        odb.close()
+        got = run(["-s", sort_by, a, b]).stdout.split("\n")
+        assert got[0] == HEADER and got[-1] == "" and got[-4:-1] == want_trailer
+
+        def groups(rows):
+            g = {}
+            for r in rows:
+                g.setdefault(r.split("\t")[14], []).append(r)
+            return g
+        gg, gw = groups(got[1:-4]), groups(want_rows)
+        assert list(gg) == list(gw)  # queries in input order
+        both = 0
+        for q in gw:
+            assert sorted(gg[q]) == sorted(gw[q]), q  # the same rows, `hits` rewritten to the joint count
+            sc = [float(r.split("\t")[col]) for r in gg[q]]
+            assert sc == sorted(sc, reverse=True), q
+            both += len({r.split("\t")[5][:6] < "g00009" for r in gw[q]}) == 2
+        assert both > 50

@@ -6,6 +6,9 @@ N=${1:-4000000}
 D=/tmp/kmcp_cli_bench
 rm -rf $D
 python tools/make_testdata.py $D --reads $N 2>&1 | tail -2
+# the reader alone (no database, no GPU): several threads on plain four-line FASTQ, then the single-threaded general reader
+for i in 1 2; do kmcp_amd/kmcp-search --parse-only $D/reads.fq 2>&1 >/dev/null | tail -n 1; done
+KMCP_SERIAL_READER=1 kmcp_amd/kmcp-search --parse-only $D/reads.fq 2>&1 >/dev/null | tail -n 1 | sed 's/$/ (KMCP_SERIAL_READER=1)/'
 for i in 1 2 3; do
   s=$(date +%s%N)
   kmcp_amd/kmcp-search -d $D/db $D/reads.fq -o $D/out.tsv 2> $D/log.txt
