@@ -6,7 +6,9 @@
 #include <stdlib.h>
 #include <string.h>
 #include <sys/mman.h>
+#include <signal.h>
 #include <sys/stat.h>
+#include <sys/wait.h>
 #include <unistd.h>
 #include <zlib.h>
 
@@ -220,11 +222,16 @@ class FastxReader {
       if (fd_ < 0) die("%s: %s", path.c_str(), strerror(errno));
       unsigned char magic[6] = {0, 0, 0, 0, 0, 0};
       const ssize_t got = pread(fd_, magic, 6, 0);
-      // the reference's xopen also reads xz, zstd and bzip2; here only gzip is built in: refuse the others instead of parsing noise
-      if (got >= 6 && memcmp(magic, "\xfd" "7zXZ\0", 6) == 0) die("%s: xz input is not supported (decompress it: xz -dc file | kmcp-search ... -)", path.c_str());
-      if (got >= 4 && memcmp(magic, "\x28\xb5\x2f\xfd", 4) == 0) die("%s: zstd input is not supported (zstd -dc file | kmcp-search ... -)", path.c_str());
-      if (got >= 3 && memcmp(magic, "BZh", 3) == 0) die("%s: bzip2 input is not supported (bzip2 -dc file | kmcp-search ... -)", path.c_str());
-      if (got >= 6 && BgzfInflater::detect(fd_)) {  // block gzip: several inflate threads
+      // the reference's xopen also reads xz, zstd and bzip2 (util-io.go:68-97).  gzip is built in; for the others the system's
+      // own decompressor is run and its output parsed like a plain stream (it must be on PATH; its exit status is checked)
+      const char* tool = nullptr;
+      if (got >= 6 && memcmp(magic, "\xfd" "7zXZ\0", 6) == 0) tool = "xz";
+      else if (got >= 4 && memcmp(magic, "\x28\xb5\x2f\xfd", 4) == 0) tool = "zstd";
+      else if (got >= 3 && memcmp(magic, "BZh", 3) == 0) tool = "bzip2";
+      if (tool) {
+        close(fd_);
+        fd_ = spawn_decompressor(tool, path);
+      } else if (got >= 6 && BgzfInflater::detect(fd_)) {  // block gzip: several inflate threads
         int w = (int)std::min(8u, std::max(2u, std::thread::hardware_concurrency() / 4));
         if (const char* e = getenv("KMCP_BGZF_THREADS")) w = std::max(1, atoi(e));
         bgzf_.reset(new BgzfInflater(fd_, path, w));
@@ -281,6 +288,10 @@ class FastxReader {
     }
     if (gz_) gzclose(gz_);
     if (fd_ >= 0) close(fd_);
+    if (child_ > 0) {  // reader dropped before the stream ended
+      kill(child_, SIGTERM);
+      waitpid(child_, nullptr, 0);
+    }
   }
   FastxReader(const FastxReader&) = delete;
   FastxReader& operator=(const FastxReader&) = delete;
@@ -390,6 +401,13 @@ class FastxReader {
         do got = read(fd_, &buf_[end_], room);
         while (got < 0 && errno == EINTR);
       if (got < 0 && !bgzf_ && !gz_) die("%s: %s", path_.c_str(), strerror(errno));
+      if (got <= 0 && child_ > 0) {  // the decompressor's verdict on the file
+        int st = 0;
+        waitpid(child_, &st, 0);
+        child_ = -1;
+        if (WIFEXITED(st) && WEXITSTATUS(st) == 127) die("%s: this is %s input and `%s` is not on PATH (decompress it: %s -dc file | kmcp-search ... -)", path_.c_str(), tool_.c_str(), tool_.c_str(), tool_.c_str());
+        if (!WIFEXITED(st) || WEXITSTATUS(st) != 0) die("%s: %s failed (corrupt or truncated input?)", path_.c_str(), tool_.c_str());
+      }
       if (got <= 0) eof_ = true;
       else end_ += (size_t)got;
     }
@@ -420,7 +438,28 @@ class FastxReader {
     std::vector<char> data = std::vector<char>(4u << 20);
     size_t n = 0;
   };
+  // `tool -dc path` with its stdout on a pipe; returns the read end
+  int spawn_decompressor(const char* tool, const std::string& path) {
+    int pfd[2];
+    if (pipe(pfd) != 0) die("%s: pipe: %s", path.c_str(), strerror(errno));
+    const pid_t pid = fork();
+    if (pid < 0) die("%s: fork: %s", path.c_str(), strerror(errno));
+    if (pid == 0) {
+      dup2(pfd[1], 1);
+      close(pfd[0]);
+      close(pfd[1]);
+      execlp(tool, tool, "-dc", "--", path.c_str(), (char*)nullptr);
+      _exit(127);  // not on PATH
+    }
+    close(pfd[1]);
+    child_ = pid;
+    tool_ = tool;
+    // a missing tool shows as exit status 127 with no output: tell it apart from an empty file right away
+    return pfd[0];
+  }
   std::string path_;
+  std::string tool_;
+  pid_t child_ = -1;
   std::string ierr_;  // set by the inflate thread
   gzFile gz_ = nullptr;
   int fd_ = -1;

@@ -625,6 +625,9 @@ int main(int argc, char** argv) {
   }
   kmcpg_info dbi;
   kmcpg_db_info(db, &dbi);
+  if (dbi.minimizer && !dbi.syncmer)
+    warn("this is a minimizer database: the reference publishes no result for minimizer sketches to check against, so this mode is "
+         "verified against a restatement of bio/sketches only (DESIGN.md section 2)");
   if (o.min_qcov <= dbi.fpr)  // search.go:405-409
     die("query coverage threshold (%f) should not be smaller than FPR of single bloom filter of index database (%f)", o.min_qcov, dbi.fpr);
   if (verbose) {

@@ -380,3 +380,35 @@ def test_truncated_gzip_is_an_error(tmp_path):
         open(p, "wb").write(blob)
         r = subprocess.run([cli, "--parse-only", "-q", p], capture_output=True, text=True, timeout=60)
         assert r.returncode != 0 and "records=" not in r.stdout, (name, r.stdout, r.stderr)
+
+
+def test_xz_and_bzip2_input_through_the_system_decompressor(tmp_path):
+    """The reference's xopen reads xz, zstd and bzip2 besides gzip (util-io.go:68-97): kmcp-search runs the system's decompressor
+    for those and parses its output; a damaged file is an error, a missing tool a message that names it."""
+    import shutil
+    import subprocess
+    cli = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "kmcp_amd", "kmcp-search")
+    rng = np.random.default_rng(9)
+    recs = [(b"r%d" % i, bytes(rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), 150))) for i in range(2000)]
+    plain = b"".join(b"@" + i + b" x\n" + s + b"\n+\n" + b"I" * 150 + b"\n" for i, s in recs)
+    want = dict(records="2000", bases=str(150 * 2000), id_bytes=str(sum(len(i) for i, _ in recs)), fnv1a="%016x" % _reader_checksum(recs))
+    done = 0
+    for tool, ext in (("xz", "xz"), ("bzip2", "bz2"), ("zstd", "zst")):
+        if not shutil.which(tool):
+            continue
+        p = str(tmp_path / ("reads.fq." + ext))
+        open(p, "wb").write(subprocess.run([tool, "-c"], input=plain, capture_output=True, check=True).stdout)
+        r = subprocess.run([cli, "--parse-only", "-q", p], capture_output=True, text=True, timeout=60)
+        assert r.returncode == 0, r.stderr
+        assert dict(x.split("=") for x in r.stdout.strip().split("\t")[1:]) == want
+        blob = open(p, "rb").read()
+        open(p, "wb").write(blob[:len(blob) // 2])
+        r = subprocess.run([cli, "--parse-only", "-q", p], capture_output=True, text=True, timeout=60)
+        assert r.returncode != 0 and "failed" in r.stderr
+        # the tool missing from PATH
+        open(p, "wb").write(blob)
+        r = subprocess.run([cli, "--parse-only", "-q", p], capture_output=True, text=True, timeout=60, env=dict(os.environ, PATH="/nonexistent"))
+        assert r.returncode != 0 and "not on PATH" in r.stderr
+        done += 1
+    if not done:
+        pytest.skip("no xz/bzip2/zstd on this box")
