@@ -812,6 +812,13 @@ int main(int argc, char** argv) {
   // (a multi-member .gz is what pgzip/gzip readers, `kmcp profile` included, accept).
   {
     const int nfmt = std::max(1, std::min(o.threads > 0 ? o.threads : 8, 16));
+    // the formatted text of a batch goes to the file on a thread of its own, while the next batch is being formatted
+    Queue<std::unique_ptr<std::vector<std::string>>> q_flush(4);
+    std::thread flusher([&] {
+      std::unique_ptr<std::vector<std::string>> parts;
+      while (q_flush.pop(&parts))
+        for (const auto& p : *parts) out.write_raw(p);
+    });
     std::unique_ptr<Batch> b, got;
     std::map<uint64_t, std::unique_ptr<Batch>> pending;  // batches that finished ahead of their turn
     uint64_t next_seq = 0;
@@ -833,7 +840,8 @@ int main(int argc, char** argv) {
       const kmcpg_result& r = b->res;
       const uint32_t n = r.n_reads;
       const int parts = (int)std::max<uint32_t>(1, std::min<uint32_t>((uint32_t)nfmt, (n + 4095) / 4096));
-      std::vector<std::string> chunk((size_t)parts);
+      std::unique_ptr<std::vector<std::string>> chunk_p(new std::vector<std::string>((size_t)parts));
+      std::vector<std::string>& chunk = *chunk_p;
       std::vector<uint64_t> part_matched((size_t)parts, 0);
       auto work = [&](int pi) {
         RowFormatter F;
@@ -858,10 +866,8 @@ int main(int argc, char** argv) {
         for (int pi = 0; pi < parts; pi++) th.emplace_back(work, pi);
         for (auto& t : th) t.join();
       }
-      for (int pi = 0; pi < parts; pi++) {
-        out.write_raw(chunk[(size_t)pi]);
-        matched += part_matched[(size_t)pi];
-      }
+      for (int pi = 0; pi < parts; pi++) matched += part_matched[(size_t)pi];
+      q_flush.push(std::move(chunk_p));
       total += n;
       kmcpg_result_free(&b->res);
       t_fmt += std::chrono::duration<double>(std::chrono::steady_clock::now() - tf0).count();
@@ -870,6 +876,8 @@ int main(int argc, char** argv) {
         fprintf(stderr, "processed queries: %llu, speed: %.3f million queries per minute\r", (unsigned long long)total, total / 1e6 / min);
       }
     }
+    q_flush.close();
+    flusher.join();
   }
   reader.join();
   for (auto& t : searchers) t.join();

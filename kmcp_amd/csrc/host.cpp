@@ -88,6 +88,8 @@ struct Lane {
 
 struct AsyncState {
   hipStream_t stream = nullptr;
+  hipStream_t copy_stream = nullptr;  // late D2H of a finished batch's hits: must not queue behind the kernels of later batches
+  std::atomic<uint64_t> hits_hint{0};  // hits per 1024 reads seen lately: sizes the hit buffers and the eager D2H of the next batches
   std::vector<std::unique_ptr<Lane>> lanes;
   size_t max_lanes = 4;
   std::mutex mu;
@@ -103,6 +105,7 @@ void async_release(kmcpg_db* db) {
   for (auto& l : db->async->lanes) l->release();
   db->async->retry.release();
   if (db->async->stream) (void)hipStreamDestroy(db->async->stream);
+  if (db->async->copy_stream) (void)hipStreamDestroy(db->async->copy_stream);
   delete db->async;
   db->async = nullptr;
 }
@@ -132,6 +135,7 @@ int async_state(kmcpg_db* db, AsyncState** out) {
     std::unique_ptr<AsyncState> a(new AsyncState());
     HIPCHK(hipSetDevice(db->opts.device));
     HIPCHK(hipStreamCreateWithFlags(&a->stream, hipStreamNonBlocking));
+    HIPCHK(hipStreamCreateWithFlags(&a->copy_stream, hipStreamNonBlocking));
     if (const char* e = getenv("KMCPG_INFLIGHT")) a->max_lanes = (size_t)std::max(1, std::min(atoi(e), 16));
     db->async = a.release();
   }
@@ -235,8 +239,11 @@ int enqueue(kmcpg_db* db, AsyncState* A, Lane* L, const kmcpg_params& p) {
   const uint32_t n = L->n;
   if (n == 0) return 0;
   hipStream_t st = A->stream;
-  const uint64_t cap = std::max<uint64_t>(L->d_hits.cap, (uint64_t)n * 8 + 1024);
-  const uint64_t first = std::min<uint64_t>(cap, (uint64_t)n * 2 + 1024);  // ~1 hit per read is typical: the rest is fetched in kmcpg_wait if needed
+  // ~1 hit per read is typical for distinct references, hundreds for a database full of close relatives: the buffers follow
+  // what the last batches produced (an overflow costs a rerun, a short eager copy a late one in kmcpg_wait)
+  const uint64_t expect = std::min<uint64_t>(A->hits_hint.load() * ((uint64_t)n + 1023) / 1024, (uint64_t)n * 32);  // bounded: 384 B of buffer per read
+  const uint64_t cap = std::max<uint64_t>(L->d_hits.cap, std::max<uint64_t>((uint64_t)n * 8 + 1024, expect + expect / 2));
+  const uint64_t first = std::min<uint64_t>(cap, std::max<uint64_t>((uint64_t)n * 2 + 1024, expect + expect / 4));
   if (L->d_seqs.ensure(L->tb1 + 16) || L->d_offs.ensure((size_t)n + 1) || L->d_cnt.ensure(2) || L->d_qk.ensure(n) || L->d_ql.ensure(n) || L->d_hits.ensure(cap) ||
       (L->paired && (L->d_seqs2.ensure(L->tb2 + 16) || L->d_offs2.ensure((size_t)n + 1))))
     return kmcpg_fail(KMCPG_ENOMEM, "hipMalloc failed");
@@ -282,9 +289,14 @@ int collect(kmcpg_db* db, AsyncState* A, Lane* L, const kmcpg_params& p, uint64_
       if (L->h_hits.ensure(cnt)) return kmcpg_fail(KMCPG_ENOMEM, "hipHostMalloc failed");
       L->copied = 0;
     }
-    HIPCHK(hipMemcpyAsync(L->h_hits.p + L->copied, L->d_hits.p + L->copied, (cnt - L->copied) * sizeof(kmcpg_hit), hipMemcpyDeviceToHost, A->stream));
-    HIPCHK(hipStreamSynchronize(A->stream));  // behind whatever later batches enqueued meanwhile: rare, bounded by the lanes
+    // the batch's kernels are done (event above): the rest of its hits comes over the copy stream, beside later batches' kernels
+    HIPCHK(hipMemcpyAsync(L->h_hits.p + L->copied, L->d_hits.p + L->copied, (cnt - L->copied) * sizeof(kmcpg_hit), hipMemcpyDeviceToHost, A->copy_stream));
+    HIPCHK(hipStreamSynchronize(A->copy_stream));
     L->copied = cnt;
+  }
+  {
+    const uint64_t per_k = cnt * 1024 / L->n + 1, old = A->hits_hint.load();
+    A->hits_hint.store(per_k > old ? per_k : old - old / 8 + per_k / 8);  // rises at once, decays slowly
   }
   *n_hits = cnt;
   return 0;
