@@ -19,6 +19,7 @@
 #include <chrono>
 #include <condition_variable>
 #include <deque>
+#include <functional>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -422,6 +423,56 @@ struct RowFormatter {
   }
 };
 
+// Formatter threads that live as long as the run: each keeps its RowFormatter (and with it the cache of FPR strings, which
+// a fresh formatter per batch would fill again and again).
+class FormatPool {
+ public:
+  explicit FormatPool(int n) {
+    for (int i = 0; i < n; i++) th_.emplace_back([this] { loop(); });
+  }
+  ~FormatPool() {
+    {
+      std::lock_guard<std::mutex> l(m_);
+      stop_ = true;
+      cv_.notify_all();
+    }
+    for (auto& t : th_) t.join();
+  }
+  // fn(part, formatter) for part = 0 .. parts-1, spread over the pool; returns when all are done
+  void run(int parts, const std::function<void(int, RowFormatter&)>& fn) {
+    std::unique_lock<std::mutex> l(m_);
+    fn_ = &fn;
+    next_ = 0;
+    parts_ = parts;
+    left_ = parts;
+    cv_.notify_all();
+    done_cv_.wait(l, [&] { return left_ == 0; });
+    fn_ = nullptr;
+  }
+
+ private:
+  void loop() {
+    RowFormatter F;
+    std::unique_lock<std::mutex> l(m_);
+    for (;;) {
+      cv_.wait(l, [&] { return stop_ || (fn_ && next_ < parts_); });
+      if (stop_) return;
+      const int pi = next_++;
+      const auto* fn = fn_;
+      l.unlock();
+      (*fn)(pi, F);
+      l.lock();
+      if (--left_ == 0) done_cv_.notify_all();
+    }
+  }
+  std::vector<std::thread> th_;
+  std::mutex m_;
+  std::condition_variable cv_, done_cv_;
+  const std::function<void(int, RowFormatter&)>* fn_ = nullptr;
+  int next_ = 0, parts_ = 0, left_ = 0;
+  bool stop_ = false;
+};
+
 static std::unordered_map<std::string, std::string> read_kvs(const std::string& file) {  // cliutil.ReadKVs
   std::unordered_map<std::string, std::string> m;
   gzFile g = gzopen(file.c_str(), "rb");
@@ -812,6 +863,7 @@ int main(int argc, char** argv) {
   // (a multi-member .gz is what pgzip/gzip readers, `kmcp profile` included, accept).
   {
     const int nfmt = std::max(1, std::min(o.threads > 0 ? o.threads : 8, 16));
+    FormatPool pool(nfmt);
     // the formatted text of a batch goes to the file on a thread of its own, while the next batch is being formatted
     Queue<std::unique_ptr<std::vector<std::string>>> q_flush(4);
     std::thread flusher([&] {
@@ -843,8 +895,7 @@ int main(int argc, char** argv) {
       std::unique_ptr<std::vector<std::string>> chunk_p(new std::vector<std::string>((size_t)parts));
       std::vector<std::string>& chunk = *chunk_p;
       std::vector<uint64_t> part_matched((size_t)parts, 0);
-      auto work = [&](int pi) {
-        RowFormatter F;
+      const std::function<void(int, RowFormatter&)> work = [&](int pi, RowFormatter& F) {
         std::string& buf = chunk[(size_t)pi];
         const uint32_t lo = (uint32_t)((uint64_t)n * pi / parts), hi = (uint32_t)((uint64_t)n * (pi + 1) / parts);
         buf.reserve((size_t)(hi - lo) * 96);
@@ -860,12 +911,7 @@ int main(int argc, char** argv) {
         }
         if (out.gz()) buf = gzip_member(buf);
       };
-      if (parts == 1) work(0);
-      else {
-        std::vector<std::thread> th;
-        for (int pi = 0; pi < parts; pi++) th.emplace_back(work, pi);
-        for (auto& t : th) t.join();
-      }
+      pool.run(parts, work);
       for (int pi = 0; pi < parts; pi++) matched += part_matched[(size_t)pi];
       q_flush.push(std::move(chunk_p));
       total += n;
