@@ -116,7 +116,7 @@ struct kmcpg_db {
   kmcpg::DevBuf<int32_t> w_nk_raw, w_nk1, w_seg_cnt;
   kmcpg::DevBuf<uint32_t> w_long_list, w_long_meta, w_long_counts;  // long-query (split) path
   kmcpg::DevBuf<uint64_t> w_huge_info;                             // whole-genome queries: (read, n, offset)
-  kmcpg::DevBuf<uint8_t> w_huge_temp;                              // hipCUB temporary storage
+  kmcpg::DevBuf<uint8_t> w_huge_temp;                              // histogram table of the device-wide radix sort
   bool synthetic = false;
   // in-process multi-GPU front handle (kmcpg_open_devices): metadata only itself, one resident shard handle per device
   std::vector<kmcpg_db*> shards;
