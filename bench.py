@@ -41,6 +41,10 @@ WORKLOADS = {
     "gtdb": dict(k=21, num_hashes=1, fpr=0.3, n_blocks=32, cols_per_block=14976, num_sigs=967708, sigs_step=64, kmers_per_col=345510,
                  batch_reads=524288, kernel="k2_cobs<64,8,false>",
                  name="gtdb-scale synthetic: 32 blocks x 14976 cols x 968700 sigs (58.03 GB), 150bp k=21"),
+    # what ONE of 8 ranks holds of the GTDB-scale index (4 of the 32 blocks): per-GPU kernel behaviour at N = 8 on one GPU
+    "gtdb_eighth": dict(k=21, num_hashes=1, fpr=0.3, n_blocks=4, cols_per_block=14976, num_sigs=967708, sigs_step=64, kmers_per_col=345510,
+                        batch_reads=524288, kernel="k2_cobs<64,8,false>",
+                        name="one eighth of the gtdb-scale synthetic index: 4 blocks x 14976 cols (7.25 GB), 150bp k=21"),
     # 10 k chunks, `kmcp index -j 32`: 32 blocks x 312 columns, 39-byte rows (BASELINE.json configs[1])
     # (equal-length chunks => the same NumSigs in every block: libkmcpgpu lays them side by side, one 1248-byte gather per k-mer)
     "config1": dict(k=21, num_hashes=1, fpr=0.3, n_blocks=32, cols_per_block=312, num_sigs=1121470, kmers_per_col=400000,

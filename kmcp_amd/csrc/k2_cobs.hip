@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <type_traits>
 
 #include "common.hpp"
 #include "device_utils.hpp"
@@ -70,6 +71,21 @@ __device__ __forceinline__ bool group_col(const Seg* __restrict__ segs, const Bl
     }
   }
   return false;
+}
+
+// the same for 4 rows (the short groups of the zone where sectors die, see k2_cobs)
+template <int NPL>
+__device__ __forceinline__ void csa4(uint32_t (&pl)[NPL], uint32_t x0, uint32_t x1, uint32_t x2, uint32_t x3) {
+  uint32_t ta, tb, e;
+  CSA(ta, pl[0], pl[0], x0, x1);
+  CSA(tb, pl[0], pl[0], x2, x3);
+  CSA(e, pl[1], pl[1], ta, tb);
+#pragma unroll
+  for (int p = 2; p < NPL; p++) {
+    uint32_t t = pl[p] & e;
+    pl[p] ^= e;
+    e = t;
+  }
 }
 
 // SPLIT = true is the long-query form: a unit is (long query, slot, chunk of a.split_chk <= 8192 k-mers); its counts are added to a
@@ -170,10 +186,12 @@ __global__ void __launch_bounds__(256) k2_cobs(const K2Args a) {
     wave_lds_fence();
 
     const int cnt = min(CH, nmax - c0);
-    for (int j = 0; j < cnt; j += 8) {
-      uint4 x[8];
+    // NR rows at a time: gather, AND (multi-hash), add to the counters, then the branch-and-bound test
+    auto group = [&](auto nr_tag, int j) -> bool {
+      constexpr int NR = decltype(nr_tag)::value;
+      uint4 x[NR];
 #pragma unroll
-      for (int i = 0; i < 8; i++) {
+      for (int i = 0; i < NR; i++) {
         uint4 v = make_uint4(0, 0, 0, 0);
         if (live) {
           const uint32_t row = s_rows[wave][0][g * CH + j + i];
@@ -188,12 +206,19 @@ __global__ void __launch_bounds__(256) k2_cobs(const K2Args a) {
         }
         x[i] = v;
       }
-      csa8<NPL>(pl[0], x[0].x, x[1].x, x[2].x, x[3].x, x[4].x, x[5].x, x[6].x, x[7].x);
-      csa8<NPL>(pl[1], x[0].y, x[1].y, x[2].y, x[3].y, x[4].y, x[5].y, x[6].y, x[7].y);
-      csa8<NPL>(pl[2], x[0].z, x[1].z, x[2].z, x[3].z, x[4].z, x[5].z, x[6].z, x[7].z);
-      csa8<NPL>(pl[3], x[0].w, x[1].w, x[2].w, x[3].w, x[4].w, x[5].w, x[6].w, x[7].w);
+      if constexpr (NR == 8) {
+        csa8<NPL>(pl[0], x[0].x, x[1].x, x[2].x, x[3].x, x[4].x, x[5].x, x[6].x, x[7].x);
+        csa8<NPL>(pl[1], x[0].y, x[1].y, x[2].y, x[3].y, x[4].y, x[5].y, x[6].y, x[7].y);
+        csa8<NPL>(pl[2], x[0].z, x[1].z, x[2].z, x[3].z, x[4].z, x[5].z, x[6].z, x[7].z);
+        csa8<NPL>(pl[3], x[0].w, x[1].w, x[2].w, x[3].w, x[4].w, x[5].w, x[6].w, x[7].w);
+      } else {
+        csa4<NPL>(pl[0], x[0].x, x[1].x, x[2].x, x[3].x);
+        csa4<NPL>(pl[1], x[0].y, x[1].y, x[2].y, x[3].y);
+        csa4<NPL>(pl[2], x[0].z, x[1].z, x[2].z, x[3].z);
+        csa4<NPL>(pl[3], x[0].w, x[1].w, x[2].w, x[3].w);
+      }
       if (!SPLIT && a.prune) {
-        const int done = min(n, c0 + j + 8);
+        const int done = min(n, c0 + j + NR);
         const int need = (int)cmin - (n - done);  // a column must already hold this many to stay in the race
         bool lane_alive = live;
         if (live && need > 0) {
@@ -211,8 +236,19 @@ __global__ void __launch_bounds__(256) k2_cobs(const K2Args a) {
         }
         const uint64_t alive = __ballot(lane_alive);
         live = live && ((alive >> (lane & ~(GRP - 1))) & ((1ULL << GRP) - 1ULL)) != 0;
-        if (alive == 0) break;  // the whole wave is done with these rows
+        if (alive == 0) return true;  // the whole wave is done with these rows
       }
+      return false;
+    };
+    // Sectors die at the first test after their last column has fallen behind: with 8 rows between tests that point is
+    // overshot by ~3.5 rows on average, with 4 rows by ~1.5 — 2.3 % of a 130-k-mer read's row traffic, for ~15 % more VALU work
+    // (the host picks the group size by regime, query.cpp; profiles/r02_group_rows.txt).
+    if (a.group_rows == 4) {
+      for (int j = 0; j < cnt; j += 4)
+        if (group(std::integral_constant<int, 4>{}, j)) break;
+    } else {
+      for (int j = 0; j < cnt; j += 8)
+        if (group(std::integral_constant<int, 8>{}, j)) break;
     }
     wave_lds_fence();
     if (!SPLIT && a.prune && __ballot(live) == 0) break;

@@ -228,6 +228,12 @@ extern "C" int kmcpg_query_device(kmcpg_db* db, const uint8_t* d_seqs, const uin
   a.num_hashes = db->info.num_hashes;
   a.nt_loads = getenv("KMCPG_NT_LOADS") ? atoi(getenv("KMCPG_NT_LOADS")) : 1;
   a.prune = getenv("KMCPG_PRUNE") ? atoi(getenv("KMCPG_PRUNE")) : 1;
+  // Rows gathered between two pruning tests.  4 instead of 8 saves 2.3 % of the row traffic (sectors are dropped ~2 rows sooner)
+  // for ~15 % more VALU work: a gain where the kernel waits for HBM (GTDB scale, 8 planes: 511 -> 488 ms per 524 k reads), a loss
+  // where it runs near its issue limits (16-plane kernels at 3 waves per SIMD: 248 -> 361 ms; indexes that half live in the
+  // Infinity Cache: 17.8 -> 19.6 ms) — profiles/r02_group_rows.txt.
+  a.group_rows = (a.prune && npl == 8 && db->info.matrix_bytes_local >= (4ull << 30)) ? 4 : 8;
+  if (const char* e = getenv("KMCPG_GROUP_ROWS")) a.group_rows = atoi(e) == 4 ? 4 : 8;
   a.split_min = n_long ? split_min : 0;
   // slot-major unit order: the waves in flight share one (block, tile) slice of the index, so the address range they gather
   // from is ~1/64 of the index (GTDB scale: 575 -> 510 ms per 524 k reads; profiles/r02_order_exp.txt)

@@ -80,9 +80,9 @@ def test_grouped_layout_equals_ungrouped(oracle_lib, cols_per_block, n_blocks, s
             rows = [db.read_rows(b, np.arange(0, db.block_info(b)["num_sigs"], 997, dtype=np.uint64)) for b in range(n_blocks)]
             for b in (0, n_blocks - 1):  # the contiguous read-back (strided copy for wide rows, packed by a kernel for narrow ones)
                 bi = db.block_info(b)
-                out = np.zeros((5000, bi["row_bytes"]), dtype=np.uint8)
-                db.read_row_range(b, bi["num_sigs"] - 5000, out)
-                assert np.array_equal(out, db.read_rows(b, np.arange(bi["num_sigs"] - 5000, bi["num_sigs"], dtype=np.uint64)))
+                tail = np.zeros((5000, bi["row_bytes"]), dtype=np.uint8)
+                db.read_row_range(b, bi["num_sigs"] - 5000, tail)
+                assert np.array_equal(tail, db.read_rows(b, np.arange(bi["num_sigs"] - 5000, bi["num_sigs"], dtype=np.uint64)))
             hits, qk = _device_hits(db, reads, params)
             # expected counts from the rows resident in HBM, by the oracle's arithmetic (exact h % NumSigs, AND over the hashes)
             want = []
