@@ -92,8 +92,14 @@ __device__ __forceinline__ void csa4(uint32_t (&pl)[NPL], uint32_t x0, uint32_t 
 // per-query u32 array with atomics and thresholded by k_threshold_long, so a whole genome spreads over the chip instead
 // of one wave per (query, slot).
 
-template <int LPR, int NPL, bool MULTI, bool SPLIT>
-__global__ void __launch_bounds__(256) k2_cobs(const K2Args a) {
+// GR = rows gathered between two pruning tests (8, or 4: its own instantiation, so that the short form's registers — 4 rows in
+// flight instead of 8 — buy a sixth wave per SIMD).
+// The short form is built for at most 4 waves per SIMD: the kernel is bound by the L2->fabric path, not by latency (the 8-row
+// form runs as fast at 2 waves per SIMD as at 5), and of the schedules the compiler produces for the 4-row form under
+// different occupancy targets this one is the fastest (GTDB scale: 488 ms; 506-510 ms at 5-6 waves, 510 ms at 3; starved at 2:
+// profiles/r02_group_rows.txt).
+template <int LPR, int NPL, bool MULTI, bool SPLIT, int GR = 8>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, GR == 4 ? 4 : 10))) k2_cobs(const K2Args a) {
   constexpr int G = 64 / LPR;
   constexpr int PAIRS = MULTI ? 256 : 1024;
   constexpr int CH = (PAIRS / G) > 64 ? 64 : (PAIRS / G);
@@ -243,13 +249,8 @@ __global__ void __launch_bounds__(256) k2_cobs(const K2Args a) {
     // Sectors die at the first test after their last column has fallen behind: with 8 rows between tests that point is
     // overshot by ~3.5 rows on average, with 4 rows by ~1.5 — 2.3 % of a 130-k-mer read's row traffic, for ~15 % more VALU work
     // (the host picks the group size by regime, query.cpp; profiles/r02_group_rows.txt).
-    if (a.group_rows == 4) {
-      for (int j = 0; j < cnt; j += 4)
-        if (group(std::integral_constant<int, 4>{}, j)) break;
-    } else {
-      for (int j = 0; j < cnt; j += 8)
-        if (group(std::integral_constant<int, 8>{}, j)) break;
-    }
+    for (int j = 0; j < cnt; j += GR)
+      if (group(std::integral_constant<int, GR>{}, j)) break;
     wave_lds_fence();
     if (!SPLIT && a.prune && __ballot(live) == 0) break;
   }
@@ -310,7 +311,12 @@ static void launch_k2_t(const K2Args& a, bool multi, hipStream_t st) {
   for (uint64_t b0 = 0; b0 < blocks; b0 += K2_MAX_BLOCKS) {  // a launch holds fewer than 2^32 threads
     const unsigned nb = (unsigned)std::min<uint64_t>(K2_MAX_BLOCKS, blocks - b0);
     b.unit_base = b0 * 4 * G;
-    if (multi)
+    if (NPL == 8 && a.group_rows == 4) {
+      if (multi)
+        hipLaunchKernelGGL((k2_cobs<LPR, 8, true, false, 4>), dim3(nb), dim3(256), 0, st, b);
+      else
+        hipLaunchKernelGGL((k2_cobs<LPR, 8, false, false, 4>), dim3(nb), dim3(256), 0, st, b);
+    } else if (multi)
       hipLaunchKernelGGL((k2_cobs<LPR, NPL, true, false>), dim3(nb), dim3(256), 0, st, b);
     else
       hipLaunchKernelGGL((k2_cobs<LPR, NPL, false, false>), dim3(nb), dim3(256), 0, st, b);
