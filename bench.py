@@ -323,6 +323,7 @@ def run_workload(name, ctx, steps, warmup, batch_reads=0, cpu_baseline=True, cpu
         "roofline": {"bound": "hbm", "kernel": wl["kernel"], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                      "wire_gbps": (traffic / (k2_avg_ms * 1e-3) / 1e9) if traffic else None,
+                     "frac_wire": (traffic / (k2_avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
                      "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": k2_avg_ms, "kmers_kernel_ms": float(np.mean(k1_ms))},
         "hits_per_step": n_hits_total / max(1, steps),
         "matches_per_step": n_matches_total / max(1, steps),
