@@ -369,6 +369,11 @@ def run_workload(name, ctx, steps, warmup, batch_reads=0, cpu_baseline=True, cpu
         per_step, _ = kernel_only(max(2, min(steps, 4)))
         out["device_only"] = {"value": B / per_step, "unit": "reads/s", "ms_per_step": per_step * 1e3,
                               "note": "reads in HBM -> raw (read, column, count) hit tuples in host memory, no host half (round 1's `value`)"}
+        # live cross-check of the committed FETCH_SIZE pass: one step with the kernel counting its own row loads
+        db.set_profiling(2)
+        kernel_only(1)
+        out["roofline"]["gathered_bytes_per_launch"] = db.last_gathered_bytes()
+        db.set_profiling(True)
         _, k2_np = kernel_only(2, {"KMCPG_PRUNE": "0"})
         out["roofline"]["kernel_ms_prune_off"] = k2_np
         out["roofline"]["achieved_prune_off"] = alg_bytes / (k2_np * 1e-3) / 1e9

@@ -196,7 +196,10 @@ int kmcpg_plant_reads_device(kmcpg_db* db, const uint8_t* d_seqs, const uint64_t
                              uint64_t total_bases, uint32_t max_read_len, const uint32_t* d_cols, void* stream);
 /* HIP-event timing of the kernels inside kmcpg_query_device (events on the caller's stream).
  * kmcpg_last_timing waits for the last call to finish; times are milliseconds. */
-int kmcpg_set_profiling(kmcpg_db* db, int enable);
+int kmcpg_set_profiling(kmcpg_db* db, int enable);  /* 0 off, 1 timing, 2 timing + count the row loads of the COBS kernel */
+/* Bytes the COBS kernel(s) of the last kmcpg_query_device call asked the memory system for (16 B per lane and row actually
+ * loaded, row padding included, pruned rows not): a live cross-check of the FETCH_SIZE counter passes.  Level 2 only. */
+int kmcpg_last_gathered_bytes(kmcpg_db* db, uint64_t* bytes);
 int kmcpg_last_timing(kmcpg_db* db, float* kmers_ms, float* cobs_ms);
 /* The same for an earlier call: age 0 = the last one, 1 = the one before ... (the last 4 are kept), so that a caller with
  * several batches in flight can read the times of a finished one without waiting for the newest. */

@@ -105,6 +105,7 @@ struct K2Args {
   kmcpg_hit* hits;
   uint64_t hit_cap;
   unsigned long long* counter;
+  unsigned long long* gathered;  // optional (profiling level 2): number of 16-byte row loads issued
 };
 
 }  // namespace kmcpg

@@ -506,6 +506,7 @@ extern "C" int kmcpg_close(kmcpg_db* db) {
   db->w_long_counts.release();
   db->w_huge_info.release();
   db->w_huge_temp.release();
+  db->w_gathered.release();
   kmcpg::async_release(db);
   if (db->ws_ev) (void)hipEventDestroy(db->ws_ev);
   for (auto& ev : db->ev)

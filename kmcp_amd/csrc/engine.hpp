@@ -121,7 +121,8 @@ struct kmcpg_db {
   // in-process multi-GPU front handle (kmcpg_open_devices): metadata only itself, one resident shard handle per device
   std::vector<kmcpg_db*> shards;
   // optional HIP-event timing of the last kmcpg_query_device call
-  bool profiling = false;
+  int profiling = 0;  // 1: HIP-event timing of the kernels; 2: + count the row loads k2_cobs issues
+  kmcpg::DevBuf<uint64_t> w_gathered;
   hipEvent_t ev[12] = {};   // ring of 4 calls x (start, k-mers done, COBS done)
   uint64_t ev_calls = 0;    // profiled calls so far
 };

@@ -212,6 +212,10 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, GR 
         }
         x[i] = v;
       }
+      if (a.gathered) {  // measurement runs only: what this wave asked the memory system for
+        const uint64_t lv = __ballot(live);
+        if (lane == 0 && lv) atomicAdd(a.gathered, (unsigned long long)__popcll(lv) * NR * (MULTI ? nh : 1));
+      }
       if constexpr (NR == 8) {
         csa8<NPL>(pl[0], x[0].x, x[1].x, x[2].x, x[3].x, x[4].x, x[5].x, x[6].x, x[7].x);
         csa8<NPL>(pl[1], x[0].y, x[1].y, x[2].y, x[3].y, x[4].y, x[5].y, x[6].y, x[7].y);

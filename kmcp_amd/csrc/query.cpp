@@ -238,6 +238,11 @@ extern "C" int kmcpg_query_device(kmcpg_db* db, const uint8_t* d_seqs, const uin
   // slot-major unit order: the waves in flight share one (block, tile) slice of the index, so the address range they gather
   // from is ~1/64 of the index (GTDB scale: 575 -> 510 ms per 524 k reads; profiles/r02_order_exp.txt)
   a.slot_major = getenv("KMCPG_SLOT_MAJOR") ? atoi(getenv("KMCPG_SLOT_MAJOR")) : 1;
+  if (db->profiling >= 2) {
+    if (db->w_gathered.ensure(1)) return kmcpg_fail(KMCPG_ENOMEM, "hipMalloc failed");
+    HIPCHK(hipMemsetAsync(db->w_gathered.p, 0, sizeof(uint64_t), st));
+    a.gathered = (unsigned long long*)db->w_gathered.p;
+  }
   a.hits = d_hits;
   a.hit_cap = hit_cap;
   a.counter = (unsigned long long*)d_counters;
@@ -281,8 +286,21 @@ extern "C" int kmcpg_query_device(kmcpg_db* db, const uint8_t* d_seqs, const uin
 extern "C" int kmcpg_set_profiling(kmcpg_db* db, int enable) {
   if (!db) return kmcpg_fail(KMCPG_EINVAL, "null argument");
   std::lock_guard<std::mutex> g(db->mu);
-  db->profiling = enable != 0;
+  db->profiling = enable < 0 ? 0 : (enable > 2 ? 2 : enable);
   db->ev_calls = 0;
+  return 0;
+}
+
+extern "C" int kmcpg_last_gathered_bytes(kmcpg_db* db, uint64_t* bytes) {
+  if (!db || !bytes) return kmcpg_fail(KMCPG_EINVAL, "null argument");
+  std::lock_guard<std::mutex> g(db->mu);
+  if (db->profiling < 2 || !db->w_gathered.p || db->ev_calls == 0) return kmcpg_fail(KMCPG_EINVAL, "no kmcpg_query_device call at profiling level 2 yet");
+  KMCPG_USE_DEVICE(db);
+  hipEvent_t* pev = db->ev + 3 * ((db->ev_calls - 1) % 4);
+  HIPCHK(hipEventSynchronize(pev[2]));
+  uint64_t n = 0;
+  HIPCHK(hipMemcpy(&n, db->w_gathered.p, sizeof n, hipMemcpyDeviceToHost));
+  *bytes = n * 16;
   return 0;
 }
 

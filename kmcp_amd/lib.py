@@ -15,7 +15,7 @@ EXPORTS = [
     "kmcpg_open", "kmcpg_close", "kmcpg_last_error", "kmcpg_db_info", "kmcpg_col_info", "kmcpg_search_batch",
     "kmcpg_result_free", "kmcpg_query_device", "kmcpg_finalize", "kmcpg_open_synthetic", "kmcpg_plant",
     "kmcpg_read_rows", "kmcpg_block_info", "kmcpg_kmers_device", "kmcpg_plant_reads_device", "kmcpg_set_profiling",
-    "kmcpg_last_timing", "kmcpg_open_devices", "kmcpg_build_db", "kmcpg_submit", "kmcpg_wait", "kmcpg_read_row_range", "kmcpg_timing_at",
+    "kmcpg_last_timing", "kmcpg_open_devices", "kmcpg_build_db", "kmcpg_submit", "kmcpg_wait", "kmcpg_read_row_range", "kmcpg_timing_at", "kmcpg_last_gathered_bytes",
 ]
 
 
@@ -140,6 +140,7 @@ def load():
     L.kmcpg_plant_reads_device.argtypes = [vp, vp, vp, C.c_uint32, C.c_uint64, C.c_uint32, vp, vp]
     L.kmcpg_set_profiling.argtypes = [vp, C.c_int]
     L.kmcpg_last_timing.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    L.kmcpg_last_gathered_bytes.argtypes = [vp, u64p]
     L.kmcpg_timing_at.argtypes = [vp, C.c_uint32, C.POINTER(C.c_float), C.POINTER(C.c_float)]
     L.kmcpg_build_db.argtypes = [C.c_char_p, C.POINTER(BuildCfg), C.POINTER(BuildCol), C.c_uint32, C.c_int32]
     _lib = L
@@ -356,7 +357,13 @@ class Database:
         _check(load().kmcpg_plant_reads_device(self._h, d_seqs, d_offs, n_reads, total_bases, max_read_len, d_cols, stream))
 
     def set_profiling(self, on=True):
+        """False/0 off, True/1 kernel timing, 2 timing + count the row loads of the COBS kernel."""
         _check(load().kmcpg_set_profiling(self._h, int(on)))
+
+    def last_gathered_bytes(self):
+        n = C.c_uint64()
+        _check(load().kmcpg_last_gathered_bytes(self._h, C.byref(n)))
+        return n.value
 
     def last_timing(self, age=0):
         """(k-mer kernels ms, COBS kernel ms) of the last query_device call (age 1: the one before, ... up to 3)."""

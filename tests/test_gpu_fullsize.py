@@ -156,7 +156,8 @@ def test_pruning_keeps_boundary_columns(oracle_lib):
                     c = np.unpackbits(rows, axis=1)[:, :cols_per_block].sum(axis=0)
                     for col in np.nonzero(c >= cmin)[0]:
                         want.add((i, b * cols_per_block + int(col), int(c[col])))
-            got = {}
+            got, gathered = {}, {}
+            db.set_profiling(2)  # the kernel counts the 16-byte row loads it issues
             for prune in ("1", "0"):
                 os.environ["KMCPG_PRUNE"] = prune
                 try:
@@ -167,5 +168,11 @@ def test_pruning_keeps_boundary_columns(oracle_lib):
                     os.environ.pop("KMCPG_PRUNE", None)
                 h = hits[:int(cnt[0].item())].cpu().numpy()
                 got[prune] = {(int(r), int(c), int(k)) for r, c, k in h}
+                gathered[prune] = db.last_gathered_bytes()
             assert got["1"] == got["0"] == want
+            # without pruning every (k-mer, group) costs one padded row (k-mers rounded up to whole groups of 8 rows: the tail
+            # reads the all-zero row); the three equal-NumSigs blocks form one group.  With pruning the kernel asks for less.
+            stride = db.block_info(0)["stride"]
+            assert gathered["0"] == sum((len(km) + 7) // 8 * 8 for km in kms) * stride
+            assert gathered["1"] < gathered["0"]
             assert len(want) >= 2 * len(reads)  # the end-loaded and the start-loaded column of every read
