@@ -174,5 +174,7 @@ def test_pruning_keeps_boundary_columns(oracle_lib):
             # reads the all-zero row); the three equal-NumSigs blocks form one group.  With pruning the kernel asks for less.
             stride = db.block_info(0)["stride"]
             assert gathered["0"] == sum((len(km) + 7) // 8 * 8 for km in kms) * stride
-            assert gathered["1"] < gathered["0"]
+            assert gathered["1"] <= gathered["0"]
+            if cols_per_block == 14976:
+                assert gathered["1"] < 0.8 * gathered["0"]  # 2 % density: almost every sector dies early (narrow rows share one sector with the planted columns)
             assert len(want) >= 2 * len(reads)  # the end-loaded and the start-loaded column of every read
