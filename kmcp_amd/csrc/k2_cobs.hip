@@ -315,11 +315,11 @@ static void launch_k2_t(const K2Args& a, bool multi, hipStream_t st) {
   for (uint64_t b0 = 0; b0 < blocks; b0 += K2_MAX_BLOCKS) {  // a launch holds fewer than 2^32 threads
     const unsigned nb = (unsigned)std::min<uint64_t>(K2_MAX_BLOCKS, blocks - b0);
     b.unit_base = b0 * 4 * G;
-    if (NPL == 8 && a.group_rows == 4) {
+    if (NPL <= 10 && a.group_rows == 4) {
       if (multi)
-        hipLaunchKernelGGL((k2_cobs<LPR, 8, true, false, 4>), dim3(nb), dim3(256), 0, st, b);
+        hipLaunchKernelGGL((k2_cobs<LPR, NPL <= 10 ? NPL : 8, true, false, 4>), dim3(nb), dim3(256), 0, st, b);
       else
-        hipLaunchKernelGGL((k2_cobs<LPR, 8, false, false, 4>), dim3(nb), dim3(256), 0, st, b);
+        hipLaunchKernelGGL((k2_cobs<LPR, NPL <= 10 ? NPL : 8, false, false, 4>), dim3(nb), dim3(256), 0, st, b);
     } else if (multi)
       hipLaunchKernelGGL((k2_cobs<LPR, NPL, true, false>), dim3(nb), dim3(256), 0, st, b);
     else
@@ -331,6 +331,7 @@ template <int LPR>
 static int launch_k2_l(const K2Args& a, int npl, bool multi, hipStream_t st) {
   switch (npl) {
     case 8: launch_k2_t<LPR, 8>(a, multi, st); return 0;
+    case 10: launch_k2_t<LPR, 10>(a, multi, st); return 0;
     case 16: launch_k2_t<LPR, 16>(a, multi, st); return 0;
     case 24: launch_k2_t<LPR, 24>(a, multi, st); return 0;
     default: return -1;

@@ -213,7 +213,8 @@ extern "C" int kmcpg_query_device(kmcpg_db* db, const uint8_t* d_seqs, const uin
   uint64_t max_short = maxn;
   if (split_min > 0 && maxn > (uint64_t)split_min)
     max_short = n_long ? (uint64_t)split_min : std::max<uint64_t>(long_meta[1], (uint64_t)split_min);
-  const int npl = max_short <= 255 ? 8 : (max_short <= 65535 ? 16 : (max_short <= 16777215 ? 24 : 0));
+  // counter planes: 8 for single short reads, 10 for pairs (2 x 150 bp = 260 k-mers, up to 2 x 500 bp), 16 for long reads
+  const int npl = max_short <= 255 ? 8 : (max_short <= 1023 ? 10 : (max_short <= 65535 ? 16 : (max_short <= 16777215 ? 24 : 0)));
   if (!npl) return kmcpg_fail(KMCPG_EUNSUPPORTED, "queries with more than 16777215 k-mers need KMCPG_SPLIT_MIN > 0");
   K2Args a{};
   a.blocks = db->d_groupdev;
@@ -232,7 +233,7 @@ extern "C" int kmcpg_query_device(kmcpg_db* db, const uint8_t* d_seqs, const uin
   // for ~15 % more VALU work: a gain where the kernel waits for HBM (GTDB scale, 8 planes: 511 -> 488 ms per 524 k reads), a loss
   // where it runs near its issue limits (16-plane kernels at 3 waves per SIMD: 248 -> 361 ms; indexes that half live in the
   // Infinity Cache: 17.8 -> 19.6 ms) — profiles/r02_group_rows.txt.
-  a.group_rows = (a.prune && npl == 8 && db->info.matrix_bytes_local >= (4ull << 30)) ? 4 : 8;
+  a.group_rows = (a.prune && npl <= 10 && db->info.matrix_bytes_local >= (4ull << 30)) ? 4 : 8;
   if (const char* e = getenv("KMCPG_GROUP_ROWS")) a.group_rows = atoi(e) == 4 ? 4 : 8;
   a.split_min = n_long ? split_min : 0;
   // slot-major unit order: the waves in flight share one (block, tile) slice of the index, so the address range they gather
