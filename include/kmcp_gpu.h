@@ -143,6 +143,7 @@ void kmcpg_result_free(kmcpg_result* r);
  *    (kmcpg_search_batch waits for a lane instead, so a thread must not call it while it holds every lane itself).  kmcpg_wait blocks until that batch's GPU work is done and runs the host half
  *    (float64 thresholds, FPR, sorting; --try-se / smaller-k retries) on the calling thread while later batches occupy the GPU.
  *    Tickets may be waited for in any order and from any thread; kmcpg_wait consumes the ticket, also when it fails.
+ *    kmcpg_close refuses (KMCPG_EBUSY) while tickets are outstanding.
  *    kmcpg_search_batch(...) == kmcpg_submit(...) + kmcpg_wait(...). */
 typedef struct kmcpg_ticket kmcpg_ticket;
 int kmcpg_submit(kmcpg_db* db, const uint8_t* seqs, const uint64_t* offs, const uint8_t* seqs2, const uint64_t* offs2,

@@ -486,6 +486,7 @@ extern "C" int kmcpg_open_synthetic(const kmcpg_synth_spec* s, const kmcpg_opts*
 
 extern "C" int kmcpg_close(kmcpg_db* db) {
   if (!db) return 0;
+  if (int n = kmcpg::async_in_flight(db)) return kmcpg_fail(KMCPG_EBUSY, "%d batch(es) still between kmcpg_submit and kmcpg_wait: wait for every ticket before closing", n);
   for (kmcpg_db* sh : db->shards) kmcpg_close(sh);
   db->shards.clear();
   if (db->opts.device >= 0) (void)hipSetDevice(db->opts.device);

@@ -86,6 +86,7 @@ struct DevBuf {
 namespace kmcpg {
 struct AsyncState;
 void async_release(kmcpg_db* db);  // host.cpp
+int async_in_flight(kmcpg_db* db);
 }  // namespace kmcpg
 
 struct kmcpg_db {

@@ -98,6 +98,16 @@ struct AsyncState {
   std::mutex retry_mu;
 };
 
+// batches between kmcpg_submit and the end of kmcpg_wait on this handle (or its shards)
+int async_in_flight(kmcpg_db* db) {
+  int n = 0;
+  for (kmcpg_db* sh : db->shards) n += async_in_flight(sh);
+  if (!db->async) return n;
+  std::lock_guard<std::mutex> g(db->async->mu);
+  for (auto& l : db->async->lanes) n += l->busy ? 1 : 0;
+  return n;
+}
+
 void async_release(kmcpg_db* db) {
   if (!db->async) return;
   if (db->opts.device >= 0) (void)hipSetDevice(db->opts.device);

@@ -42,6 +42,7 @@ def test_batches_in_flight_out_of_order(world, oracle_lib):
 
         for i in range(4):
             submit(i)
+        assert lib.load().kmcpg_close(db._h) == -7  # tickets outstanding: the handle stays open
         with pytest.raises(lib.KmcpGpuError) as e:  # four lanes, all in flight: submit reports it instead of blocking
             submit(4)
         assert e.value.code == -7
