@@ -7,7 +7,7 @@
 // in 64 rounds of 64, so "earlier in the buffer" is (wave, round, lane) order and every pass is stable without any
 // cross-wave coordination:
 //   k_rs_hist     per-wave digit histogram (LDS atomics)                         -> hist[digit][wave]
-//   k_scan_u32    exclusive scan of that table in (digit, wave) order (one workgroup; the table has n/4 entries)
+//   scan_u32      exclusive scan of that table in (digit, wave) order (tile sums, scan of the sums, scan inside the tiles)
 //   k_rs_scatter  the wave re-reads its keys; lanes with equal digits find each other with 8 ballots, rank = popcount of the
 //                 lower lanes in the group, destination = scanned base + keys of that digit the wave has already placed
 // unique: k_uq_count (heads per wave) -> k_scan_u32 -> k_uq_scatter.
@@ -27,7 +27,10 @@ constexpr int ROUNDS = KEYS_PER_WAVE / 64;
 inline uint32_t n_waves(uint32_t n) { return (n + KEYS_PER_WAVE - 1) / KEYS_PER_WAVE; }
 }  // namespace
 
-size_t huge_dedup_temp_bytes(uint32_t max_n) { return ((size_t)256 * n_waves(max_n) + n_waves(max_n) + 64) * sizeof(uint32_t) + 256; }
+size_t huge_dedup_temp_bytes(uint32_t max_n) {
+  const size_t table = (size_t)256 * n_waves(max_n);  // histogram table + the per-wave head counts + the scan's tile sums
+  return (table + n_waves(max_n) + table / 4096 + 64) * sizeof(uint32_t) + 256;
+}
 
 __global__ void __launch_bounds__(256) k_rs_hist(const uint64_t* __restrict__ keys, uint32_t n, int shift, uint32_t* __restrict__ hist, uint32_t nw) {
   __shared__ uint32_t cnt[4][256];
@@ -46,7 +49,46 @@ __global__ void __launch_bounds__(256) k_rs_hist(const uint64_t* __restrict__ ke
   }
 }
 
-// exclusive scan of data[0..total) in place by ONE workgroup of 1024 threads; the grand total goes to *total_out (if given)
+// ---- exclusive scan of a u32 array in place, three launches: sums of 4096-element tiles -> scan of the tile sums (one
+// workgroup) -> scan inside every tile seeded with its sum.  A thread owns 16 consecutive elements (one 64-byte line).
+constexpr uint32_t SCAN_TILE = 4096;
+
+__device__ __forceinline__ uint32_t wg_exclusive_scan_256(uint32_t v, uint32_t* lds /*[4]*/, uint32_t* total) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  uint32_t inc = v;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const uint32_t u = __shfl_up(inc, off);
+    if (lane >= off) inc += u;
+  }
+  if (lane == 63) lds[wv] = inc;
+  __syncthreads();
+  uint32_t base = 0, all = 0;
+#pragma unroll
+  for (int w = 0; w < 4; w++) {
+    const uint32_t t = lds[w];
+    if (w < wv) base += t;
+    all += t;
+  }
+  __syncthreads();  // lds is reused by the caller's next round
+  if (total) *total = all;
+  return base + inc - v;
+}
+
+__global__ void __launch_bounds__(256) k_scan_tile_sums(const uint32_t* __restrict__ data, uint32_t total, uint32_t* __restrict__ tile_sum) {
+  __shared__ uint32_t lds[4];
+  const uint64_t base = (uint64_t)blockIdx.x * SCAN_TILE + (uint64_t)threadIdx.x * 16;
+  uint32_t s = 0;
+#pragma unroll
+  for (int i = 0; i < 16; i++)
+    if (base + i < total) s += data[base + i];
+  uint32_t all = 0;
+  (void)wg_exclusive_scan_256(s, lds, &all);
+  if (threadIdx.x == 0) tile_sum[blockIdx.x] = all;
+}
+
+// exclusive scan of data[0..total) in place by ONE workgroup of 1024 threads (the tile sums: total / 4096 entries); the grand
+// total goes to *total_out (if given)
 __global__ void __launch_bounds__(1024) k_scan_u32(uint32_t* __restrict__ data, uint32_t total, uint32_t* __restrict__ total_out) {
   __shared__ uint32_t part[1024];
   const uint32_t t = threadIdx.x;
@@ -69,6 +111,31 @@ __global__ void __launch_bounds__(1024) k_scan_u32(uint32_t* __restrict__ data, 
     run += v;
   }
   if (total_out && t == 1023) *total_out = part[1023];
+}
+
+__global__ void __launch_bounds__(256) k_scan_tiles(uint32_t* __restrict__ data, uint32_t total, const uint32_t* __restrict__ tile_base) {
+  __shared__ uint32_t lds[4];
+  const uint64_t base = (uint64_t)blockIdx.x * SCAN_TILE + (uint64_t)threadIdx.x * 16;
+  uint32_t v[16], s = 0;
+#pragma unroll
+  for (int i = 0; i < 16; i++) {
+    v[i] = base + i < total ? data[base + i] : 0;
+    s += v[i];
+  }
+  uint32_t run = tile_base[blockIdx.x] + wg_exclusive_scan_256(s, lds, nullptr);
+#pragma unroll
+  for (int i = 0; i < 16; i++) {
+    if (base + i < total) data[base + i] = run;
+    run += v[i];
+  }
+}
+
+// data[0..total) -> exclusive prefix sums in place; tile_sum: (total + 4095) / 4096 words of scratch; *total_out = grand total
+static void scan_u32(uint32_t* data, uint32_t total, uint32_t* tile_sum, uint32_t* total_out, hipStream_t st) {
+  const uint32_t tiles = (total + SCAN_TILE - 1) / SCAN_TILE;
+  hipLaunchKernelGGL(k_scan_tile_sums, dim3(tiles), dim3(256), 0, st, data, total, tile_sum);
+  hipLaunchKernelGGL(k_scan_u32, dim3(1), dim3(1024), 0, st, tile_sum, tiles, total_out);
+  hipLaunchKernelGGL(k_scan_tiles, dim3(tiles), dim3(256), 0, st, data, total, tile_sum);
 }
 
 __global__ void __launch_bounds__(256) k_rs_scatter(const uint64_t* __restrict__ in, uint64_t* __restrict__ out, uint32_t n, int shift,
@@ -167,16 +234,17 @@ int huge_dedup(uint64_t* keys, uint64_t* tmp, uint32_t n, int* d_num, void* d_te
   const unsigned blocks = (nw + 3) / 4;
   uint32_t* hist = (uint32_t*)d_temp;           // 256 * nw
   uint32_t* wave_cnt = hist + (size_t)256 * nw; // nw
+  uint32_t* tile_sum = wave_cnt + nw;           // (256 * nw + 4095) / 4096
   uint64_t *src = keys, *dst = tmp;
   for (int pass = 0; pass < 8; pass++) {
     hipLaunchKernelGGL(k_rs_hist, dim3(blocks), dim3(256), 0, st, src, n, pass * 8, hist, nw);
-    hipLaunchKernelGGL(k_scan_u32, dim3(1), dim3(1024), 0, st, hist, 256u * nw, (uint32_t*)nullptr);
+    scan_u32(hist, 256u * nw, tile_sum, nullptr, st);
     hipLaunchKernelGGL(k_rs_scatter, dim3(blocks), dim3(256), 0, st, src, dst, n, pass * 8, hist, nw);
     std::swap(src, dst);
   }
   // eight passes: the sorted keys are back in `keys`
   hipLaunchKernelGGL(k_uq_count, dim3(blocks), dim3(256), 0, st, keys, n, wave_cnt, nw);
-  hipLaunchKernelGGL(k_scan_u32, dim3(1), dim3(1024), 0, st, wave_cnt, nw, (uint32_t*)d_num);
+  scan_u32(wave_cnt, nw, tile_sum, (uint32_t*)d_num, st);
   hipLaunchKernelGGL(k_uq_scatter, dim3(blocks), dim3(256), 0, st, keys, n, wave_cnt, tmp, nw);
   if (hipMemcpyAsync(keys, tmp, (size_t)n * sizeof(uint64_t), hipMemcpyDeviceToDevice, st) != hipSuccess) return -1;
   hipLaunchKernelGGL(k_set_nk_huge, dim3(1), dim3(1), 0, st, nk_search, r, d_num, (int)n, min_matched);
