@@ -165,9 +165,19 @@ def test_finalize_worker_threads_agree(small_db):
             sel = h[(h["read"] >= lo) & (h["read"] < lo + step)].copy()
             sel["read"] -= lo
             pieces.append(db.finalize(sel, qk[lo:lo + step], ql[lo:lo + step], params=p))
+        # odd worker counts, more workers than the library would pick, a single one: the ranges of reads move, the result does not
+        others = []
+        for t in ("1", "3", "13", "64"):
+            os.environ["KMCPG_FINALIZE_THREADS"] = t
+            try:
+                others.append(db.finalize(h, qk, ql, params=p))
+            finally:
+                os.environ.pop("KMCPG_FINALIZE_THREADS", None)
     assert len(whole.matches) > 100000
     assert np.array_equal(whole.matches, np.concatenate([x.matches for x in pieces]))
     assert np.array_equal(np.diff(whole.offs), np.concatenate([np.diff(x.offs) for x in pieces]))
+    for o in others:
+        assert np.array_equal(o.matches, whole.matches) and np.array_equal(o.offs, whole.offs)
 
 
 def test_dist_search_fastx_reader(tmp_path):
