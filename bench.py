@@ -366,7 +366,7 @@ def run_workload(name, ctx, steps, warmup, batch_reads=0, cpu_baseline=True, cpu
                     else:
                         os.environ[k_] = v_
             return dt / nsteps, float(np.mean(ms))
-        per_step, _ = kernel_only(max(2, steps))
+        per_step, _ = kernel_only(max(2, min(steps, 8)))
         out["device_only"] = {"value": B / per_step, "unit": "reads/s", "ms_per_step": per_step * 1e3,
                               "note": "reads in HBM -> raw (read, column, count) hit tuples in host memory, no host half (round 1's `value`)"}
         # live cross-check of the committed FETCH_SIZE pass: one step with the kernel counting its own row loads
@@ -392,7 +392,7 @@ def run_workload(name, ctx, steps, warmup, batch_reads=0, cpu_baseline=True, cpu
         n_matches = db.search_packed_count(hb[0][0], hb[0][1], params=params)  # the C call alone, result freed, nothing copied to numpy
         single = time.perf_counter() - t1
         import threading
-        NB = max(8, 2 * steps)
+        NB = min(max(8, 2 * steps), 16)
         HT = 2  # host threads, each keeping two batches in flight (the C++ CLI runs two searcher threads the same way)
 
         def pump(t_):
