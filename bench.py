@@ -518,7 +518,7 @@ def main():
     out = run_workload(args.workload, ctx, args.steps, args.warmup, args.batch_reads, cpu_baseline=not args.no_cpu_baseline,
                        cpu_sample_reads=args.cpu_sample_reads, extras=not args.no_extras)
     if ctx.world == 1 and args.workload == "gtdb" and not args.no_secondary and not args.batch_reads:
-        sec = run_workload("config1", ctx, min(args.steps, 5), 1, cpu_baseline=not args.no_cpu_baseline, cpu_target_s=3.0)
+        sec = run_workload("config1", ctx, min(max(args.steps, 5), 20), 2, cpu_baseline=not args.no_cpu_baseline, cpu_target_s=3.0)
         keys = ("value", "unit", "ms_per_step", "config", "roofline", "planted_recall", "device_only", "host_boundary", "cpu_baseline")
         out["secondary"] = {"config1": {k: sec[k] for k in keys if k in sec}}
         # the same index with every block on its own (what a database with a different NumSigs per block gets): KMCPG_FUSE=0
