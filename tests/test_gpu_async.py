@@ -161,3 +161,15 @@ def test_multi_k_database_falls_back_to_smaller_k(oracle_lib, tmp_path):
         with pytest.raises(Exception):
             db.search(reads, params=default_params(k=25))
     odb.close()
+
+
+def test_async_stress_short():
+    """tools/stress_async.py for a few seconds: four threads, random submit / wait / search_batch patterns on a single-GPU
+    handle and on a two-shard in-process handle, every result compared with the batch searched alone (a 60-second run of the
+    same script checked 375 000 batches on the final build)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "stress_async.py"), "6", "4"], capture_output=True, text=True, timeout=300, cwd=root)
+    assert r.returncode == 0 and "stress ok" in r.stdout, (r.stdout[-1000:], r.stderr[-2000:])
