@@ -374,6 +374,14 @@ def run_workload(name, ctx, steps, warmup, batch_reads=0, cpu_baseline=True, cpu
         kernel_only(1)
         out["roofline"]["gathered_bytes_per_launch"] = db.last_gathered_bytes()
         db.set_profiling(True)
+        stride0 = db.block_info(0)["stride"]
+        if stride0 <= 64:
+            # narrow rows (one 64-byte request per (k-mer, block)): the bound is the rate at which the L2->fabric path serves
+            # requests that miss L2, not bytes — 56e9/s whatever their size up to 128 B (profiles/r02_ubench_cache.txt)
+            req = out["roofline"]["gathered_bytes_per_launch"] / stride0
+            out["roofline"]["request_bound"] = {"bound": "L2->fabric request rate", "requests_per_launch": req, "achieved": req / (k2_avg_ms * 1e-3),
+                                                "peak": 56e9, "unit": "requests/s", "frac": req / (k2_avg_ms * 1e-3) / 56e9,
+                                                "peak_source": "profiles/r02_ubench_cache.txt (64-B gathers over >= 64 MiB: 55-60 G/s)"}
         _, k2_np = kernel_only(2, {"KMCPG_PRUNE": "0"})
         out["roofline"]["kernel_ms_prune_off"] = k2_np
         out["roofline"]["achieved_prune_off"] = alg_bytes / (k2_np * 1e-3) / 1e9
