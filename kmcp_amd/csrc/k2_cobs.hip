@@ -15,12 +15,14 @@ namespace kmcpg {
 // ------------------------------------------------------------------------------------------------
 // K2: the COBS query.
 //
-// Work unit = (read, slot) with slot = (resident block, tile of LPR*16 bytes of its rows).  LPR lanes
-// serve one unit, so a wave carries G = 64/LPR units: LPR = 64 for wide rows (GTDB-scale, 1872 B),
-// 16 or 4 for narrow rows (a 312-column block has 39-byte rows).  Each lane owns 16 bytes = 128
-// columns of its unit's rows and keeps their match counts as NPL bit-sliced planes (vertical
-// counters): 8 rows are reduced with a carry-save adder tree (7 CSAs) and the carry word rippled into
-// the upper planes, ~4 VALU ops per loaded dword, which keeps the kernel HBM-bound.
+// Work unit = (read, slot) with slot = (group of resident blocks that share NumSigs, tile of LPR*16 bytes of its rows).  LPR
+// lanes serve one unit, so a wave carries G = 64/LPR units: LPR = 64 for every whole KiB of a row (GTDB-scale: 1872 B), 16 or 4
+// for what is left of it or for narrow rows (a lone 312-column block has 39-byte rows).  Units are numbered slot-major: all
+// waves in flight gather from one (group, tile) slice of the index.  Each lane owns 16 bytes = 128 columns of its unit's rows
+// and keeps their match counts as NPL bit-sliced planes (vertical counters): the rows of a group of GR = 8 (or 4) are reduced
+// with a carry-save adder tree and the carry word rippled into the upper planes, ~4 VALU ops per loaded dword, which keeps the
+// kernel memory-bound; after every group the sectors whose columns cannot reach the threshold any more stop
+// loading (exact branch and bound).
 // Row indices of a chunk of CH k-mers are computed cooperatively (one exact fastmod per (k-mer,
 // block)) into a per-wave LDS table; k-mers past the end of a read map to the all-zero row appended to
 // each block, so the inner loop has no tail code.
@@ -32,8 +34,8 @@ namespace kmcpg {
     l = u_ ^ (c_);                         \
   }
 
-// 16 bytes of a row.  Index rows are read once and never reused: non-temporal loads keep them from displacing the
-// hash/offset lines in L2 (+2 % on the random-gather microbenchmark, profiles/).
+// 16 bytes of a row.  Index rows are read once per launch and L2 cannot hold a slice (cache note): non-temporal
+// loads keep them from displacing the hash/offset lines in L2 (no measurable difference either way in the kernel).
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ uint4 load_row16(const uint8_t* p, int nt) {
   const u32x4* q = reinterpret_cast<const u32x4*>(p);
@@ -92,12 +94,11 @@ __device__ __forceinline__ void csa4(uint32_t (&pl)[NPL], uint32_t x0, uint32_t 
 // per-query u32 array with atomics and thresholded by k_threshold_long, so a whole genome spreads over the chip instead
 // of one wave per (query, slot).
 
-// GR = rows gathered between two pruning tests (8, or 4: its own instantiation, so that the short form's registers — 4 rows in
-// flight instead of 8 — buy a sixth wave per SIMD).
-// The short form is built for at most 4 waves per SIMD: the kernel is bound by the L2->fabric path, not by latency (the 8-row
-// form runs as fast at 2 waves per SIMD as at 5), and of the schedules the compiler produces for the 4-row form under
-// different occupancy targets this one is the fastest (GTDB scale: 488 ms; 506-510 ms at 5-6 waves, 510 ms at 3; starved at 2:
-// profiles/r02_group_rows.txt).
+// GR = rows gathered between two pruning tests: 8, or 4 where the launch waits for HBM (the host decides, query.cpp).  The
+// short form is its own instantiation (4 rows in flight: 75 VGPRs instead of 91) built for at most 4 waves per SIMD: the kernel
+// is bound by the L2->fabric path, not by latency (the 8-row form runs as fast at 2 waves per SIMD as at 5), and of the
+// occupancy targets tried for the 4-row form this one is the fastest (GTDB scale: 488 ms; 506-510 ms at 5-6 waves, 510 ms at 3,
+// starved at 2: profiles/r02_group_rows.txt).
 template <int LPR, int NPL, bool MULTI, bool SPLIT, int GR = 8>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, GR == 4 ? 4 : 10))) k2_cobs(const K2Args a) {
   constexpr int G = 64 / LPR;
