@@ -374,8 +374,9 @@ def run_workload(name, ctx, steps, warmup, batch_reads=0, cpu_baseline=True, cpu
         kernel_only(1)
         out["roofline"]["gathered_bytes_per_launch"] = db.last_gathered_bytes()
         db.set_profiling(True)
-        stride0 = db.block_info(0)["stride"]
-        if stride0 <= 64:
+        local_strides = [bi["stride"] for bi in (db.block_info(b_) for b_ in range(int(info.n_blocks))) if bi["local"]]
+        stride0 = max(local_strides) if local_strides else 0
+        if 0 < stride0 <= 64:
             # narrow rows (one 64-byte request per (k-mer, block)): the bound is the rate at which the L2->fabric path serves
             # requests that miss L2, not bytes — 56e9/s whatever their size up to 128 B (profiles/r02_ubench_cache.txt)
             req = out["roofline"]["gathered_bytes_per_launch"] / stride0
