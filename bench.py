@@ -132,6 +132,7 @@ def run_workload(name, ctx, steps, warmup, batch_reads=0, cpu_baseline=True, cpu
     from kmcp_amd.dist import gather_hits
 
     world, rank, dev, dev_index = ctx.world, ctx.rank, ctx.dev, ctx.dev_index
+    coll = ctx.collective  # the N > 1 code path (also taken by a one-rank RCCL group under KMCP_BENCH_FORCE_DIST=1: tests)
     wl = dict(WORKLOADS[name])
     B = batch_reads or wl["batch_reads"]
     spec = lib.SynthSpec(k=wl["k"], num_hashes=wl["num_hashes"], fpr=wl["fpr"], n_blocks=wl["n_blocks"],
@@ -179,7 +180,7 @@ def run_workload(name, ctx, steps, warmup, batch_reads=0, cpu_baseline=True, cpu
             self.copied = torch.cuda.Event()
             self.used = False
 
-    bufs = [Buf(), Buf()] if world == 1 else [Buf()]
+    bufs = [Buf(), Buf()] if not coll else [Buf()]
 
     def gpu_half(i, bf):
         """Enqueues K1+K2 of batch i on this rank's blocks (nothing waits here)."""
@@ -195,7 +196,7 @@ def run_workload(name, ctx, steps, warmup, batch_reads=0, cpu_baseline=True, cpu
     def exchange(bf):
         """Waits for the step's kernels; hit lists to rank 0 (RCCL when N > 1) and on their way to pinned host memory
         (`copied` fires when the host may read).  Returns #hits on rank 0.  Holds collectives when N > 1."""
-        if world == 1:
+        if not coll:
             bf.kernels_done.synchronize()
             n = int(bf.h_cnt[0])
             assert n <= cap, "hit buffer overflow"
@@ -206,7 +207,7 @@ def run_workload(name, ctx, steps, warmup, batch_reads=0, cpu_baseline=True, cpu
                 bf.h_ql.copy_(bf.d_ql, non_blocking=True)
                 bf.copied.record(side)
             return n
-        parts = gather_hits(bf.d_hits, bf.d_cnt[:1], dst=0)  # RCCL: all_gather(counts) + gather(hit buffers) over xGMI
+        parts = gather_hits(bf.d_hits, bf.d_cnt[:1], dst=0, force_collectives=True)  # RCCL: all_gather(counts) + gather(hit buffers) over xGMI
         n = 0
         if rank == 0:
             for part in parts:
@@ -226,7 +227,7 @@ def run_workload(name, ctx, steps, warmup, batch_reads=0, cpu_baseline=True, cpu
         return db.finalize_count(bf.h_hits[:n].numpy(), bf.h_qk.numpy(), bf.h_ql.numpy(), params=params)
 
     def barrier():
-        if world > 1:
+        if coll:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -236,7 +237,7 @@ def run_workload(name, ctx, steps, warmup, batch_reads=0, cpu_baseline=True, cpu
         runs while the kernels of step i+1 do.  Returns (#hits, #matches) on rank 0."""
         hits = matches = 0
         pending = None  # (buffers, #hits) of the step whose host half is still to run
-        if world == 1:
+        if not coll:
             gpu_half(first, bufs[0])
             for j in range(count):
                 bf = bufs[j % 2]
@@ -276,7 +277,7 @@ def run_workload(name, ctx, steps, warmup, batch_reads=0, cpu_baseline=True, cpu
     elapsed = time.perf_counter() - t_start
     k1_ms = [t_[0] for t_ in times]
     k2_ms = [t_[1] for t_ in times]
-    if world > 1:
+    if coll:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if ctx.same_gpu else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -517,9 +518,14 @@ def main():
     ctx.dev_index = 0 if ctx.same_gpu else local_rank
     torch.cuda.set_device(ctx.dev_index)
     ctx.dev = torch.device("cuda", ctx.dev_index)
-    if ctx.world > 1:
+    # KMCP_BENCH_FORCE_DIST=1 (tests on a 1-GPU box): a one-rank RCCL group, and the N > 1 code path of this script with it
+    force = os.environ.get("KMCP_BENCH_FORCE_DIST") == "1" and ctx.world == 1
+    ctx.collective = ctx.world > 1 or force
+    if ctx.collective:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        if ctx.same_gpu:
+        if force:
+            dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%s" % os.environ.get("MASTER_PORT", "29749"), world_size=1, rank=0, device_id=ctx.dev)
+        elif ctx.same_gpu:
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=ctx.dev)
@@ -539,7 +545,7 @@ def main():
         out["secondary"]["config1_ungrouped"] = {k: unf[k] for k in keys if k in unf}
     if ctx.rank == 0:
         print(json.dumps(out))
-    if ctx.world > 1:
+    if ctx.collective:
         dist.destroy_process_group()
 
 

@@ -14,14 +14,14 @@ import torch.distributed as dist
 from .lib import HIT_DTYPE
 
 
-def gather_hits(hits: torch.Tensor, count: torch.Tensor, dst: int = 0, group=None):
+def gather_hits(hits: torch.Tensor, count: torch.Tensor, dst: int = 0, group=None, force_collectives: bool = False):
     """hits: int32 [cap, 3] buffer of this rank, count: int64 [1] number of valid rows (device tensors for nccl,
     CPU tensors for gloo).  Returns on `dst` a list with every rank's valid rows (tensors on the same device,
     rank order), None elsewhere.  Two collectives: all_gather of the 8-byte counts, gather of the padded buffers —
     a few bytes per read, nowhere near the xGMI links' 153 GB/s."""
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
-    if world == 1:
+    if world == 1 and not force_collectives:  # (tests run the collectives on a one-rank RCCL group too)
         return [hits[:int(count.item())]]
     if dist.get_backend(group) == "gloo" and hits.is_cuda:
         # debugging aid (several ranks sharing one GPU, where RCCL refuses duplicate devices): stage through the host

@@ -66,6 +66,14 @@ def test_bench_two_ranks_equal_one_rank():
     assert j2["roofline"]["algorithmic_bytes_per_launch"] * 2 == pytest.approx(j1["roofline"]["algorithmic_bytes_per_launch"], rel=0.02)
     assert j2["value"] > 0 and "host_boundary" not in j2  # per-rank extras ride along only at N = 1
     assert ("nccl" if multi else "gloo")  # which exchange ran is decided by the GPUs visible; both go through gather_hits
+    # the same N > 1 code path of bench.py over RCCL itself: a one-rank nccl group (all_gather_into_tensor, gather, barrier,
+    # all_reduce on device tensors) must reproduce the plain one-rank numbers
+    env_f = dict(env, KMCP_BENCH_FORCE_DIST="1", MASTER_PORT="29745")
+    env_f.pop("KMCP_BENCH_SAME_GPU", None)
+    forced = subprocess.run([sys.executable, "bench.py", "--gpus", "1"] + args, capture_output=True, text=True, timeout=900, env=env_f, cwd=ROOT)
+    assert forced.returncode == 0, forced.stderr[-3000:]
+    jf = _bench_line(forced.stdout)
+    assert jf["hits_per_step"] == j1["hits_per_step"] and jf["matches_per_step"] == j1["matches_per_step"] and jf["planted_recall"] == j1["planted_recall"]
 
 
 def test_sharded_searcher_overflow_loop(oracle_lib, tmp_path):
@@ -87,3 +95,35 @@ def test_sharded_searcher_overflow_loop(oracle_lib, tmp_path):
     out = str(tmp_path / "o.tsv")
     _launch(2, 29743, ["-m", "kmcp_amd.dist_search", "-d", os.path.dirname(db_dir), fq, "-o", out, "-t", "0.31", "-f", "1", "-c", "1"], env)
     compare(open(out).read().split("\n"), want, trailer)
+
+
+def test_gather_hits_over_rccl_with_one_rank(tmp_path):
+    """The nccl (= RCCL) flavour of the exchange — all_gather_into_tensor of the counts, gather of the padded hit buffers, on
+    device tensors — cannot meet a second GPU on this box, but it can run as a one-rank group: the calls, dtypes and shapes are
+    the ones the N-GPU run makes."""
+    script = tmp_path / "one_rank_rccl.py"
+    script.write_text('''
+import os, sys
+sys.path.insert(0, %r)
+import torch, torch.distributed as dist
+from kmcp_amd.dist import gather_hits
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29747", world_size=1, rank=0, device_id=torch.device("cuda", 0))
+dev = torch.device("cuda", 0)
+hits = torch.arange(3000, dtype=torch.int32, device=dev).reshape(1000, 3).contiguous()
+for n in (0, 1, 417, 1000):
+    cnt = torch.tensor([n], dtype=torch.int64, device=dev)
+    parts = gather_hits(hits, cnt, dst=0, force_collectives=True)
+    assert len(parts) == 1 and parts[0].shape == (n, 3) and torch.equal(parts[0], hits[:n]), n
+t = torch.tensor([1.5], dtype=torch.float64, device=dev)
+dist.all_reduce(t, op=dist.ReduceOp.MAX)
+dist.barrier()
+assert float(t.item()) == 1.5
+dist.destroy_process_group()
+print("rccl one-rank ok")
+''' % ROOT)
+    env, _ = _env("KMCP_UNUSED")
+    env.pop("KMCP_UNUSED", None)
+    r = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+    assert r.returncode == 0 and "rccl one-rank ok" in r.stdout, (r.stdout[-1000:], r.stderr[-3000:])
