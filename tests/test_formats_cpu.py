@@ -422,3 +422,25 @@ def test_xz_and_bzip2_input_through_the_system_decompressor(tmp_path):
         done += 1
     if not done:
         pytest.skip("no xz/bzip2/zstd on this box")
+
+
+def test_multi_k_database_metadata(oracle_lib, tmp_path):
+    """`ks: [21, 31]` in __db.yml (block or flow style): the handle reports the largest k (the .uniki headers carry it,
+    util-db-search.go:690) and refuses a database whose headers disagree with it."""
+    import re
+    from kmcp_amd import Database, lib
+    O = oracle_lib
+    genomes = synth.random_genomes(4, 2000, seed=8)
+    cols = [(f"g{i}", len(g), 0, 1, O.sort_unique(np.concatenate([O.generate_kmers(g, O.sketch_cfg(k=k)) for k in (21, 31)]))) for i, g in enumerate(genomes)]
+    db_dir = O.build_db(str(tmp_path / "a"), O.sketch_cfg(k=31), cols, num_hashes=1, fpr=0.3, threads=1)
+    yml = open(db_dir + "/__db.yml").read()
+    for style in ("ks:\n- 21\n- 31\n", "ks: [31, 21]\n"):
+        open(db_dir + "/__db.yml", "w").write(re.sub(r"ks:\n- 31\n", style, yml))
+        with Database.open(db_dir, device=-1) as db:
+            assert db.info.k == 31 and int(db.info.n_cols) == 4
+        odb = O.OracleDB(db_dir)
+        assert odb.cfg.k == 31
+        odb.close()
+    open(db_dir + "/__db.yml", "w").write(re.sub(r"ks:\n- 31\n", "ks:\n- 31\n- 33\n", yml))  # headers say 31, the list's maximum is 33
+    with pytest.raises(lib.KmcpGpuError):
+        Database.open(db_dir, device=-1)
