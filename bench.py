@@ -33,7 +33,10 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.2-6.3 TB/s is what copies/gathers reach
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+# what random 128-byte gathers that miss L2 reach on this device (tools/ubench_cache.cpp, profiles/r02_ubench_cache.txt: 7.0-7.4 TB/s
+# for working sets of 64 MiB .. 1 GiB, Infinity-Cache- or HBM-resident alike): the L2->fabric path, the kernel's practical ceiling
+FABRIC_CEILING_GBS = 7200.0
 
 WORKLOADS = {
     # GTDB r202 k=21 x10 chunks: 58.03 GB in 32 blocks (docs/database-time-and-mem-v2021.12.md:20-36)
@@ -325,6 +328,9 @@ def run_workload(name, ctx, steps, warmup, batch_reads=0, cpu_baseline=True, cpu
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                      "wire_gbps": (traffic / (k2_avg_ms * 1e-3) / 1e9) if traffic else None,
                      "frac_wire": (traffic / (k2_avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
+                     "measured_ceiling": {"gbps": FABRIC_CEILING_GBS, "what": "random 128-B gathers that miss L2 (L2->fabric path), tools/ubench_cache.cpp",
+                                          "source": "profiles/r02_ubench_cache.txt",
+                                          "frac_wire": (traffic / (k2_avg_ms * 1e-3) / 1e9 / FABRIC_CEILING_GBS) if traffic else None},
                      "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": k2_avg_ms, "kmers_kernel_ms": float(np.mean(k1_ms))},
         "hits_per_step": n_hits_total / max(1, steps),
         "matches_per_step": n_matches_total / max(1, steps),
