@@ -140,8 +140,9 @@ void kmcpg_result_free(kmcpg_result* r);
  *    here a few BATCHES are.  kmcpg_submit copies the batch into pinned staging (the caller's buffers are free again when it
  *    returns), enqueues H2D copy, kernels and D2H copy on the handle's private stream and returns.  It never blocks: with all
  *    lanes (KMCPG_INFLIGHT, default 4) in flight it fails with KMCPG_EBUSY and the caller waits for one of its tickets first
- *    (kmcpg_search_batch waits for a lane instead, so a thread must not call it while it holds every lane itself).  kmcpg_wait blocks until that batch's GPU work is done and runs the host half
- *    (float64 thresholds, FPR, sorting; --try-se / smaller-k retries) on the calling thread while later batches occupy the GPU.
+ *    (kmcpg_search_batch waits for a lane instead, so a thread must not call it while it holds every lane itself).
+ *    kmcpg_wait blocks until that batch's GPU work is done and runs the host half (float64 thresholds, FPR, sorting;
+ *    --try-se / smaller-k retries) on the calling thread while later batches occupy the GPU.
  *    Tickets may be waited for in any order and from any thread; kmcpg_wait consumes the ticket, also when it fails.
  *    kmcpg_close refuses (KMCPG_EBUSY) while tickets are outstanding.
  *    kmcpg_search_batch(...) == kmcpg_submit(...) + kmcpg_wait(...). */
@@ -153,8 +154,10 @@ int kmcpg_wait(kmcpg_ticket* ticket, kmcpg_result* out);
 /* -- the GPU half only (k-mer generation + COBS query on the local blocks), device-resident in and
  *    out: generateKmers (util-db-search.go:1037-1107) + dedup (:874-908) + the UnikIndex workers
  *    (:6611-7742, integer thresholds only).  All pointers are DEVICE pointers; `stream` is a
- *    hipStream_t (NULL = default stream).  d_counters[0] receives the number of hits produced (which
- *    may exceed hit_cap: then only hit_cap were stored and the caller retries with a larger buffer).
+ *    hipStream_t (NULL = default stream).  d_counters points at TWO 64-bit words: [0] receives the number of hits
+ *    produced (which may exceed hit_cap: then only hit_cap were stored and the caller retries with a larger buffer), [1] the
+ *    largest NumKmers of the batch — if it exceeds what max_read_len allows (max_read_len - k + 1, twice that for pairs),
+ *    max_read_len was under-reported, the match counters may have wrapped and the hits must be discarded.
  *    d_qkmers[i] receives NumKmers of read i (0 if not searched), d_qlen[i] its QueryLen.
  *    max_read_len must be >= the longest read (mate) of the batch: it sizes the counters.  The call only enqueues work on
  *    `stream` for short-read batches; when a query may exceed 2048 k-mers it reads 8 bytes back (which queries are long is
