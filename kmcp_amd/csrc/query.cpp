@@ -196,7 +196,13 @@ extern "C" int kmcpg_query_device(kmcpg_db* db, const uint8_t* d_seqs, const uin
   const char* sm_env = getenv("KMCPG_SPLIT_MIN");
   const int32_t split_min = sm_env ? atoi(sm_env) : 2048;
   uint32_t long_meta[2] = {0, 0};
-  if (split_min > 0 && maxn > (uint64_t)split_min) {
+  size_t total_slots = 0;
+  for (const auto& c : db->classes) total_slots += c.slots.size();
+  // The read-back below costs a host round trip in the middle of the batch (~2.5 ms: more than the kernels of a batch of HiFi
+  // reads take).  It is only worth it when splitting could pay: a batch that fills the chip with its (query, slot) pairs anyway
+  // and whose queries are bounded by 32 768 k-mers (HiFi reads, contigs) runs the plain kernel on 16 planes without asking.
+  const bool ask = split_min > 0 && maxn > (uint64_t)split_min && (sm_env || maxn > 32768 || (uint64_t)n_reads * total_slots <= 16384);
+  if (ask) {
     if (db->w_long_list.ensure(n_reads + 1) || db->w_long_meta.ensure(2)) return kmcpg_fail(KMCPG_ENOMEM, "hipMalloc failed");
     HIPCHK(hipMemsetAsync(db->w_long_meta.p, 0, 2 * sizeof(uint32_t), st));
     launch_list_long(d_qkmers, n_reads, split_min, db->w_long_list.p, db->w_long_meta.p, st);
@@ -204,14 +210,12 @@ extern "C" int kmcpg_query_device(kmcpg_db* db, const uint8_t* d_seqs, const uin
     HIPCHK(hipStreamSynchronize(st));
   }
   uint32_t n_long = long_meta[0];
-  size_t total_slots = 0;
-  for (const auto& c : db->classes) total_slots += c.slots.size();
   // splitting pays when the long queries alone would leave the chip idle (few (query, slot) pairs) or need more than 16
   // counter planes; a batch of thousands of 10-kb reads already fills it and keeps the plain kernel (unless forced by env)
   if (n_long && !sm_env && (uint64_t)n_long * total_slots > 16384 && long_meta[1] <= 65535) n_long = 0;
   // largest NumKmers the plain kernel will meet: bounded by the read length, and exactly known once the long ones were listed
   uint64_t max_short = maxn;
-  if (split_min > 0 && maxn > (uint64_t)split_min)
+  if (ask)
     max_short = n_long ? (uint64_t)split_min : std::max<uint64_t>(long_meta[1], (uint64_t)split_min);
   // counter planes: 8 for single short reads, 10 for pairs (2 x 150 bp = 260 k-mers, up to 2 x 500 bp), 16 for long reads
   const int npl = max_short <= 255 ? 8 : (max_short <= 1023 ? 10 : (max_short <= 65535 ? 16 : (max_short <= 16777215 ? 24 : 0)));
