@@ -160,8 +160,9 @@ int kmcpg_wait(kmcpg_ticket* ticket, kmcpg_result* out);
  *    max_read_len was under-reported, the match counters may have wrapped and the hits must be discarded.
  *    d_qkmers[i] receives NumKmers of read i (0 if not searched), d_qlen[i] its QueryLen.
  *    max_read_len must be >= the longest read (mate) of the batch: it sizes the counters.  The call only enqueues work on
- *    `stream` for short-read batches; when a query may exceed 2048 k-mers it reads 8 bytes back (which queries are long is
- *    known only on the device) and therefore synchronises the stream once or twice. */
+ *    `stream` for short-read batches; when a query may exceed 32 768 k-mers — or 2048, in a batch too small to fill the GPU
+ *    by itself — it reads 8 bytes back (which queries are long is known only on the device; they may take the chunked form of
+ *    the kernel) and therefore synchronises the stream once or twice. */
 int kmcpg_query_device(kmcpg_db* db, const uint8_t* d_seqs, const uint64_t* d_offs, const uint8_t* d_seqs2,
                        const uint64_t* d_offs2, uint32_t n_reads, uint64_t total_bases, uint32_t max_read_len,
                        const kmcpg_params* params, kmcpg_hit* d_hits, uint64_t hit_cap, uint64_t* d_counters,
