@@ -373,33 +373,49 @@ struct RowFormatter {
   char tmp[64];
   std::unordered_map<uint64_t, std::string> fpr_cache;  // the FPR of a match depends on (qKmers, mKmers) only
 
-  static void put_u64(std::string& b, uint64_t v) {
+  // A row is assembled in a fixed scratch line through a moving pointer (no capacity checks per character) and appended to the
+  // batch's text in one go; rows that could not fit (IDs or target names of kilobytes) take the std::string path below.
+  static char* w_u64(char* p, uint64_t v) {
     char t[24];
     int n = 0;
     do { t[n++] = (char)('0' + v % 10); v /= 10; } while (v);
-    while (n) b.push_back(t[--n]);
+    while (n) *p++ = t[--n];
+    return p;
   }
-  static void put_i(std::string& b, int64_t v) {
-    if (v < 0) { b.push_back('-'); put_u64(b, (uint64_t)(-v)); } else put_u64(b, (uint64_t)v);
+  static char* w_i(char* p, int64_t v) {
+    if (v < 0) { *p++ = '-'; return w_u64(p, (uint64_t)(-v)); }
+    return w_u64(p, (uint64_t)v);
   }
-  void put_f4(std::string& b, double v) {  // "%.4f"
+  static char* w_f4(char* p, double v) {  // "%.4f"
     if (v >= 0 && v < 1e9) {
       const double sc = v * 10000.0;
       const double fl = floor(sc);
       const double fr = sc - fl;
       if (fabs(fr - 0.5) > 1e-6) {  // far from a tie: the scaled value rounds like the exact decimal expansion
-        uint64_t q = (uint64_t)fl + (fr > 0.5 ? 1 : 0);
-        put_u64(b, q / 10000);
-        b.push_back('.');
+        const uint64_t q = (uint64_t)fl + (fr > 0.5 ? 1 : 0);
+        p = w_u64(p, q / 10000);
+        *p++ = '.';
         const unsigned f = (unsigned)(q % 10000);
-        b.push_back((char)('0' + f / 1000));
-        b.push_back((char)('0' + f / 100 % 10));
-        b.push_back((char)('0' + f / 10 % 10));
-        b.push_back((char)('0' + f % 10));
-        return;
+        *p++ = (char)('0' + f / 1000);
+        *p++ = (char)('0' + f / 100 % 10);
+        *p++ = (char)('0' + f / 10 % 10);
+        *p++ = (char)('0' + f % 10);
+        return p;
       }
     }
-    b.append(tmp, (size_t)snprintf(tmp, sizeof tmp, "%.4f", v));
+    return p + snprintf(p, 48, "%.4f", v);
+  }
+  static void put_u64(std::string& b, uint64_t v) {
+    char t[24];
+    b.append(t, (size_t)(w_u64(t, v) - t));
+  }
+  static void put_i(std::string& b, int64_t v) {
+    char t[24];
+    b.append(t, (size_t)(w_i(t, v) - t));
+  }
+  void put_f4(std::string& b, double v) {
+    char t[64];
+    b.append(t, (size_t)(w_f4(t, v) - t));
   }
   const std::string& fpr(int n, int c, double v) {
     const uint64_t key = ((uint64_t)(uint32_t)n << 32) | (uint32_t)c;
@@ -408,14 +424,37 @@ struct RowFormatter {
     if (fpr_cache.size() > (1u << 20)) fpr_cache.clear();
     return fpr_cache.emplace(key, std::string(tmp, (size_t)snprintf(tmp, sizeof tmp, "%.4e", v))).first->second;
   }
+  static constexpr size_t LINE = 8192;
+  char line[LINE];
   void row(std::string& b, std::string_view id, int qlen, int qkmers, uint64_t hits, const std::string& target, const kmcpg_match& m, int k,
            uint64_t qidx) {
-    b += id; b.push_back('\t'); put_i(b, qlen); b.push_back('\t'); put_i(b, qkmers); b.push_back('\t');
-    b += fpr(qkmers, m.mkmers, m.fpr); b.push_back('\t'); put_u64(b, hits); b.push_back('\t');
-    b += target; b.push_back('\t'); put_u64(b, (uint16_t)m.target_idx); b.push_back('\t'); put_u64(b, m.target_idx >> 16); b.push_back('\t');
-    put_u64(b, m.gsize); b.push_back('\t'); put_i(b, k); b.push_back('\t'); put_i(b, m.mkmers); b.push_back('\t');
-    put_f4(b, m.qcov); b.push_back('\t'); put_f4(b, m.tcov); b.push_back('\t'); put_f4(b, m.jacc); b.push_back('\t');
-    put_u64(b, qidx); b.push_back('\n');
+    const std::string& f = fpr(qkmers, m.mkmers, m.fpr);
+    if (id.size() + target.size() + f.size() + 400 > LINE) {  // oversized names: the slow, unbounded path
+      b += id; b.push_back('\t'); put_i(b, qlen); b.push_back('\t'); put_i(b, qkmers); b.push_back('\t');
+      b += f; b.push_back('\t'); put_u64(b, hits); b.push_back('\t');
+      b += target; b.push_back('\t'); put_u64(b, (uint16_t)m.target_idx); b.push_back('\t'); put_u64(b, m.target_idx >> 16); b.push_back('\t');
+      put_u64(b, m.gsize); b.push_back('\t'); put_i(b, k); b.push_back('\t'); put_i(b, m.mkmers); b.push_back('\t');
+      put_f4(b, m.qcov); b.push_back('\t'); put_f4(b, m.tcov); b.push_back('\t'); put_f4(b, m.jacc); b.push_back('\t');
+      put_u64(b, qidx); b.push_back('\n');
+      return;
+    }
+    char* p = line;
+    memcpy(p, id.data(), id.size()); p += id.size(); *p++ = '\t';
+    p = w_i(p, qlen); *p++ = '\t';
+    p = w_i(p, qkmers); *p++ = '\t';
+    memcpy(p, f.data(), f.size()); p += f.size(); *p++ = '\t';
+    p = w_u64(p, hits); *p++ = '\t';
+    memcpy(p, target.data(), target.size()); p += target.size(); *p++ = '\t';
+    p = w_u64(p, (uint16_t)m.target_idx); *p++ = '\t';
+    p = w_u64(p, m.target_idx >> 16); *p++ = '\t';
+    p = w_u64(p, m.gsize); *p++ = '\t';
+    p = w_i(p, k); *p++ = '\t';
+    p = w_i(p, m.mkmers); *p++ = '\t';
+    p = w_f4(p, m.qcov); *p++ = '\t';
+    p = w_f4(p, m.tcov); *p++ = '\t';
+    p = w_f4(p, m.jacc); *p++ = '\t';
+    p = w_u64(p, qidx); *p++ = '\n';
+    b.append(line, (size_t)(p - line));
   }
   void unmatched(std::string& b, std::string_view id, int qlen, int qkmers, int k, uint64_t qidx) {
     b += id; b.push_back('\t'); put_i(b, qlen); b.push_back('\t'); put_i(b, qkmers);
