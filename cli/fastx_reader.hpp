@@ -532,7 +532,8 @@ class ParallelFastq {
     return ok;
   }
 
-  ParallelFastq(const std::string& path, size_t chunk_reads, int workers) : path_(path) {
+  // chunks of about `chunk_reads` records, and of at most `max_chunk_bytes` of file (0: no limit) — long reads
+  ParallelFastq(const std::string& path, size_t chunk_reads, int workers, size_t max_chunk_bytes = 0) : path_(path) {
     fd_ = open(path.c_str(), O_RDONLY);
     if (fd_ < 0) die("%s: %s", path.c_str(), strerror(errno));
     struct stat st;
@@ -557,6 +558,7 @@ class ParallelFastq {
     }
     const size_t per_rec = recs ? std::max<size_t>(1, p / recs) : 320;
     chunk_bytes_ = std::max<size_t>(1u << 16, per_rec * std::max<size_t>(1, chunk_reads));
+    if (max_chunk_bytes) chunk_bytes_ = std::min(chunk_bytes_, std::max<size_t>(1u << 16, max_chunk_bytes));
     if (const char* e = getenv("KMCP_READER_CHUNK")) chunk_bytes_ = std::max<size_t>(64, (size_t)atol(e));
     for (int i = 0; i < std::max(1, workers); i++) pool_.emplace_back([this] { work(); });
     cutter_ = std::thread([this] { cut(); });

@@ -295,7 +295,7 @@ static uint64_t read_single_end(const std::string& file, size_t batch_reads, siz
   if (ParallelFastq::eligible(file)) {
     int w = (int)std::min(8u, std::max(2u, std::thread::hardware_concurrency() / 2));
     if (const char* e = getenv("KMCP_READER_THREADS")) w = std::max(1, atoi(e));
-    ParallelFastq pf(file, batch_reads, w);
+    ParallelFastq pf(file, batch_reads, w, 2 * max_bases);  // a record is its bases twice (qualities) plus the header
     serial = false;
     while (std::unique_ptr<FastqChunk> c = pf.next()) {
       if (!c->strict) {  // not four-line FASTQ from here on: the general reader takes over at the chunk's first byte
@@ -319,6 +319,65 @@ static uint64_t read_single_end(const std::string& file, size_t batch_reads, siz
     while (r.next(&rec)) add(rec);
     flush();
   }
+  return n;
+}
+
+// The records of two mate files as batches of pairs (IDs of read 1), in file order; ends with the shorter file, like the
+// reference's loop (search.go:807-826).  Both files go through read_single_end — several parser threads each for plain FASTQ —
+// the mates on a thread of their own; read 2's batches are re-cut at read 1's batch boundaries (buffers are taken over
+// without a copy where the boundaries agree, which they do for reads of equal length).  Returns the number of pairs.
+template <class Emit>
+static uint64_t read_paired(const std::string& file1, const std::string& file2, size_t batch_reads, size_t max_bases, Emit&& emit) {
+  Queue<std::unique_ptr<Batch>> q2(4);
+  std::thread mate_reader([&] {
+    read_single_end(file2, batch_reads, std::max<size_t>(1, max_bases / 2), [&](std::unique_ptr<Batch> b) { q2.push(std::move(b)); });
+    q2.close();
+  });
+  std::unique_ptr<Batch> cur;  // the batch of read 2 being consumed
+  size_t ci = 0;               // records of it already handed out
+  bool ended = false;          // read 2 is exhausted: whatever read 1 still holds is ignored
+  uint64_t n = 0;
+  read_single_end(file1, batch_reads, std::max<size_t>(1, max_bases / 2), [&](std::unique_ptr<Batch> b) {
+    if (ended) return;
+    const size_t want = b->size();
+    size_t have = 0;
+    b->paired = true;
+    while (have < want) {
+      if (!cur || ci == cur->size()) {
+        ci = 0;
+        cur.reset();
+        if (!q2.pop(&cur)) {
+          ended = true;
+          break;
+        }
+        continue;
+      }
+      if (have == 0 && ci == 0 && cur->size() == want) {
+        b->seqs2.swap(cur->seqs);
+        b->offs2.swap(cur->offs);
+        cur.reset();
+        have = want;
+        break;
+      }
+      const size_t take = std::min(want - have, cur->size() - ci);
+      const uint64_t lo = cur->offs[ci], hi = cur->offs[ci + take], base = b->seqs2.size();
+      b->seqs2.insert(b->seqs2.end(), cur->seqs.begin() + (ptrdiff_t)lo, cur->seqs.begin() + (ptrdiff_t)hi);
+      for (size_t i = 1; i <= take; i++) b->offs2.push_back(base + (cur->offs[ci + i] - lo));
+      ci += take;
+      have += take;
+    }
+    if (have < want) {  // read 2 ended inside this batch
+      b->id_buf.resize((size_t)b->id_offs[have]);
+      b->id_offs.resize(have + 1);
+      b->seqs.resize((size_t)b->offs[have]);
+      b->offs.resize(have + 1);
+    }
+    if (have == 0) return;
+    n += have;
+    emit(std::move(b));
+  });
+  while (q2.pop(&cur)) {}  // read 1 ended first: let the mates' thread finish
+  mate_reader.join();
   return n;
 }
 
@@ -554,7 +613,10 @@ int main(int argc, char** argv) {
   if (o.parse_only) {  // reader check, no database and no GPU: one summary line per input file
     // checksum = sum over records i (0-based, in file order) of fnv1a("id\tseq\n") * (2 i + 1) mod 2^64: order-sensitive, yet
     // every batch can be summed on its own thread
-    for (const auto& file : o.files) {
+    // (pairs, -1/-2: "id\tseq1\tseq2\n")
+    const bool pe = !o.read1.empty() && !o.read2.empty();
+    std::vector<std::string> inputs = pe ? std::vector<std::string>{o.read1 + "," + o.read2} : o.files;
+    for (const auto& file : inputs) {
       const auto t0 = std::chrono::steady_clock::now();
       Queue<std::unique_ptr<Batch>> q(8);
       std::mutex mu;
@@ -573,11 +635,15 @@ int main(int argc, char** argv) {
               mix(b->id_buf.data() + b->id_offs[i], (size_t)(b->id_offs[i + 1] - b->id_offs[i]));
               mix("\t", 1);
               mix((const char*)b->seqs.data() + b->offs[i], (size_t)(b->offs[i + 1] - b->offs[i]));
+              if (b->paired) {
+                mix("\t", 1);
+                mix((const char*)b->seqs2.data() + b->offs2[i], (size_t)(b->offs2[i + 1] - b->offs2[i]));
+              }
               mix("\n", 1);
               my_sum += h * (2 * (b->first_idx + i) + 1);
             }
             my_n += b->size();
-            my_bases += b->seqs.size();
+            my_bases += b->seqs.size() + b->seqs2.size();
             my_ids += b->id_buf.size();
           }
           std::lock_guard<std::mutex> g(mu);
@@ -587,11 +653,13 @@ int main(int argc, char** argv) {
           id_bytes += my_ids;
         });
       uint64_t idx = 0;
-      read_single_end(file, (size_t)o.batch, 64u << 20, [&](std::unique_ptr<Batch> b) {
+      auto emit = [&](std::unique_ptr<Batch> b) {
         b->first_idx = idx;
         idx += b->size();
         q.push(std::move(b));
-      });
+      };
+      if (pe) read_paired(o.read1, o.read2, (size_t)o.batch, 64u << 20, emit);
+      else read_single_end(file, (size_t)o.batch, 64u << 20, emit);
       q.close();
       for (auto& t : th) t.join();
       const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
@@ -800,34 +868,13 @@ int main(int argc, char** argv) {
     std::string id1, s1, id2, s2;
     if (paired) {
       if (verbose) info("reading from paired-end files: %s, %s", o.read1.c_str(), o.read2.c_str());
-      // the mates are decoded by their own thread (two gzip streams inflate in parallel) and handed over in chunks
-      struct MateChunk { std::vector<std::string> seqs; };
-      Queue<std::unique_ptr<MateChunk>> q2(8);
-      std::thread mate_reader([&] {
-        FastxReader r2(o.read2);
-        std::unique_ptr<MateChunk> c(new MateChunk());
-        std::string mid, ms;
-        while (r2.next(&mid, &ms)) {
-          c->seqs.push_back(ms);
-          if (c->seqs.size() == 4096) { q2.push(std::move(c)); c.reset(new MateChunk()); }
-        }
-        if (!c->seqs.empty()) q2.push(std::move(c));
-        q2.close();
+      flush();
+      read_paired(o.read1, o.read2, (size_t)o.batch, max_bases, [&](std::unique_ptr<Batch> nb) {
+        nb->first_idx = id;
+        id += nb->size();
+        b = std::move(nb);
+        flush();
       });
-      FastxReader r1(o.read1);
-      std::unique_ptr<MateChunk> cur;
-      size_t ci = 0;
-      FastxRec rec;
-      while (r1.next(&rec)) {
-        if (!cur || ci == cur->seqs.size()) {
-          ci = 0;
-          if (!q2.pop(&cur)) break;  // read2 ended first: stop like the reference (search.go:818-826)
-        }
-        add(std::string_view(rec.id, rec.id_len), std::string_view(rec.seq, rec.seq_len), &cur->seqs[ci++]);
-      }
-      // drain whatever read2 still holds so that its thread can finish
-      while (q2.pop(&cur)) {}
-      mate_reader.join();
       if (id == 0) warn("no valid sequences in files: %s, %s", o.read1.c_str(), o.read2.c_str());
     } else {
       const std::string nnn((size_t)std::max(0, dbi.k - 1), 'N');

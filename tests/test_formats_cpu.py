@@ -371,6 +371,52 @@ def test_parallel_fastq_reader(tmp_path):
                            fnv1a="%016x" % _reader_checksum(want)), (p, env["KMCP_READER_CHUNK"], break_at)
 
 
+def test_paired_reader_zips_mates_in_order(tmp_path):
+    """`kmcp-search --parse-only -1 a -2 b`: the two mate files are parsed independently (several threads each for plain
+    FASTQ, the general reader for gzip) and zipped back record by record.  Reads of different lengths put the chunk cuts of
+    the two files at different records, so the mates are re-cut; the pairs end with the shorter file (search.go:807-826).
+    Checked against the independent Python reader: checksum over "id1\tseq1\tseq2\n" in order."""
+    import gzip
+    import subprocess
+    from kmcp_amd.dist_search import read_fastx
+    cli = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "kmcp_amd", "kmcp-search")
+    if not os.path.exists(cli):
+        import __graft_entry__ as g
+        g.build()
+    rng = np.random.default_rng(5)
+    acgt = np.frombuffer(b"ACGTN", dtype=np.uint8)
+    for it in range(60):
+        n1 = int(rng.integers(0, 600))
+        n2 = n1 if rng.random() < 0.6 else int(rng.integers(0, 600))
+        fixed = rng.random() < 0.4  # equal lengths: both files are cut at the same records (the no-copy path)
+        paths = []
+        for mate, n in ((1, n1), (2, n2)):
+            out = bytearray()
+            for r in range(n):
+                L = 150 if fixed else int(rng.choice([0, 1, 30, 100, 150, 151, 250]))
+                s = bytes(rng.choice(acgt, L))
+                out += b"@r%d/%d\n" % (r, mate) + s + b"\n+\n" + b"I" * L + b"\n"
+            p = str(tmp_path / ("m%d_%d.fq" % (it, mate)))
+            if rng.random() < 0.25:
+                p += ".gz"
+                with gzip.open(p, "wb") as fh:
+                    fh.write(bytes(out))
+            else:
+                open(p, "wb").write(bytes(out))
+            paths.append(p)
+        a, b = list(read_fastx(paths[0])), list(read_fastx(paths[1]))
+        m = min(len(a), len(b))
+        want = [(a[i][0], a[i][1] + b"\t" + b[i][1]) for i in range(m)]
+        env = dict(os.environ, KMCP_PARALLEL_MIN_BYTES="1", KMCP_READER_CHUNK=str(int(rng.choice([64, 333, 1000, 4096, 65536]))),
+                   KMCP_READER_THREADS=str(int(rng.integers(1, 5))))
+        r = subprocess.run([cli, "--parse-only", "-q", "--gpu-batch", str(int(rng.choice([1, 7, 100, 100000]))), "-1", paths[0], "-2", paths[1]],
+                           capture_output=True, text=True, env=env, timeout=60)
+        assert r.returncode == 0, (paths, r.stderr)
+        got = dict(x.split("=") for x in r.stdout.strip().split("\t")[1:])
+        assert got == dict(records=str(m), bases=str(sum(len(x[1]) + len(y[1]) for x, y in zip(a[:m], b[:m]))), id_bytes=str(sum(len(x[0]) for x in a[:m])),
+                           fnv1a="%016x" % _reader_checksum(want)), (paths, env["KMCP_READER_CHUNK"], n1, n2)
+
+
 def test_truncated_gzip_is_an_error(tmp_path):
     """A .fastq.gz cut short (or with a damaged tail) must not produce a well-formed result for the part that could be read:
     the reference's gzip reader aborts with 'unexpected EOF'."""
