@@ -44,8 +44,8 @@ def oracle_tsv(O, odb, ids, reads, reads2=None, params=None, keep_unmatched=Fals
     return lines, trailer
 
 
-def run_cli(args, out_path):
-    r = subprocess.run([CLI] + args + ["-o", out_path, "-q"], capture_output=True, text=True, timeout=300)
+def run_cli(args, out_path, env=None):
+    r = subprocess.run([CLI] + args + ["-o", out_path, "-q"], capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode == 0, r.stderr
     opener = gzip.open if out_path.endswith(".gz") else open
     with opener(out_path, "rt") as fh:
@@ -261,6 +261,30 @@ def test_cli_empty_and_ragged_inputs(oracle_lib, tmp_path):
     compare(run_cli(["-d", db_root, "-1", str(tmp_path / "a.fq"), "-2", str(tmp_path / "b.fq")], str(tmp_path / "pe.tsv")), want, trailer)
     compare(run_cli(["-d", db_root, "-1", str(tmp_path / "b.fq"), "-2", str(tmp_path / "a.fq")], str(tmp_path / "pe2.tsv")),
             *oracle_tsv_swapped(O, db_dir, ids[:17], r2[:17], r1[:17]))
+
+
+def test_cli_paired_ragged_reads_through_the_parallel_reader(oracle_lib, tmp_path):
+    """Paired files whose reads have different lengths: the two parser pools cut their files at different records and the
+    mates are re-cut at read 1's batch boundaries (cli/kmcp_search.cpp read_paired).  Small chunks and batches put the cuts
+    everywhere; the TSV must be the oracle's for the pairs in file order."""
+    O = oracle_lib
+    genomes = synth.random_genomes(5, 4000, seed=31)
+    db_dir = synth.make_db(tmp_path / "db", genomes, k=21, threads=2)
+    db_root = os.path.dirname(db_dir)
+    rng = np.random.default_rng(8)
+    n = 700
+    r1 = [synth.sample_reads(genomes, 1, int(rng.choice([60, 100, 150, 151, 250])), seed=1000 + i)[0] for i in range(n)]
+    r2 = [synth.sample_reads(genomes, 1, int(rng.choice([60, 100, 150, 151, 250])), seed=5000 + i)[0] for i in range(n)]
+    ids = [f"pair{i}" for i in range(n)]
+    write_fastq(str(tmp_path / "a.fq"), ids, r1)
+    write_fastq(str(tmp_path / "b.fq"), ids, r2)
+    odb = O.OracleDB(db_dir)
+    want, trailer = oracle_tsv(O, odb, ids, r1, r2, params=O.default_params(fpr_buf_size=499))
+    odb.close()
+    for chunk, batch in ((1000, 64), (7777, 100), (1 << 20, 100000)):
+        env = dict(os.environ, KMCP_PARALLEL_MIN_BYTES="1", KMCP_READER_CHUNK=str(chunk), KMCP_READER_THREADS="3")
+        got = run_cli(["-d", db_root, "-1", str(tmp_path / "a.fq"), "-2", str(tmp_path / "b.fq"), "--gpu-batch", str(batch)], str(tmp_path / "pe.tsv"), env=env)
+        compare(got, want, trailer)
 
 
 def oracle_tsv_swapped(O, db_dir, ids, a, b):

@@ -15,6 +15,14 @@ for i in 1 2 3; do
   e=$(date +%s%N)
   echo "run $i: $(( (e - s) / 1000000 )) ms wall; $(grep -o 'pipeline:.*' $D/log.txt)"
 done
+# paired input (the same file as both mates): two parser pools, mates zipped at read 1's batch boundaries
+kmcp_amd/kmcp-search --parse-only -1 $D/reads.fq -2 $D/reads.fq 2>&1 >/dev/null | tail -n 1
+for i in 1 2; do
+  s=$(date +%s%N)
+  kmcp_amd/kmcp-search -d $D/db -1 $D/reads.fq -2 $D/reads.fq -o $D/out_pe.tsv 2> $D/log.txt
+  e=$(date +%s%N)
+  echo "paired run $i: $(( (e - s) / 1000000 )) ms wall; $(grep -o 'pipeline:.*' $D/log.txt)"
+done
 kmcp_amd/kmcp-search -d $D/db $D/reads.fq -o $D/out2.tsv --gpu-batch 100000 -q
 cmp $D/out.tsv $D/out2.tsv && echo "batch size does not change the output"
 tail -3 $D/out.tsv
