@@ -77,6 +77,11 @@ bool match_less(const kmcpg_match& x, const kmcpg_match& y, int sort_by) {
   return x.col < y.col;  // deterministic tie-break; the reference's order among exact ties is arbitrary
 }
 
+struct SortKey {
+  double s, t;  // score and tie score of match_less for the sort mode in force
+  uint32_t col, idx;
+};
+
 }  // namespace
 
 extern "C" int kmcpg_finalize(const kmcpg_db* db, const kmcpg_hit* hits, uint64_t n_hits, const int32_t* qkmers, const int32_t* qlen, uint32_t n_reads,
@@ -99,7 +104,8 @@ extern "C" int kmcpg_finalize(const kmcpg_db* db, const kmcpg_hit* hits, uint64_
   //     range's first hit on; the gaps the filters leave are closed afterwards.
   static thread_local std::vector<kmcpg_hit, NoInitAlloc<kmcpg_hit>> parted;
   static thread_local std::vector<uint64_t> per_read;
-  int W = (int)std::max<uint64_t>(1, std::min<uint64_t>(8, n_hits / 32768));
+  const uint64_t w_cap = std::max(8u, std::min(16u, std::thread::hardware_concurrency()));
+  int W = (int)std::max<uint64_t>(1, std::min<uint64_t>(w_cap, n_hits / 32768));
   if ((uint64_t)W > n_reads) W = n_reads ? (int)n_reads : 1;
   if (const char* e = getenv("KMCPG_FINALIZE_THREADS")) W = std::max(1, std::min(atoi(e), 64));
   if ((uint64_t)W > std::max<uint32_t>(1, n_reads)) W = (int)std::max<uint32_t>(1, n_reads);
@@ -127,16 +133,21 @@ extern "C" int kmcpg_finalize(const kmcpg_db* db, const kmcpg_hit* hits, uint64_
     *lo = n_hits * (uint64_t)a / (uint64_t)W;
     *hi = n_hits * (uint64_t)(a + 1) / (uint64_t)W;
   };
+  // ... and notes the NumKmers values of the queries that have hits: their FPR rows are fetched once, before phase C
+  std::vector<char> seen((size_t)W * (QueryFpr::kCachedMaxN + 1), 0);
   run([&](int a) {
     uint64_t lo, hi;
     slice(a, &lo, &hi);
     uint64_t* c = cnt.data() + (size_t)a * W;
+    char* sn = seen.data() + (size_t)a * (QueryFpr::kCachedMaxN + 1);
     for (uint64_t i = lo; i < hi; i++) {
       if (hits[i].read >= n_reads || hits[i].col >= n_cols) {
         bad.store(1);
         return;
       }
       c[hits[i].read / per_range]++;
+      const int n = qkmers[hits[i].read];
+      if (n > 0 && n <= QueryFpr::kCachedMaxN) sn[n] = 1;
     }
   });
   if (bad.load()) {
@@ -165,16 +176,12 @@ extern "C" int kmcpg_finalize(const kmcpg_db* db, const kmcpg_hit* hits, uint64_
   // FPR rows of the NumKmers values present (a handful for short reads), fetched once so that the workers below never lock
   QueryFpr* F = db->fpr.get();
   std::unordered_map<int, const std::vector<double>*> fpr_rows;
-  {
-    std::vector<char> seen((size_t)QueryFpr::kCachedMaxN + 1, 0);
-    const kmcpg_hit* ph = parted_p;
-    for (uint64_t i = 0; i < n_hits; i++) {  // only queries with hits need a row
-      const int n = qkmers[ph[i].read];
-      if (n <= 0 || n > QueryFpr::kCachedMaxN || seen[(size_t)n]) continue;
-      seen[(size_t)n] = 1;
-      fpr_rows.emplace(n, F->ensure_row(n));
-    }
-  }
+  for (int n = 1; n <= QueryFpr::kCachedMaxN; n++)
+    for (int a = 0; a < W; a++)
+      if (seen[(size_t)a * (QueryFpr::kCachedMaxN + 1) + (size_t)n]) {
+        fpr_rows.emplace(n, F->ensure_row(n));
+        break;
+      }
   t_2 = now();
   kmcpg_match* const mbase = o->matches.data();
   uint64_t* const per_read_p = per_read.data();
@@ -201,6 +208,7 @@ extern "C" int kmcpg_finalize(const kmcpg_db* db, const kmcpg_hit* hits, uint64_
     }
     const uint64_t* const start_p = start.data();
     const kmcpg_hit* const sorted_p = sorted.data();
+    const double tw1 = timing && w == 0 ? now() : 0;
     uint64_t pos2 = h0;
     int row_n = -1;
     const std::vector<double>* row_of_n = nullptr;
@@ -242,11 +250,36 @@ extern "C" int kmcpg_finalize(const kmcpg_db* db, const kmcpg_hit* hits, uint64_
         mbase[pos2++] = m;
       }
       uint64_t cnt2 = pos2 - first;
-      if (cnt2 > 1 && !p.do_not_sort) {
-        const int sb = p.sort_by;
-        std::sort(mbase + first, mbase + pos2, [sb](const kmcpg_match& x, const kmcpg_match& y) { return match_less(x, y, sb); });
+      if (cnt2 > 1 && cnt2 <= 8) {  // the usual case: a handful of matches, sorted in place
+        if (!p.do_not_sort) {
+          const int sb = p.sort_by;
+          std::sort(mbase + first, mbase + pos2, [sb](const kmcpg_match& x, const kmcpg_match& y) { return match_less(x, y, sb); });
+        } else {
+          std::sort(mbase + first, mbase + pos2, [](const kmcpg_match& x, const kmcpg_match& y) { return x.col < y.col; });
+        }
       } else if (cnt2 > 1) {
-        std::sort(mbase + first, mbase + pos2, [](const kmcpg_match& x, const kmcpg_match& y) { return x.col < y.col; });
+        // many matches (a database full of close relatives): 24-byte keys are sorted instead of the 64-byte records, which
+        // are then put in place in one pass.  Same order as match_less: score and tie score descending, column ascending.
+        static thread_local std::vector<SortKey> keys;
+        static thread_local std::vector<kmcpg_match> tmp;
+        keys.resize(cnt2);
+        tmp.assign(mbase + first, mbase + pos2);
+        for (uint64_t i = 0; i < cnt2; i++) {
+          const kmcpg_match& m = tmp[i];
+          SortKey& k = keys[i];
+          k.idx = (uint32_t)i;
+          k.col = m.col;
+          if (p.do_not_sort) k.s = k.t = 0;
+          else if (p.sort_by == 1) { k.s = m.tcov; k.t = m.mkmers; }
+          else if (p.sort_by == 2) { k.s = m.jacc; k.t = m.mkmers; }
+          else { k.s = m.qcov; k.t = m.tcov; }
+        }
+        std::sort(keys.begin(), keys.end(), [](const SortKey& x, const SortKey& y) {
+          if (x.s != y.s) return x.s > y.s;
+          if (x.t != y.t) return x.t > y.t;
+          return x.col < y.col;
+        });
+        for (uint64_t i = 0; i < cnt2; i++) mbase[first + i] = tmp[keys[i].idx];
       }
       if (cnt2 > 0 && p.top_n_scores > 0 && !p.do_not_sort) {  // --keep-top-scores (:285-311), including its [:i+1]
         int nn = 0;
@@ -267,6 +300,7 @@ extern "C" int kmcpg_finalize(const kmcpg_db* db, const kmcpg_hit* hits, uint64_
       per_read_p[r] = pos2 - first;
     }
     wcount[(size_t)w] = pos2 - h0;
+    if (timing && w == 0) fprintf(stderr, "finalize worker 0: counting sort %.2f, matches %.2f ms (%llu hits)\n", tw1 - t_2, now() - tw1, (unsigned long long)(h1 - h0));
   });
   t_3 = now();
   uint64_t total = 0;

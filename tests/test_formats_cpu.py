@@ -180,6 +180,46 @@ def test_finalize_worker_threads_agree(small_db):
         assert np.array_equal(o.matches, whole.matches) and np.array_equal(o.offs, whole.offs)
 
 
+def test_finalize_orders_many_matches_per_read(small_db):
+    """Reads with dozens of matches (a database of close relatives) take kmcpg_finalize's key-sort path: the order must be
+    Matches.Less / SortByTCov / SortByJacc (util-db-search.go:105-145) — score, then tie score, both descending — with the
+    column as the last resort, for every sort mode; -S/--do-not-sort lists by column; --keep-top-scores keeps a prefix."""
+    from kmcp_amd.lib import HIT_DTYPE, Database, default_params
+    db_dir, _ = small_db
+    rng = np.random.default_rng(17)
+    n_reads, per = 3000, 40
+    cols = np.argsort(rng.random((n_reads, 63)), axis=1)[:, :per]
+    h = np.zeros(n_reads * per, dtype=HIT_DTYPE)
+    h["read"] = np.repeat(np.arange(n_reads, dtype=np.uint32), per)
+    h["col"] = cols.reshape(-1)
+    h["count"] = rng.integers(20, 26, n_reads * per)  # few distinct counts: ties in qcov everywhere
+    h = h[rng.permutation(len(h))]
+    qk = rng.choice([130, 97], n_reads).astype(np.int32)
+    ql = np.full(n_reads, 150, dtype=np.int32)
+    with Database.open(db_dir, device=-1) as db:
+        for flags in (dict(sort_by=0), dict(sort_by=1), dict(sort_by=2), dict(do_not_sort=1)):
+            p = default_params(min_qcov=0.1, max_fpr=1.0, **flags)
+            res = db.finalize(h, qk, ql, params=p)
+            m, offs = res.matches, res.offs
+            assert len(m) == len(h)  # nothing filtered: every read keeps its 40
+            for r in range(0, n_reads, 37):
+                mm = m[offs[r]:offs[r + 1]]
+                if flags.get("do_not_sort"):
+                    key = [(int(x["col"]),) for x in mm]
+                elif flags["sort_by"] == 0:
+                    key = [(-x["qcov"], -x["tcov"], int(x["col"])) for x in mm]
+                else:
+                    key = [(-x["tcov" if flags["sort_by"] == 1 else "jacc"], -int(x["mkmers"]), int(x["col"])) for x in mm]
+                assert key == sorted(key), (flags, r)
+                assert sorted(int(x["col"]) for x in mm) == sorted(int(c) for c in cols[r])
+            if not flags.get("do_not_sort"):
+                top = db.finalize(h, qk, ql, params=default_params(min_qcov=0.1, max_fpr=1.0, top_n_scores=2, **flags))
+                assert 0 < len(top.matches) < len(m)
+                for r in range(0, n_reads, 37):
+                    t = top.matches[top.offs[r]:top.offs[r + 1]]
+                    assert 1 <= len(t) < per and np.array_equal(t, m[offs[r]:offs[r] + len(t)])
+
+
 def test_dist_search_fastx_reader(tmp_path):
     """The record reader of kmcp_amd.dist_search: multi-line FASTA, FASTQ with '@' leading a quality line, gzip, empty records."""
     import gzip
