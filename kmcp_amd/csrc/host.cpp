@@ -257,7 +257,8 @@ int enqueue(kmcpg_db* db, AsyncState* A, Lane* L, const kmcpg_params& p) {
   hipStream_t st = A->stream;
   // ~1 hit per read is typical for distinct references, hundreds for a database full of close relatives: the buffers follow
   // what the last batches produced (an overflow costs a rerun, a short eager copy a late one in kmcpg_wait)
-  const uint64_t expect = std::min<uint64_t>(A->hits_hint.load() * ((uint64_t)n + 1023) / 1024, (uint64_t)n * 32);  // bounded: 384 B of buffer per read
+  // (the hint is what was seen, so the memory is needed anyway: the bound only keeps a corrupt value from asking for the moon)
+  const uint64_t expect = std::min<uint64_t>(A->hits_hint.load() * ((uint64_t)n + 1023) / 1024, (uint64_t)n * 4096);
   const uint64_t cap = std::max<uint64_t>(L->d_hits.cap, std::max<uint64_t>((uint64_t)n * 8 + 1024, expect + expect / 2));
   const uint64_t first = std::min<uint64_t>(cap, std::max<uint64_t>((uint64_t)n * 2 + 1024, expect + expect / 4));
   if (L->d_seqs.ensure(L->tb1 + 16) || L->d_offs.ensure((size_t)n + 1) || L->d_cnt.ensure(2) || L->d_qk.ensure(n) || L->d_ql.ensure(n) || L->d_hits.ensure(cap) ||
