@@ -255,15 +255,23 @@ int enqueue(kmcpg_db* db, AsyncState* A, Lane* L, const kmcpg_params& p) {
   const uint32_t n = L->n;
   if (n == 0) return 0;
   hipStream_t st = A->stream;
-  // ~1 hit per read is typical for distinct references, hundreds for a database full of close relatives: the buffers follow
-  // what the last batches produced (an overflow costs a rerun, a short eager copy a late one in kmcpg_wait)
-  // (the hint is what was seen, so the memory is needed anyway: the bound only keeps a corrupt value from asking for the moon)
-  const uint64_t expect = std::min<uint64_t>(A->hits_hint.load() * ((uint64_t)n + 1023) / 1024, (uint64_t)n * 4096);
-  const uint64_t cap = std::max<uint64_t>(L->d_hits.cap, std::max<uint64_t>((uint64_t)n * 8 + 1024, expect + expect / 2));
-  const uint64_t first = std::min<uint64_t>(cap, std::max<uint64_t>((uint64_t)n * 2 + 1024, expect + expect / 4));
-  if (L->d_seqs.ensure(L->tb1 + 16) || L->d_offs.ensure((size_t)n + 1) || L->d_cnt.ensure(2) || L->d_qk.ensure(n) || L->d_ql.ensure(n) || L->d_hits.ensure(cap) ||
+  // ~1 hit per read is typical for distinct references, dozens to hundreds for a database full of close relatives: the
+  // buffers follow what the last large batches produced (hits_hint = hits per 1024 reads).  Too small a device buffer costs
+  // a rerun of the batch (collect), too short an eager copy a late one on the copy stream, so the device buffer is generous
+  // (up to 512 hits = 6 KB per read, and never smaller than it already is) while the eager copy stays within 32 hits per
+  // read: a burst of hit-heavy queries must not make every later batch drag gigabytes over PCIe.
+  const uint64_t expect = std::min<uint64_t>(A->hits_hint.load() * (uint64_t)n / 1024, (uint64_t)n * 512);
+  const uint64_t base_cap = (uint64_t)n * 8 + 1024;
+  uint64_t cap = std::max<uint64_t>(L->d_hits.cap, std::max<uint64_t>(base_cap, expect + expect / 2));
+  if (L->d_seqs.ensure(L->tb1 + 16) || L->d_offs.ensure((size_t)n + 1) || L->d_cnt.ensure(2) || L->d_qk.ensure(n) || L->d_ql.ensure(n) ||
       (L->paired && (L->d_seqs2.ensure(L->tb2 + 16) || L->d_offs2.ensure((size_t)n + 1))))
     return kmcpg_fail(KMCPG_ENOMEM, "hipMalloc failed");
+  if (L->d_hits.ensure(cap)) {  // no room for the generous size next to the index: the plain one, and a rerun if it overflows
+    (void)hipGetLastError();
+    cap = base_cap;
+    if (L->d_hits.ensure(cap)) return kmcpg_fail(KMCPG_ENOMEM, "hipMalloc failed");
+  }
+  const uint64_t first = std::min<uint64_t>(cap, std::max<uint64_t>((uint64_t)n * 2 + 1024, std::min<uint64_t>(expect + expect / 4, (uint64_t)n * 32)));
   if (L->h_cnt.ensure(2) || L->h_qk.ensure(n) || L->h_ql.ensure(n) || L->h_hits.ensure(first)) return kmcpg_fail(KMCPG_ENOMEM, "hipHostMalloc failed");
   // the reads go up on a stream of their own (150 MB per million reads: 4 ms of PCIe that would otherwise sit between the
   // kernels of consecutive batches); the lane's device buffers are idle, its previous batch was waited for
@@ -316,7 +324,7 @@ int collect(kmcpg_db* db, AsyncState* A, Lane* L, const kmcpg_params& p, uint64_
     HIPCHK(hipStreamSynchronize(A->copy_stream));
     L->copied = cnt;
   }
-  {
+  if (L->n >= 1024) {  // a batch large enough to say something about the data (one genome with 5 000 matches does not)
     const uint64_t per_k = cnt * 1024 / L->n + 1, old = A->hits_hint.load();
     A->hits_hint.store(per_k > old ? per_k : old - old / 8 + per_k / 8);  // rises at once, decays slowly
   }
