@@ -106,6 +106,8 @@ struct K2Args {
   uint64_t hit_cap;
   unsigned long long* counter;
   unsigned long long* gathered;  // optional (profiling level 2): number of 16-byte row loads issued
+  const uint16_t* cmin_fpr;      // optional: [n] = smallest count whose FPR(n, count) passes -f, n <= cmin_fpr_n (query.cpp fpr_bound)
+  int32_t cmin_fpr_n;
 };
 
 }  // namespace kmcpg

@@ -508,6 +508,7 @@ extern "C" int kmcpg_close(kmcpg_db* db) {
   db->w_huge_info.release();
   db->w_huge_temp.release();
   db->w_gathered.release();
+  db->w_cmin_fpr.release();
   kmcpg::async_release(db);
   if (db->ws_ev) (void)hipEventDestroy(db->ws_ev);
   for (auto& ev : db->ev)

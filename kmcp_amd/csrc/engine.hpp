@@ -124,6 +124,9 @@ struct kmcpg_db {
   // optional HIP-event timing of the last kmcpg_query_device call
   int profiling = 0;  // 1: HIP-event timing of the kernels; 2: + count the row loads k2_cobs issues
   kmcpg::DevBuf<uint64_t> w_gathered;
+  kmcpg::DevBuf<uint16_t> w_cmin_fpr;  // device copy of the -f bound table (query.cpp fpr_bound)
+  std::vector<uint16_t> h_cmin_fpr;
+  uint64_t cmin_fpr_key = ~0ull;       // bits of the max_fpr the table was built for
   hipEvent_t ev[12] = {};   // ring of 4 calls x (start, k-mers done, COBS done)
   uint64_t ev_calls = 0;    // profiled calls so far
 };

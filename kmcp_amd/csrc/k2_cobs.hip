@@ -150,6 +150,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, GR 
   const double thr = __dmul_rn((double)n, a.min_qcov);
   uint32_t cmin = (uint32_t)thr + 1u;  // smallest integer c with (double)c > thr  (thr >= 0)
   if (cmin < (uint32_t)a.min_matched) cmin = (uint32_t)a.min_matched;
+  // counts below this fail the host's FPR(n, count) <= max_fpr test (:7474-7478), see fpr_bound in query.cpp
+  if (!SPLIT && a.cmin_fpr && n <= a.cmin_fpr_n) cmin = max(cmin, (uint32_t)a.cmin_fpr[n]);
   // Branch and bound: once count + (k-mers still to come) < cmin for every column of a 128-byte sector of the row, nothing
   // in it can become a hit any more and its lanes stop loading.  Unrelated references are dead after ~80 % of a read's
   // k-mers (Bloom density <= fpr), so the tail of the row traffic is never fetched; results are unchanged.

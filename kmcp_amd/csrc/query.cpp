@@ -133,6 +133,40 @@ int ws_end(kmcpg_db* db, hipStream_t st) {
   return 0;
 }
 
+// The reference drops a column whose FPR(n, count) exceeds -f right where it counts it (util-db-search.go:7474-7478); here
+// that test runs on the host in float64, but the GPU can already leave out every count that cannot pass it: for each
+// NumKmers n <= kFprBoundMaxN the smallest count c with FPR(n, c) <= max_fpr (the very values kmcpg_finalize compares, so a
+// count below it fails there by definition; nothing is assumed about monotonicity).  With the defaults the query-coverage
+// threshold is the stricter one; with -t just above the database's FPR it is this bound that keeps the hit list — and, through
+// the pruning test, the row traffic — from exploding (n = 130, p = 0.3, -t 0.31: 45 % of all columns would be "hits").
+constexpr int kFprBoundMaxN = 512;
+
+int fpr_bound(kmcpg_db* db, double max_fpr, hipStream_t st, const uint16_t** out) {
+  *out = nullptr;
+  if (const char* e = getenv("KMCPG_FPR_BOUND"))
+    if (atoi(e) == 0) return 0;
+  uint64_t key;
+  memcpy(&key, &max_fpr, sizeof key);
+  if (key != db->cmin_fpr_key || !db->w_cmin_fpr.p) {
+    QueryFpr* F = db->fpr.get();
+    std::vector<uint16_t> t((size_t)kFprBoundMaxN + 1, 0);
+    for (int n = 1; n <= kFprBoundMaxN; n++) {
+      const std::vector<double>& row = *F->ensure_row(n);
+      int c = 0;
+      while (c <= n && !(row[(size_t)c] <= max_fpr)) c++;
+      t[(size_t)n] = (uint16_t)c;  // n + 1: no count passes
+    }
+    if (db->w_cmin_fpr.ensure(t.size())) return kmcpg_fail(KMCPG_ENOMEM, "hipMalloc failed");
+    // stream-ordered behind the kernels of earlier calls, which may still read the previous table
+    HIPCHK(hipMemcpyAsync(db->w_cmin_fpr.p, t.data(), t.size() * sizeof(uint16_t), hipMemcpyHostToDevice, st));
+    HIPCHK(hipStreamSynchronize(st));  // `t` is pageable and dies here; once per max_fpr value
+    db->h_cmin_fpr.swap(t);
+    db->cmin_fpr_key = key;
+  }
+  *out = db->w_cmin_fpr.p;
+  return 0;
+}
+
 }  // namespace
 
 extern "C" int kmcpg_kmers_device(kmcpg_db* db, const uint8_t* d_seqs, const uint64_t* d_offs, uint32_t n_reads, uint64_t total_bases,
@@ -248,6 +282,8 @@ extern "C" int kmcpg_query_device(kmcpg_db* db, const uint8_t* d_seqs, const uin
     HIPCHK(hipMemsetAsync(db->w_gathered.p, 0, sizeof(uint64_t), st));
     a.gathered = (unsigned long long*)db->w_gathered.p;
   }
+  if (int rcb = fpr_bound(db, p.max_fpr, st, &a.cmin_fpr)) return rcb;
+  a.cmin_fpr_n = kFprBoundMaxN;
   a.hits = d_hits;
   a.hit_cap = hit_cap;
   a.counter = (unsigned long long*)d_counters;

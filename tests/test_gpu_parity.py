@@ -532,3 +532,53 @@ def test_degenerate_batches(G, oracle_lib, tmp_path):
                         params=G["default_params"]())
         torch.cuda.synchronize()
         assert int(cnt[0].item()) >= 64 and int(qk.min().item()) == 130
+
+
+def test_fpr_bound_on_the_device_changes_nothing_but_the_raw_hit_list(G, oracle_lib, tmp_path):
+    """-t just above the database's FPR (0.3): counts of 41..51 of 130 k-mers pass the coverage threshold in ~40 % of all
+    columns by chance, and every one of them fails -f 0.01 on the host.  The kernel leaves them out (fpr_bound in query.cpp):
+    same finalized result as with KMCPG_FPR_BOUND=0 and as the oracle's, a fraction of the raw hits; paired reads (n = 260),
+    a stricter and a lax -f too."""
+    import os
+    import torch
+    O = oracle_lib
+    genomes = synth.random_genomes(64, 4000, seed=51)  # equal sizes: every column is as dense as the block allows (~0.3)
+    db_dir = synth.make_db(tmp_path, genomes, k=21, threads=2)
+    reads = synth.sample_reads(genomes, 400, 150, sub_rate=0.02, seed=52, frac_random=0.5)
+    reads2 = synth.sample_reads(genomes, 400, 150, sub_rate=0.02, seed=53, frac_random=0.5)
+    odb = O.OracleDB(db_dir)
+    dev = torch.device("cuda:0")
+    try:
+        with G["Database"].open(db_dir, device=0) as db:
+            for kw, r2 in ((dict(min_qcov=0.31), None), (dict(min_qcov=0.31, max_fpr=1e-6), None), (dict(min_qcov=0.31, max_fpr=0.9), None),
+                           (dict(min_qcov=0.31, fpr_buf_size=499), reads2)):
+                res, raw = {}, {}
+                for bound in ("1", "0"):
+                    os.environ["KMCPG_FPR_BOUND"] = bound
+                    try:
+                        res[bound] = db.search(reads, r2, params=G["default_params"](**kw))
+                        if r2 is None:
+                            seqs, offs = G["lib"].pack_reads(reads)
+                            t_seqs = torch.from_numpy(seqs).to(dev)
+                            t_offs = torch.from_numpy(offs.view(np.int64)).to(dev)
+                            cap = 64 * len(reads)
+                            hits = torch.zeros((cap, 3), dtype=torch.int32, device=dev)
+                            cnt = torch.zeros(2, dtype=torch.int64, device=dev)
+                            qk = torch.zeros(len(reads), dtype=torch.int32, device=dev)
+                            ql = torch.zeros(len(reads), dtype=torch.int32, device=dev)
+                            db.query_device(t_seqs.data_ptr(), t_offs.data_ptr(), len(reads), len(seqs), 150, hits.data_ptr(), cap, cnt.data_ptr(), qk.data_ptr(),
+                                            ql.data_ptr(), params=G["default_params"](**kw))
+                            torch.cuda.synchronize()
+                            raw[bound] = int(cnt[0].item())
+                    finally:
+                        os.environ.pop("KMCPG_FPR_BOUND", None)
+                assert np.array_equal(res["1"].matches, res["0"].matches) and np.array_equal(res["1"].offs, res["0"].offs), kw
+                assert synth.assert_parity(odb, res["1"], reads, r2, O.default_params(**kw)) > 100
+                if r2 is None:
+                    assert raw["1"] <= raw["0"]
+                    if kw.get("max_fpr", 0.01) <= 0.01:
+                        assert raw["1"] < 0.5 * raw["0"], (kw, raw)  # most chance columns never leave the GPU
+                    else:
+                        assert raw["1"] == raw["0"]  # -f 0.9: the coverage threshold is the stricter one again
+    finally:
+        odb.close()
