@@ -85,7 +85,7 @@ typedef struct {
 
 /* One (read, reference chunk) pair that passed the integer thresholds on the GPU:
  * count >= max(min_matched, smallest c with float64(c) > n*min_qcov)   (util-db-search.go:7468-7470),
- * and, for queries of up to 512 k-mers, count >= the smallest c whose FPR(n, c) <= max_fpr (:7474-7478): a pair that
+ * and, for queries of up to 1024 k-mers, count >= the smallest c whose FPR(n, c) <= max_fpr (:7474-7478): a pair that
  * kmcpg_finalize would drop for its FPR anyway is not reported (KMCPG_FPR_BOUND=0 reports it). */
 typedef struct {
   uint32_t read;  /* index of the read in the batch */

@@ -139,31 +139,41 @@ int ws_end(kmcpg_db* db, hipStream_t st) {
 // count below it fails there by definition; nothing is assumed about monotonicity).  With the defaults the query-coverage
 // threshold is the stricter one; with -t just above the database's FPR it is this bound that keeps the hit list — and, through
 // the pruning test, the row traffic — from exploding (n = 130, p = 0.3, -t 0.31: 45 % of all columns would be "hits").
-constexpr int kFprBoundMaxN = 512;
+// The table covers n <= 512 (every short read, single or paired up to 2 x 250; 18 ms of FPR rows on first use) and grows to
+// 1024 when a batch may hold longer queries (+60 ms once).  Beyond ~1 100 k-mers the reference's FPR is numerically dead
+// anyway: BinomialCoeff leaves the float64 range, the running value drops below zero and is clamped (util-fpr.go:32-50), so
+// FPR(n, c) = 0 long before the crossing and the bound could never be the stricter threshold.
+constexpr int kFprBoundMinN = 512, kFprBoundMaxN = 1024;
 
-int fpr_bound(kmcpg_db* db, double max_fpr, hipStream_t st, const uint16_t** out) {
+int fpr_bound(kmcpg_db* db, double max_fpr, uint64_t max_kmers, hipStream_t st, const uint16_t** out, int32_t* out_n) {
   *out = nullptr;
+  *out_n = 0;
   if (const char* e = getenv("KMCPG_FPR_BOUND"))
     if (atoi(e) == 0) return 0;
+  int want_n = kFprBoundMinN;
+  while (want_n < kFprBoundMaxN && (uint64_t)want_n < max_kmers) want_n *= 2;
   uint64_t key;
   memcpy(&key, &max_fpr, sizeof key);
-  if (key != db->cmin_fpr_key || !db->w_cmin_fpr.p) {
+  const int have_n = (int)db->h_cmin_fpr.size() - 1;
+  if (key != db->cmin_fpr_key || !db->w_cmin_fpr.p || have_n < want_n) {
+    want_n = std::max(want_n, have_n);
     QueryFpr* F = db->fpr.get();
-    std::vector<uint16_t> t((size_t)kFprBoundMaxN + 1, 0);
-    for (int n = 1; n <= kFprBoundMaxN; n++) {
+    std::vector<uint16_t> t((size_t)want_n + 1, 0);
+    for (int n = 1; n <= want_n; n++) {
       const std::vector<double>& row = *F->ensure_row(n);
       int c = 0;
       while (c <= n && !(row[(size_t)c] <= max_fpr)) c++;
       t[(size_t)n] = (uint16_t)c;  // n + 1: no count passes
     }
+    // earlier calls' kernels may still read the table in place: wait for them before it is replaced (once per -f value / growth)
+    HIPCHK(hipStreamSynchronize(st));
     if (db->w_cmin_fpr.ensure(t.size())) return kmcpg_fail(KMCPG_ENOMEM, "hipMalloc failed");
-    // stream-ordered behind the kernels of earlier calls, which may still read the previous table
-    HIPCHK(hipMemcpyAsync(db->w_cmin_fpr.p, t.data(), t.size() * sizeof(uint16_t), hipMemcpyHostToDevice, st));
-    HIPCHK(hipStreamSynchronize(st));  // `t` is pageable and dies here; once per max_fpr value
+    HIPCHK(hipMemcpy(db->w_cmin_fpr.p, t.data(), t.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
     db->h_cmin_fpr.swap(t);
     db->cmin_fpr_key = key;
   }
   *out = db->w_cmin_fpr.p;
+  *out_n = (int32_t)db->h_cmin_fpr.size() - 1;
   return 0;
 }
 
@@ -282,8 +292,7 @@ extern "C" int kmcpg_query_device(kmcpg_db* db, const uint8_t* d_seqs, const uin
     HIPCHK(hipMemsetAsync(db->w_gathered.p, 0, sizeof(uint64_t), st));
     a.gathered = (unsigned long long*)db->w_gathered.p;
   }
-  if (int rcb = fpr_bound(db, p.max_fpr, st, &a.cmin_fpr)) return rcb;
-  a.cmin_fpr_n = kFprBoundMaxN;
+  if (int rcb = fpr_bound(db, p.max_fpr, max_short, st, &a.cmin_fpr, &a.cmin_fpr_n)) return rcb;
   a.hits = d_hits;
   a.hit_cap = hit_cap;
   a.counter = (unsigned long long*)d_counters;
