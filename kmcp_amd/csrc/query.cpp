@@ -306,6 +306,7 @@ extern "C" int kmcpg_query_device(kmcpg_db* db, const uint8_t* d_seqs, const uin
     // ~64 chunks for the largest query, 1024..8192 k-mers each (at most 8192: the chunk's counts fit 16 planes)
     uint32_t chk = 1024;
     while (chk < 8192 && (uint64_t)chk * 64 < long_meta[1]) chk <<= 1;
+    if (const char* e = getenv("KMCPG_SPLIT_CHUNK")) chk = (uint32_t)std::max(64, std::min(atoi(e), 8192));
     a.split_chk = chk;
     a.split_chunks = (long_meta[1] + chk - 1) / chk;
     // count arrays of at most ~2 GB at a time

@@ -45,9 +45,10 @@ def run(db, seqs, offs, n, total, maxlen, params, seqs2=None, offs2=None, reps=3
 
 def main():
     out = {}
+    only = sys.argv[1] if len(sys.argv) > 1 else ""  # "gtdb": the two GTDB-scale shapes only
     # sigs_step 0: every block has the same NumSigs (equal-length chunks, as BASELINE configs[1] is built) and the 32 narrow
     # blocks share one group of 1248-byte rows; sigs_step 7: a different NumSigs per block, every block on its own (39-byte rows)
-    for tag, step in (("", 0), ("_distinct_numsigs", 7)):
+    for tag, step in ((("", 0), ("_distinct_numsigs", 7)) if only != "gtdb" else ()):
         # paired-end 2 x 150 against the 10k-chunk index
         spec = lib.SynthSpec(k=21, num_hashes=1, fpr=0.3, n_blocks=32, cols_per_block=312, num_sigs=1121470, kmers_per_col=400000, seed=1, sigs_step=step)
         with Database.open_synthetic(spec) as db:
@@ -69,7 +70,7 @@ def main():
     # genome search: 4-Mbp queries against a FracMinHash (scale 1000), 3-hash, fpr 0.001 index of 50 k references
     spec = lib.SynthSpec(k=21, num_hashes=3, fpr=0.001, n_blocks=8, cols_per_block=6256, num_sigs=431000, kmers_per_col=10000, seed=3, scale=1000, sigs_step=13)
     with Database.open_synthetic(spec) as db:
-        n = 64
+        n = 64 if only != "gtdb" else 1
         lens = torch.full((n,), 4000000, dtype=torch.int64)
         s, o, t = rand_reads(n, lens, 5)
         out["genome_4Mbp_fracminhash_vs_50k_refs"] = run(db, s, o, n, t, 4000000, default_params(min_qcov=0.4, sort_by=2))
