@@ -95,7 +95,7 @@ __device__ __forceinline__ void csa4(uint32_t (&pl)[NPL], uint32_t x0, uint32_t 
 // of one wave per (query, slot).
 
 // GR = rows gathered between two pruning tests: 8, or 4 where the launch waits for HBM (the host decides, query.cpp).  The
-// short form is its own instantiation (4 rows in flight: 75 VGPRs instead of 91) built for at most 4 waves per SIMD: the kernel
+// short form is its own instantiation (4 rows in flight; 97 VGPRs, the 8-row form 91) built for at most 4 waves per SIMD: the kernel
 // is bound by the L2->fabric path, not by latency (the 8-row form runs as fast at 2 waves per SIMD as at 5), and of the
 // occupancy targets tried for the 4-row form this one is the fastest (GTDB scale: 488 ms; 506-510 ms at 5-6 waves, 510 ms at 3,
 // starved at 2: profiles/r02_group_rows.txt).
