@@ -126,6 +126,11 @@ int kmcpg_open_devices(const char* db_dir, const int32_t* devices, int32_t n_dev
 int kmcpg_close(kmcpg_db* db);
 const char* kmcpg_last_error(void);
 int kmcpg_db_info(const kmcpg_db* db, kmcpg_info* info);
+/* The k-mer sizes of the database, largest first (`ks` of __db.yml, util-db-info.go:50; one entry for most databases):
+ * *n = how many there are, the first min(*n, cap) are written to ks.  kmcpg_search_batch walks them by itself
+ * (util-db-search.go:764, :1016-1022); a host that drives kmcpg_query_device + kmcpg_finalize per shard repeats the
+ * search of its unmatched queries with kmcpg_params.k set to the next entry. */
+int kmcpg_db_ks(const kmcpg_db* db, int32_t* ks, int32_t cap, int32_t* n);
 /* Header.Names/GSizes/Indices/Sizes of one column (serialization.go:73-79) */
 int kmcpg_col_info(const kmcpg_db* db, uint32_t col, const char** name, uint32_t* target_idx, uint64_t* gsize,
                    uint64_t* size);

@@ -523,6 +523,13 @@ extern "C" int kmcpg_db_info(const kmcpg_db* db, kmcpg_info* info) {
   return 0;
 }
 
+extern "C" int kmcpg_db_ks(const kmcpg_db* db, int32_t* ks, int32_t cap, int32_t* n) {
+  if (!db || !n || (cap > 0 && !ks)) return kmcpg_fail(KMCPG_EINVAL, "null argument");
+  *n = (int32_t)db->ks_desc.size();
+  for (int32_t i = 0; i < cap && i < *n; i++) ks[i] = db->ks_desc[(size_t)i];
+  return 0;
+}
+
 extern "C" int kmcpg_col_info(const kmcpg_db* db, uint32_t col, const char** name, uint32_t* target_idx, uint64_t* gsize, uint64_t* size) {
   if (!db) return kmcpg_fail(KMCPG_EINVAL, "null argument");
   if (col >= db->col_block.size()) return kmcpg_fail(KMCPG_EINVAL, "column %u out of range", col);

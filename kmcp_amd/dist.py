@@ -50,6 +50,15 @@ def hits_to_numpy(parts):
     return np.ascontiguousarray(cat).view(np.uint32).reshape(-1, 3).copy().view(HIT_DTYPE).reshape(-1)
 
 
+def _take_reads(seqs, offs, idx):
+    """the reads `idx` of a packed batch as a packed batch of their own"""
+    o = offs.astype(np.int64)
+    lens = o[idx + 1] - o[idx]
+    so = np.concatenate([[0], np.cumsum(lens)])
+    src = np.repeat(o[idx] - so[:-1], lens) + np.arange(int(so[-1]))
+    return np.ascontiguousarray(seqs[src]), so.astype(offs.dtype)
+
+
 class ShardedSearcher:
     """kmcp search over N GPUs of one node: rank r holds shard r of the database."""
 
@@ -63,9 +72,71 @@ class ShardedSearcher:
         self.db = Database.open(db_dir, device=self.dev_index, shard_rank=self.rank, shard_count=self.world)
 
     def search(self, seqs: np.ndarray, offs: np.ndarray, params=None, seqs2=None, offs2=None):
-        """Every rank passes the same batch (host arrays).  Returns a BatchResult on rank 0, None elsewhere."""
+        """Every rank passes the same batch (host arrays).  Returns a BatchResult on rank 0, None elsewhere.
+
+        A database with several k-mer sizes is walked as the reference does (util-db-search.go:764, :1016-1022): queries that
+        were searched with the largest k and matched nothing go again with the next smaller one — rank 0 knows which (it holds
+        the finalized result) and tells the others."""
         from .lib import default_params
         p = params or default_params()
+        n = len(offs) - 1
+        if p.try_se and seqs2 is not None:
+            raise NotImplementedError("--try-se is served by kmcpg_search_batch (kmcp-search --gpus N), not by the per-shard pair")
+        res = self._search_once(seqs, offs, p, seqs2, offs2)
+        ks = [int(p.k)] if p.k > 0 else list(self.db.ks)
+        if len(ks) < 2 or n == 0:
+            return res
+        final = None
+        if self.rank == 0:  # matched, or never searched (too short / fewer than MinMatched k-mers): final (:854-869)
+            final = (np.diff(res.offs.astype(np.int64)) > 0) | (res.qkmers <= 0)
+        for k in ks[1:]:
+            todo = self._bcast_indices(np.nonzero(~final)[0].astype(np.int64) if self.rank == 0 else None)
+            if len(todo) == 0:
+                break
+            sub, so = _take_reads(seqs, offs, todo)
+            sub2 = so2 = None
+            if seqs2 is not None:
+                sub2, so2 = _take_reads(seqs2, offs2, todo)
+            q = type(p).from_buffer_copy(p)
+            q.k = k
+            q.try_se = 0
+            r2 = self._search_once(sub, so, q, sub2, so2)
+            if self.rank != 0:
+                continue
+            # splice the sub-batch into the batch result (the queries of `todo` had no matches so far)
+            res.qlen[todo] = r2.qlen
+            res.ksize[todo] = k
+            searched = r2.qkmers > 0
+            res.qkmers[todo] = np.where(searched, r2.qkmers, 0)
+            got = np.diff(r2.offs.astype(np.int64))
+            final[todo[~searched | (got > 0)]] = True
+            if got.sum():
+                old_cnt = np.diff(res.offs.astype(np.int64))
+                new_cnt = old_cnt.copy()
+                new_cnt[todo] = got
+                new_offs = np.concatenate([[0], np.cumsum(new_cnt)]).astype(res.offs.dtype)
+                merged = np.empty(int(new_offs[-1]), dtype=res.matches.dtype)
+                owner = np.repeat(np.arange(n), old_cnt)
+                merged[new_offs[owner].astype(np.int64) + (np.arange(len(res.matches)) - res.offs[owner].astype(np.int64))] = res.matches
+                owner2 = np.repeat(np.arange(len(todo)), got)
+                merged[new_offs[todo[owner2]].astype(np.int64) + (np.arange(len(r2.matches)) - r2.offs[owner2].astype(np.int64))] = r2.matches
+                res.matches, res.offs = merged, new_offs
+        return res
+
+    def _bcast_indices(self, idx):
+        """rank 0's int64 index array on every rank"""
+        if self.world == 1:
+            return idx
+        on_host = dist.get_backend(self.group) == "gloo"
+        dev = torch.device("cpu") if on_host else self.dev
+        m = torch.tensor([len(idx) if self.rank == 0 else 0], dtype=torch.int64, device=dev)
+        dist.broadcast(m, src=0, group=self.group)
+        t = torch.from_numpy(idx).to(dev) if self.rank == 0 else torch.empty(int(m.item()), dtype=torch.int64, device=dev)
+        if int(m.item()):
+            dist.broadcast(t, src=0, group=self.group)
+        return t.cpu().numpy()
+
+    def _search_once(self, seqs, offs, p, seqs2=None, offs2=None):
         n = len(offs) - 1
         t_seqs = torch.from_numpy(seqs).to(self.dev)
         t_offs = torch.from_numpy(offs.view(np.int64)).to(self.dev)

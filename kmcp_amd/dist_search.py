@@ -115,9 +115,9 @@ def main(argv=None):
         if rank != 0:
             total += len(ids)
             return
-        k = res.k
         for i, qid in enumerate(ids):
             qidx = total + i
+            k = int(res.ksize[i])  # the k-mer size that answered (multi-k databases, search.go:530)
             ms = res.read(i)
             if len(ms) == 0:
                 if a.keep_unmatched:

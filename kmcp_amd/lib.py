@@ -16,6 +16,7 @@ EXPORTS = [
     "kmcpg_result_free", "kmcpg_query_device", "kmcpg_finalize", "kmcpg_open_synthetic", "kmcpg_plant",
     "kmcpg_read_rows", "kmcpg_block_info", "kmcpg_kmers_device", "kmcpg_plant_reads_device", "kmcpg_set_profiling",
     "kmcpg_last_timing", "kmcpg_open_devices", "kmcpg_build_db", "kmcpg_submit", "kmcpg_wait", "kmcpg_read_row_range", "kmcpg_timing_at", "kmcpg_last_gathered_bytes",
+    "kmcpg_db_ks",
 ]
 
 
@@ -121,6 +122,7 @@ def load():
     L.kmcpg_open_devices.argtypes = [C.c_char_p, C.POINTER(C.c_int32), C.c_int32, C.POINTER(vp)]
     L.kmcpg_close.argtypes = [vp]
     L.kmcpg_db_info.argtypes = [vp, C.POINTER(Info)]
+    L.kmcpg_db_ks.argtypes = [vp, i32p, C.c_int32, i32p]
     L.kmcpg_col_info.argtypes = [vp, C.c_uint32, C.POINTER(C.c_char_p), C.POINTER(C.c_uint32), u64p, u64p]
     L.kmcpg_block_info.argtypes = [vp, C.c_uint32, u64p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32),
                                    C.POINTER(C.c_uint32), i32p, C.POINTER(C.c_uint32)]
@@ -216,6 +218,11 @@ class Database:
         _check(load().kmcpg_db_info(self._h, C.byref(info)))
         self.info = info
         self._names = {}
+        n = C.c_int32(0)
+        _check(load().kmcpg_db_ks(self._h, None, 0, C.byref(n)))
+        buf = (C.c_int32 * max(1, n.value))()
+        _check(load().kmcpg_db_ks(self._h, buf, n.value, C.byref(n)))
+        self.ks = [int(buf[i]) for i in range(n.value)]  # the database's k-mer sizes, largest first
 
     @classmethod
     def open(cls, db_dir, device=0, shard_rank=0, shard_count=1):

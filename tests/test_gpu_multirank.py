@@ -34,6 +34,10 @@ def _env(same_gpu_var):
 def _launch(n, port, args, env):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1", "--master-port", str(port)] + args
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    if r.returncode != 0:  # the ranks' tracebacks sit in the middle of torchrun's stderr: keep all of it where gpurun brings it back
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(ROOT, "gpurun_out", "launch_failure.txt"), "w") as fh:
+            fh.write(" ".join(cmd) + "\n" + r.stdout + "\n" + r.stderr)
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
     return r
 
@@ -95,6 +99,66 @@ def test_sharded_searcher_overflow_loop(oracle_lib, tmp_path):
     out = str(tmp_path / "o.tsv")
     _launch(2, 29743, ["-m", "kmcp_amd.dist_search", "-d", os.path.dirname(db_dir), fq, "-o", out, "-t", "0.31", "-f", "1", "-c", "1"], env)
     compare(open(out).read().split("\n"), want, trailer)
+
+
+def test_sharded_searcher_walks_the_k_sizes_of_a_multi_k_database(oracle_lib, tmp_path):
+    """One process per GPU against a database with `ks: [21, 31]`: queries that match nothing with k=31 go again with k=21 on
+    every rank (rank 0 broadcasts which), as kmcpg_search_batch does inside one process and the reference in handleQuery
+    (util-db-search.go:764, :1016-1022).  Two ranks through python -m kmcp_amd.dist_search against the oracle's TSV (kSize
+    column included), and the in-process ShardedSearcher against Database.search."""
+    import re
+    import numpy as np
+    from kmcp_amd import Database, default_params, lib
+    from kmcp_amd.dist import ShardedSearcher
+    O = oracle_lib
+    genomes = synth.random_genomes(12, 8000, seed=277)
+    cols = []
+    for gi, g in enumerate(genomes):
+        h = np.concatenate([O.generate_kmers(g, O.sketch_cfg(k=k)) for k in (21, 31)])
+        cols.append((f"g{gi}", len(g), 0, 1, O.sort_unique(h)))
+    db_dir = O.build_db(str(tmp_path / "db"), O.sketch_cfg(k=31), cols, num_hashes=1, fpr=0.1, threads=4, block_size=8)  # 2 blocks: one per rank; -t 0.2 must exceed the FPR
+    yml = open(db_dir + "/__db.yml").read()
+    yml2 = re.sub(r"ks:\n- 31\n", "ks:\n- 21\n- 31\n", yml)
+    assert yml2 != yml
+    open(db_dir + "/__db.yml", "w").write(yml2)
+    rng = np.random.default_rng(3)
+    reads = []
+    for i in range(240):
+        g = genomes[i % len(genomes)]
+        pos = int(rng.integers(0, len(g) - 150))
+        r = bytearray(g[pos:pos + 150])
+        if i % 3 == 2:  # a substitution every 28 bases: no intact 31-mer, runs of 27 leave 7 intact 21-mers each
+            for j in range(5, 150, 28):
+                r[j] = ord("A") if r[j] != ord("A") else ord("C")
+        elif i % 7 == 0:
+            r = bytearray(rng.choice(list(b"ACGT"), 150).astype(np.uint8))  # matches with neither size
+        reads.append(bytes(r))
+    ids = [f"q{i}" for i in range(len(reads))]
+    fq = str(tmp_path / "reads.fq")
+    write_fastq(fq, ids, reads)
+    odb = O.OracleDB(db_dir)
+    p = O.default_params(min_qcov=0.2)
+    want, trailer = oracle_tsv(O, odb, ids, reads, params=p)
+    ks = {odb.search(r, None, params=p)["k"] for r in reads}
+    odb.close()
+    assert ks == {21, 31}
+    env, _ = _env("KMCP_DIST_SAME_GPU")
+    out = str(tmp_path / "o.tsv")
+    _launch(2, 29741, ["-m", "kmcp_amd.dist_search", "-d", os.path.dirname(db_dir), fq, "-o", out, "-t", "0.2", "--gpu-batch", "100"], env)
+    compare(open(out).read().split("\n"), want, trailer)
+    # in process, one rank: the same walk through the per-shard pair == the library's own
+    seqs, offs = lib.pack_reads(reads)
+    srch = ShardedSearcher(db_dir, device=0)
+    try:
+        assert srch.db.ks == [31, 21]
+        a = srch.search(seqs, offs, params=default_params(min_qcov=0.2))
+    finally:
+        srch.close()
+    with Database.open(db_dir) as db:
+        b = db.search(reads, params=default_params(min_qcov=0.2))
+    for f in ("qlen", "qkmers", "ksize", "offs", "matches"):
+        assert np.array_equal(getattr(a, f), getattr(b, f)), f
+    assert set(a.ksize.tolist()) == {21, 31}
 
 
 def test_gather_hits_over_rccl_with_one_rank(tmp_path):
