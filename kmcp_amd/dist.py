@@ -76,38 +76,48 @@ class ShardedSearcher:
 
         A database with several k-mer sizes is walked as the reference does (util-db-search.go:764, :1016-1022): queries that
         were searched with the largest k and matched nothing go again with the next smaller one — rank 0 knows which (it holds
-        the finalized result) and tells the others."""
+        the finalized result) and tells the others.  --try-se (paired input) searches the mates of such queries on their own
+        first (:831-850, :1001-1014)."""
         from .lib import default_params
         p = params or default_params()
         n = len(offs) - 1
-        if p.try_se and seqs2 is not None:
-            raise NotImplementedError("--try-se is served by kmcpg_search_batch (kmcp-search --gpus N), not by the per-shard pair")
-        res = self._search_once(seqs, offs, p, seqs2, offs2)
+        try_se = bool(p.try_se) and seqs2 is not None
+        q0 = type(p).from_buffer_copy(p)
+        q0.try_se = 0
+        res = self._search_once(seqs, offs, q0, seqs2, offs2)
         ks = [int(p.k)] if p.k > 0 else list(self.db.ks)
-        if len(ks) < 2 or n == 0:
+        if n == 0 or (len(ks) < 2 and not try_se):
             return res
         final = None
         if self.rank == 0:  # matched, or never searched (too short / fewer than MinMatched k-mers): final (:854-869)
             final = (np.diff(res.offs.astype(np.int64)) > 0) | (res.qkmers <= 0)
-        for k in ks[1:]:
+
+        def again(k, mate, whole_query):
+            """the queries rank 0 still holds open, searched again: all of the query (mate None) or one mate on its own"""
             todo = self._bcast_indices(np.nonzero(~final)[0].astype(np.int64) if self.rank == 0 else None)
             if len(todo) == 0:
-                break
-            sub, so = _take_reads(seqs, offs, todo)
-            sub2 = so2 = None
-            if seqs2 is not None:
-                sub2, so2 = _take_reads(seqs2, offs2, todo)
+                return False
             q = type(p).from_buffer_copy(p)
             q.k = k
             q.try_se = 0
+            if mate is None:
+                sub, so = _take_reads(seqs, offs, todo)
+                sub2, so2 = _take_reads(seqs2, offs2, todo) if seqs2 is not None else (None, None)
+            else:
+                sub, so = _take_reads(seqs2 if mate else seqs, offs2 if mate else offs, todo)
+                sub2 = so2 = None
+                q.min_qlen = 0  # the length gate was applied once, before k-mer generation (:831-850)
             r2 = self._search_once(sub, so, q, sub2, so2)
             if self.rank != 0:
-                continue
+                return True
             # splice the sub-batch into the batch result (the queries of `todo` had no matches so far)
             res.qlen[todo] = r2.qlen
             res.ksize[todo] = k
             searched = r2.qkmers > 0
-            res.qkmers[todo] = np.where(searched, r2.qkmers, 0)
+            if whole_query:
+                res.qkmers[todo] = np.where(searched, r2.qkmers, 0)  # a fresh QueryResult: NumKmers never set
+            else:
+                res.qkmers[todo] = np.where(searched, r2.qkmers, res.qkmers[todo])
             got = np.diff(r2.offs.astype(np.int64))
             final[todo[~searched | (got > 0)]] = True
             if got.sum():
@@ -121,6 +131,17 @@ class ShardedSearcher:
                 owner2 = np.repeat(np.arange(len(todo)), got)
                 merged[new_offs[todo[owner2]].astype(np.int64) + (np.arange(len(r2.matches)) - r2.offs[owner2].astype(np.int64))] = r2.matches
                 res.matches, res.offs = merged, new_offs
+            return True
+
+        # the order of handleQuery: the whole query, then with --try-se read 1 and read 2 on their own (:831-850, :1001-1014),
+        # then everything again with the next smaller k (:1016-1022)
+        for ik, k in enumerate(ks):
+            if ik > 0 and not again(k, None, True):
+                break
+            if try_se:
+                for mate in (0, 1):
+                    if not again(k, mate, False):
+                        break
         return res
 
     def _bcast_indices(self, idx):

@@ -6,7 +6,8 @@
 Every rank opens shard rank/N of the database (libkmcpgpu partitions the index blocks by bytes), reads the same input,
 searches each batch against its blocks; the per-read hit lists are gathered on rank 0 (kmcp_amd.dist.gather_hits), finalized
 there (kmcpg_finalize) and written as the reference's 15-column TSV with its trailer (kmcp/cmd/search.go:436-438, 517-575,
-1022-1025).  Single-end input only; the single-process C++ CLI `kmcp-search --gpus N` covers the rest of the flags.
+1022-1025).  Single-end input only here (ShardedSearcher.search itself takes pairs and --try-se); the single-process C++ CLI
+`kmcp-search --gpus N` covers the rest of the flags.
 """
 import argparse
 import gzip

@@ -152,13 +152,20 @@ def test_sharded_searcher_walks_the_k_sizes_of_a_multi_k_database(oracle_lib, tm
     try:
         assert srch.db.ks == [31, 21]
         a = srch.search(seqs, offs, params=default_params(min_qcov=0.2))
+        # pairs with --try-se: mates of unmatched pairs searched on their own before the next k (:831-850, :1001-1014)
+        reads2 = [genomes[(i + 5) % len(genomes)][40:190] if i % 4 else bytes(rng.choice(list(b"ACGT"), 150).astype(np.uint8)) for i in range(len(reads))]
+        seqs2, offs2 = lib.pack_reads(reads2)
+        pe = default_params(min_qcov=0.4, try_se=1, fpr_buf_size=499)
+        a2 = srch.search(seqs, offs, params=pe, seqs2=seqs2, offs2=offs2)
     finally:
         srch.close()
     with Database.open(db_dir) as db:
         b = db.search(reads, params=default_params(min_qcov=0.2))
-    for f in ("qlen", "qkmers", "ksize", "offs", "matches"):
-        assert np.array_equal(getattr(a, f), getattr(b, f)), f
-    assert set(a.ksize.tolist()) == {21, 31}
+        b2 = db.search(reads, reads2, params=pe)
+    for x, y in ((a, b), (a2, b2)):
+        for f in ("qlen", "qkmers", "ksize", "offs", "matches"):
+            assert np.array_equal(getattr(x, f), getattr(y, f)), f
+    assert set(a.ksize.tolist()) == {21, 31} and len(a2.matches) > 50 and len(set(a2.qlen.tolist())) > 1  # some pairs answered by one mate (qLen 150)
 
 
 def test_gather_hits_over_rccl_with_one_rank(tmp_path):
