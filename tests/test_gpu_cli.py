@@ -287,6 +287,34 @@ def test_cli_paired_ragged_reads_through_the_parallel_reader(oracle_lib, tmp_pat
         compare(got, want, trailer)
 
 
+def test_cli_long_reads_through_the_parallel_reader(oracle_lib, tmp_path):
+    """A plain FASTQ file of ~10-kb reads (12 MB: above the parallel reader's threshold without any test knob): several parser
+    threads, chunks capped in bytes, the syncmer index's dedup path.  Same TSV as through the serial reader and with tiny
+    chunks; the oracle's lines for the whole file."""
+    O = oracle_lib
+    genomes = synth.random_genomes(6, 60000, seed=71)
+    db_dir = synth.make_db(tmp_path / "db", genomes, k=21, threads=2, syncmer_s=11)
+    db_root = os.path.dirname(db_dir)
+    rng = np.random.default_rng(72)
+    reads = []
+    for i in range(600):
+        L = int(np.clip(rng.normal(10000, 2000), 2000, 20000))
+        reads.append(synth.sample_reads(genomes, 1, L, sub_rate=0.002, seed=7000 + i, frac_random=0.1)[0])
+    ids = [f"hifi{i}" for i in range(len(reads))]
+    fq = str(tmp_path / "long.fq")
+    write_fastq(fq, ids, reads)
+    assert os.path.getsize(fq) > (8 << 20)
+    odb = O.OracleDB(db_dir)
+    want, trailer = oracle_tsv(O, odb, ids, reads)
+    odb.close()
+    assert len(want) > 400
+    base = run_cli(["-d", db_root, fq], str(tmp_path / "a.tsv"))
+    compare(base, want, trailer)
+    serial = run_cli(["-d", db_root, fq], str(tmp_path / "b.tsv"), env=dict(os.environ, KMCP_SERIAL_READER="1"))
+    small = run_cli(["-d", db_root, fq, "--gpu-batch", "50"], str(tmp_path / "c.tsv"), env=dict(os.environ, KMCP_READER_CHUNK="300000", KMCP_READER_THREADS="3"))
+    assert base == serial == small
+
+
 def oracle_tsv_swapped(O, db_dir, ids, a, b):
     odb = O.OracleDB(db_dir)
     try:
