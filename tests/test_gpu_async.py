@@ -173,3 +173,49 @@ def test_async_stress_short():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "stress_async.py"), "6", "4"], capture_output=True, text=True, timeout=300, cwd=root)
     assert r.returncode == 0 and "stress ok" in r.stdout, (r.stdout[-1000:], r.stderr[-2000:])
+
+
+def test_hit_heavy_batches_follow_the_data(oracle_lib, tmp_path):
+    """A database of 70 close relatives: every read matches ~60 columns.  The hit buffers of the lanes learn that from the first
+    large batch (kmcpg_wait reruns it once with room for every hit), later batches fit at once; the eager read-back stays
+    bounded at 32 hits per read, so the rest of every batch's hits arrives through the late copy in kmcpg_wait.  Batches of
+    2 000 reads in flight on all lanes, a small one (below the size that updates the estimate) and a hit-free one in between."""
+    from kmcp_amd import Database, default_params, lib
+    O = oracle_lib
+    rng = np.random.default_rng(91)
+    base = synth.random_genomes(1, 6000, seed=90)[0]
+    genomes = []
+    for i in range(70):
+        g = np.frombuffer(base, dtype=np.uint8).copy()
+        m = rng.random(len(g)) < 0.004
+        g[m] = rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), int(m.sum()))
+        genomes.append(g.tobytes())
+    db_dir = synth.make_db(tmp_path, genomes, k=21, threads=1)
+    odb = O.OracleDB(db_dir)
+    heavy = [synth.sample_reads([base], 2000, 150, sub_rate=0.0, seed=200 + i, frac_random=0.0) for i in range(6)]
+    small = synth.sample_reads([base], 40, 150, sub_rate=0.0, seed=300, frac_random=0.0)
+    empty = synth.sample_reads([base], 1500, 150, seed=301, frac_random=1.0)
+    order = [heavy[0], heavy[1], small, heavy[2], empty, heavy[3], heavy[4], heavy[5]]
+    with Database.open(db_dir) as db:
+        alone = [db.search(b, params=default_params()) for b in order]  # one at a time (also the first overflow + rerun)
+        assert alone[0].offs[-1] > 40 * len(order[0]) and alone[4].offs[-1] == 0
+        tickets = []
+        got = []
+        for b in order:
+            seqs, offs = lib.pack_reads(b)
+            while True:
+                try:
+                    tickets.append(db.submit(seqs, offs, params=default_params()))
+                    break
+                except lib.KmcpGpuError as e:
+                    assert e.code == -7
+                    got.append(db.wait(tickets.pop(0)))
+        while tickets:
+            got.append(db.wait(tickets.pop(0)))
+        for a, g in zip(alone, got):
+            for f in ("qlen", "qkmers", "offs", "matches"):
+                assert np.array_equal(getattr(a, f), getattr(g, f)), f
+        # the oracle on a sample of a heavy batch
+        sub = order[3][:80]
+        assert synth.assert_parity(odb, db.search(sub, params=default_params()), sub) > 40 * len(sub)
+    odb.close()
