@@ -183,7 +183,7 @@ def run_workload(name, ctx, steps, warmup, batch_reads=0, cpu_baseline=True, cpu
             self.copied = torch.cuda.Event()
             self.used = False
 
-    bufs = [Buf(), Buf()] if not coll else [Buf()]
+    bufs = [Buf(), Buf()]  # two steps in flight, with and without a collective
 
     def gpu_half(i, bf):
         """Enqueues K1+K2 of batch i on this rank's blocks (nothing waits here)."""
@@ -210,16 +210,21 @@ def run_workload(name, ctx, steps, warmup, batch_reads=0, cpu_baseline=True, cpu
                 bf.h_ql.copy_(bf.d_ql, non_blocking=True)
                 bf.copied.record(side)
             return n
-        parts = gather_hits(bf.d_hits, bf.d_cnt[:1], dst=0, force_collectives=True)  # RCCL: all_gather(counts) + gather(hit buffers) over xGMI
+        # N > 1: the exchange of step i runs on the side stream, behind step i's kernels only — the kernels of step i+1 are already
+        # enqueued on `main` and keep the GPU busy while the counts are all-gathered, the hit buffers gathered (RCCL over xGMI)
+        # and rank 0 copies the merged list to pinned host memory
+        side.wait_event(bf.kernels_done)
         n = 0
-        if rank == 0:
-            for part in parts:
-                c = part.shape[0]
-                bf.h_hits[n:n + c].copy_(part, non_blocking=True)
-                n += c
-            bf.h_qk.copy_(bf.d_qk, non_blocking=True)
-            bf.h_ql.copy_(bf.d_ql, non_blocking=True)
-        bf.copied.record(main)
+        with torch.cuda.stream(side):
+            parts = gather_hits(bf.d_hits, bf.d_cnt[:1], dst=0, force_collectives=True)  # all_gather(counts) + gather(hit buffers)
+            if rank == 0:
+                for part in parts:
+                    c = part.shape[0]
+                    bf.h_hits[n:n + c].copy_(part, non_blocking=True)
+                    n += c
+                bf.h_qk.copy_(bf.d_qk, non_blocking=True)
+                bf.h_ql.copy_(bf.d_ql, non_blocking=True)
+            bf.copied.record(side)
         return n
 
     def host_half(bf, n):
@@ -235,40 +240,27 @@ def run_workload(name, ctx, steps, warmup, batch_reads=0, cpu_baseline=True, cpu
         torch.cuda.synchronize()
 
     def run_steps(first, count, with_host=True, times=None):
-        """`count` steps starting at batch `first`.  N = 1: two steps in flight (the kernels of step i+1 are enqueued before
-        step i's hits are fetched and finalized).  N > 1: the collective keeps the steps in order; the host half of step i still
-        runs while the kernels of step i+1 do.  Returns (#hits, #matches) on rank 0."""
+        """`count` steps starting at batch `first`, two in flight: the kernels of step i+1 are enqueued before step i's hits are
+        exchanged (N > 1: RCCL on the side stream), fetched and finalized.  Returns (#hits, #matches) on rank 0."""
         hits = matches = 0
-        pending = None  # (buffers, #hits) of the step whose host half is still to run
-        if not coll:
-            gpu_half(first, bufs[0])
-            for j in range(count):
-                bf = bufs[j % 2]
-                if j + 1 < count:
-                    gpu_half(first + j + 1, bufs[(j + 1) % 2])
-                ta = time.perf_counter()
-                n = exchange(bf)
-                tb = time.perf_counter()
-                hits += n
-                if with_host:
-                    matches += host_half(bf, n)
-                tc = time.perf_counter()
-                if times is not None:
-                    times.append(db.last_timing(age=1 if j + 1 < count else 0))
-                if os.environ.get("KMCP_BENCH_TRACE"):
-                    print(f"step {j}: exchange {1e3*(tb-ta):.2f} ms, host half {1e3*(tc-tb):.2f} ms, timing {1e3*(time.perf_counter()-tc):.2f} ms", file=sys.stderr)
+        if count <= 0:
             return hits, matches
+        gpu_half(first, bufs[0])
         for j in range(count):
-            gpu_half(first + j, bufs[0])
-            if pending is not None and with_host:
-                matches += host_half(*pending)
-            n = exchange(bufs[0])
+            bf = bufs[j % 2]
+            if j + 1 < count:
+                gpu_half(first + j + 1, bufs[(j + 1) % 2])
+            ta = time.perf_counter()
+            n = exchange(bf)
+            tb = time.perf_counter()
             hits += n
-            pending = (bufs[0], n)
+            if with_host:
+                matches += host_half(bf, n)
+            tc = time.perf_counter()
             if times is not None:
-                times.append(db.last_timing())
-        if pending is not None and with_host:
-            matches += host_half(*pending)
+                times.append(db.last_timing(age=1 if j + 1 < count else 0))
+            if os.environ.get("KMCP_BENCH_TRACE"):
+                print(f"rank {rank} step {j}: exchange {1e3*(tb-ta):.2f} ms, host half {1e3*(tc-tb):.2f} ms, timing {1e3*(time.perf_counter()-tc):.2f} ms", file=sys.stderr)
         return hits, matches
 
     run_steps(0, warmup)
@@ -285,25 +277,29 @@ def run_workload(name, ctx, steps, warmup, batch_reads=0, cpu_baseline=True, cpu
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    # ---- roofline of the dominant kernel (k2_cobs) on this rank: algorithmic bytes per launch:
-    #      sum over reads of kept k-mers x sum over local blocks of numHashes x NumRowBytes, + qLen, + 12 B per hit
+    # ---- roofline of the dominant kernel (k2_cobs) on this rank.
+    #  algorithmic bytes per launch: sum over reads of kept k-mers x sum over local blocks of numHashes x NumRowBytes,
+    #  + qLen, + 12 B per hit.  The kernel does NOT move all of them: exact sector pruning stops loading rows whose columns cannot
+    #  reach the threshold any more, so algorithmic bytes / time can exceed the chip's peak and is reported as `effective_gbps`.
+    #  `achieved` / `frac` are what the kernel actually moved, measured in this run (below: the kernel counts its own row loads
+    #  on the very batches of the timed steps; the committed --pmc FETCH_SIZE pass of the same command is carried beside it).
     last = (warmup + steps - 1) % n_batches
     qk = bufs[(steps - 1) % len(bufs)].d_qk.cpu().numpy().astype(np.int64)
     kmers_per_launch = int(qk.sum())
     alg_bytes = kmers_per_launch * int(info.row_bytes_sum_local) * int(info.num_hashes) + B * READ_LEN + 12 * (n_hits_total // max(1, steps))
     k2_avg_ms = float(np.mean(k2_ms))
-    achieved = alg_bytes / (k2_avg_ms * 1e-3) / 1e9
-    traffic, traffic_src = None, None
+    effective = alg_bytes / (k2_avg_ms * 1e-3) / 1e9
+    pmc, pmc_src = None, None
     tfile = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tfile):
         try:
             tj = json.load(open(tfile))
             key = f"{name}{'_ungrouped' if os.environ.get('KMCPG_FUSE') == '0' else ''}:{B}:{world}"
             if key in tj:
-                traffic = tj[key]["hbm_bytes_per_launch"]
-                traffic_src = tj[key].get("source")
+                pmc = tj[key]["hbm_bytes_per_launch"]
+                pmc_src = tj[key].get("source")
         except Exception:
-            traffic = None
+            pmc = None
 
     out = {
         "metric": "reads/sec searched (150bp, k=21) vs GTDB-scale index",
@@ -324,14 +320,16 @@ def run_workload(name, ctx, steps, warmup, batch_reads=0, cpu_baseline=True, cpu
                    "index_bytes": int(info.matrix_bytes), "index_bytes_this_rank": int(info.matrix_bytes_local),
                    "blocks": int(info.n_blocks), "columns": n_cols, "parallelism": f"block-shard x{world}",
                    "search_flags": "-t 0.55 -c 10 -m 30 -f 0.01 -u 256"},
-        "roofline": {"bound": "hbm", "kernel": wl["kernel"], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                     "wire_gbps": (traffic / (k2_avg_ms * 1e-3) / 1e9) if traffic else None,
-                     "frac_wire": (traffic / (k2_avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
+        "roofline": {"bound": "hbm", "kernel": wl["kernel"], "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
+                     "traffic_source": None,
+                     "definition": "achieved = bytes the kernel moved per launch (traffic) / its mean HIP-event duration over the timed steps; "
+                                   "frac = achieved / peak.  effective_gbps = ALGORITHMIC bytes (SURVEY 8d) / the same duration: larger than "
+                                   "achieved, and possibly than peak, by what exact sector pruning never fetches",
+                     "algorithmic_bytes_per_launch": alg_bytes, "effective_gbps": effective, "frac_algorithmic": effective / HBM_PEAK_GBS,
+                     "traffic_pmc": pmc, "traffic_pmc_source": pmc_src,
                      "measured_ceiling": {"gbps": FABRIC_CEILING_GBS, "what": "random 128-B gathers that miss L2 (L2->fabric path), tools/ubench_cache.cpp",
-                                          "source": "profiles/r02_ubench_cache.txt",
-                                          "frac_wire": (traffic / (k2_avg_ms * 1e-3) / 1e9 / FABRIC_CEILING_GBS) if traffic else None},
-                     "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": k2_avg_ms, "kmers_kernel_ms": float(np.mean(k1_ms))},
+                                          "source": "profiles/r02_ubench_cache.txt"},
+                     "kernel_ms": k2_avg_ms, "kmers_kernel_ms": float(np.mean(k1_ms))},
         "hits_per_step": n_hits_total / max(1, steps),
         "matches_per_step": n_matches_total / max(1, steps),
         "setup_s": setup_s,
@@ -349,6 +347,47 @@ def run_workload(name, ctx, steps, warmup, batch_reads=0, cpu_baseline=True, cpu
         got = set(zip(hh[:, 0].tolist(), hh[:, 1].tolist()))
         planted = np.nonzero(cols_last >= 0)[0]
         out["planted_recall"] = sum((int(r), int(cols_last[r])) in got for r in planted[:20000]) / max(1, min(len(planted), 20000))
+
+    # ---- what the kernel moved: every distinct batch of the timed steps once more with the kernel counting its own row loads
+    #      (profiling level 2: one atomic per wave and row group, 16 B per lane and row actually loaded, row padding included,
+    #      pruned rows not; the counts do not depend on timing, so this is the traffic of the timed launches themselves)
+    def measure_gathered(env=None):
+        old = {}
+        for k_, v_ in (env or {}).items():
+            old[k_] = os.environ.get(k_)
+            os.environ[k_] = v_
+        try:
+            db.set_profiling(2)
+            per_batch = []
+            for i in range(n_batches):
+                gpu_half(i, bufs[0])
+                torch.cuda.synchronize()
+                bufs[0].copied.record(main)
+                per_batch.append(db.last_gathered_bytes())
+        finally:
+            db.set_profiling(True)
+            for k_, v_ in old.items():
+                if v_ is None:
+                    os.environ.pop(k_, None)
+                else:
+                    os.environ[k_] = v_
+        return per_batch
+
+    rf = out["roofline"]
+    per_batch = measure_gathered()
+    gathered = float(np.mean([per_batch[(warmup + j) % n_batches] for j in range(steps)]))
+    rf["gathered_bytes_per_launch"] = gathered
+    rf["traffic"] = gathered
+    rf["traffic_source"] = ("live: row bytes the k2_cobs launches of the timed steps asked the memory system for (kernel-side counter, "
+                            "kmcpg_last_gathered_bytes); cross-check = traffic_pmc (rocprofv3 --pmc FETCH_SIZE pass of the same command)")
+    rf["achieved"] = gathered / (k2_avg_ms * 1e-3) / 1e9
+    rf["frac"] = rf["achieved"] / HBM_PEAK_GBS
+    rf["traffic_over_algorithmic"] = gathered / alg_bytes
+    rf["measured_ceiling"]["frac"] = rf["achieved"] / FABRIC_CEILING_GBS
+    if pmc:
+        rf["pmc_gbps"] = pmc / (k2_avg_ms * 1e-3) / 1e9
+        rf["frac_pmc"] = rf["pmc_gbps"] / HBM_PEAK_GBS
+        rf["live_over_pmc"] = gathered / pmc
 
     if extras:
         # ---- the kernel alone and the data-independent variant: no host half; then sector pruning switched off (every row byte
@@ -376,24 +415,22 @@ def run_workload(name, ctx, steps, warmup, batch_reads=0, cpu_baseline=True, cpu
         per_step, _ = kernel_only(max(2, min(steps, 8)))
         out["device_only"] = {"value": B / per_step, "unit": "reads/s", "ms_per_step": per_step * 1e3,
                               "note": "reads in HBM -> raw (read, column, count) hit tuples in host memory, no host half (round 1's `value`)"}
-        # live cross-check of the committed FETCH_SIZE pass: one step with the kernel counting its own row loads
-        db.set_profiling(2)
-        kernel_only(1)
-        out["roofline"]["gathered_bytes_per_launch"] = db.last_gathered_bytes()
-        db.set_profiling(True)
         local_strides = [bi["stride"] for bi in (db.block_info(b_) for b_ in range(int(info.n_blocks))) if bi["local"]]
         stride0 = max(local_strides) if local_strides else 0
         if 0 < stride0 <= 64:
             # narrow rows (one 64-byte request per (k-mer, block)): the bound is the rate at which the L2->fabric path serves
             # requests that miss L2, not bytes — 56e9/s whatever their size up to 128 B (profiles/r02_ubench_cache.txt)
-            req = out["roofline"]["gathered_bytes_per_launch"] / stride0
+            req = rf["gathered_bytes_per_launch"] / stride0
             out["roofline"]["request_bound"] = {"bound": "L2->fabric request rate", "requests_per_launch": req, "achieved": req / (k2_avg_ms * 1e-3),
                                                 "peak": 56e9, "unit": "requests/s", "frac": req / (k2_avg_ms * 1e-3) / 56e9,
                                                 "peak_source": "profiles/r02_ubench_cache.txt (64-B gathers over >= 64 MiB: 55-60 G/s)"}
-        _, k2_np = kernel_only(2, {"KMCPG_PRUNE": "0"})
-        out["roofline"]["kernel_ms_prune_off"] = k2_np
-        out["roofline"]["achieved_prune_off"] = alg_bytes / (k2_np * 1e-3) / 1e9
-        out["roofline"]["frac_prune_off"] = out["roofline"]["achieved_prune_off"] / HBM_PEAK_GBS
+        # sector pruning switched off: every row byte of every k-mer is fetched whatever the index holds (traffic = algorithmic
+        # bytes + row padding), the data-independent figure of the same kernel
+        _, k2_np = kernel_only(max(2, min(steps, 4)), {"KMCPG_PRUNE": "0"})
+        g_np = float(np.mean(measure_gathered({"KMCPG_PRUNE": "0"})))
+        rf["prune_off"] = {"kernel_ms": k2_np, "traffic": g_np, "achieved": g_np / (k2_np * 1e-3) / 1e9, "frac": g_np / (k2_np * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                           "effective_gbps": alg_bytes / (k2_np * 1e-3) / 1e9, "frac_algorithmic": alg_bytes / (k2_np * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                           "traffic_over_algorithmic": g_np / alg_bytes}
 
     # ---- the drop-in boundary with host buffers (PCIe-inclusive; reported beside `value`, never as `value`): batches through
     #      kmcpg_submit / kmcpg_wait — reads in host memory in; H2D, K1, K2, D2H of the hits, float64 thresholds, FPR, sort;

@@ -90,7 +90,8 @@ def gpu_tuples(res, i):
 
 
 def assert_parity(odb, res, reads, reads2=None, oparams=None, check_order=True):
-    """Bit-exact per-read sets of (target column, mKmers, qCov, tCov, jacc); FPR within 1e-12 abs / 1e-9 rel."""
+    """Bit-exact per-read sets of (target column, mKmers, qCov, tCov, jacc), and the FPR doubles bit for bit (product and oracle
+    restate the same Go arithmetic, util-fpr.go:32-71; both reproduce the reference's printed values, tests/test_fpr_golden.py)."""
     n_hits = 0
     for i, r in enumerate(reads):
         want = oracle_tuples(odb, r, reads2[i] if reads2 is not None else None, oparams)
@@ -100,7 +101,7 @@ def assert_parity(odb, res, reads, reads2=None, oparams=None, check_order=True):
         assert got[2] == want[2], f"read {i}: matches differ\n gpu={got[2]}\n ora={want[2]}"
         for c, f in want[3].items():
             g = got[3][c]
-            assert abs(g - f) <= 1e-12 or abs(g - f) <= 1e-9 * abs(f), f"read {i} col {c}: FPR {g} vs {f}"
+            assert g == f, f"read {i} col {c}: FPR {g!r} vs {f!r}"
         if check_order:
             # both sides break exact score ties by column, so even the order agrees
             assert got[4] == want[4], f"read {i}: order differs {got[4]} vs {want[4]}"

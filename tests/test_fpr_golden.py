@@ -1,0 +1,84 @@
+"""The FPR column pinned by the reference's own numbers: the nine `kmcp search` rows of
+docs/tutorial/profiling/index.md:203-211 (fixture tests/golden/tutorial_profiling_fpr.json, lifted by
+tests/golden/make_fpr_golden.py) carry Theorem-2 query FPRs (util-fpr.go:32-71) for n = 130 k-mers at the default index FPR 0.3 —
+exactly the regime where `1 - sum` collapses to rounding noise (7.4626e-15 ... 7.8754e-15), so the digits only come out right if
+Go's math.Pow and the 53-bit big.Float binomial coefficients are restated faithfully.  Checked here: the oracle
+(ko_query_fpr), the product's fpr.cpp through kmcpg_finalize on a metadata-only handle (no GPU), and bit-equality of the two
+over a sweep of (n, k, p)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from tests import synth
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "tutorial_profiling_fpr.json")
+
+
+@pytest.fixture(scope="module")
+def golden():
+    g = json.load(open(GOLDEN))
+    assert len(g["rows"]) == 9 and g["db_fpr"] == 0.3
+    return g
+
+
+def go_e4(x):
+    """strconv.FormatFloat(x, 'e', 4, 64) (search.go:539): four decimals, at least two exponent digits — C's %.4e."""
+    return "%.4e" % x
+
+
+def test_oracle_reproduces_tutorial_fpr_column(oracle_lib, golden):
+    L = oracle_lib.lib()
+    for row in golden["rows"]:
+        assert go_e4(L.ko_query_fpr(row["qKmers"], row["mKmers"], golden["db_fpr"])) == row["FPR"], row
+        assert "%.4f" % (row["mKmers"] / row["qKmers"]) == row["qCov"], row
+        assert row["qKmers"] == row["qLen"] - row["kSize"] + 1
+
+
+def _finalize_all_counts(db, n, extra=()):
+    """kmcpg_finalize over one query of n k-mers per count c = 1..n (every threshold open): {c: FPR(n, c)} of the product."""
+    from kmcp_amd.lib import HIT_DTYPE, default_params
+    cs = sorted(set(range(1, n + 1)) | set(extra))
+    hits = np.array([(i, 0, c) for i, c in enumerate(cs)], dtype=np.uint32).view(HIT_DTYPE).reshape(-1)
+    p = default_params(min_qcov=0.0, min_matched=1, max_fpr=1.0, min_tcov=0.0)
+    res = db.finalize(hits, np.full(len(cs), n, dtype=np.int32), np.full(len(cs), n + 20, dtype=np.int32), params=p)
+    out = {}
+    for i, c in enumerate(cs):
+        ms = res.read(i)
+        assert len(ms) == 1 and int(ms[0]["mkmers"]) == c, (n, c, ms)
+        out[c] = float(ms[0]["fpr"])
+    return out
+
+
+@pytest.fixture(scope="module")
+def dbs(oracle_lib, tmp_path_factory):
+    out = {}
+    for p in (0.3, 0.05, 0.01):
+        tmp = tmp_path_factory.mktemp("fprdb")
+        out[p] = synth.make_db(tmp, synth.random_genomes(3, 2000, seed=3), k=21, fpr=p, threads=1)
+    return out
+
+
+def test_product_reproduces_tutorial_fpr_column(golden, dbs):
+    """fpr.cpp, reached the way every result reaches it: kmcpg_finalize (here on a metadata-only handle, no GPU needed)."""
+    from kmcp_amd.lib import Database
+    with Database.open(dbs[0.3], device=-1) as db:
+        assert db.info.fpr == 0.3
+        got = _finalize_all_counts(db, 130)
+    for row in golden["rows"]:
+        assert go_e4(got[row["mKmers"]]) == row["FPR"], (row, got[row["mKmers"]])
+
+
+def test_product_fpr_bit_equal_to_oracle(oracle_lib, dbs):
+    """Both restate the same Go arithmetic (util-fpr.go:32-71: math.Pow, big.Float(prec 53) binomials, clamp at 0): every double
+    must agree bit for bit — short reads, pairs (n up to 499 is the cached triangle of search.go:250-255), and beyond it."""
+    from kmcp_amd.lib import Database
+    L = oracle_lib.lib()
+    for p, d in dbs.items():
+        with Database.open(d, device=-1) as db:
+            for n in (1, 2, 10, 33, 70, 130, 131, 249, 250, 260, 499, 500, 733, 1200):
+                got = _finalize_all_counts(db, n)
+                for c, v in got.items():
+                    w = L.ko_query_fpr(n, c, p)
+                    assert v == w and np.float64(v).tobytes() == np.float64(w).tobytes(), (p, n, c, v, w)

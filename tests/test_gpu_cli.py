@@ -18,7 +18,7 @@ HEADER = "#query\tqLen\tqKmers\tFPR\thits\ttarget\tchunkIdx\tchunks\ttLen\tkSize
 
 
 def oracle_tsv(O, odb, ids, reads, reads2=None, params=None, keep_unmatched=False, name_map=None):
-    """What `kmcp search` would print (FPR column kept as float for a tolerant compare)."""
+    """What `kmcp search` would print."""
     L = O.lib()
     p = params or O.default_params()
     lines, matched = [], 0
@@ -62,10 +62,7 @@ def compare(got_lines, want_rows, want_trailer, header=True):
     rows = got[:-3]
     assert len(rows) == len(want_rows)
     for g, w in zip(rows, want_rows):
-        gf, wf = g.split("\t"), w.split("\t")
-        assert gf[:3] == wf[:3] and gf[4:] == wf[4:], (g, w)
-        a, b = float(gf[3]), float(wf[3])
-        assert abs(a - b) <= 1e-12 or abs(a - b) <= 1e-4 * abs(b), (g, w)  # printed with 5 significant digits
+        assert g == w, (g, w)  # every field as a string, the FPR's %.4e digits included (pinned: tests/test_fpr_golden.py)
 
 
 def write_fastq(path, ids, reads, gz=False):
@@ -321,3 +318,41 @@ def oracle_tsv_swapped(O, db_dir, ids, a, b):
         return oracle_tsv(O, odb, ids, a, b, params=O.default_params(fpr_buf_size=499))
     finally:
         odb.close()
+
+
+def test_cli_fpr_column_reproduces_the_reference_tutorial(oracle_lib, tmp_path):
+    """The FPR digits end to end: reads whose best match has 83 / 84 / 86 / 89 / ... / 130 of 130 k-mers must print the very
+    strings of the reference's demo result (docs/tutorial/profiling/index.md:203-211, tests/golden/tutorial_profiling_fpr.json:
+    default index FPR 0.3, 150-bp reads, k = 21) in column 4 of kmcp-search's TSV."""
+    import json
+    O = oracle_lib
+    gold = json.load(open(os.path.join(ROOT, "tests", "golden", "tutorial_profiling_fpr.json")))
+    want_fpr = {r["mKmers"]: r["FPR"] for r in gold["rows"]}
+    genomes = synth.random_genomes(8, 20000, seed=70)
+    db_dir = synth.make_db(tmp_path / "db", genomes, k=21, n_chunks=2, overlap=150, fpr=gold["db_fpr"], threads=2)
+    odb = O.OracleDB(db_dir)
+    # reads with 2-3 substitutions lose 40-50 k-mers; keep one read per golden mKmers value (the oracle says which they are)
+    cand = synth.sample_reads(genomes, 4000, 150, sub_rate=0.017, seed=71, frac_random=0.0)
+    pick = {}
+    for r in cand:
+        ms = odb.search(r)["matches"] or []
+        for m in ms:
+            if m["mkmers"] in want_fpr and m["mkmers"] not in pick:
+                pick[m["mkmers"]] = r
+    assert set(pick) == set(want_fpr), sorted(set(want_fpr) - set(pick))
+    reads = [pick[m] for m in sorted(pick)]
+    ids = [f"m{m}" for m in sorted(pick)]
+    fq = str(tmp_path / "r.fq")
+    write_fastq(fq, ids, reads)
+    got = run_cli(["-d", os.path.dirname(db_dir), fq], str(tmp_path / "o.tsv"))
+    want, trailer = oracle_tsv(O, odb, ids, reads)
+    compare(got, want, trailer)
+    seen = set()
+    for line in got[1:-4]:
+        f = line.split("\t")
+        assert f[2] == "130"
+        if int(f[10]) in want_fpr:
+            assert f[3] == want_fpr[int(f[10])], line
+            seen.add(int(f[10]))
+    assert seen == set(want_fpr)
+    odb.close()
