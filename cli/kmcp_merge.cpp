@@ -274,7 +274,8 @@ int main(int argc, char** argv) {
     if (x <= 0) die("value of flag --%s should be positive: %ld", flag, x);
     return (int)x;
   };
-  for (int i = 1; i < argc; i++) {
+  // `kmcp-merge merge ...` = `kmcp merge ...`: cobra's sub-command word, accepted (only) as the first argument
+  for (int i = (argc > 1 && strcmp(argv[1], "merge") == 0) ? 2 : 1; i < argc; i++) {
     std::string a = argv[i];
     if (a == "-o" || a == "--out-file") out_file = need(i);
     else if (a == "-s" || a == "--sort-by") sort_by = need(i);

@@ -78,7 +78,8 @@ static void warn(const char* fmt, ...) {
 struct Options {
   std::string db_dir, out_file = "-", read1, read2, query_id, sort_by = "qcov", infile_list, log_file;
   std::vector<std::string> name_maps, files;
-  int min_qlen = 30, min_kmers = 10, dedup = 256, top_scores = 0, threads = 0, device = 0, batch = 131072, gpus = 1;
+  int min_qlen = 30, min_kmers = 10, dedup = 256, top_scores = 0, threads = 0, device = 0, batch = 131072, gpus = 1, gpu_passes = -1;
+  bool batch_given = false;
   std::vector<int32_t> gpu_ids;
   double min_qcov = 0.55, min_tcov = 0, max_fpr = 0.01;
   bool load_whole = false, low_mem = false, whole_file = false, use_filename = false, keep_unmatched = false, no_header = false,
@@ -103,6 +104,8 @@ static void usage() {
       "  -j, --threads int  -i, --infile-list file  -q, --quiet  --log file\n"
       "GPU flags: --gpu int (device, default 0)  --gpus int (use devices 0..N-1, index blocks partitioned over them)\n"
       "           --gpu-ids a,b,c (explicit device list)  --gpu-batch int (queries per GPU call, default 131072)\n"
+      "           --gpu-passes int (an index larger than the GPU's memory is searched in this many passes per batch, one part\n"
+      "                             resident at a time; 0 = as few as fit; default: only when the index does not fit)\n"
       "           --parse-only (read the inputs and print records / bases / checksum per file; no database, no GPU)\n",
       stderr);
 }
@@ -129,7 +132,7 @@ static Options parse_args(int argc, char** argv) {
       {"min-kmers", 'c', 1}, {"min-query-len", 'm', 1}, {"min-query-cov", 't', 1}, {"min-target-cov", 'T', 1}, {"max-fpr", 'f', 1},
       {"name-map", 'N', 1}, {"default-name-map", 'D', 0}, {"keep-unmatched", 'K', 0}, {"keep-top-scores", 'n', 1}, {"no-header-row", 'H', 0},
       {"sort-by", 's', 1}, {"do-not-sort", 'S', 0}, {"threads", 'j', 1}, {"quiet", 'q', 0}, {"infile-list", 'i', 1}, {"log", 0, 1},
-      {"gpu", 0, 1}, {"gpu-batch", 0, 1}, {"gpus", 0, 1}, {"gpu-ids", 0, 1}, {"parse-only", 0, 0}, {"help", 'h', 0}, {"version", 'V', 0}};
+      {"gpu", 0, 1}, {"gpu-batch", 0, 1}, {"gpus", 0, 1}, {"gpu-ids", 0, 1}, {"gpu-passes", 0, 1}, {"parse-only", 0, 0}, {"help", 'h', 0}, {"version", 'V', 0}};
   auto apply = [&](const std::string& name, const std::string& v) {
     if (name == "db-dir") o.db_dir = v;
     else if (name == "out-file") o.out_file = v;
@@ -166,7 +169,8 @@ static Options parse_args(int argc, char** argv) {
     else if (name == "infile-list") o.infile_list = v;
     else if (name == "log") o.log_file = v;
     else if (name == "gpu") o.device = to_i(name, v);
-    else if (name == "gpu-batch") o.batch = to_i(name, v);
+    else if (name == "gpu-batch") { o.batch = to_i(name, v); o.batch_given = true; }
+    else if (name == "gpu-passes") o.gpu_passes = to_i(name, v);
     else if (name == "parse-only") o.parse_only = true;
     else if (name == "gpus") o.gpus = to_i(name, v);
     else if (name == "gpu-ids") {
@@ -182,7 +186,10 @@ static Options parse_args(int argc, char** argv) {
     else if (name == "version") { printf("kmcp-search v%s\n", VERSION); exit(0); }
   };
   bool only_pos = false;
-  for (int i = 1; i < argc; i++) {
+  int first = 1;
+  // `kmcp-search search ...` = `kmcp search ...`: cobra's sub-command word, accepted (only) as the first argument
+  if (argc > 1 && strcmp(argv[1], "search") == 0) first = 2;
+  for (int i = first; i < argc; i++) {
     std::string a = argv[i];
     if (only_pos || a == "-" || a.empty() || a[0] != '-') { o.files.push_back(a); continue; }
     if (a == "--") { only_pos = true; continue; }
@@ -273,8 +280,9 @@ class Queue {
 // The records of one single-end input file as batches of about `batch_reads` queries, in file order.  Plain four-line FASTQ
 // files are cut and parsed by several threads (ParallelFastq: every chunk becomes a batch without another copy); everything
 // else — gzip, BGZF, FASTA, wrapped FASTQ, pipes — goes through the single-threaded FastxReader.  Returns the number of records.
+// `stop` (optional) is looked at between batches / records: once set the rest of the file is left unread.
 template <class Emit>
-static uint64_t read_single_end(const std::string& file, size_t batch_reads, size_t max_bases, Emit&& emit) {
+static uint64_t read_single_end(const std::string& file, size_t batch_reads, size_t max_bases, Emit&& emit, const std::atomic<bool>* stop = nullptr) {
   uint64_t n = 0;
   std::unique_ptr<Batch> b(new Batch());
   auto flush = [&] {
@@ -298,6 +306,7 @@ static uint64_t read_single_end(const std::string& file, size_t batch_reads, siz
     ParallelFastq pf(file, batch_reads, w, 2 * max_bases);  // a record is its bases twice (qualities) plus the header
     serial = false;
     while (std::unique_ptr<FastqChunk> c = pf.next()) {
+      if (stop && stop->load(std::memory_order_relaxed)) return n;
       if (!c->strict) {  // not four-line FASTQ from here on: the general reader takes over at the chunk's first byte
         resume = c->file_off;
         serial = true;
@@ -316,8 +325,8 @@ static uint64_t read_single_end(const std::string& file, size_t batch_reads, siz
   if (serial) {
     FastxReader r(file, resume);
     FastxRec rec;
-    while (r.next(&rec)) add(rec);
-    flush();
+    while (!(stop && stop->load(std::memory_order_relaxed)) && r.next(&rec)) add(rec);
+    if (!(stop && stop->load(std::memory_order_relaxed))) flush();
   }
   return n;
 }
@@ -329,13 +338,15 @@ static uint64_t read_single_end(const std::string& file, size_t batch_reads, siz
 template <class Emit>
 static uint64_t read_paired(const std::string& file1, const std::string& file2, size_t batch_reads, size_t max_bases, Emit&& emit) {
   Queue<std::unique_ptr<Batch>> q2(4);
+  // the pairs end with the shorter file (search.go:807-826): whichever reader is still going when the other file is exhausted
+  // stops at its next batch instead of parsing the rest of a file nobody will look at
+  std::atomic<bool> ended{false}, stop2{false};
   std::thread mate_reader([&] {
-    read_single_end(file2, batch_reads, std::max<size_t>(1, max_bases / 2), [&](std::unique_ptr<Batch> b) { q2.push(std::move(b)); });
+    read_single_end(file2, batch_reads, std::max<size_t>(1, max_bases / 2), [&](std::unique_ptr<Batch> b) { q2.push(std::move(b)); }, &stop2);
     q2.close();
   });
   std::unique_ptr<Batch> cur;  // the batch of read 2 being consumed
   size_t ci = 0;               // records of it already handed out
-  bool ended = false;          // read 2 is exhausted: whatever read 1 still holds is ignored
   uint64_t n = 0;
   read_single_end(file1, batch_reads, std::max<size_t>(1, max_bases / 2), [&](std::unique_ptr<Batch> b) {
     if (ended) return;
@@ -375,8 +386,9 @@ static uint64_t read_paired(const std::string& file1, const std::string& file2, 
     if (have == 0) return;
     n += have;
     emit(std::move(b));
-  });
-  while (q2.pop(&cur)) {}  // read 1 ended first: let the mates' thread finish
+  }, &ended);
+  stop2 = true;            // read 1 ended first (or both did): the mates' thread stops at its next batch
+  while (q2.pop(&cur)) {}  // ... and is not left blocked on a full queue
   mate_reader.join();
   return n;
 }
@@ -772,6 +784,7 @@ int main(int argc, char** argv) {
 
   if (verbose) info("loading database into GPU memory ...");
   kmcpg_db* db = nullptr;
+  int32_t paged_passes = 0;
   if (o.gpu_ids.empty() && o.gpus > 1)
     for (int i = 0; i < o.gpus; i++) o.gpu_ids.push_back(i);
   if (!o.gpu_ids.empty()) {  // one process, several GPUs: blocks partitioned over the devices, hits merged on the host
@@ -779,7 +792,20 @@ int main(int argc, char** argv) {
       die("open kmcp db: %s: %s", db_dirs[0].c_str(), kmcpg_last_error());
   } else {
     kmcpg_opts gopts{o.device, 0, 1, 0};
-    if (kmcpg_open(db_dirs[0].c_str(), &gopts, &db) != 0) die("open kmcp db: %s: %s", db_dirs[0].c_str(), kmcpg_last_error());
+    int rc = o.gpu_passes >= 0 ? KMCPG_ENOMEM : kmcpg_open(db_dirs[0].c_str(), &gopts, &db);
+    if (rc == KMCPG_ENOMEM) {
+      // the index is larger than the GPU's memory (or --gpu-passes asks for it): one part of it resident at a time, every batch
+      // searched against all parts in turn (the reference's counterpart: mmap / --low-mem, search.go:80)
+      if (o.gpu_passes < 0) warn("%s", kmcpg_last_error());
+      if (kmcpg_open_paged(db_dirs[0].c_str(), o.device, std::max(0, o.gpu_passes), &db) != 0) die("open kmcp db: %s: %s", db_dirs[0].c_str(), kmcpg_last_error());
+      int32_t passes = 0;
+      kmcpg_paged_info(db, &passes, nullptr);
+      paged_passes = passes;
+      if (passes > 1) {
+        if (!o.batch_given) o.batch = 4 << 20;  // a batch costs passes - 1 uploads of index parts: large batches keep their share small
+        warn("the index is searched in %d passes per batch of %d queries (one part resident in GPU memory at a time); more GPUs (--gpus) avoid this", passes, o.batch);
+      }
+    } else if (rc != 0) die("open kmcp db: %s: %s", db_dirs[0].c_str(), kmcpg_last_error());
   }
   kmcpg_info dbi;
   kmcpg_db_info(db, &dbi);
@@ -835,7 +861,8 @@ int main(int argc, char** argv) {
 
   Queue<std::unique_ptr<Batch>> q_in(3), q_out(3);
   uint64_t total = 0, matched = 0;
-  const size_t max_bases = 64u << 20;  // a batch also closes at 64 Mbases (long queries)
+  // a batch also closes at 64 Mbases (long queries); paged indexes want the largest batches the host can hold
+  const size_t max_bases = paged_passes > 1 ? std::min<size_t>((size_t)o.batch * 512, (size_t)2 << 30) : (size_t)64 << 20;
 
   double t_reader_blocked = 0, t_reader_total = 0;  // the reader thread: waiting for a free queue slot / its whole life
   std::thread reader([&] {

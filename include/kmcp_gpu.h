@@ -123,6 +123,17 @@ int kmcpg_open(const char* db_dir, const kmcpg_opts* opts, kmcpg_db** out);
  * kmcpg_search_batch fans every batch out to all of them from one host thread per GPU and merges the hit lists on the
  * host.  kmcpg_query_device is not available on such a handle. */
 int kmcpg_open_devices(const char* db_dir, const int32_t* devices, int32_t n_devices, kmcpg_db** out);
+/* A database LARGER than the HBM at hand, on one GPU (the reference searches any size through mmap / --low-mem,
+ * util-db-search.go:1238-1280, :6975-7335; search.go:80): the index is cut into `passes` shards (the byte-balanced partition of
+ * kmcpg_open with shard_count = passes; 0 = as few as fit the free HBM of `device`), and kmcpg_search_batch / kmcpg_submit
+ * search every batch against one resident shard after the other — upload shard, K1 + K2, keep the hit tuples, next shard —
+ * then finalize the concatenated hit lists once: results are those of a resident database.  The search of a batch runs inside
+ * kmcpg_submit on such a handle (it blocks); the shard searched last stays resident for the next batch, so a batch costs
+ * passes - 1 uploads (11-44 GB/s from the page cache): use large batches.  If the index fits (1 pass) this is kmcpg_open.
+ * kmcpg_open itself reports an index that does not fit with KMCPG_ENOMEM and the bytes needed / free in the message. */
+int kmcpg_open_paged(const char* db_dir, int32_t device, int32_t passes, kmcpg_db** out);
+/* passes of a paged handle (0 for every other handle) and how many shard uploads it has done so far */
+int kmcpg_paged_info(const kmcpg_db* db, int32_t* passes, uint64_t* uploads);
 int kmcpg_close(kmcpg_db* db);
 const char* kmcpg_last_error(void);
 int kmcpg_db_info(const kmcpg_db* db, kmcpg_info* info);
@@ -169,7 +180,10 @@ int kmcpg_wait(kmcpg_ticket* ticket, kmcpg_result* out);
  *    max_read_len must be >= the longest read (mate) of the batch: it sizes the counters.  The call only enqueues work on
  *    `stream` for short-read batches; when a query may exceed 32 768 k-mers — or 2048, in a batch too small to fill the GPU
  *    by itself — it reads 8 bytes back (which queries are long is known only on the device; they may take the chunked form of
- *    the kernel) and therefore synchronises the stream once or twice. */
+ *    the kernel) and therefore synchronises the stream once or twice.
+ *    The hit list depends on params->min_qcov, min_matched AND max_fpr (see kmcpg_hit: counts that cannot pass -f are left out
+ *    on the device): finalize it with the SAME params — a looser max_fpr/min_qcov in kmcpg_finalize cannot bring back what
+ *    the GPU already dropped (a stricter one is fine, kmcpg_finalize applies every threshold again). */
 int kmcpg_query_device(kmcpg_db* db, const uint8_t* d_seqs, const uint64_t* d_offs, const uint8_t* d_seqs2,
                        const uint64_t* d_offs2, uint32_t n_reads, uint64_t total_bases, uint32_t max_read_len,
                        const kmcpg_params* params, kmcpg_hit* d_hits, uint64_t hit_cap, uint64_t* d_counters,
@@ -177,7 +191,9 @@ int kmcpg_query_device(kmcpg_db* db, const uint8_t* d_seqs, const uint64_t* d_of
 
 /* -- the host half: thresholds that need float64/FPR (util-db-search.go:7471-7489), Match values,
  *    sorting, --keep-top-scores.  `hits` may be the concatenation of the hit lists of all shards
- *    (any order).  Every rank knows every column's metadata, so this can run on the gathering rank. */
+ *    (any order).  Every rank knows every column's metadata, so this can run on the gathering rank.
+ *    `params` must not be looser (max_fpr, min_qcov, min_matched) than the ones the hits were produced with by
+ *    kmcpg_query_device, which already filters on them. */
 int kmcpg_finalize(const kmcpg_db* db, const kmcpg_hit* hits, uint64_t n_hits, const int32_t* qkmers,
                    const int32_t* qlen, uint32_t n_reads, const kmcpg_params* params, kmcpg_result* out);
 

@@ -119,15 +119,52 @@ void form_groups(kmcpg_db* db) {
   }
 }
 
+// HBM this process may still take on the current device.  KMCPG_HBM_LIMIT_MB caps it (tests of the larger-than-HBM path; a
+// host that shares the GPU).
+uint64_t hbm_free_bytes() {
+  size_t free_b = 0, total_b = 0;
+  if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) {
+    (void)hipGetLastError();
+    return 0;
+  }
+  uint64_t f = free_b;
+  if (const char* e = getenv("KMCPG_HBM_LIMIT_MB")) f = std::min<uint64_t>(f, (uint64_t)std::max(0ll, atoll(e)) << 20);
+  return f;
+}
+
+// what this rank's blocks take in HBM with the layout form_groups chose, plus what the query path needs beside them
+// (k-mer workspace, lanes, hit buffers of the first batches)
+uint64_t resident_bytes(const kmcpg_db* db) {
+  uint64_t need = 0;
+  for (const auto& G : db->groups) need += (G.num_sigs + 1) * (uint64_t)G.stride;
+  return need;
+}
+uint64_t workspace_reserve() {
+  if (const char* e = getenv("KMCPG_WORKSPACE_RESERVE_MB")) return (uint64_t)std::max(0ll, atoll(e)) << 20;
+  return 1ull << 30;
+}
+
 // rows of every group: zero-filled (row padding, the all-zero row at index NumSigs, the target of the OR-ing repack)
 int alloc_groups(kmcpg_db* db) {
+  // The reference searches a database of any size through mmap / --low-mem (util-db-search.go:1238-1280, :6975-7335); here the
+  // local blocks must be resident.  Say so with numbers before the first allocation fails half-way: the caller can then split
+  // the index over more GPUs (shard_count) or search it in passes (kmcpg_open_paged).
+  const uint64_t need = resident_bytes(db), free_b = hbm_free_bytes(), kWorkspaceReserve = workspace_reserve();
+  if (need + kWorkspaceReserve > free_b)
+    return kmcpg_fail(KMCPG_ENOMEM, "index does not fit in HBM: shard %d/%d needs %.2f GB for its %zu block group(s) + %.1f GB of workspace, %.2f GB free on device %d "
+                      "(more GPUs: kmcpg_open_devices / --gpus; one GPU: kmcpg_open_paged / --gpu-passes)",
+                      db->opts.shard_rank, db->opts.shard_count, need / 1e9, db->groups.size(), kWorkspaceReserve / 1e9, free_b / 1e9, db->opts.device);
   for (auto& G : db->groups) {
     // the kernel addresses rows in 16-byte units with 32 bits
     if ((G.num_sigs + 1) * (uint64_t)(G.stride >> 4) > 0xffffffffULL)
       return kmcpg_fail(KMCPG_EUNSUPPORTED, "%s: block larger than 64 GB in HBM (NumSigs %llu x %u B)", db->blocks[(size_t)G.members[0]].path.c_str(),
                         (unsigned long long)G.num_sigs, G.stride);
     const uint64_t bytes = (G.num_sigs + 1) * (uint64_t)G.stride;
-    HIPCHK(hipMalloc((void**)&G.d_rows, bytes));
+    if (hipError_t e = hipMalloc((void**)&G.d_rows, bytes); e != hipSuccess) {
+      (void)hipGetLastError();
+      return kmcpg_fail(e == hipErrorOutOfMemory ? KMCPG_ENOMEM : KMCPG_EDEVICE, "hipMalloc of %.2f GB for the rows of %s failed: %s", bytes / 1e9,
+                        db->blocks[(size_t)G.members[0]].path.c_str(), hipGetErrorString(e));
+    }
     HIPCHK(hipMemsetAsync(G.d_rows, 0, bytes, nullptr));
     for (int m : G.members) db->blocks[(size_t)m].d_rows = G.d_rows + db->blocks[(size_t)m].byte_off;
   }
@@ -354,6 +391,39 @@ int check_opts(const kmcpg_opts* o, kmcpg_opts* out) {
 
 }  // namespace
 
+namespace kmcpg {
+// Passes a paged handle needs (kmcpg_open_paged): the smallest number S of shards (same byte-balanced partition as
+// kmcpg_open with shard_count = S) whose largest shard fits the free HBM of `device` next to the workspace.  `front` is a
+// metadata-only handle of the whole database; its own partition is restored before returning.  0 = not even one block fits.
+int plan_passes(kmcpg_db* front, int device, uint64_t* largest_shard_bytes, uint64_t* free_bytes) {
+  if (hipSetDevice(device) != hipSuccess) return 0;
+  // a paged handle lives on large batches (every batch pays passes - 1 uploads): room for the k-mer workspace of a few million
+  // reads (8-25 B per base) is kept free beside the resident shard
+  const uint64_t free_b = hbm_free_bytes();
+  const uint64_t reserve = getenv("KMCPG_WORKSPACE_RESERVE_MB") ? workspace_reserve() : std::max<uint64_t>(workspace_reserve(), std::min<uint64_t>(free_b / 8, 24ull << 30));
+  if (free_bytes) *free_bytes = free_b;
+  const kmcpg_opts keep = front->opts;
+  int found = 0;
+  const int nb = (int)front->blocks.size();
+  for (int S = 1; S <= std::max(1, nb) && !found; S++) {
+    uint64_t worst = 0;
+    for (int r = 0; r < S; r++) {
+      front->opts.shard_count = S;
+      front->opts.shard_rank = r;
+      assign_shards(front);
+      form_groups(front);
+      worst = std::max(worst, resident_bytes(front));
+    }
+    if (largest_shard_bytes) *largest_shard_bytes = worst;
+    if (worst + reserve <= free_b) found = S;
+  }
+  front->opts = keep;
+  assign_shards(front);
+  form_groups(front);
+  return found;
+}
+}  // namespace kmcpg
+
 extern "C" int kmcpg_open(const char* db_dir, const kmcpg_opts* opts, kmcpg_db** out) {
   if (!db_dir || !out) return kmcpg_fail(KMCPG_EINVAL, "null argument");
   *out = nullptr;
@@ -363,6 +433,7 @@ extern "C" int kmcpg_open(const char* db_dir, const kmcpg_opts* opts, kmcpg_db**
   const bool meta_only = db->opts.device < 0;
   if (!meta_only) HIPCHK(hipSetDevice(db->opts.device));
   const std::string dir(db_dir);
+  db->db_dir = dir;
   DbYml y;
   std::string e = read_db_yml(dir + "/__db.yml", &y);
   if (!e.empty()) return kmcpg_fail(e.find("open") != std::string::npos ? KMCPG_EIO : KMCPG_EFORMAT, "%s", e.c_str());
@@ -489,6 +560,8 @@ extern "C" int kmcpg_close(kmcpg_db* db) {
   if (int n = kmcpg::async_in_flight(db)) return kmcpg_fail(KMCPG_EBUSY, "%d batch(es) still between kmcpg_submit and kmcpg_wait: wait for every ticket before closing", n);
   for (kmcpg_db* sh : db->shards) kmcpg_close(sh);
   db->shards.clear();
+  if (db->paged_resident) kmcpg_close(db->paged_resident);
+  db->paged_resident = nullptr;
   if (db->opts.device >= 0) (void)hipSetDevice(db->opts.device);
   for (auto& G : db->groups)
     if (G.d_rows) (void)hipFree(G.d_rows);
@@ -508,7 +581,7 @@ extern "C" int kmcpg_close(kmcpg_db* db) {
   db->w_huge_info.release();
   db->w_huge_temp.release();
   db->w_gathered.release();
-  db->w_cmin_fpr.release();
+  kmcpg::release_fpr_bounds(db);
   kmcpg::async_release(db);
   if (db->ws_ev) (void)hipEventDestroy(db->ws_ev);
   for (auto& ev : db->ev)

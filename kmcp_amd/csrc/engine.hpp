@@ -84,6 +84,15 @@ struct DevBuf {
 }  // namespace kmcpg
 
 namespace kmcpg {
+// smallest count whose FPR(n, count) passes -f, for n = 0..n (query.cpp fpr_bound); h = pinned source of the upload
+struct FprBoundTable {
+  uint64_t key = 0;  // bits of max_fpr
+  int n = 0;
+  uint16_t* d = nullptr;
+  uint16_t* h = nullptr;
+};
+void release_fpr_bounds(kmcpg_db* db);  // query.cpp
+int plan_passes(kmcpg_db* front, int device, uint64_t* largest_shard_bytes, uint64_t* free_bytes);  // engine.cpp
 struct AsyncState;
 void async_release(kmcpg_db* db);  // host.cpp
 int async_in_flight(kmcpg_db* db);
@@ -121,12 +130,18 @@ struct kmcpg_db {
   bool synthetic = false;
   // in-process multi-GPU front handle (kmcpg_open_devices): metadata only itself, one resident shard handle per device
   std::vector<kmcpg_db*> shards;
+  // paged handle (kmcpg_open_paged): metadata only itself; every batch is searched against the index one shard at a time
+  // (paged_passes shards, the same partition kmcpg_open makes for shard_count = paged_passes); the shard searched last stays
+  // resident and is the first one of the next batch
+  std::string db_dir;
+  int paged_passes = 0, paged_device = 0, paged_rank = -1;
+  kmcpg_db* paged_resident = nullptr;
+  std::mutex paged_mu;
+  uint64_t paged_uploads = 0;  // shards made resident so far (tests / logs)
   // optional HIP-event timing of the last kmcpg_query_device call
   int profiling = 0;  // 1: HIP-event timing of the kernels; 2: + count the row loads k2_cobs issues
   kmcpg::DevBuf<uint64_t> w_gathered;
-  kmcpg::DevBuf<uint16_t> w_cmin_fpr;  // device copy of the -f bound table (query.cpp fpr_bound)
-  std::vector<uint16_t> h_cmin_fpr;
-  uint64_t cmin_fpr_key = ~0ull;       // bits of the max_fpr the table was built for
+  std::vector<kmcpg::FprBoundTable> fpr_bounds;  // -f bound tables (query.cpp fpr_bound): one per (max_fpr, size), never rewritten
   hipEvent_t ev[12] = {};   // ring of 4 calls x (start, k-mers done, COBS done)
   uint64_t ev_calls = 0;    // profiled calls so far
 };

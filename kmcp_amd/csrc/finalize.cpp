@@ -7,11 +7,14 @@
 #include <errno.h>
 #include <fcntl.h>
 #include <string.h>
+#include <sched.h>
 #include <unistd.h>
 
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
+#include <functional>
 #include <memory>
 #include <mutex>
 #include <string>
@@ -82,6 +85,130 @@ struct SortKey {
   uint32_t col, idx;
 };
 
+// Host cores this process may use: the affinity mask capped by the cgroup CPU quota (a GPU box shows 256 cores and grants 16).
+unsigned usable_cpus() {
+  unsigned n = std::max(1u, std::thread::hardware_concurrency());
+  cpu_set_t set;
+  if (sched_getaffinity(0, sizeof set, &set) == 0) n = std::max(1, CPU_COUNT(&set));
+  if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+    char q[64];
+    long long period = 0;
+    if (fscanf(f, "%63s %lld", q, &period) == 2 && strcmp(q, "max") != 0 && period > 0) n = std::min<unsigned>(n, (unsigned)std::max(1ll, atoll(q) / period));
+    fclose(f);
+  } else {
+    long long quota = -1, period = 0;
+    if (FILE* g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) {
+      if (fscanf(g, "%lld", &quota) != 1) quota = -1;
+      fclose(g);
+    }
+    if (FILE* g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) {
+      if (fscanf(g, "%lld", &period) != 1) period = 0;
+      fclose(g);
+    }
+    if (quota > 0 && period > 0) n = std::min<unsigned>(n, (unsigned)std::max(1ll, quota / period));
+  }
+  return n;
+}
+
+// The workers of kmcpg_finalize: ONE set of threads per process, alive for its lifetime.  kmcpg_finalize is called from every
+// waiter at once (the CLI's searcher threads, the shim's flushers) and has three parallel phases per call; starting fresh
+// threads for each of them oversubscribed the host (16 new threads x 3 phases x every concurrent caller) and threw away the
+// workers' thread-local scratch vectors with every call.  Here a call posts a job (a range of indices), the pool's threads and
+// the caller itself take indices until none is left; concurrent callers share the same threads, so the number of runnable
+// finalize threads stays at the pool size plus the callers whatever the load.
+class WorkerPool {
+ public:
+  static WorkerPool& get() {
+    static WorkerPool* p = new WorkerPool();  // never destroyed: its threads may outlive static destructors at exit
+    return *p;
+  }
+  int width() const { return (int)threads_ + 1; }
+  template <class F>
+  void parallel_for(int n, F&& fn) {
+    if (n <= 0) return;
+    if (n == 1 || threads_ == 0) {
+      for (int i = 0; i < n; i++) fn(i);
+      return;
+    }
+    Job job;
+    job.n = n;
+    job.fn = [&fn](int i) { fn(i); };
+    {
+      std::lock_guard<std::mutex> g(mu_);
+      jobs_.push_back(&job);
+    }
+    cv_.notify_all();
+    work(&job);  // the caller takes indices too
+    {
+      std::lock_guard<std::mutex> g(mu_);  // nobody new may pick the job up
+      jobs_.erase(std::remove(jobs_.begin(), jobs_.end(), &job), jobs_.end());
+    }
+    std::unique_lock<std::mutex> lk(job.mu);
+    job.cv.wait(lk, [&] { return job.done == job.n && job.refs == 0; });
+  }
+
+ private:
+  struct Job {
+    int n = 0;
+    std::function<void(int)> fn;
+    std::atomic<int> next{0};
+    std::mutex mu;
+    std::condition_variable cv;
+    int done = 0, refs = 0;  // under mu
+  };
+  WorkerPool() {
+    unsigned t = std::min(16u, usable_cpus());
+    if (const char* e = getenv("KMCPG_FINALIZE_POOL")) t = (unsigned)std::max(1, std::min(atoi(e), 64));
+    threads_ = t > 1 ? t - 1 : 0;
+    for (unsigned i = 0; i < threads_; i++) std::thread([this] { loop(); }).detach();
+  }
+  void work(Job* j) {
+    int did = 0;
+    for (;;) {
+      const int i = j->next.fetch_add(1);
+      if (i >= j->n) break;
+      j->fn(i);
+      did++;
+    }
+    if (did) {
+      std::lock_guard<std::mutex> g(j->mu);
+      j->done += did;
+      if (j->done == j->n) j->cv.notify_all();
+    }
+  }
+  void loop() {
+    std::unique_lock<std::mutex> lk(mu_);
+    for (;;) {
+      Job* j = nullptr;
+      for (Job* c : jobs_)
+        if (c->next.load() < c->n) {
+          j = c;
+          break;
+        }
+      if (!j) {
+        cv_.wait(lk);
+        continue;
+      }
+      {
+        std::lock_guard<std::mutex> g(j->mu);
+        j->refs++;
+      }
+      lk.unlock();
+      work(j);
+      {
+        std::lock_guard<std::mutex> g(j->mu);
+        j->refs--;
+        j->cv.notify_all();  // last touch of the job: its owner may destroy it once we let go of j->mu
+      }
+      lk.lock();
+    }
+  }
+  std::mutex mu_;
+  std::condition_variable cv_;
+  std::vector<Job*> jobs_;
+  unsigned threads_ = 0;
+};
+
 }  // namespace
 
 extern "C" int kmcpg_finalize(const kmcpg_db* db, const kmcpg_hit* hits, uint64_t n_hits, const int32_t* qkmers, const int32_t* qlen, uint32_t n_reads,
@@ -104,7 +231,8 @@ extern "C" int kmcpg_finalize(const kmcpg_db* db, const kmcpg_hit* hits, uint64_
   //     range's first hit on; the gaps the filters leave are closed afterwards.
   static thread_local std::vector<kmcpg_hit, NoInitAlloc<kmcpg_hit>> parted;
   static thread_local std::vector<uint64_t> per_read;
-  const uint64_t w_cap = std::max(8u, std::min(16u, std::thread::hardware_concurrency()));
+  WorkerPool& pool = WorkerPool::get();
+  const uint64_t w_cap = (uint64_t)pool.width();
   int W = (int)std::max<uint64_t>(1, std::min<uint64_t>(w_cap, n_hits / 32768));
   if ((uint64_t)W > n_reads) W = n_reads ? (int)n_reads : 1;
   if (const char* e = getenv("KMCPG_FINALIZE_THREADS")) W = std::max(1, std::min(atoi(e), 64));
@@ -119,16 +247,7 @@ extern "C" int kmcpg_finalize(const kmcpg_db* db, const kmcpg_hit* hits, uint64_
   o->matches.resize(n_hits);
   std::vector<uint64_t> cnt((size_t)W * W, 0);  // cnt[slice a][range b]
   std::atomic<int> bad{0};
-  auto run = [&](auto&& fn) {
-    if (W == 1) {
-      fn(0);
-      return;
-    }
-    std::vector<std::thread> th;
-    for (int w = 1; w < W; w++) th.emplace_back(fn, w);
-    fn(0);
-    for (auto& t : th) t.join();
-  };
+  auto run = [&](auto&& fn) { pool.parallel_for(W, fn); };  // W pieces of work on the process-wide workers (+ this thread)
   auto slice = [&](int a, uint64_t* lo, uint64_t* hi) {
     *lo = n_hits * (uint64_t)a / (uint64_t)W;
     *hi = n_hits * (uint64_t)(a + 1) / (uint64_t)W;

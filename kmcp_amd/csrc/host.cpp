@@ -92,6 +92,7 @@ struct AsyncState {
   hipStream_t copy_stream = nullptr;  // late D2H of a finished batch's hits: must not queue behind the kernels of later batches
   hipStream_t up_stream = nullptr;    // H2D of a batch's reads, beside the kernels of the batches before it
   std::atomic<uint64_t> hits_hint{0};  // hits per 1024 reads seen lately: sizes the hit buffers and the eager D2H of the next batches
+  uint64_t lane_hit_budget = 0;        // entries a lane's device hit buffer may grow to beyond the plain size (from free HBM at first use)
   std::vector<std::unique_ptr<Lane>> lanes;
   size_t max_lanes = 4;
   std::mutex mu;
@@ -138,6 +139,15 @@ struct kmcpg_ticket {
   uint32_t n = 0;
   bool paired = false;
   kmcpg_params p{};
+  // the batch as staged (retries re-read it): the first lane's pinned copy, or — paged handles — the ticket's own
+  const uint8_t* S[2] = {nullptr, nullptr};
+  const uint64_t* O[2] = {nullptr, nullptr};
+  // paged handles (kmcpg_open_paged): the search ran inside kmcpg_submit, one resident shard after the other; results wait here
+  bool paged = false;
+  std::vector<uint8_t> seqs, seqs2;
+  std::vector<uint64_t> offs, offs2;
+  std::vector<kmcpg_hit, NoInitAlloc<kmcpg_hit>> hits;
+  std::vector<int32_t> qk, ql;
 };
 
 namespace {
@@ -152,6 +162,14 @@ int async_state(kmcpg_db* db, AsyncState** out) {
     HIPCHK(hipStreamCreateWithFlags(&a->copy_stream, hipStreamNonBlocking));
     HIPCHK(hipStreamCreateWithFlags(&a->up_stream, hipStreamNonBlocking));
     if (const char* e = getenv("KMCPG_INFLIGHT")) a->max_lanes = (size_t)std::max(1, std::min(atoi(e), 16));
+    // Hit buffers follow the data (a database full of close relatives returns hundreds of hits per read) but must never crowd
+    // out the k-mer workspace next to a large index: all lanes together may take a quarter of what is free now (the index is
+    // resident already), at most 16 GB.
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = 0;
+    uint64_t budget = std::min<uint64_t>(free_b / 4, 16ull << 30);
+    if (const char* e = getenv("KMCPG_HIT_BUDGET_MB")) budget = (uint64_t)std::max(0ll, atoll(e)) << 20;
+    a->lane_hit_budget = budget / sizeof(kmcpg_hit) / (a->max_lanes + 1);
     db->async = a.release();
   }
   *out = db->async;
@@ -262,7 +280,12 @@ int enqueue(kmcpg_db* db, AsyncState* A, Lane* L, const kmcpg_params& p) {
   // read: a burst of hit-heavy queries must not make every later batch drag gigabytes over PCIe.
   const uint64_t expect = std::min<uint64_t>(A->hits_hint.load() * (uint64_t)n / 1024, (uint64_t)n * 512);
   const uint64_t base_cap = (uint64_t)n * 8 + 1024;
-  uint64_t cap = std::max<uint64_t>(L->d_hits.cap, std::max<uint64_t>(base_cap, expect + expect / 2));
+  // what this batch should have: the recent hit rate + 50 %, within the lane's share of the handle's hit-buffer budget
+  const uint64_t want = std::max<uint64_t>(base_cap, std::min<uint64_t>(expect + expect / 2, std::max<uint64_t>(base_cap, A->lane_hit_budget)));
+  // a buffer left over from a burst of hit-heavy batches goes back once the data has calmed down (hits_hint decays by 1/8 per
+  // batch): HBM pinned for the life of the handle is HBM the workspace of a later, larger batch may need
+  if (L->d_hits.cap > 4 * want && L->d_hits.cap > (1u << 20)) L->d_hits.release();
+  uint64_t cap = std::max<uint64_t>(L->d_hits.cap, want);
   if (L->d_seqs.ensure(L->tb1 + 16) || L->d_offs.ensure((size_t)n + 1) || L->d_cnt.ensure(2) || L->d_qk.ensure(n) || L->d_ql.ensure(n) ||
       (L->paired && (L->d_seqs2.ensure(L->tb2 + 16) || L->d_offs2.ensure((size_t)n + 1))))
     return kmcpg_fail(KMCPG_ENOMEM, "hipMalloc failed");
@@ -285,6 +308,22 @@ int enqueue(kmcpg_db* db, AsyncState* A, Lane* L, const kmcpg_params& p) {
   HIPCHK(hipEventRecord(L->uploaded, up));
   HIPCHK(hipStreamWaitEvent(st, L->uploaded, 0));
   int rc = enqueue_query(db, A, L, p);
+  if (rc == KMCPG_ENOMEM) {
+    // the shared workspace (hashes, dedup scratch, long-query counters) did not fit: hit buffers above the plain size are the
+    // one thing on this handle that can give memory back — those of the idle lanes and this lane's own — then once more
+    (void)hipGetLastError();
+    {
+      std::lock_guard<std::mutex> g(A->mu);
+      for (auto& l : A->lanes)
+        if (!l->busy && l.get() != L && l->d_hits.cap > 0) l->d_hits.release();
+    }
+    if (L->d_hits.cap > base_cap + base_cap / 8 + 64) {
+      HIPCHK(hipStreamSynchronize(st));  // kernels of the failed attempt may have been enqueued with the old buffer
+      L->d_hits.release();
+      if (L->d_hits.ensure(base_cap)) return kmcpg_fail(KMCPG_ENOMEM, "hipMalloc failed");
+    }
+    rc = enqueue_query(db, A, L, p);
+  }
   if (rc) return rc;
   HIPCHK(hipMemcpyAsync(L->h_qk.p, L->d_qk.p, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, st));
   HIPCHK(hipMemcpyAsync(L->h_ql.p, L->d_ql.p, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, st));
@@ -346,6 +385,77 @@ void drop_ticket(kmcpg_ticket* t, bool failed = false) {
   delete t;
 }
 
+// A database larger than the HBM at hand (the reference reads any size through mmap / --low-mem, util-db-search.go:1238-1280,
+// :6975-7335): the batch is searched against one shard of the index after the other on the same GPU — make shard r resident
+// (kmcpg_open with shard r of S), K1 + K2, keep the hit tuples, drop it, next shard — and the concatenated hit lists are
+// finalized once, exactly as the lists of S GPUs would be.  The shard searched last stays resident and is the first one of
+// the next batch, so a batch costs S - 1 uploads: the larger the batch, the smaller their share.
+int search_paged(kmcpg_db* front, const uint8_t* seqs, const uint64_t* offs, const uint8_t* seqs2, const uint64_t* offs2, uint32_t n, const kmcpg_params& p,
+                 kmcpg_ticket* t) {
+  std::lock_guard<std::mutex> g(front->paged_mu);
+  t->paged = true;
+  t->hits.clear();
+  t->qk.assign(n, 0);
+  t->ql.assign(n, 0);
+  if (n == 0) return 0;
+  if (offs[0] != 0 || (seqs2 && offs2[0] != 0)) return kmcpg_fail(KMCPG_EINVAL, "offs[0] must be 0");
+  for (uint32_t i = 0; i < n; i++)
+    if (offs[i + 1] < offs[i] || (seqs2 && offs2[i + 1] < offs2[i])) return kmcpg_fail(KMCPG_EINVAL, "offsets must not decrease (read %u)", i);
+  // retries (--try-se, smaller k) read the batch again after kmcpg_submit has returned the caller's buffers
+  t->seqs.assign(seqs, seqs + offs[n]);
+  t->offs.assign(offs, offs + n + 1);
+  if (seqs2) {
+    t->seqs2.assign(seqs2, seqs2 + offs2[n]);
+    t->offs2.assign(offs2, offs2 + n + 1);
+  }
+  t->S[0] = t->seqs.data();
+  t->O[0] = t->offs.data();
+  t->S[1] = seqs2 ? t->seqs2.data() : nullptr;
+  t->O[1] = seqs2 ? t->offs2.data() : nullptr;
+  const int S = front->paged_passes;
+  const int first = front->paged_rank >= 0 ? front->paged_rank : 0;
+  for (int i = 0; i < S; i++) {
+    const int r = (first + i) % S;
+    if (!front->paged_resident || front->paged_rank != r) {
+      if (front->paged_resident) {
+        int rc = kmcpg_close(front->paged_resident);
+        front->paged_resident = nullptr;
+        front->paged_rank = -1;
+        if (rc) return rc;
+      }
+      kmcpg_opts so{front->paged_device, r, S, 0};
+      kmcpg_db* sh = nullptr;
+      int rc = kmcpg_open(front->db_dir.c_str(), &so, &sh);
+      if (rc) return kmcpg_fail(rc, "pass %d of %d: %s", r + 1, S, std::string(kmcpg_err_ref()).c_str());
+      front->paged_resident = sh;
+      front->paged_rank = r;
+      front->paged_uploads++;
+    }
+    kmcpg_db* sh = front->paged_resident;
+    if (sh->info.n_blocks_local == 0) continue;
+    AsyncState* A = nullptr;
+    int rc = async_state(sh, &A);
+    if (rc) return rc;
+    Lane* L = acquire_lane(A, false, true);
+    uint64_t cnt = 0;
+    rc = stage(L, seqs, offs, seqs2, offs2, n);
+    if (rc == 0) rc = enqueue(sh, A, L, p);
+    if (rc == 0) rc = collect(sh, A, L, p, &cnt);
+    if (rc == 0) {
+      t->hits.insert(t->hits.end(), L->h_hits.p, L->h_hits.p + cnt);
+      if (i == 0) {  // every shard generates the same k-mers
+        memcpy(t->qk.data(), L->h_qk.p, (size_t)n * sizeof(int32_t));
+        memcpy(t->ql.data(), L->h_ql.p, (size_t)n * sizeof(int32_t));
+      }
+    } else {
+      (void)hipStreamSynchronize(A->stream);
+    }
+    release_lane(A, L, false);
+    if (rc) return kmcpg_fail(rc, "pass %d of %d: %s", r + 1, S, std::string(kmcpg_err_ref()).c_str());
+  }
+  return 0;
+}
+
 int submit_impl(kmcpg_db* db, const uint8_t* seqs, const uint64_t* offs, const uint8_t* seqs2, const uint64_t* offs2, uint32_t n, const kmcpg_params& p, bool retry,
                 bool block, kmcpg_ticket** out) {
   std::unique_ptr<kmcpg_ticket> t(new kmcpg_ticket());
@@ -353,6 +463,12 @@ int submit_impl(kmcpg_db* db, const uint8_t* seqs, const uint64_t* offs, const u
   t->n = n;
   t->paired = seqs2 != nullptr;
   t->p = p;
+  if (db->paged_passes > 0) {
+    int rc = search_paged(db, seqs, offs, seqs2, offs2, n, p, t.get());
+    if (rc) return rc;
+    *out = t.release();
+    return 0;
+  }
   std::vector<kmcpg_db*> targets = db->shards.empty() ? std::vector<kmcpg_db*>{db} : db->shards;
   for (kmcpg_db* sh : targets) {
     AsyncState* A = nullptr;
@@ -390,6 +506,11 @@ int submit_impl(kmcpg_db* db, const uint8_t* seqs, const uint64_t* offs, const u
       drop_ticket(t.release(), true);
       return kmcpg_fail(rc, "%s", msg.c_str());
     }
+  Lane* L0 = t->parts[0].lane;
+  t->S[0] = L0->h_seqs.p;
+  t->O[0] = L0->h_offs.p;
+  t->S[1] = t->paired ? L0->h_seqs2.p : nullptr;
+  t->O[1] = t->paired ? L0->h_offs2.p : nullptr;
   *out = t.release();
   return 0;
 }
@@ -400,6 +521,8 @@ int finish_raw(kmcpg_ticket* t, kmcpg_result* out) {
   const kmcpg_hit* hits = nullptr;
   uint64_t n_hits = 0;
   static thread_local std::vector<kmcpg_hit, NoInitAlloc<kmcpg_hit>> merged;
+  if (t->paged)
+    return kmcpg_finalize(t->db, t->hits.data(), t->hits.size(), t->n ? t->qk.data() : nullptr, t->n ? t->ql.data() : nullptr, t->n, &t->p, out);
   if (t->parts.size() == 1) {
     auto& pt = t->parts[0];
     int rc = collect(pt.shard, pt.shard->async, pt.lane, t->p, &n_hits);
@@ -446,9 +569,8 @@ int retry_unmatched(kmcpg_ticket* t, kmcpg_result* out) {
   const bool try_se = p.try_se && t->paired;
   if (n == 0 || (!try_se && ks.size() < 2)) return 0;
   ResultOwner* o = (ResultOwner*)out->owner;
-  Lane* L = t->parts[0].lane;  // the batch as staged
-  const uint8_t* S[2] = {L->h_seqs.p, t->paired ? L->h_seqs2.p : nullptr};
-  const uint64_t* O[2] = {L->h_offs.p, t->paired ? L->h_offs2.p : nullptr};
+  const uint8_t* S[2] = {t->S[0], t->S[1]};  // the batch as staged
+  const uint64_t* O[2] = {t->O[0], t->O[1]};
   std::vector<char> final_(n, 0);
   std::vector<uint32_t> todo;
   std::vector<uint8_t> sub[2];
@@ -567,6 +689,47 @@ extern "C" int kmcpg_open_devices(const char* db_dir, const int32_t* devices, in
   return 0;
 }
 
+extern "C" int kmcpg_open_paged(const char* db_dir, int32_t device, int32_t passes, kmcpg_db** out) {
+  if (!db_dir || !out || passes < 0) return kmcpg_fail(KMCPG_EINVAL, "bad argument");
+  *out = nullptr;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return kmcpg_fail(KMCPG_EDEVICE, "no HIP device available: libkmcpgpu has no CPU fallback");
+  if (device < 0 || device >= ndev) return kmcpg_fail(KMCPG_EINVAL, "device %d out of range (%d devices)", device, ndev);
+  kmcpg_opts mo{-1, 0, 1, 0};
+  kmcpg_db* front = nullptr;
+  int rc = kmcpg_open(db_dir, &mo, &front);  // metadata of every block: names, sizes, FPR table
+  if (rc) return rc;
+  uint64_t largest = 0, free_b = 0;
+  const int fit = plan_passes(front, device, &largest, &free_b);
+  if (passes == 0) passes = fit;
+  if (fit == 0 || passes < fit) {
+    kmcpg_close(front);
+    if (fit == 0)
+      return kmcpg_fail(KMCPG_ENOMEM, "index does not fit in HBM even one block at a time: the largest block needs %.2f GB, %.2f GB free on device %d", largest / 1e9,
+                        free_b / 1e9, device);
+    return kmcpg_fail(KMCPG_ENOMEM, "%d pass(es) do not fit in HBM (%.2f GB free on device %d): at least %d are needed", passes, free_b / 1e9, device, fit);
+  }
+  if (passes > (int)std::max<size_t>(1, front->blocks.size())) passes = (int)std::max<size_t>(1, front->blocks.size());
+  if (passes == 1) {  // it fits after all: an ordinary resident handle
+    kmcpg_close(front);
+    kmcpg_opts so{device, 0, 1, 0};
+    return kmcpg_open(db_dir, &so, out);
+  }
+  front->paged_passes = passes;
+  front->paged_device = device;
+  front->info.n_blocks_local = front->info.n_blocks;
+  front->info.matrix_bytes_local = front->info.matrix_bytes;
+  *out = front;
+  return 0;
+}
+
+extern "C" int kmcpg_paged_info(const kmcpg_db* db, int32_t* passes, uint64_t* uploads) {
+  if (!db) return kmcpg_fail(KMCPG_EINVAL, "null argument");
+  if (passes) *passes = db->paged_passes;
+  if (uploads) *uploads = db->paged_uploads;
+  return 0;
+}
+
 static int submit_checked(kmcpg_db* db, const uint8_t* seqs, const uint64_t* offs, const uint8_t* seqs2, const uint64_t* offs2, uint32_t n_reads,
                           const kmcpg_params* params, bool block, kmcpg_ticket** out) {
   if (!db || !out || (n_reads && (!seqs || !offs))) return kmcpg_fail(KMCPG_EINVAL, "null argument");
@@ -574,7 +737,7 @@ static int submit_checked(kmcpg_db* db, const uint8_t* seqs, const uint64_t* off
   if ((seqs2 == nullptr) != (offs2 == nullptr)) return kmcpg_fail(KMCPG_EINVAL, "seqs2 and offs2 must be given together");
   if (db->opts.shard_count != 1)
     return kmcpg_fail(KMCPG_EINVAL, "kmcpg_submit/kmcpg_search_batch need the whole database: open it on one GPU or with kmcpg_open_devices; use kmcpg_query_device + kmcpg_finalize per shard");
-  if (db->shards.empty() && db->opts.device < 0) return kmcpg_fail(KMCPG_EDEVICE, "metadata-only handle (device -1): no GPU work possible");
+  if (db->shards.empty() && db->opts.device < 0 && db->paged_passes == 0) return kmcpg_fail(KMCPG_EDEVICE, "metadata-only handle (device -1): no GPU work possible");
   const kmcpg_params p = params ? *params : default_params();
   if (p.min_matched < 1) return kmcpg_fail(KMCPG_EINVAL, "min_matched must be >= 1");
   return submit_impl(db, seqs, offs, seqs2, offs2, n_reads, p, false, block, out);

@@ -262,8 +262,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, GR 
     if (!SPLIT && a.prune && __ballot(live) == 0) break;
   }
 
-  if (!live) return;
   if (SPLIT) {
+    if (!live) return;
     // partial counts of this chunk -> the query's count array (consecutive lanes hit consecutive words)
     uint32_t* __restrict__ acc = a.long_counts + (uint64_t)li_long * a.ncols_total;
 #pragma unroll
@@ -278,30 +278,62 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, GR 
     }
     return;
   }
-  if (NPL < 32 && (cmin >> NPL) != 0) return;  // unreachable count
+  // ---- hit emission (:7462-7731 scan of the counters + Match append), wave-aggregated: every lane finds its columns with
+  //      count >= cmin by a bit-sliced compare, the wave reserves room for all of them with ONE atomic on the global counter
+  //      (ballot + prefix sum over the lanes' hit counts) and the lanes write their tuples side by side.  Hits are rare for
+  //      distinct references (~1 per read) but come in runs for a family of close relatives (neighbouring columns = one lane):
+  //      one device-scope atomic per hit serialised the epilogue there.
+  const bool emit = live && !(NPL < 32 && (cmin >> NPL) != 0);  // else: unreachable count / nothing left alive
+  uint32_t ge[4];
+  uint32_t mine = 0;
 #pragma unroll
   for (int d = 0; d < 4; d++) {
-    uint32_t ge = 0xffffffffu;  // bit-sliced (count >= cmin), LSB to MSB
+    uint32_t v = emit ? 0xffffffffu : 0u;  // bit-sliced (count >= cmin), LSB to MSB
 #pragma unroll
-    for (int p = 0; p < NPL; p++) ge = ((cmin >> p) & 1u) ? (ge & pl[d][p]) : (ge | pl[d][p]);
-    while (ge) {
-      const int q = __ffs(ge) - 1;
-      ge &= ge - 1;
+    for (int p = 0; p < NPL; p++) v = ((cmin >> p) & 1u) ? (v & pl[d][p]) : (v | pl[d][p]);
+    // padding bits of a row are zero in the index, so they never reach cmin >= 1; group_col stays as the guard it was
+    uint32_t w = v;
+    while (w) {
+      const int q = __ffs(w) - 1;
+      w &= w - 1;
+      uint32_t col;
+      if (!group_col(a.segs, bd, boff + (uint32_t)d * 4u + (uint32_t)(q >> 3), (uint32_t)(q & 7), &col)) v &= ~(1u << q);
+    }
+    ge[d] = v;
+    mine += (uint32_t)__popc(v);
+  }
+  if (__ballot(mine != 0) == 0) return;  // wave-uniform: the common case
+  uint32_t incl = mine;  // inclusive prefix sum over the wave
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const uint32_t t = __shfl_up(incl, off);
+    if (lane >= off) incl += t;
+  }
+  const uint32_t total = __shfl(incl, 63);
+  unsigned long long base_idx = 0;
+  if (lane == 63) base_idx = atomicAdd(a.counter, (unsigned long long)total);
+  base_idx = __shfl(base_idx, 63);
+  unsigned long long idx = base_idx + (incl - mine);
+#pragma unroll
+  for (int d = 0; d < 4; d++) {
+    uint32_t w = ge[d];
+    while (w) {
+      const int q = __ffs(w) - 1;
+      w &= w - 1;
       uint32_t count = 0;
 #pragma unroll
       for (int p = 0; p < NPL; p++) count |= ((pl[d][p] >> q) & 1u) << p;
       // byte (q>>3) of this dword, bit (q&7): bit 7 = first column of the byte (index.go:1157)
-      uint32_t col;
-      if (group_col(a.segs, bd, boff + (uint32_t)d * 4u + (uint32_t)(q >> 3), (uint32_t)(q & 7), &col)) {
-        const unsigned long long idx = atomicAdd(a.counter, 1ULL);
-        if (idx < a.hit_cap) {
-          kmcpg_hit hit;
-          hit.read = r;
-          hit.col = col;
-          hit.count = count;
-          a.hits[idx] = hit;
-        }
+      uint32_t col = 0;
+      (void)group_col(a.segs, bd, boff + (uint32_t)d * 4u + (uint32_t)(q >> 3), (uint32_t)(q & 7), &col);
+      if (idx < a.hit_cap) {
+        kmcpg_hit hit;
+        hit.read = r;
+        hit.col = col;
+        hit.count = count;
+        a.hits[idx] = hit;
       }
+      idx++;
     }
   }
 }
@@ -406,19 +438,33 @@ void launch_max_nk(const int32_t* nk, uint32_t n_reads, unsigned long long* out,
   hipLaunchKernelGGL(k_max_nk, dim3(blocks), dim3(256), 0, st, nk, n_reads, out);
 }
 
-// threshold over the accumulated counts of the long queries (same integer rule as the k2_cobs epilogue)
+// threshold over the accumulated counts of the long queries (same integer rule as the k2_cobs epilogue); one atomic per wave
+// and pass: the lanes that hold a hit get consecutive places (ballot + popcount of the lower lanes)
 __global__ void k_threshold_long(const K2Args a) {
   const uint64_t total = (uint64_t)a.n_long * a.ncols_total;
-  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (uint64_t)gridDim.x * blockDim.x) {
-    const uint32_t c = a.long_counts[i];
-    if (c == 0) continue;
-    const uint32_t li = (uint32_t)(i / a.ncols_total), col = (uint32_t)(i % a.ncols_total);
-    const uint32_t r = a.long_list[li];
-    const double thr = __dmul_rn((double)a.nk[r], a.min_qcov);
-    uint32_t cmin = (uint32_t)thr + 1u;
-    if (cmin < (uint32_t)a.min_matched) cmin = (uint32_t)a.min_matched;
-    if (c >= cmin) {
-      const unsigned long long idx = atomicAdd(a.counter, 1ULL);
+  const int lane = threadIdx.x & 63;
+  const uint64_t step = (uint64_t)gridDim.x * blockDim.x;
+  for (uint64_t i0 = (uint64_t)blockIdx.x * blockDim.x + (threadIdx.x & ~63u); i0 < total; i0 += step) {  // wave-uniform trip count
+    const uint64_t i = i0 + (uint64_t)lane;
+    uint32_t c = 0, r = 0, col = 0;
+    bool pass = false;
+    if (i < total && (c = a.long_counts[i]) != 0) {
+      const uint32_t li = (uint32_t)(i / a.ncols_total);
+      col = (uint32_t)(i % a.ncols_total);
+      r = a.long_list[li];
+      const double thr = __dmul_rn((double)a.nk[r], a.min_qcov);
+      uint32_t cmin = (uint32_t)thr + 1u;
+      if (cmin < (uint32_t)a.min_matched) cmin = (uint32_t)a.min_matched;
+      pass = c >= cmin;
+    }
+    const uint64_t m = __ballot(pass);
+    if (m == 0) continue;
+    const int leader = __ffsll((unsigned long long)m) - 1;
+    unsigned long long base = 0;
+    if (lane == leader) base = atomicAdd(a.counter, (unsigned long long)__popcll(m));
+    base = __shfl(base, leader);
+    if (pass) {
+      const unsigned long long idx = base + (unsigned long long)__popcll(m & ((1ULL << lane) - 1ULL));
       if (idx < a.hit_cap) {
         kmcpg_hit hit;
         hit.read = r;

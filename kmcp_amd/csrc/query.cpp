@@ -27,6 +27,16 @@
 
 using namespace kmcpg;
 
+namespace kmcpg {
+void release_fpr_bounds(kmcpg_db* db) {
+  for (auto& t : db->fpr_bounds) {
+    if (t.d) (void)hipFree(t.d);
+    if (t.h) (void)hipHostFree(t.h);
+  }
+  db->fpr_bounds.clear();
+}
+}  // namespace kmcpg
+
 // ------------------------------------------------------------------------------------------------
 // GPU half
 // ------------------------------------------------------------------------------------------------
@@ -133,6 +143,22 @@ int ws_end(kmcpg_db* db, hipStream_t st) {
   return 0;
 }
 
+// Every way out of a GPU-half call that has passed ws_begin leaves the event behind, error paths included: kernels that use
+// the workspace may already be on the stream when a later step fails (an allocation, the FPR table, a launch), and the next
+// call — possibly on another stream — must still be ordered behind them.
+struct WsGuard {
+  kmcpg_db* db;
+  hipStream_t st;
+  bool armed = true;
+  ~WsGuard() {
+    if (armed && db->ws_ev && hipEventRecord(db->ws_ev, st) == hipSuccess) db->ws_ev_valid = true;
+  }
+  int finish() {  // the success path: errors of the record are reported
+    armed = false;
+    return ws_end(db, st);
+  }
+};
+
 // The reference drops a column whose FPR(n, count) exceeds -f right where it counts it (util-db-search.go:7474-7478); here
 // that test runs on the host in float64, but the GPU can already leave out every count that cannot pass it: for each
 // NumKmers n <= kFprBoundMaxN the smallest count c with FPR(n, c) <= max_fpr (the very values kmcpg_finalize compares, so a
@@ -154,26 +180,40 @@ int fpr_bound(kmcpg_db* db, double max_fpr, uint64_t max_kmers, hipStream_t st, 
   while (want_n < kFprBoundMaxN && (uint64_t)want_n < max_kmers) want_n *= 2;
   uint64_t key;
   memcpy(&key, &max_fpr, sizeof key);
-  const int have_n = (int)db->h_cmin_fpr.size() - 1;
-  if (key != db->cmin_fpr_key || !db->w_cmin_fpr.p || have_n < want_n) {
-    want_n = std::max(want_n, have_n);
-    QueryFpr* F = db->fpr.get();
-    std::vector<uint16_t> t((size_t)want_n + 1, 0);
-    for (int n = 1; n <= want_n; n++) {
-      const std::vector<double>& row = *F->ensure_row(n);
-      int c = 0;
-      while (c <= n && !(row[(size_t)c] <= max_fpr)) c++;
-      t[(size_t)n] = (uint16_t)c;  // n + 1: no count passes
+  // One immutable table per (-f value, size): kernels of earlier calls may still read theirs, so a table is never rewritten —
+  // another -f value, or a batch with longer queries, gets a table of its own (uploaded from its pinned copy on the caller's
+  // stream: nothing here waits for the GPU, kmcpg_submit stays non-blocking).  Tables live until kmcpg_close.
+  for (const auto& t : db->fpr_bounds)
+    if (t.key == key && t.n >= want_n) {
+      *out = t.d;
+      *out_n = t.n;
+      return 0;
     }
-    // earlier calls' kernels may still read the table in place: wait for them before it is replaced (once per -f value / growth)
-    HIPCHK(hipStreamSynchronize(st));
-    if (db->w_cmin_fpr.ensure(t.size())) return kmcpg_fail(KMCPG_ENOMEM, "hipMalloc failed");
-    HIPCHK(hipMemcpy(db->w_cmin_fpr.p, t.data(), t.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
-    db->h_cmin_fpr.swap(t);
-    db->cmin_fpr_key = key;
+  if (db->fpr_bounds.size() >= 64) {  // a host that sweeps -f: start over once nothing can be reading the old tables
+    HIPCHK(hipDeviceSynchronize());
+    release_fpr_bounds(db);
   }
-  *out = db->w_cmin_fpr.p;
-  *out_n = (int32_t)db->h_cmin_fpr.size() - 1;
+  FprBoundTable t{};
+  t.key = key;
+  t.n = want_n;
+  const size_t bytes = ((size_t)want_n + 1) * sizeof(uint16_t);
+  HIPCHK(hipHostMalloc((void**)&t.h, bytes, hipHostMallocDefault));
+  if (hipMalloc((void**)&t.d, bytes) != hipSuccess) {
+    (void)hipHostFree(t.h);
+    return kmcpg_fail(KMCPG_ENOMEM, "hipMalloc failed");
+  }
+  QueryFpr* F = db->fpr.get();
+  t.h[0] = 0;
+  for (int n = 1; n <= want_n; n++) {
+    const std::vector<double>& row = *F->ensure_row(n);
+    int c = 0;
+    while (c <= n && !(row[(size_t)c] <= max_fpr)) c++;
+    t.h[n] = (uint16_t)c;  // n + 1: no count passes
+  }
+  db->fpr_bounds.push_back(t);
+  HIPCHK(hipMemcpyAsync(t.d, t.h, bytes, hipMemcpyHostToDevice, st));
+  *out = t.d;
+  *out_n = t.n;
   return 0;
 }
 
@@ -189,6 +229,7 @@ extern "C" int kmcpg_kmers_device(kmcpg_db* db, const uint8_t* d_seqs, const uin
   const kmcpg_params p = params ? *params : default_params();
   hipStream_t st = (hipStream_t)stream;
   if (int rc0 = ws_begin(db, st)) return rc0;
+  WsGuard wsg{db, st};
   if (db->w_scratch.ensure(2 * total_bases + 2) || db->w_nk_raw.ensure(n_reads + 1) || db->w_nk1.ensure(n_reads + 1)) return kmcpg_fail(KMCPG_ENOMEM, "hipMalloc failed");
   DevBuf<int32_t> ql;
   if (ql.ensure(n_reads + 1)) return kmcpg_fail(KMCPG_ENOMEM, "hipMalloc failed");
@@ -217,6 +258,7 @@ extern "C" int kmcpg_query_device(kmcpg_db* db, const uint8_t* d_seqs, const uin
   const int k_used = p.k > 0 ? p.k : db->info.k;
   hipStream_t st = (hipStream_t)stream;
   if (int rc0 = ws_begin(db, st)) return rc0;
+  WsGuard wsg{db, st};
   if (db->w_hashes.ensure(total_bases + 1) || db->w_nk_raw.ensure(n_reads + 1) || db->w_nk1.ensure(n_reads + 1)) return kmcpg_fail(KMCPG_ENOMEM, "hipMalloc failed");
   uint64_t ub = max_read_len >= (uint32_t)k_used ? (uint64_t)(max_read_len - k_used + 1) : 0;
   if (d_seqs2) ub *= 2;
@@ -329,7 +371,7 @@ extern "C" int kmcpg_query_device(kmcpg_db* db, const uint8_t* d_seqs, const uin
     HIPCHK(hipEventRecord(pev[2], st));
     db->ev_calls++;
   }
-  if (int rc1 = ws_end(db, st)) return rc1;
+  if (int rc1 = wsg.finish()) return rc1;
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -379,6 +421,7 @@ extern "C" int kmcpg_plant_reads_device(kmcpg_db* db, const uint8_t* d_seqs, con
   KMCPG_USE_DEVICE(db);
   hipStream_t st = (hipStream_t)stream;
   if (int rc0 = ws_begin(db, st)) return rc0;
+  WsGuard wsg{db, st};
   if (db->w_hashes.ensure(total_bases + 1) || db->w_nk_raw.ensure(n_reads + 1) || db->w_nk1.ensure(n_reads + 1)) return kmcpg_fail(KMCPG_ENOMEM, "hipMalloc failed");
   DevBuf<int32_t> tmp;
   if (tmp.ensure(2 * (size_t)n_reads + 2)) return kmcpg_fail(KMCPG_ENOMEM, "hipMalloc failed");

@@ -16,7 +16,7 @@ EXPORTS = [
     "kmcpg_result_free", "kmcpg_query_device", "kmcpg_finalize", "kmcpg_open_synthetic", "kmcpg_plant",
     "kmcpg_read_rows", "kmcpg_block_info", "kmcpg_kmers_device", "kmcpg_plant_reads_device", "kmcpg_set_profiling",
     "kmcpg_last_timing", "kmcpg_open_devices", "kmcpg_build_db", "kmcpg_submit", "kmcpg_wait", "kmcpg_read_row_range", "kmcpg_timing_at", "kmcpg_last_gathered_bytes",
-    "kmcpg_db_ks",
+    "kmcpg_db_ks", "kmcpg_open_paged", "kmcpg_paged_info",
 ]
 
 
@@ -120,6 +120,8 @@ def load():
     L.kmcpg_open.argtypes = [C.c_char_p, C.POINTER(Opts), C.POINTER(vp)]
     L.kmcpg_open_synthetic.argtypes = [C.POINTER(SynthSpec), C.POINTER(Opts), C.POINTER(vp)]
     L.kmcpg_open_devices.argtypes = [C.c_char_p, C.POINTER(C.c_int32), C.c_int32, C.POINTER(vp)]
+    L.kmcpg_open_paged.argtypes = [C.c_char_p, C.c_int32, C.c_int32, C.POINTER(vp)]
+    L.kmcpg_paged_info.argtypes = [vp, i32p, u64p]
     L.kmcpg_close.argtypes = [vp]
     L.kmcpg_db_info.argtypes = [vp, C.POINTER(Info)]
     L.kmcpg_db_ks.argtypes = [vp, i32p, C.c_int32, i32p]
@@ -238,6 +240,19 @@ class Database:
         arr = (C.c_int32 * len(devices))(*devices)
         _check(load().kmcpg_open_devices(os.fsencode(db_dir), arr, len(devices), C.byref(h)))
         return cls(h)
+
+    @classmethod
+    def open_paged(cls, db_dir, device=0, passes=0):
+        """A database larger than the free HBM of one GPU: searched in `passes` shards per batch (0 = as few as fit)."""
+        h = C.c_void_p()
+        _check(load().kmcpg_open_paged(os.fsencode(db_dir), device, passes, C.byref(h)))
+        return cls(h)
+
+    def paged_info(self):
+        """(passes, shard uploads so far); passes == 0 for resident handles"""
+        p, u = C.c_int32(0), C.c_uint64(0)
+        _check(load().kmcpg_paged_info(self._h, C.byref(p), C.byref(u)))
+        return int(p.value), int(u.value)
 
     @classmethod
     def open_synthetic(cls, spec: SynthSpec, device=0, shard_rank=0, shard_count=1):

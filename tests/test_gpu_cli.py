@@ -356,3 +356,41 @@ def test_cli_fpr_column_reproduces_the_reference_tutorial(oracle_lib, tmp_path):
             seen.add(int(f[10]))
     assert seen == set(want_fpr)
     odb.close()
+
+
+def test_kmcp_search_spelling_and_profile_contract(oracle_lib, tmp_path):
+    """`kmcp search ...` (dispatcher, cli/kmcp_dispatch.cpp) and `kmcp-search search ...` print what `kmcp-search ...` prints, and
+    that result read by the rules `kmcp profile` applies to its input (tests/profile_contract.py: util-profile.go:94-182,
+    profile.go:1939-1962) yields the oracle's values."""
+    from tests import profile_contract as PC
+    O = oracle_lib
+    genomes = synth.random_genomes(12, 15000, seed=80)
+    db_dir = synth.make_db(tmp_path / "db", genomes, k=21, n_chunks=3, overlap=150, threads=4, names=[f"GCF_{i:09d}.1" for i in range(12)])
+    db_root = os.path.dirname(db_dir)
+    reads = synth.sample_reads(genomes, 1500, 150, sub_rate=0.02, seed=81, frac_random=0.2)
+    ids = [f"r{i}/1" for i in range(len(reads))]
+    fq = str(tmp_path / "r.fq.gz")
+    write_fastq(fq, ids, reads, gz=True)
+    outs = []
+    for argv in ([CLI], [CLI, "search"], [os.path.join(ROOT, "kmcp_amd", "kmcp"), "search"], [os.path.join(ROOT, "kmcp_amd", "kmcp"), "-q", "-j", "8", "search"]):
+        out = str(tmp_path / f"o{len(outs)}.tsv.gz")
+        r = subprocess.run(argv + ["-d", db_root, fq, "-o", out, "-q"], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, (argv, r.stderr)
+        outs.append(gzip.open(out, "rt").read())
+    assert outs[0] == outs[1] == outs[2] == outs[3]
+    odb = O.OracleDB(db_dir)
+    want, trailer = oracle_tsv(O, odb, ids, reads)
+    compare(outs[0].split("\n"), want, trailer)
+    ms, total, stats = PC.read_search_result(outs[0], max_fpr=0.05, min_qcov=0.55)
+    assert total == len(reads) and stats["matched queries"] == trailer[1].split(": ")[1]
+    # what profile would work with: one record per (query, target chunk) that passes its two filters, values as the oracle has them
+    expect = []
+    for i, r in enumerate(reads):
+        o = odb.search(r)
+        for m in (o["matches"] or []):
+            if float("%.4f" % m["qcov"]) >= 0.55 and float("%.4e" % m["fpr"]) <= 0.05:
+                name, tidx, gsize, _ = odb.col_info(m["col_global"])
+                expect.append((ids[i], o["qlen"], o["qkmers"], len(o["matches"]), name, tidx & 0xffff, tidx >> 16, gsize, 21, m["mkmers"]))
+    got = [(m["query"], m["qlen"], m["qkmers"], m["hits"], m["target"], m["chunk_idx"], m["chunks"], m["gsize"], m["k"], m["mkmers"]) for m in ms]
+    assert got == expect and len(got) > 500
+    odb.close()
