@@ -48,6 +48,13 @@ WORKLOADS = {
     "gtdb_eighth": dict(k=21, num_hashes=1, fpr=0.3, n_blocks=4, cols_per_block=14976, num_sigs=967708, sigs_step=64, kmers_per_col=345510,
                         batch_reads=524288, kernel="k2_cobs<64,8,false>",
                         name="one eighth of the gtdb-scale synthetic index: 4 blocks x 14976 cols (7.25 GB), 150bp k=21"),
+    # ... and what one of 2 / 4 ranks holds (16 / 8 blocks): the per-GPU step at N = 2 and N = 4, measured on one GPU
+    "gtdb_half": dict(k=21, num_hashes=1, fpr=0.3, n_blocks=16, cols_per_block=14976, num_sigs=967708, sigs_step=64, kmers_per_col=345510,
+                      batch_reads=524288, kernel="k2_cobs<64,8,false>",
+                      name="one half of the gtdb-scale synthetic index: 16 blocks x 14976 cols (29 GB), 150bp k=21"),
+    "gtdb_quarter": dict(k=21, num_hashes=1, fpr=0.3, n_blocks=8, cols_per_block=14976, num_sigs=967708, sigs_step=64, kmers_per_col=345510,
+                         batch_reads=524288, kernel="k2_cobs<64,8,false>",
+                         name="one quarter of the gtdb-scale synthetic index: 8 blocks x 14976 cols (14.5 GB), 150bp k=21"),
     # 10 k chunks, `kmcp index -j 32`: 32 blocks x 312 columns, 39-byte rows (BASELINE.json configs[1])
     # (equal-length chunks => the same NumSigs in every block: libkmcpgpu lays them side by side, one 1248-byte gather per k-mer)
     "config1": dict(k=21, num_hashes=1, fpr=0.3, n_blocks=32, cols_per_block=312, num_sigs=1121470, kmers_per_col=400000,
@@ -534,6 +541,11 @@ def run_workload(name, ctx, steps, warmup, batch_reads=0, cpu_baseline=True, cpu
 
 
 def main():
+    # The contract is ONE JSON line on stdout.  Libraries write there too (RCCL prints its version banner to stdout when a
+    # communicator is created): for the duration of the run file descriptor 1 points at stderr, and only the JSON line goes
+    # to the real stdout at the very end.
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
@@ -586,10 +598,17 @@ def main():
         finally:
             os.environ.pop("KMCPG_FUSE", None)
         out["secondary"]["config1_ungrouped"] = {k: unf[k] for k in keys if k in unf}
-    if ctx.rank == 0:
-        print(json.dumps(out))
     if ctx.collective:
         dist.destroy_process_group()
+    sys.stdout.flush()
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)  # C stdio buffers of the libraries (they go where fd 1 points now: stderr)
+    except Exception:
+        pass
+    os.dup2(real_stdout, 1)
+    if ctx.rank == 0:
+        os.write(1, (json.dumps(out) + "\n").encode())
 
 
 if __name__ == "__main__":

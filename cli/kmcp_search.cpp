@@ -790,6 +790,7 @@ int main(int argc, char** argv) {
   if (!o.gpu_ids.empty()) {  // one process, several GPUs: blocks partitioned over the devices, hits merged on the host
     if (kmcpg_open_devices(db_dirs[0].c_str(), o.gpu_ids.data(), (int32_t)o.gpu_ids.size(), &db) != 0)
       die("open kmcp db: %s: %s", db_dirs[0].c_str(), kmcpg_last_error());
+    if (verbose) info("  %zu GPUs, exchange of the hit lists: %s", o.gpu_ids.size(), kmcpg_exchange_info(db));
   } else {
     kmcpg_opts gopts{o.device, 0, 1, 0};
     int rc = o.gpu_passes >= 0 ? KMCPG_ENOMEM : kmcpg_open(db_dirs[0].c_str(), &gopts, &db);

@@ -119,10 +119,17 @@ typedef struct {
 /* -- lifecycle: replaces NewUnikIndexDB / NewUnikIndex (util-db-search.go:648-743, 1196-1280) and
  *    UnikIndexDB.Close (:1119-1150).  db_dir is the directory holding __db.yml (e.g. <db>/R001). */
 int kmcpg_open(const char* db_dir, const kmcpg_opts* opts, kmcpg_db** out);
-/* One host process, several GPUs (what a cgo host needs): the blocks are partitioned over `devices` (ordinals may repeat),
- * kmcpg_search_batch fans every batch out to all of them from one host thread per GPU and merges the hit lists on the
- * host.  kmcpg_query_device is not available on such a handle. */
+/* One host process, several GPUs (what a cgo host needs): the blocks are partitioned over `devices`, kmcpg_search_batch fans
+ * every batch out to all of them from one host thread per GPU; the per-read hit lists of the shards are gathered on the first
+ * GPU with RCCL (grouped ncclSend/ncclRecv over xGMI of exactly the bytes each shard produced; librccl is bound at run time)
+ * and reach the host in one copy — the reference's concatenation of its per-block workers' replies (util-db-search.go:939-964).
+ * When RCCL cannot serve (ordinals repeat — RCCL wants one rank per device —, no librccl, KMCPG_RCCL=0, its self-test at open
+ * fails) the shards' lists are copied to the host one by one and merged there; kmcpg_exchange_info says which it is.
+ * kmcpg_query_device is not available on such a handle. */
 int kmcpg_open_devices(const char* db_dir, const int32_t* devices, int32_t n_devices, kmcpg_db** out);
+/* "RCCL gather over N device(s)" / "host merge of the shards' hit lists (<reason>)" / "single device: no exchange step";
+ * the string lives until the calling thread's next call of this function */
+const char* kmcpg_exchange_info(const kmcpg_db* db);
 /* A database LARGER than the HBM at hand, on one GPU (the reference searches any size through mmap / --low-mem,
  * util-db-search.go:1238-1280, :6975-7335; search.go:80): the index is cut into `passes` shards (the byte-balanced partition of
  * kmcpg_open with shard_count = passes; 0 = as few as fit the free HBM of `device`), and kmcpg_search_batch / kmcpg_submit
@@ -264,7 +271,11 @@ typedef struct {
   /* big-genome block rules, flags -x / -X / -8 / -1 of `kmcp index` (index.go:1453-1463); 0 = the reference's default */
   uint64_t kmers_x;     /* -x 10M (M = 2^20): columns with more k-mers go to blocks of block_size_x columns */
   int32_t block_size_x; /* -X 256 */
-  int32_t reserved;
+  int32_t uniform_sigs; /* 0 = NumSigs per block as `kmcp index` sizes it (index.go:936-946, :1023: files byte-identical to the
+                           reference's).  Not in the reference: 1 = every block of a size tier gets the tier's largest NumSigs,
+                           2 = NumSigs rounded up to a 5/4 ladder (< 25 % larger files).  Blocks with equal NumSigs are served
+                           by ONE gather when resident (grouped rows): a `-j 32` index of 39-byte rows runs at the speed of
+                           1248-byte rows.  A larger filter only lowers a block's FPR; any kmcp reader accepts the files. */
   uint64_t kmers_8;     /* -8 20M: ... to blocks of 8 columns */
   uint64_t kmers_1;     /* -1 200M: ... to a block of their own */
 } kmcpg_build_cfg;

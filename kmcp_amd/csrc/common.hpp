@@ -59,6 +59,10 @@ struct K1Args {
   int32_t* qlen;
   int32_t* seg_cnt;      // whole-genome path: kept hashes per (read, segment), n_reads * segs_max entries; else nullptr
   uint32_t segs_max;
+  // window sketches of long reads (k1_kmers_wg<1|2>): emissions without adjacent repeats go to scratch[], their number here
+  // (queries above max(dedup_threshold, 512) emissions; the others keep their raw emissions in hashes[]); nullptr = raw only
+  int32_t* nk_adj;
+  int32_t dedup_threshold;
 };
 
 struct DedupArgs {
@@ -70,6 +74,7 @@ struct DedupArgs {
   int32_t lo, hi;        // this workgroup-class launch sorts queries with lo < m <= hi elements (m: after k_adj_unique)
   int32_t n_lo, n_hi;    // ... among those whose raw count n is in (n_lo, n_hi]
   int32_t pre;           // window-sketch database: k_adj_unique runs first (input of the sort = scratch, m in nk_search)
+  int32_t pre_done;      // ... and the k-mer kernel has already done it (k1_kmers_wg<1|2>: fused)
   uint64_t* hashes;
   uint64_t* scratch;
   const int32_t* nk_raw;

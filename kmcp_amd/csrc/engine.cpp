@@ -25,6 +25,7 @@
 #include "common.hpp"
 #include "dbformat.hpp"
 #include "engine.hpp"
+#include "exchange.hpp"
 #include "fpr.hpp"
 #include "kernels.hpp"
 
@@ -345,7 +346,7 @@ int upload_blocks(kmcpg_db* db) {
         set_err(KMCPG_EDEVICE, "uploading " + c.b->path + ": " + hipGetErrorString(he));
         break;
       }
-      launch_repack(d_tmp, db->groups[(size_t)c.b->group].d_rows + c.r0 * c.b->stride, c.nr, rb, c.b->stride, c.b->byte_off, st);
+      launch_repack(d_tmp, db->groups[(size_t)c.b->group].d_rows + c.r0 * c.b->stride, c.nr, rb, c.b->stride, c.b->byte_off, (uint32_t)c.b->h.names.size(), st);
     }
     if (st) {
       he = hipStreamSynchronize(st);
@@ -558,6 +559,8 @@ extern "C" int kmcpg_open_synthetic(const kmcpg_synth_spec* s, const kmcpg_opts*
 extern "C" int kmcpg_close(kmcpg_db* db) {
   if (!db) return 0;
   if (int n = kmcpg::async_in_flight(db)) return kmcpg_fail(KMCPG_EBUSY, "%d batch(es) still between kmcpg_submit and kmcpg_wait: wait for every ticket before closing", n);
+  if (db->exchange) kmcpg::exchange_destroy(db->exchange);
+  db->exchange = nullptr;
   for (kmcpg_db* sh : db->shards) kmcpg_close(sh);
   db->shards.clear();
   if (db->paged_resident) kmcpg_close(db->paged_resident);

@@ -84,6 +84,7 @@ struct DevBuf {
 }  // namespace kmcpg
 
 namespace kmcpg {
+struct Exchange;
 // smallest count whose FPR(n, count) passes -f, for n = 0..n (query.cpp fpr_bound); h = pinned source of the upload
 struct FprBoundTable {
   uint64_t key = 0;  // bits of max_fpr
@@ -130,6 +131,8 @@ struct kmcpg_db {
   bool synthetic = false;
   // in-process multi-GPU front handle (kmcpg_open_devices): metadata only itself, one resident shard handle per device
   std::vector<kmcpg_db*> shards;
+  kmcpg::Exchange* exchange = nullptr;  // RCCL gather of the shards' hit lists (exchange.cpp); nullptr = host merge
+  std::string exchange_why;             // why not, when nullptr
   // paged handle (kmcpg_open_paged): metadata only itself; every batch is searched against the index one shard at a time
   // (paged_passes shards, the same partition kmcpg_open makes for shard_count = paged_passes); the shard searched last stays
   // resident and is the first one of the next batch

@@ -23,6 +23,7 @@
 #include "common.hpp"
 #include "dbformat.hpp"
 #include "engine.hpp"
+#include "exchange.hpp"
 #include "fpr.hpp"
 #include "kernels.hpp"
 
@@ -93,6 +94,7 @@ struct AsyncState {
   hipStream_t up_stream = nullptr;    // H2D of a batch's reads, beside the kernels of the batches before it
   std::atomic<uint64_t> hits_hint{0};  // hits per 1024 reads seen lately: sizes the hit buffers and the eager D2H of the next batches
   uint64_t lane_hit_budget = 0;        // entries a lane's device hit buffer may grow to beyond the plain size (from free HBM at first use)
+  bool hits_stay_on_device = false;    // shard of a handle that gathers the hit lists over RCCL: no per-shard D2H of hits
   std::vector<std::unique_ptr<Lane>> lanes;
   size_t max_lanes = 4;
   std::mutex mu;
@@ -327,14 +329,15 @@ int enqueue(kmcpg_db* db, AsyncState* A, Lane* L, const kmcpg_params& p) {
   if (rc) return rc;
   HIPCHK(hipMemcpyAsync(L->h_qk.p, L->d_qk.p, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, st));
   HIPCHK(hipMemcpyAsync(L->h_ql.p, L->d_ql.p, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, st));
-  L->copied = std::min<uint64_t>(first, L->d_hits.cap);
-  HIPCHK(hipMemcpyAsync(L->h_hits.p, L->d_hits.p, L->copied * sizeof(kmcpg_hit), hipMemcpyDeviceToHost, st));
+  L->copied = A->hits_stay_on_device ? 0 : std::min<uint64_t>(first, L->d_hits.cap);
+  if (L->copied) HIPCHK(hipMemcpyAsync(L->h_hits.p, L->d_hits.p, L->copied * sizeof(kmcpg_hit), hipMemcpyDeviceToHost, st));
   HIPCHK(hipEventRecord(L->done, st));
   return 0;
 }
 
-// waits for the lane; afterwards h_hits[0..*n_hits), h_qk, h_ql are complete
-int collect(kmcpg_db* db, AsyncState* A, Lane* L, const kmcpg_params& p, uint64_t* n_hits) {
+// waits for the lane; afterwards h_hits[0..*n_hits), h_qk, h_ql are complete (fetch = false: the hits stay in d_hits[0..*n_hits),
+// the caller gathers them on the device)
+int collect(kmcpg_db* db, AsyncState* A, Lane* L, const kmcpg_params& p, uint64_t* n_hits, bool fetch = true) {
   *n_hits = 0;
   if (L->n == 0) return 0;
   KMCPG_USE_DEVICE(db);
@@ -353,7 +356,7 @@ int collect(kmcpg_db* db, AsyncState* A, Lane* L, const kmcpg_params& p, uint64_
   // the k-mer count the counter planes were sized for (the longest read) bounds every query's NumKmers
   const uint64_t bound = (uint64_t)L->maxlen * (L->paired ? 2 : 1);
   if (L->h_cnt.p[1] > bound) return kmcpg_fail(KMCPG_EDEVICE, "internal: a query reported %llu k-mers, more than its length allows", (unsigned long long)L->h_cnt.p[1]);
-  if (cnt > L->copied) {
+  if (fetch && cnt > L->copied) {
     if (cnt > L->h_hits.cap) {
       if (L->h_hits.ensure(cnt)) return kmcpg_fail(KMCPG_ENOMEM, "hipHostMalloc failed");
       L->copied = 0;
@@ -523,11 +526,29 @@ int finish_raw(kmcpg_ticket* t, kmcpg_result* out) {
   static thread_local std::vector<kmcpg_hit, NoInitAlloc<kmcpg_hit>> merged;
   if (t->paged)
     return kmcpg_finalize(t->db, t->hits.data(), t->hits.size(), t->n ? t->qk.data() : nullptr, t->n ? t->ql.data() : nullptr, t->n, &t->p, out);
-  if (t->parts.size() == 1) {
+  if (t->parts.size() == 1 && !t->db->exchange) {
     auto& pt = t->parts[0];
     int rc = collect(pt.shard, pt.shard->async, pt.lane, t->p, &n_hits);
     if (rc) return rc;
     hits = pt.lane->h_hits.p;
+  } else if (Exchange* x = t->db->exchange) {
+    // the shards' lists meet on the first GPU (RCCL send/recv over xGMI, exactly the bytes each shard produced) and come to
+    // the host in one copy
+    std::vector<const void*> src;
+    std::vector<uint64_t> bytes;
+    for (auto& pt : t->parts) {
+      uint64_t c = 0;
+      int rc = collect(pt.shard, pt.shard->async, pt.lane, t->p, &c, false);
+      if (rc) return kmcpg_fail(rc, "device %d: %s", pt.shard->opts.device, std::string(kmcpg_err_ref()).c_str());
+      src.push_back(pt.lane->d_hits.p);
+      bytes.push_back(c * sizeof(kmcpg_hit));
+      n_hits += c;
+    }
+    Lane* L0 = t->parts[0].lane;
+    if (hipSetDevice(t->parts[0].shard->opts.device) != hipSuccess || L0->h_hits.ensure(n_hits + 1)) return kmcpg_fail(KMCPG_ENOMEM, "hipHostMalloc failed");
+    int rc = exchange_gather(x, src, bytes, (uint8_t*)L0->h_hits.p);
+    if (rc) return rc;
+    hits = L0->h_hits.p;
   } else {
     merged.clear();
     for (auto& pt : t->parts) {
@@ -685,8 +706,30 @@ extern "C" int kmcpg_open_devices(const char* db_dir, const int32_t* devices, in
     front->info.matrix_bytes_local += sh->info.matrix_bytes_local;
     front->info.row_bytes_sum_local += sh->info.row_bytes_sum_local;
   }
+  // the exchange step: RCCL gather of the hit lists onto the first GPU when the devices allow it, host merge otherwise
+  front->exchange = exchange_create(std::vector<int>(devices, devices + n_devices), &front->exchange_why);
+  if (front->exchange)
+    for (kmcpg_db* sh : front->shards) {
+      AsyncState* A = nullptr;
+      rc = async_state(sh, &A);
+      if (rc) {
+        std::string keep = kmcpg_err_ref();
+        kmcpg_close(front);
+        kmcpg_err_ref() = keep;
+        return rc;
+      }
+      A->hits_stay_on_device = true;
+    }
   *out = front;
   return 0;
+}
+
+extern "C" const char* kmcpg_exchange_info(const kmcpg_db* db) {
+  if (!db) return "";
+  if (db->exchange) return exchange_note(db->exchange);
+  static thread_local std::string s;
+  s = db->shards.empty() ? "single device: no exchange step" : "host merge of the shards' hit lists (" + db->exchange_why + ")";
+  return s.c_str();
 }
 
 extern "C" int kmcpg_open_paged(const char* db_dir, int32_t device, int32_t passes, kmcpg_db** out) {

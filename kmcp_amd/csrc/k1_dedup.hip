@@ -253,7 +253,7 @@ void launch_dedup(DedupArgs a, uint64_t max_n, hipStream_t st) {
   a.n_lo = DW_CAP;
   a.n_hi = max_n > HUGE_MIN ? (int32_t)HUGE_MIN : 0x7fffffff;  // beyond that: device-wide sort (sort_huge.hip)
   const unsigned grid = a.n_reads > (1u << 20) ? (1u << 20) : a.n_reads;  // the workgroup kernels stride over the reads
-  if (a.pre) hipLaunchKernelGGL(k_adj_unique, dim3(grid), dim3(ADJ_NT), 0, st, a);
+  if (a.pre && !a.pre_done) hipLaunchKernelGGL(k_adj_unique, dim3(grid), dim3(ADJ_NT), 0, st, a);
   a.lo = 0;
   a.hi = 4096;
   hipLaunchKernelGGL((k_dedup<256, 4096>), dim3(grid), dim3(256), 0, st, a);

@@ -288,6 +288,7 @@ __global__ void __launch_bounds__(256) k1_kmers(const K1Args a) {
 
 // ---- long queries (HiFi reads, -g whole genomes): one 1024-thread workgroup per read -------------------------
 constexpr int K1WG = 1024;
+constexpr int K1_WAVE_SORT_CAP = 512;  // queries of up to this many emissions are sorted by k_dedup_wave, which reads them from hashes[] (k1_dedup.hip DW_CAP)
 
 // ordered compaction of one tile of K1WG candidates into out[cnt...]; returns the new (uniform) count
 __device__ __forceinline__ int wg_compact(bool keep, uint64_t h, uint64_t* __restrict__ out, int cnt, int* s_wave, int tid) {
@@ -304,7 +305,7 @@ __device__ __forceinline__ int wg_compact(bool keep, uint64_t h, uint64_t* __res
   }
   if (keep) out[cnt + before + __popcll(m & ((1ULL << lane) - 1ULL))] = h;
   __syncthreads();
-  return cnt + total;
+  return cnt + __builtin_amdgcn_readfirstlane(total);
 }
 
 __device__ __forceinline__ uint64_t hash_at(const uint8_t* __restrict__ s, int i, int kk, const uint64_t* tab) {
@@ -390,6 +391,8 @@ struct K1Lds {
   uint64_t iq[K1CAP + 1];                   // iq[n] = Q(n)
   uint64_t tp[K1CAP / 64], tq[K1CAP / 64];  // totals of the 64-base groups, then their exclusive prefixes
   uint64_t hw[K1WG + K1H];                  // the hashes the windows scan: s-mers (syncmer) or k-mers (minimizer)
+  uint64_t m4v[K1WG + K1H];                 // m4v[i] = min(hw[i..i+3]), m4i[i] = its leftmost position: the windows' arg-min reads
+  uint16_t m4i[K1WG + K1H];                 // a quarter of the values (two-level scan)
 };
 
 // builds L.ip / L.iq over the nb (<= K1CAP) bases at s; all K1WG threads call it; ends with a barrier
@@ -444,6 +447,118 @@ __device__ __forceinline__ uint64_t lds_hash(const K1Lds& L, int i, int kk) {
   return f < r ? f : r;
 }
 
+// second level of the window arg-min: leftmost minima of every 4 consecutive entries of hw[0..n); ends with a barrier
+__device__ __forceinline__ void wg_min4(K1Lds& L, int n, int tid) {
+  for (int i = tid; i + 3 < n; i += K1WG) {
+    uint64_t mv = L.hw[i];
+    int m = i;
+#pragma unroll
+    for (int j = 1; j < 4; j++) {
+      const uint64_t v = L.hw[i + j];
+      if (v < mv) {  // strict: the leftmost of equal values wins
+        mv = v;
+        m = i + j;
+      }
+    }
+    L.m4v[i] = mv;
+    L.m4i[i] = (uint16_t)m;
+  }
+  __syncthreads();
+}
+
+// leftmost minimum of hw[b .. b+n): whole groups of 4 through m4v/m4i, the rest one by one (same result as argmin_left)
+__device__ __forceinline__ int argmin_left4(const K1Lds& L, int b, int n) {
+  if (n < 4) return argmin_left(L.hw, b, n);
+  uint64_t mv = L.m4v[b];
+  int m = b;       // group whose minimum is the best so far (its position is looked up once, at the end)
+  bool grp = true;  // m names a group of 4 (true) or a single position (false)
+  int i = b + 4;
+  for (; i + 4 <= b + n; i += 4) {
+    const uint64_t v = L.m4v[i];
+    if (v < mv) {
+      mv = v;
+      m = i;
+    }
+  }
+  for (; i < b + n; i++) {
+    const uint64_t v = L.hw[i];
+    if (v < mv) {
+      mv = v;
+      m = i;
+      grp = false;
+    }
+  }
+  return grp ? (int)L.m4i[m] : m;
+}
+
+// Ordered compaction of one tile of K1WG candidates with the adjacent repeats dropped on the way (window sketches emit the same
+// k-mer for runs of consecutive windows: ~10 k emissions of a HiFi read hold ~1.4 k distinct adjacent values): a candidate is
+// written to out[cnt ...] unless it equals the candidate before it in sequence order (the previous kept lane of its wave, else
+// the last candidate of an earlier wave of the tile, else `last` = the last candidate of the tiles — and the mate — before).
+// raw counts every candidate.  Returns the new (uniform) count.
+struct AdjCarry {
+  uint64_t last = 0;
+  int have = 0;
+  int raw = 0;
+};
+__device__ __forceinline__ int wg_compact_adj(bool keep, uint64_t h, uint64_t* __restrict__ out, int cnt, AdjCarry& c, int* s_wave, int* s_wave2, uint64_t* s_last,
+                                              int tid) {
+  const int lane = tid & 63, w = tid >> 6;
+  const uint64_t m = __ballot(keep);
+  const uint64_t lower = m & ((1ULL << lane) - 1ULL);
+  if (lane == 0) s_wave[w] = __popcll(m);
+  if (m && lane == 63 - __clzll((unsigned long long)m)) s_last[w] = h;  // the wave's last candidate
+  __syncthreads();
+  // the candidate before this one
+  const int src = lower ? 63 - __clzll((unsigned long long)lower) : lane;
+  uint64_t prev = __shfl(h, src);
+  bool has_prev = lower != 0;
+  int raw_total = 0, last_w = -1;
+#pragma unroll
+  for (int i = 0; i < K1WG / 64; i++) {
+    const int cw = s_wave[i];
+    raw_total += cw;
+    if (cw > 0) last_w = i;
+  }
+  if (!has_prev) {
+    int pw = -1;
+    for (int i = w - 1; i >= 0; i--)
+      if (s_wave[i] > 0) {
+        pw = i;
+        break;
+      }
+    if (pw >= 0) {
+      prev = s_last[pw];
+      has_prev = true;
+    } else if (c.have) {
+      prev = c.last;
+      has_prev = true;
+    }
+  }
+  const bool keep2 = keep && !(has_prev && h == prev);
+  const uint64_t m2 = __ballot(keep2);
+  if (lane == 0) s_wave2[w] = __popcll(m2);
+  const uint64_t tile_last = last_w >= 0 ? s_last[last_w] : 0;
+  __syncthreads();
+  int before = 0, total = 0;
+#pragma unroll
+  for (int i = 0; i < K1WG / 64; i++) {
+    const int cw = s_wave2[i];
+    if (i < w) before += cw;
+    total += cw;
+  }
+  if (keep2) out[cnt + before + __popcll(m2 & ((1ULL << lane) - 1ULL))] = h;
+  // uniform values: kept in scalar registers (the compiler cannot see that every thread computed the same)
+  c.raw += __builtin_amdgcn_readfirstlane(raw_total);
+  if (__builtin_amdgcn_readfirstlane(last_w) >= 0) {
+    c.last = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(tile_last >> 32)) << 32) |
+             (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)tile_last);
+    c.have = 1;
+  }
+  __syncthreads();
+  return cnt + __builtin_amdgcn_readfirstlane(total);
+}
+
 // positions per tile: with a small halo the tile shrinks so that positions + halo fit one scan round of K1WG bases
 __device__ __forceinline__ int wg_tile_step(int halo) { return halo <= K1WG / 2 ? K1WG - halo : K1WG; }
 
@@ -470,6 +585,24 @@ __device__ __forceinline__ int wg_sketch_mate_lds(const K1Args& a, int mode, con
     }
     return cnt;
   }
+  return cnt;
+}
+
+// The window sketches (Closed Syncmer, Minimizer) of one mate in the LDS tile form.  ADJ = false: every emission is written to
+// out[cnt...] (what the reference's generateKmers returns); ADJ = true: adjacent repeats are dropped on the way and c.raw counts
+// the emissions (input of the sort + unique that queries above -u get anyway).  The arg-min of a window reads the 4-wide minima
+// of wg_min4 (two-level scan): 5 + 0 look-ups instead of 20 for the 20-s-mer windows of k = 21, s = 11.
+template <bool ADJ>
+__device__ __forceinline__ int wg_window_mate_lds(const K1Args& a, int mode, const uint8_t* __restrict__ s, int len, const uint64_t* tab, K1Lds& L,
+                                                  uint64_t* __restrict__ out, int cnt, AdjCarry& c, int* s_wave, int* s_wave2, uint64_t* s_last, int tid) {
+  const int k = a.k;
+  const bool scaled = a.scaled != 0;
+  const int nk = len - k + 1;  // k-mer positions
+  if (nk <= 0) return cnt;
+  auto emit = [&](bool keep, uint64_t h) {
+    if (ADJ) cnt = wg_compact_adj(keep, h, out, cnt, c, s_wave, s_wave2, s_last, tid);
+    else cnt = wg_compact(keep, h, out, cnt, s_wave, tid);
+  };
   if (mode == 2) {  // closed syncmer (see syncmer_mate)
     const int sm = (int)a.w_or_s, Lw = 2 * k - sm - 1;
     if (len < Lw) return cnt;
@@ -482,17 +615,18 @@ __device__ __forceinline__ int wg_sketch_mate_lds(const K1Args& a, int mode, con
       const int nst = min(ns - p0, T + max(wsz - 1, 0));
       for (int i = tid; i < nst; i += K1WG) L.hw[i] = lds_hash(L, i, sm);
       __syncthreads();
+      if (wsz >= 4) wg_min4(L, nst, tid);
       const bool v = tid < T && p0 + tid < nw;
       uint64_t h = 0;
       if (v) {
         int pos = tid;
         if (wsz > 0) {
-          const int m = argmin_left(L.hw, tid, wsz);
+          const int m = argmin_left4(L, tid, wsz);
           pos = (m - tid < k - sm) ? m : m + sm - k;
         }
         h = lds_hash(L, pos, k);
       }
-      cnt = wg_compact(v && h != 0 && (!scaled || h <= a.max_hash), h, out, cnt, s_wave, tid);
+      emit(v && h != 0 && (!scaled || h <= a.max_hash), h);
     }
     return cnt;
   }
@@ -507,15 +641,16 @@ __device__ __forceinline__ int wg_sketch_mate_lds(const K1Args& a, int mode, con
     const int nkt = min(nk - b0, T + w);
     for (int i = tid; i < nkt; i += K1WG) L.hw[i] = lds_hash(L, i, k);
     __syncthreads();
+    if (w >= 4) wg_min4(L, nkt, tid);
     const int w0 = p0 + tid;
     const bool v = tid < T && w0 < nw;
     int m = -1, pm = -2;
     if (v) {
-      m = argmin_left(L.hw, off + tid, w);
-      pm = w0 > 0 ? argmin_left(L.hw, off + tid - 1, w) : -2;
+      m = argmin_left4(L, off + tid, w);
+      pm = w0 > 0 ? argmin_left4(L, off + tid - 1, w) : -2;
     }
     const uint64_t h = (v && m != pm) ? L.hw[m] : 0;
-    cnt = wg_compact(v && m != pm && h != 0 && (!scaled || h <= a.max_hash), h, out, cnt, s_wave, tid);
+    emit(v && m != pm && h != 0 && (!scaled || h <= a.max_hash), h);
   }
   return cnt;
 }
@@ -557,6 +692,56 @@ __device__ __forceinline__ void wg_reads(const K1Args& a, int mode, const uint64
   }
 }
 
+// The same for the window sketches in the LDS form, with the adjacent-repeat filter of the dedup path fused in.  A query whose
+// emissions exceed -u is sorted and uniqued afterwards (:874-908), and window sketches emit runs of equal values, so what the sort
+// needs is the sequence without adjacent repeats: it is written to scratch[...] (its length to nk_adj[r]) while the emissions are
+// only counted — 1.4 k values instead of 10 k per HiFi read, and no separate k_adj_unique pass.  The emissions themselves are only
+// needed as they are for queries that are not deduplicated (<= -u), for those the wave sort takes (<= K1_WAVE_SORT_CAP) and for
+// whole-genome queries (device-wide sort): those — short reads in a long-read batch, rare — are sketched a second time into
+// hashes[...].  A query that cannot exceed the bound by its length skips the first pass.
+template <int MODE>
+__device__ __forceinline__ void wg_reads_windows(const K1Args& a, const uint64_t* tab, int* s_wave, int* s_wave2, uint64_t* s_last, K1Lds& L, int tid) {
+  const int raw_bound = a.dedup_threshold > K1_WAVE_SORT_CAP ? a.dedup_threshold : K1_WAVE_SORT_CAP;
+  for (uint32_t r = blockIdx.x; r < a.n_reads; r += gridDim.x) {
+    const uint64_t o1 = a.offs[r];
+    const int len1 = (int)(a.offs[r + 1] - o1);
+    uint64_t o2 = 0;
+    int len2 = 0;
+    const bool pe = a.offs2 != nullptr;
+    if (pe) {
+      o2 = a.offs2[r];
+      len2 = (int)(a.offs2[r + 1] - o2);
+    }
+    const bool skip = len1 < a.min_qlen && !(pe && len2 >= a.min_qlen);
+    int raw = 0, raw1 = 0;
+    if (!skip) {
+      bool need_raw = true;
+      if (a.nk_adj && a.scratch && len1 + len2 > raw_bound) {  // (a mate emits at most one value per base)
+        AdjCarry c;
+        uint64_t* adj = a.scratch + o1 + o2;
+        int m = wg_window_mate_lds<true>(a, MODE, a.seqs + o1, len1, tab, L, adj, 0, c, s_wave, s_wave2, s_last, tid);
+        raw1 = c.raw;
+        if (pe) m = wg_window_mate_lds<true>(a, MODE, a.seqs2 + o2, len2, tab, L, adj, m, c, s_wave, s_wave2, s_last, tid);
+        raw = c.raw;
+        need_raw = raw <= raw_bound || raw > (int)HUGE_MIN;
+        if (!need_raw && tid == 0) a.nk_adj[r] = m;
+      }
+      if (need_raw) {
+        AdjCarry c;
+        uint64_t* out = a.hashes + o1 + o2;
+        raw = wg_window_mate_lds<false>(a, MODE, a.seqs + o1, len1, tab, L, out, 0, c, s_wave, s_wave2, s_last, tid);
+        raw1 = raw;
+        if (pe) raw = wg_window_mate_lds<false>(a, MODE, a.seqs2 + o2, len2, tab, L, out, raw, c, s_wave, s_wave2, s_last, tid);
+      }
+    }
+    if (tid == 0) {
+      a.nk_raw[r] = raw;
+      a.nk1[r] = raw1;
+      a.qlen[r] = len1 + len2;
+    }
+  }
+}
+
 // One kernel per sketch mode (the other modes' code and registers stay out of it); 64 VGPRs => two workgroups per CU.
 template <int MODE>
 __global__ void __launch_bounds__(K1WG, 8) k1_kmers_wg(const K1Args a) {
@@ -566,7 +751,13 @@ __global__ void __launch_bounds__(K1WG, 8) k1_kmers_wg(const K1Args a) {
   const int tid = threadIdx.x;
   if (tid < 256) tab[tid] = seed_of(tid);
   __syncthreads();
-  wg_reads<true>(a, MODE, tab, s_wave, &lds, tid);
+  if constexpr (MODE == 0) {
+    wg_reads<true>(a, MODE, tab, s_wave, &lds, tid);
+  } else {
+    __shared__ int s_wave2[K1WG / 64];
+    __shared__ uint64_t s_last[K1WG / 64];
+    wg_reads_windows<MODE>(a, tab, s_wave, s_wave2, s_last, lds, tid);
+  }
 }
 
 // halo too large for the LDS tiles (2k-s-1 > 512, w >= 511, k > 255): window scans over scratch arrays in global memory
@@ -647,13 +838,14 @@ __global__ void k_nk_simple(const int32_t* nk_raw, int32_t* nk_search, uint32_t 
 
 int k1_segment_len() { return K1SEG; }
 
-void launch_k1(const K1Args& a, uint32_t max_read_len, hipStream_t st) {
-  if (a.n_reads == 0) return;
+// true when the kernel that ran drops the adjacent repeats itself (window sketches of long reads: scratch[] + nk_adj[])
+bool launch_k1(const K1Args& a, uint32_t max_read_len, hipStream_t st) {
+  if (a.n_reads == 0) return false;
   if (a.seg_cnt && a.segs_max > 1) {  // whole genomes: one workgroup per 65536-position segment, then an ordered pack
     const unsigned blocks = a.n_reads * a.segs_max;
     hipLaunchKernelGGL(k1_seg_hash, dim3(blocks), dim3(K1WG), 0, st, a);
     hipLaunchKernelGGL(k1_seg_pack, dim3(blocks), dim3(256), 0, st, a);
-    return;
+    return false;
   }
   if (max_read_len > 2048) {  // long queries: a whole workgroup per read
     unsigned blocks = a.n_reads > 65536 ? 65536 : a.n_reads;
@@ -661,13 +853,14 @@ void launch_k1(const K1Args& a, uint32_t max_read_len, hipStream_t st) {
     else if (a.mode == 2) hipLaunchKernelGGL(k1_kmers_wg<2>, dim3(blocks), dim3(K1WG), 0, st, a);
     else if (a.mode == 1) hipLaunchKernelGGL(k1_kmers_wg<1>, dim3(blocks), dim3(K1WG), 0, st, a);
     else hipLaunchKernelGGL(k1_kmers_wg<0>, dim3(blocks), dim3(K1WG), 0, st, a);
-    return;
+    return wg_lds_usable(a) && a.mode != 0 && a.nk_adj && a.scratch;
   }
   unsigned blocks = (a.n_reads + 3) / 4;
   if (blocks > 32768) blocks = 32768;
   if (a.mode == 2) hipLaunchKernelGGL(k1_kmers<2>, dim3(blocks), dim3(256), 0, st, a);
   else if (a.mode == 1) hipLaunchKernelGGL(k1_kmers<1>, dim3(blocks), dim3(256), 0, st, a);
   else hipLaunchKernelGGL(k1_kmers<0>, dim3(blocks), dim3(256), 0, st, a);
+  return false;
 }
 
 void launch_nk_simple(const int32_t* nk_raw, int32_t* nk_search, uint32_t n, int32_t min_matched, hipStream_t st) {

@@ -281,8 +281,12 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, GR 
   // ---- hit emission (:7462-7731 scan of the counters + Match append), wave-aggregated: every lane finds its columns with
   //      count >= cmin by a bit-sliced compare, the wave reserves room for all of them with ONE atomic on the global counter
   //      (ballot + prefix sum over the lanes' hit counts) and the lanes write their tuples side by side.  Hits are rare for
-  //      distinct references (~1 per read) but come in runs for a family of close relatives (neighbouring columns = one lane):
-  //      one device-scope atomic per hit serialised the epilogue there.
+  //      distinct references (~1 per read) but come in runs for a family of close relatives (neighbouring columns = one lane).
+  //      Padding bits of a row are zero in the resident index (k_repack masks them at load time, the synthetic fill and the
+  //      planting helpers never set them), so a count >= cmin >= 1 always belongs to a real column and nothing needs to be
+  //      validated before room is reserved.  The byte -> column mapping of a lane's hits keeps the segment of the previous hit
+  //      in registers: the dependent global loads of a table walk per hit (58 hits in one lane = 58 round trips to memory in a
+  //      row, under a saturated memory system) were what made hit-heavy batches 5 % slower, not the atomics.
   const bool emit = live && !(NPL < 32 && (cmin >> NPL) != 0);  // else: unreachable count / nothing left alive
   uint32_t ge[4];
   uint32_t mine = 0;
@@ -291,14 +295,6 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, GR 
     uint32_t v = emit ? 0xffffffffu : 0u;  // bit-sliced (count >= cmin), LSB to MSB
 #pragma unroll
     for (int p = 0; p < NPL; p++) v = ((cmin >> p) & 1u) ? (v & pl[d][p]) : (v | pl[d][p]);
-    // padding bits of a row are zero in the index, so they never reach cmin >= 1; group_col stays as the guard it was
-    uint32_t w = v;
-    while (w) {
-      const int q = __ffs(w) - 1;
-      w &= w - 1;
-      uint32_t col;
-      if (!group_col(a.segs, bd, boff + (uint32_t)d * 4u + (uint32_t)(q >> 3), (uint32_t)(q & 7), &col)) v &= ~(1u << q);
-    }
     ge[d] = v;
     mine += (uint32_t)__popc(v);
   }
@@ -314,6 +310,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, GR 
   if (lane == 63) base_idx = atomicAdd(a.counter, (unsigned long long)total);
   base_idx = __shfl(base_idx, 63);
   unsigned long long idx = base_idx + (incl - mine);
+  uint32_t sg_lo = 1, sg_hi = 0, sg_col = 0;  // the segment of the previous hit: bytes [sg_lo, sg_hi), column of its first bit
+  const Seg* __restrict__ segs = a.segs + bd->seg0;
+  const uint32_t nsegs = bd->nsegs;
 #pragma unroll
   for (int d = 0; d < 4; d++) {
     uint32_t w = ge[d];
@@ -324,12 +323,22 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, GR 
 #pragma unroll
       for (int p = 0; p < NPL; p++) count |= ((pl[d][p] >> q) & 1u) << p;
       // byte (q>>3) of this dword, bit (q&7): bit 7 = first column of the byte (index.go:1157)
-      uint32_t col = 0;
-      (void)group_col(a.segs, bd, boff + (uint32_t)d * 4u + (uint32_t)(q >> 3), (uint32_t)(q & 7), &col);
+      const uint32_t byte = boff + (uint32_t)d * 4u + (uint32_t)(q >> 3);
+      if (byte < sg_lo || byte >= sg_hi) {
+        for (uint32_t i = 0; i < nsegs; i++) {
+          const Seg sg = segs[i];
+          if (byte < sg.byte_end) {
+            sg_lo = sg.byte_start;
+            sg_hi = sg.byte_end;
+            sg_col = sg.col_base;
+            break;
+          }
+        }
+      }
       if (idx < a.hit_cap) {
         kmcpg_hit hit;
         hit.read = r;
-        hit.col = col;
+        hit.col = sg_col + (byte - sg_lo) * 8u + (7u - (uint32_t)(q & 7));
         hit.count = count;
         a.hits[idx] = hit;
       }

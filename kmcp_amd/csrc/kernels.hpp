@@ -6,7 +6,7 @@
 
 namespace kmcpg {
 
-void launch_k1(const K1Args& a, uint32_t max_read_len, hipStream_t st);
+bool launch_k1(const K1Args& a, uint32_t max_read_len, hipStream_t st);  // true: adjacent repeats already dropped (scratch[], nk_adj[])
 int k1_segment_len();  // positions per workgroup on the whole-genome path
 void launch_nk_simple(const int32_t* nk_raw, int32_t* nk_search, uint32_t n, int32_t min_matched, hipStream_t st);
 void launch_dedup(DedupArgs a, uint64_t max_n, hipStream_t st);  // queries above HUGE_MIN are left to huge_dedup
@@ -17,7 +17,7 @@ int launch_k2_split(const K2Args& a, int lpr, hipStream_t st);
 void launch_list_long(const int32_t* nk, uint32_t n_reads, int32_t split_min, uint32_t* list, uint32_t* meta, hipStream_t st);
 void launch_threshold_long(const K2Args& a, hipStream_t st);
 void launch_max_nk(const int32_t* nk, uint32_t n_reads, unsigned long long* out, hipStream_t st);
-void launch_repack(const uint8_t* src, uint8_t* dst, uint64_t n_rows, uint32_t row_bytes, uint32_t stride, uint32_t byte_off, hipStream_t st);
+void launch_repack(const uint8_t* src, uint8_t* dst, uint64_t n_rows, uint32_t row_bytes, uint32_t stride, uint32_t byte_off, uint32_t ncols, hipStream_t st);
 void launch_gather_rows(const uint8_t* rows, uint32_t stride, uint32_t row_bytes, const uint64_t* idx, uint64_t first, uint64_t n, uint8_t* out,
                         hipStream_t st);
 void launch_synth_fill(uint8_t* rows, uint64_t n_rows, uint32_t stride, uint32_t own_stride, uint32_t ncols, uint64_t key, uint32_t p8, hipStream_t st);

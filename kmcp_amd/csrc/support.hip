@@ -15,8 +15,10 @@ namespace kmcpg {
 // ------------------------------------------------------------------------------------------------
 // dst = the group's rows (zero-filled beforehand); this block's bytes land at [byte_off, byte_off + row_bytes) of every row.
 // Interior dwords are stored, the (at most two) dwords a block shares with its neighbours in the group are OR-ed in.
+// The padding bits of a row's last byte (columns ncols .. 8*row_bytes-1; zero in every file `kmcp index` writes, index.go:1157)
+// are cleared here, so the query kernel may rely on "count > 0 => real column" whatever a file holds.
 __global__ void k_repack(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, uint64_t n_rows, uint32_t row_bytes,
-                         uint32_t stride, uint32_t byte_off) {
+                         uint32_t stride, uint32_t byte_off, uint32_t last_mask) {
   const uint32_t w0 = byte_off / 4, w1 = (byte_off + row_bytes + 3) / 4;  // dst dwords touched per row
   const uint32_t wpr = w1 - w0;
   const uint64_t total = n_rows * wpr;
@@ -28,7 +30,11 @@ __global__ void k_repack(const uint8_t* __restrict__ src, uint8_t* __restrict__ 
 #pragma unroll
     for (int t = 0; t < 4; t++) {
       const uint32_t b = w * 4 + t;  // byte of the dst row
-      if (b >= byte_off && b < byte_off + row_bytes) v |= (uint32_t)s[b - byte_off] << (8 * t);
+      if (b >= byte_off && b < byte_off + row_bytes) {
+        uint32_t x = s[b - byte_off];
+        if (b - byte_off == row_bytes - 1) x &= last_mask;
+        v |= x << (8 * t);
+      }
     }
     uint32_t* d = reinterpret_cast<uint32_t*>(dst + row * stride) + w;
     if (w * 4 >= byte_off && w * 4 + 4 <= byte_off + row_bytes) *d = v;
@@ -36,11 +42,13 @@ __global__ void k_repack(const uint8_t* __restrict__ src, uint8_t* __restrict__ 
   }
 }
 
-void launch_repack(const uint8_t* src, uint8_t* dst, uint64_t n_rows, uint32_t row_bytes, uint32_t stride, uint32_t byte_off, hipStream_t st) {
+void launch_repack(const uint8_t* src, uint8_t* dst, uint64_t n_rows, uint32_t row_bytes, uint32_t stride, uint32_t byte_off, uint32_t ncols, hipStream_t st) {
   if (n_rows == 0) return;
+  const uint32_t pad = row_bytes * 8u - ncols;                      // 0..7 unused low bits in the last byte (bit 7 = first column)
+  const uint32_t last_mask = pad < 8 ? (0xffu << pad) & 0xffu : 0;  // a header whose counts disagree is refused at open
   uint64_t total = n_rows * ((byte_off + row_bytes + 3) / 4 - byte_off / 4);
   unsigned blocks = (unsigned)((total + 255) / 256 > 65536 ? 65536 : (total + 255) / 256);
-  hipLaunchKernelGGL(k_repack, dim3(blocks), dim3(256), 0, st, src, dst, n_rows, row_bytes, stride, byte_off);
+  hipLaunchKernelGGL(k_repack, dim3(blocks), dim3(256), 0, st, src, dst, n_rows, row_bytes, stride, byte_off, last_mask);
 }
 
 // rows idx[0..n) — or first .. first+n-1 when idx is null — of a block, packed at the on-disk width

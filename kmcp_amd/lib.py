@@ -16,7 +16,7 @@ EXPORTS = [
     "kmcpg_result_free", "kmcpg_query_device", "kmcpg_finalize", "kmcpg_open_synthetic", "kmcpg_plant",
     "kmcpg_read_rows", "kmcpg_block_info", "kmcpg_kmers_device", "kmcpg_plant_reads_device", "kmcpg_set_profiling",
     "kmcpg_last_timing", "kmcpg_open_devices", "kmcpg_build_db", "kmcpg_submit", "kmcpg_wait", "kmcpg_read_row_range", "kmcpg_timing_at", "kmcpg_last_gathered_bytes",
-    "kmcpg_db_ks", "kmcpg_open_paged", "kmcpg_paged_info",
+    "kmcpg_db_ks", "kmcpg_open_paged", "kmcpg_paged_info", "kmcpg_exchange_info",
 ]
 
 
@@ -69,7 +69,7 @@ class BuildCfg(C.Structure):
     _fields_ = [("k", C.c_int32), ("canonical", C.c_int32), ("num_hashes", C.c_int32), ("fpr", C.c_double), ("threads", C.c_int32),
                 ("block_size", C.c_int32), ("scale", C.c_uint32), ("minimizer_w", C.c_uint32), ("syncmer_s", C.c_uint32),
                 ("split_seq", C.c_int32), ("split_size", C.c_int32), ("split_num", C.c_int32), ("split_overlap", C.c_int32),
-                ("alias", C.c_char_p), ("kmers_x", C.c_uint64), ("block_size_x", C.c_int32), ("reserved", C.c_int32), ("kmers_8", C.c_uint64),
+                ("alias", C.c_char_p), ("kmers_x", C.c_uint64), ("block_size_x", C.c_int32), ("uniform_sigs", C.c_int32), ("kmers_8", C.c_uint64),
                 ("kmers_1", C.c_uint64)]
 
 
@@ -122,6 +122,8 @@ def load():
     L.kmcpg_open_devices.argtypes = [C.c_char_p, C.POINTER(C.c_int32), C.c_int32, C.POINTER(vp)]
     L.kmcpg_open_paged.argtypes = [C.c_char_p, C.c_int32, C.c_int32, C.POINTER(vp)]
     L.kmcpg_paged_info.argtypes = [vp, i32p, u64p]
+    L.kmcpg_exchange_info.argtypes = [vp]
+    L.kmcpg_exchange_info.restype = C.c_char_p
     L.kmcpg_close.argtypes = [vp]
     L.kmcpg_db_info.argtypes = [vp, C.POINTER(Info)]
     L.kmcpg_db_ks.argtypes = [vp, i32p, C.c_int32, i32p]
@@ -166,11 +168,12 @@ def pack_reads(reads):
 
 
 def build_db(out_dir, columns, k=21, num_hashes=1, fpr=0.3, threads=32, block_size=0, scale=1, minimizer_w=0, syncmer_s=0, device=0,
-             alias="kmcp-gpu-db", kmers_x=0, block_size_x=0, kmers_8=0, kmers_1=0):
-    """`kmcp index` on the GPU.  columns: list of (name, gsize, chunk_idx, chunks, sorted-unique uint64 hashes)."""
+             alias="kmcp-gpu-db", kmers_x=0, block_size_x=0, kmers_8=0, kmers_1=0, uniform_sigs=0):
+    """`kmcp index` on the GPU.  columns: list of (name, gsize, chunk_idx, chunks, sorted-unique uint64 hashes).
+    uniform_sigs: 0 = the reference's per-block NumSigs; 1 / 2 = blocks share NumSigs (groupable in HBM), see kmcp_gpu.h."""
     cfg = BuildCfg(k=k, canonical=1, num_hashes=num_hashes, fpr=fpr, threads=threads, block_size=block_size, scale=scale,
                    minimizer_w=minimizer_w, syncmer_s=syncmer_s, alias=alias.encode(), kmers_x=kmers_x, block_size_x=block_size_x, kmers_8=kmers_8,
-                   kmers_1=kmers_1)
+                   kmers_1=kmers_1, uniform_sigs=uniform_sigs)
     arr = (BuildCol * len(columns))()
     keep = []
     for i, (name, gsize, ci, nch, h) in enumerate(columns):
@@ -247,6 +250,9 @@ class Database:
         h = C.c_void_p()
         _check(load().kmcpg_open_paged(os.fsencode(db_dir), device, passes, C.byref(h)))
         return cls(h)
+
+    def exchange_info(self):
+        return load().kmcpg_exchange_info(self._h).decode()
 
     def paged_info(self):
         """(passes, shard uploads so far); passes == 0 for resident handles"""

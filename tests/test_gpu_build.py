@@ -99,3 +99,53 @@ def test_build_refuses_bad_input(tmp_path):
         lib.build_db(str(tmp_path / "x"), [("a", 10, 0, 1, np.arange(5, dtype=np.uint64))], num_hashes=7)
     with pytest.raises(lib.KmcpGpuError):
         lib.build_db(str(tmp_path / "y"), [("a", 10, 0, 1, np.arange(5, dtype=np.uint64))], fpr=1.5)
+
+
+@pytest.mark.parametrize("mode", [1, 2])
+def test_uniform_num_sigs_makes_blocks_groupable(oracle_lib, tmp_path, mode):
+    """kmcpg_build_cfg.uniform_sigs: chunks of varied length give every block of a `-j 32`-style index its own
+    NumSigs (columns are sorted by k-mer count before they are cut into blocks), so nothing can share a gather; with the option the
+    blocks of a size tier agree on NumSigs (1: all of them, 2: a 5/4 ladder), the files stay ordinary `.uniki` blocks — the oracle's
+    reader (index/serialization.go:383-593 restated) takes them and finds what the GPU finds — and the resident layout puts them side
+    by side: one wide row instead of many narrow ones."""
+    import numpy as np
+    from kmcp_amd import Database, default_params, lib
+    O = oracle_lib
+    rng = np.random.default_rng(5)
+    lens = rng.integers(3000, 9000, size=320)  # a 3x spread of chunk sizes, like genomes of different species
+    genomes = [g[:n] for g, n in zip(synth.random_genomes(320, 9000, seed=83), lens)]
+    cfg = O.sketch_cfg(k=21)
+    cols = synth.make_columns(genomes, cfg)
+    plain = lib.build_db(str(tmp_path / "plain"), cols, k=21, threads=8)          # 8 blocks of 40 columns (5-byte rows)
+    uni = lib.build_db(str(tmp_path / "uni"), cols, k=21, threads=8, uniform_sigs=mode)
+    reads = synth.sample_reads(genomes, 600, 150, sub_rate=0.01, seed=84, frac_random=0.1)
+    with Database.open(plain, device=0) as dp, Database.open(uni, device=0) as du:
+        nb = dp.info.n_blocks
+        assert nb == du.info.n_blocks == 8
+        sig_p = [dp.block_info(b)["num_sigs"] for b in range(nb)]
+        sig_u = [du.block_info(b)["num_sigs"] for b in range(nb)]
+        assert len(set(sig_p)) == nb                                 # the reference's sizing: nothing to group
+        assert all(u >= p_ for u, p_ in zip(sig_u, sig_p))           # only ever larger filters
+        assert max(sig_u) == max(sig_p)
+        if mode == 1:
+            assert len(set(sig_u)) == 1
+            assert all(du.block_info(b)["stride"] == 64 for b in range(nb))   # 8 x 5 bytes side by side in one 64-byte row
+            assert all(dp.block_info(b)["stride"] == 16 for b in range(nb))
+        else:
+            assert len(set(sig_u)) < nb and du.info.matrix_bytes < 1.25 * dp.info.matrix_bytes
+        res_u = du.search(reads, params=default_params())
+        res_p = dp.search(reads, params=default_params())
+    odb = O.OracleDB(uni)
+    try:
+        assert [odb.block_info(b)[0] for b in range(odb.nblocks)] == sig_u
+        assert synth.assert_parity(odb, res_u, reads, None, O.default_params()) > 300
+    finally:
+        odb.close()
+    # the strong matches (reads sampled from a genome) are the same in both databases: only chance k-mers differ with NumSigs
+    same = 0
+    for i in range(len(reads)):
+        top_u = {int(m["col"]) for m in res_u.read(i) if m["qcov"] >= 0.8}
+        top_p = {int(m["col"]) for m in res_p.read(i) if m["qcov"] >= 0.8}
+        assert top_u == top_p, (i, top_u, top_p)
+        same += len(top_u)
+    assert same > 300

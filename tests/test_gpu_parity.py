@@ -283,6 +283,50 @@ def test_in_process_multi_device_handle(G, oracle_lib, tmp_path):
         odb.close()
 
 
+def test_rccl_exchange_of_the_in_process_handle(G, oracle_lib, tmp_path, monkeypatch):
+    """The exchange step of kmcpg_open_devices (exchange.cpp): hit lists gathered on the first GPU with RCCL send/recv and
+    copied to the host once.  One GPU here, so the communicator has one rank (KMCPG_RCCL=force: send/recv to self goes through
+    the same group calls, buffers and single copy); duplicate ordinals must fall back to the host merge and say why."""
+    O = oracle_lib
+    genomes = synth.random_genomes(30, 10000, seed=83)
+    db_dir = synth.make_db(tmp_path, genomes, k=21, n_chunks=2, overlap=150, threads=8)
+    r1 = synth.sample_reads(genomes, 2500, 150, seed=84, frac_random=0.05)
+    r2 = synth.sample_reads(genomes, 2500, 150, seed=85, frac_random=0.5)
+    odb = O.OracleDB(db_dir)
+    try:
+        with G["Database"].open_devices(db_dir, [0, 0]) as db:
+            assert db.exchange_info().startswith("host merge") and "duplicate device ordinals" in db.exchange_info()
+        with G["Database"].open(db_dir, device=0) as db:
+            assert db.exchange_info().startswith("single device")
+        monkeypatch.setenv("KMCPG_RCCL", "force")
+        with G["Database"].open_devices(db_dir, [0]) as db:
+            assert db.exchange_info() == "RCCL gather over 1 device(s)", db.exchange_info()
+            res = db.search(r1, params=G["default_params"]())
+            assert synth.assert_parity(odb, res, r1) > 1500
+            res = db.search(r1, r2, params=G["default_params"](try_se=1))  # retries run through the exchange too
+            assert synth.assert_parity(odb, res, r1, r2, O.default_params(try_se=1)) > 500
+            # several batches in flight, gathered from two waiter threads
+            import threading
+            seqs, offs = G["lib"].pack_reads(r1)
+            ref = db.search_packed(seqs, offs, params=G["default_params"]())
+            out = {}
+
+            def pump(t):
+                tk = [db.submit(seqs, offs, params=G["default_params"]()) for _ in range(2)]
+                out[t] = [db.wait(x) for x in tk]
+            th = [threading.Thread(target=pump, args=(t,)) for t in range(2)]
+            [x.start() for x in th]
+            [x.join() for x in th]
+            for t in range(2):
+                for r in out[t]:
+                    assert np.array_equal(r.offs, ref.offs) and np.array_equal(r.matches, ref.matches)
+        monkeypatch.setenv("KMCPG_RCCL", "0")
+        with G["Database"].open_devices(db_dir, [0]) as db:
+            assert "KMCPG_RCCL=0" in db.exchange_info()
+    finally:
+        odb.close()
+
+
 @pytest.mark.parametrize("split_min", ["50", "3000"])
 def test_long_query_split_path(G, oracle_lib, tmp_path, monkeypatch, split_min):
     """The chunked long-query form of the COBS kernel (whole genomes): forced onto ordinary reads with KMCPG_SPLIT_MIN so

@@ -1,0 +1,105 @@
+"""A real-genome, hit-heavy database (tools/family_db.py: the reference's demo genomes + mutated family members, 10 chunks per
+strain, `-j 32` block rules): what synthetic i.i.d. indexes do not have — uneven column densities (a block's filter is sized for
+its fullest column, index.go:936-946), relatives that share sectors, tens to hundreds of hits per read.  Reduced size here
+(a few hundred columns); tools/bench_real_families.py builds the 21 000-column / 1.3 GB one and
+test_full_size_sample checks a sample of it against the oracle when KMCP_FAMILY_DB points at what that tool left behind."""
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from tests import synth
+from tests.test_gpu_cli import compare, oracle_tsv, run_cli
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+
+def _reads_list(reads):
+    return [reads[i].tobytes() for i in range(reads.shape[0])]
+
+
+@pytest.mark.parametrize("uniform_sigs", [0, 1])
+def test_family_database_reduced(oracle_lib, tmp_path, uniform_sigs):
+    import family_db
+    from kmcp_amd import Database, default_params
+    O = oracle_lib
+    info, reads = family_db.build(str(tmp_path / "db"), ecoli_strains=6, small_strains=3, n_reads=3000, uniform_sigs=uniform_sigs, threads=8)
+    assert info["columns"] == (6 + 15 * 3) * 10 and info["kmers_per_col_max"] > 10 * info["kmers_per_col_min"]  # uneven columns
+    rl = _reads_list(reads)
+    odb = O.OracleDB(info["db_dir"])
+    try:
+        # the GPU builder's columns = the oracle's restatement of `kmcp compute` on the same strain sequences: spot-check one strain
+        with Database.open(info["db_dir"], device=0) as db:
+            res = db.search(rl, params=default_params())
+            n = synth.assert_parity(odb, res, rl)
+            hits_per_read = n / len(rl)
+            assert hits_per_read > 2, hits_per_read  # families: a read matches several strains (and overlapping chunks)
+            if uniform_sigs:
+                assert len({db.block_info(b)["num_sigs"] for b in range(db.info.n_blocks)}) < db.info.n_blocks
+        # end to end: the TSV with many rows per read, line for line
+        fq = str(tmp_path / "r.fq")
+        family_db.write_fastq(fq, reads[:1500])
+        ids = [f"r{i}" for i in range(1500)]
+        want, trailer = oracle_tsv(O, odb, ids, rl[:1500])
+        compare(run_cli(["-d", os.path.dirname(info["db_dir"]), fq], str(tmp_path / "o.tsv")), want, trailer)
+        # a kept-top-scores run (what `kmcp profile` users add for families): -n 2
+        want, trailer = oracle_tsv(O, odb, ids, rl[:1500], params=O.default_params(top_n_scores=2))
+        compare(run_cli(["-d", os.path.dirname(info["db_dir"]), fq, "-n", "2"], str(tmp_path / "o2.tsv")), want, trailer)
+    finally:
+        odb.close()
+
+
+def test_strain_columns_equal_the_oracles_compute(oracle_lib):
+    """The generator's columns (K1 on the GPU + torch sort/unique) are what the oracle's `kmcp compute` restatement yields for the
+    same sequence: k-mers of 10 overlapping chunks of a real genome with N's and several records."""
+    import torch
+
+    import family_db
+    O = oracle_lib
+    B = family_db.Builder(0, seed=1)
+    try:
+        acc, seq = family_db.base_genomes()[4]  # Enterococcus faecalis: two records joined by k-1 N's
+        base = torch.frombuffer(bytearray(seq), dtype=torch.uint8).to(B.dev)
+        s = B.strain(base, 4, 3)
+        B.add_genome("x", s)
+        hs = s.cpu().numpy().tobytes()
+        cfg = O.sketch_cfg(k=family_db.K)
+        bounds = family_db.split_bounds(len(hs))
+        for (a, b), col in zip(bounds, B.columns):
+            want = O.sort_unique(O.generate_kmers(hs[a:b], cfg))
+            assert np.array_equal(col[4], want)
+        assert [c for c in synth.split_chunks(hs, 10, 150)] == [hs[a:b] for a, b in bounds]
+    finally:
+        B.close()
+
+
+def test_full_size_sample(oracle_lib):
+    """Parity on a sample of the full-size database left behind by tools/bench_real_families.py (same gpurun call)."""
+    root = os.environ.get("KMCP_FAMILY_DB")
+    if not root or not os.path.exists(os.path.join(root, "family_db.json")):
+        pytest.skip("KMCP_FAMILY_DB not set: run tools/bench_real_families.py first")
+    from kmcp_amd import Database, default_params
+    O = oracle_lib
+    info = json.load(open(os.path.join(root, "family_db.json")))
+    reads = []
+    with open(os.path.join(root, "reads.fq"), "rb") as fh:
+        for i, line in enumerate(fh):
+            if i % 4 == 1:
+                reads.append(line.rstrip(b"\n"))
+            if len(reads) == 400:
+                break
+    for mode, db_dir in info["db_dirs"].items():
+        odb = O.OracleDB(db_dir)
+        try:
+            with Database.open(db_dir, device=0) as db:
+                res = db.search(reads, params=default_params())
+            n = synth.assert_parity(odb, res, reads)
+            assert n > 400
+            print(f"full-size family database, uniform_sigs={mode}: {len(reads)} reads, {n} (read, column) tuples identical to the oracle")
+        finally:
+            odb.close()

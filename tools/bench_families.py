@@ -51,6 +51,14 @@ def main():
             torch.cuda.synchronize()
             ms.append(db.last_timing()[1])
         n_hits = int(d_cnt[0].item())
+        # what the kernel fetched (it counts its own row loads at profiling level 2) beside the algorithmic bytes
+        db.set_profiling(2)
+        db.query_device(reads.data_ptr(), offs.data_ptr(), B, B * bench.READ_LEN, bench.READ_LEN, d_hits.data_ptr(), cap, d_cnt.data_ptr(), d_qk.data_ptr(),
+                        d_ql.data_ptr(), params=params)
+        torch.cuda.synchronize()
+        gathered = db.last_gathered_bytes()
+        db.set_profiling(True)
+        alg = int(d_qk.sum().item()) * int(db.info.row_bytes_sum_local) + B * bench.READ_LEN + 12 * n_hits
         h_reads = reads.cpu().numpy()
         h_offs = offs.cpu().numpy().astype(np.uint64)
         db.search_packed_count(h_reads, h_offs, params=params)
@@ -70,7 +78,8 @@ def main():
         [x.join() for x in th]
         dt = (time.perf_counter() - t0) / NB
         out[f"F={F}"] = dict(hits_per_read=n_hits / B, k2_ms=min(ms), device_reads_per_s=B / (min(ms) * 1e-3), host_boundary_reads_per_s=B / dt,
-                             host_boundary_ms_per_batch=dt * 1e3)
+                             host_boundary_ms_per_batch=dt * 1e3, gathered_bytes=gathered, algorithmic_bytes=alg, gathered_over_algorithmic=gathered / alg,
+                             achieved_gbps=gathered / (min(ms) * 1e-3) / 1e9)
         db.close()
         del d_hits
         torch.cuda.empty_cache()
