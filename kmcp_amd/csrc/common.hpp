@@ -63,6 +63,7 @@ struct K1Args {
   // (queries above max(dedup_threshold, 512) emissions; the others keep their raw emissions in hashes[]); nullptr = raw only
   int32_t* nk_adj;
   int32_t dedup_threshold;
+  int32_t flags;         // experiments (KMCPG_K1_FLAGS): bit 0 = two-level window arg-min, bit 1 = fused adjacent-repeat filter
 };
 
 struct DedupArgs {
@@ -75,6 +76,7 @@ struct DedupArgs {
   int32_t n_lo, n_hi;    // ... among those whose raw count n is in (n_lo, n_hi]
   int32_t pre;           // window-sketch database: k_adj_unique runs first (input of the sort = scratch, m in nk_search)
   int32_t pre_done;      // ... and the k-mer kernel has already done it (k1_kmers_wg<1|2>: fused)
+  int32_t key_shift;     // leading zero bits of the largest possible hash (0, or clz(maxHash) for FracMinHash databases): k_dedup_bucket
   uint64_t* hashes;
   uint64_t* scratch;
   const int32_t* nk_raw;

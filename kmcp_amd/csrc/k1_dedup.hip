@@ -245,6 +245,99 @@ __global__ void __launch_bounds__(NT) k_dedup(const DedupArgs a) {
 }
 
 
+// Queries of up to 2048 elements to sort (a 10-kb HiFi read leaves ~1 400 after the adjacent-repeat filter): the bitonic network
+// above needs 66 barrier-separated stages for them; the hashes are uniform, so one distribution pass gets them almost sorted:
+// 1024 buckets by the top bits (after shifting the largest value of the query up to bit 63, which also covers FracMinHash
+// databases whose hashes all lie below maxHash), a scan of the bucket sizes, a scatter, and an insertion sort of every bucket
+// (2 elements on average) — ten barriers in all, same output as the sort (ascending, then unique).  A query whose values are
+// not spread out (some bucket above 24 elements: low-complexity sequence) takes the bitonic network instead, in this kernel.
+constexpr int DB_NT = 256, DB_MAXB = 24;
+template <int CAP, int NB>
+__global__ void __launch_bounds__(DB_NT) k_dedup_bucket(const DedupArgs a) {
+  constexpr int BPT = NB / DB_NT;  // buckets per thread
+  constexpr int SHIFT = 64 - (NB == 1024 ? 10 : 11);
+  static_assert(NB == 1024 || NB == 2048, "bucket bits");
+  __shared__ uint64_t o[CAP];
+  __shared__ int cnt[NB];
+  __shared__ int st[NB + 1];
+  __shared__ int scan[DB_NT / 64];
+  __shared__ int s_bad;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  for (uint32_t r = blockIdx.x; r < a.n_reads; r += gridDim.x) {
+    const int n = a.nk_raw[r];
+    if (n <= a.dedup_threshold || n <= a.n_lo || n > a.n_hi) continue;
+    const int m = a.pre ? a.nk_search[r] : n;
+    if (m <= a.lo || m > a.hi) continue;
+    const uint64_t koff = a.offs[r] + (a.offs2 ? a.offs2[r] : 0);
+    uint64_t* g = a.hashes + koff;
+    const uint64_t* __restrict__ in = a.pre ? a.scratch + koff : g;
+    if (tid == 0) s_bad = 0;
+    for (int i = tid; i < NB; i += DB_NT) cnt[i] = 0;
+    __syncthreads();
+    // the elements stay in global memory (L2) for the two passes that read them: LDS holds the sorted copy only.
+    // lz: the hashes are uniform over [0, maxHash] (FracMinHash) or the whole 64-bit range; the host passes the shift that
+    // brings the top of that range to bit 63
+    const int lz = a.key_shift;
+    for (int i = tid; i < m; i += DB_NT) atomicAdd(&cnt[(int)((in[i] << lz) >> SHIFT)], 1);
+    __syncthreads();
+    // exclusive scan of the bucket sizes (BPT buckets per thread)
+    int c4[BPT], sum = 0, big = 0;
+#pragma unroll
+    for (int j = 0; j < BPT; j++) {
+      c4[j] = cnt[tid * BPT + j];
+      sum += c4[j];
+      big |= c4[j] > DB_MAXB;
+    }
+    if (big) s_bad = 1;
+    const int incl = wave_add_scan(sum);
+    if (lane == 63) scan[w] = incl;
+    __syncthreads();
+    int before = 0;
+#pragma unroll
+    for (int j = 0; j < DB_NT / 64; j++)
+      if (j < w) before += scan[j];
+    int pos = before + incl - sum;
+#pragma unroll
+    for (int j = 0; j < BPT; j++) {
+      st[tid * BPT + j] = pos;
+      cnt[tid * BPT + j] = pos;  // the scatter's cursor
+      pos += c4[j];
+    }
+    if (tid == DB_NT - 1) st[NB] = pos;
+    const bool bad = s_bad != 0;
+    __syncthreads();
+    if (!bad) {
+      for (int i = tid; i < m; i += DB_NT) {
+        const uint64_t x = in[i];
+        o[atomicAdd(&cnt[(int)((x << lz) >> SHIFT)], 1)] = x;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int j = 0; j < BPT; j++) {  // insertion sort of this thread's buckets
+        const int b0 = st[tid * BPT + j], b1 = st[tid * BPT + j + 1];
+        for (int i = b0 + 1; i < b1; i++) {
+          const uint64_t x = o[i];
+          int q = i - 1;
+          while (q >= b0 && o[q] > x) {
+            o[q + 1] = o[q];
+            q--;
+          }
+          o[q + 1] = x;
+        }
+      }
+      __syncthreads();
+    } else {
+      for (int i = tid; i < m; i += DB_NT) o[i] = in[i];
+      __syncthreads();
+      bitonic_sort(o, m, tid, DB_NT);
+    }
+    const int total = block_unique<DB_NT>(o, m, g, scan, tid);
+    // MinMatched is tested on the raw count (:854), NumKmers is the unique count (:910)
+    if (tid == 0) a.nk_search[r] = n >= a.min_matched ? total : 0;
+    __syncthreads();
+  }
+}
+
 void launch_dedup(DedupArgs a, uint64_t max_n, hipStream_t st) {
   if (a.n_reads == 0) return;
   // the wave class settles every query at or below the dedup threshold and sorts those of at most 512 k-mers
@@ -254,13 +347,18 @@ void launch_dedup(DedupArgs a, uint64_t max_n, hipStream_t st) {
   a.n_hi = max_n > HUGE_MIN ? (int32_t)HUGE_MIN : 0x7fffffff;  // beyond that: device-wide sort (sort_huge.hip)
   const unsigned grid = a.n_reads > (1u << 20) ? (1u << 20) : a.n_reads;  // the workgroup kernels stride over the reads
   if (a.pre && !a.pre_done) hipLaunchKernelGGL(k_adj_unique, dim3(grid), dim3(ADJ_NT), 0, st, a);
+  // classes by the number m of elements to sort; the grids stride over the reads, sized for what the chip holds at once
   a.lo = 0;
+  a.hi = 2048;
+  hipLaunchKernelGGL((k_dedup_bucket<2048, 1024>), dim3(std::min(grid, 256u * 12)), dim3(DB_NT), 0, st, a);
+  if (max_n <= 2048) return;
+  a.lo = 2048;  // (a query the class before finished shows its NumKmers <= lo here)
   a.hi = 4096;
-  hipLaunchKernelGGL((k_dedup<256, 4096>), dim3(grid), dim3(256), 0, st, a);
+  hipLaunchKernelGGL((k_dedup_bucket<4096, 2048>), dim3(std::min(grid, 256u * 6)), dim3(DB_NT), 0, st, a);
   if (max_n > 4096) {
     a.lo = 4096;
     a.hi = 0x7fffffff;
-    hipLaunchKernelGGL((k_dedup<1024, 16384>), dim3(grid), dim3(1024), 0, st, a);
+    hipLaunchKernelGGL((k_dedup<1024, 16384>), dim3(std::min(grid, 1024u)), dim3(1024), 0, st, a);
   }
 }
 

@@ -615,13 +615,14 @@ __device__ __forceinline__ int wg_window_mate_lds(const K1Args& a, int mode, con
       const int nst = min(ns - p0, T + max(wsz - 1, 0));
       for (int i = tid; i < nst; i += K1WG) L.hw[i] = lds_hash(L, i, sm);
       __syncthreads();
-      if (wsz >= 4) wg_min4(L, nst, tid);
+      const bool two = wsz >= 4 && (a.flags & 1);
+      if (two) wg_min4(L, nst, tid);
       const bool v = tid < T && p0 + tid < nw;
       uint64_t h = 0;
       if (v) {
         int pos = tid;
         if (wsz > 0) {
-          const int m = argmin_left4(L, tid, wsz);
+          const int m = two ? argmin_left4(L, tid, wsz) : argmin_left(L.hw, tid, wsz);
           pos = (m - tid < k - sm) ? m : m + sm - k;
         }
         h = lds_hash(L, pos, k);
@@ -641,13 +642,14 @@ __device__ __forceinline__ int wg_window_mate_lds(const K1Args& a, int mode, con
     const int nkt = min(nk - b0, T + w);
     for (int i = tid; i < nkt; i += K1WG) L.hw[i] = lds_hash(L, i, k);
     __syncthreads();
-    if (w >= 4) wg_min4(L, nkt, tid);
+    const bool two = w >= 4 && (a.flags & 1);
+    if (two) wg_min4(L, nkt, tid);
     const int w0 = p0 + tid;
     const bool v = tid < T && w0 < nw;
     int m = -1, pm = -2;
     if (v) {
-      m = argmin_left4(L, off + tid, w);
-      pm = w0 > 0 ? argmin_left4(L, off + tid - 1, w) : -2;
+      m = two ? argmin_left4(L, off + tid, w) : argmin_left(L.hw, off + tid, w);
+      pm = w0 <= 0 ? -2 : (two ? argmin_left4(L, off + tid - 1, w) : argmin_left(L.hw, off + tid - 1, w));
     }
     const uint64_t h = (v && m != pm) ? L.hw[m] : 0;
     emit(v && m != pm && h != 0 && (!scaled || h <= a.max_hash), h);
@@ -716,7 +718,7 @@ __device__ __forceinline__ void wg_reads_windows(const K1Args& a, const uint64_t
     int raw = 0, raw1 = 0;
     if (!skip) {
       bool need_raw = true;
-      if (a.nk_adj && a.scratch && len1 + len2 > raw_bound) {  // (a mate emits at most one value per base)
+      if ((a.flags & 2) && a.nk_adj && a.scratch && len1 + len2 > raw_bound) {  // (a mate emits at most one value per base)
         AdjCarry c;
         uint64_t* adj = a.scratch + o1 + o2;
         int m = wg_window_mate_lds<true>(a, MODE, a.seqs + o1, len1, tab, L, adj, 0, c, s_wave, s_wave2, s_last, tid);
@@ -757,6 +759,309 @@ __global__ void __launch_bounds__(K1WG, 8) k1_kmers_wg(const K1Args a) {
     __shared__ int s_wave2[K1WG / 64];
     __shared__ uint64_t s_last[K1WG / 64];
     wg_reads_windows<MODE>(a, tab, s_wave, s_wave2, s_last, lds, tid);
+  }
+}
+
+// ---- window sketches of long reads, barrier-free form (k <= 65, windows of at most 64 hashes: every practical setting) ---------
+// The 1024-thread tile form above spends its time in workgroup barriers (eight per tile of ~1000 windows: prefix arrays,
+// hashes, minima, ordered compaction).  Here the 16 waves of the workgroup never wait for each other while they sketch: the
+// windows of a mate are cut into 16 contiguous segments, one per wave; a wave walks its segment in tiles of 64 windows with the
+// wave-level machinery of the short-read kernel (prefix XOR scans on DPP, wave_hash), keeps the s-mer / k-mer hashes of the current
+// and the next tile in a 2-slot ring in LDS that only it touches (wave-level fences), finds the windows' leftmost minima there,
+// filters adjacent repeats with ballot + shuffle and appends to a private piece of a temporary array.  Two workgroup barriers per
+// mate remain: one before and one after the pieces are moved together in order (dropping an element that repeats across a segment
+// boundary).  Semantics are those of syncmer_mate / minimizer_mate.
+constexpr int K1W_THREADS = 512;
+constexpr int K1W_WAVES = K1W_THREADS / 64;
+// Per wave: a ring over two tiles (position p relative to the segment start lives at p & 127) of the inclusive prefix XORs, the
+// hashes the windows scan (s-mers for syncmers, k-mers for minimizers), the k-mer hashes, and the second level of the window
+// arg-min: m4v[p] = min(hw[p..p+3]), m4i[p] = offset of its leftmost position.  The kernel is bound by VALU issue (a wave64
+// instruction takes four cycles on a 16-lane SIMD), so what counts is instructions per window: hashes come from two LDS look-ups
+// of the prefix ring instead of eight cross-lane permutes, and a 20-wide window costs 5 + 8 look-ups instead of 20.
+struct K1WRing {
+  uint64_t ip[128], iq[128];
+  uint64_t hw[128];
+  uint64_t hk[128];
+  uint64_t m4v[128];
+  uint8_t m4i[128];
+};
+struct K1WShared {
+  int cnt[K1W_WAVES], raw[K1W_WAVES];
+  uint64_t first[K1W_WAVES], last[K1W_WAVES];
+};
+struct SeqCarry {  // uniform over the workgroup
+  uint64_t last = 0;
+  int have = 0, raw = 0, cnt = 0;
+};
+
+__host__ __device__ __forceinline__ bool wave_windows_usable(const K1Args& a) {
+  if (a.k > K1_SCAN_MAX_K || a.k < 1) return false;
+  const int ws = (int)a.w_or_s;
+  if (a.mode == 2) return ws >= 1 && ws <= a.k && 2 * (a.k - ws) <= 60;
+  if (a.mode == 1) return ws >= 1 && ws <= 60;
+  return false;
+}
+
+__device__ __forceinline__ uint64_t readfirst64(uint64_t v) {
+  return ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
+}
+
+// canonical hash of the kk-mer at ring position p = 64 T + lane of the tile whose scan is `t` (its exclusive prefixes are in
+// registers, the inclusive prefix at the kk-mer's last base comes from the ring)
+__device__ __forceinline__ uint64_t ring_hash(const K1WRing& ring, const WTile& t, int p, int kk, int lane) {
+  const int e = (p + kk - 1) & 127;
+  const uint64_t f = rolv(ring.ip[e] ^ t.ip ^ t.xp, kk - 1 + lane), r = rorv(ring.iq[e] ^ t.iq ^ t.xq, lane);
+  return f < r ? f : r;
+}
+
+// m4v / m4i of ring position p (needs hw[p .. p+3])
+__device__ __forceinline__ void ring_min4(K1WRing& ring, int p) {
+  uint64_t mv = ring.hw[p & 127];
+  int m = 0;
+#pragma unroll
+  for (int j = 1; j < 4; j++) {
+    const uint64_t x = ring.hw[(p + j) & 127];
+    if (x < mv) {  // strict: the leftmost of equal values wins
+      mv = x;
+      m = j;
+    }
+  }
+  ring.m4v[p & 127] = mv;
+  ring.m4i[p & 127] = (uint8_t)m;
+}
+
+// leftmost minimum of hw[p0 .. p0+n) through the 4-wide minima (n >= 1); returns the position, *val = the value
+__device__ __forceinline__ int ring_argmin(const K1WRing& ring, int p0, int n, uint64_t* val) {
+  int i = 0;
+  uint64_t mv;
+  int m;       // start of the best group (grp) or the best single position
+  bool grp;
+  if (n >= 4) {
+    mv = ring.m4v[p0 & 127];
+    m = p0;
+    grp = true;
+    for (i = 4; i + 4 <= n; i += 4) {
+      const uint64_t x = ring.m4v[(p0 + i) & 127];
+      if (x < mv) {
+        mv = x;
+        m = p0 + i;
+      }
+    }
+  } else {
+    mv = ring.hw[p0 & 127];
+    m = p0;
+    grp = false;
+    i = 1;
+  }
+  for (; i < n; i++) {
+    const uint64_t x = ring.hw[(p0 + i) & 127];
+    if (x < mv) {
+      mv = x;
+      m = p0 + i;
+      grp = false;
+    }
+  }
+  *val = mv;
+  return grp ? m + (int)ring.m4i[m & 127] : m;
+}
+
+template <int MODE, bool ADJ>
+__device__ __forceinline__ void wgw_mate(const K1Args& a, const uint8_t* __restrict__ s, int len, const uint64_t* tab, K1WRing& ring, K1WShared& sh,
+                                         uint64_t* __restrict__ temp, uint64_t* __restrict__ fin, SeqCarry& c, int tid) {
+  const int lane = tid & 63, w = tid >> 6;
+  const int k = a.k;
+  const bool scaled = a.scaled != 0;
+  const int nk = len - k + 1;
+  int wsz = 0, nw = 0, sm = 0;
+  if (MODE == 2) {
+    sm = (int)a.w_or_s;
+    const int Lw = 2 * k - sm - 1;
+    wsz = 2 * (k - sm);
+    nw = (nk <= 0 || len < Lw) ? 0 : (wsz > 0 ? len - Lw + 1 : nk);
+  } else {
+    wsz = (int)a.w_or_s;
+    nw = (nk <= 0 || len < k + wsz - 1) ? 0 : nk - wsz + 1;
+  }
+  if (nw <= 0) return;  // ErrShortSeq (uniform)
+  const int segw = ((nw + K1W_WAVES * 64 - 1) / (K1W_WAVES * 64)) * 64;  // windows per wave, a multiple of 64
+  const int w0s = w * segw, w0e = min(nw, w0s + segw);
+  int cnt = 0, raw = 0;
+  uint64_t first = 0, last = 0;
+  bool any = false;
+  if (w0s < w0e) {
+    const int ntiles = (w0e - w0s + 63) / 64;
+    uint64_t cp = 0, cq = 0;
+    WTile B = wave_tile(s, len, w0s, tab, cp, cq, lane);
+    ring.ip[lane] = B.ip;
+    ring.iq[lane] = B.iq;
+    int pm_carry = -2;  // minimizer: arg-min of the window before the tile's first one
+    // iteration t: scan tile t+1, hash tile t, windows of tile t-1 (their hashes reach into tile t)
+    for (int t = 0; t <= ntiles; t++) {
+      const WTile C = wave_tile(s, len, w0s + 64 * (t + 1), tab, cp, cq, lane);
+      const int nslot = ((t + 1) & 1) * 64;
+      ring.ip[nslot + lane] = C.ip;
+      ring.iq[nslot + lane] = C.iq;
+      wave_lds_fence();
+      const int pt = 64 * t + lane;
+      const uint64_t hkv = ring_hash(ring, B, pt, k, lane);
+      ring.hk[pt & 127] = hkv;
+      ring.hw[pt & 127] = MODE == 2 ? ring_hash(ring, B, pt, sm, lane) : hkv;
+      B = C;
+      wave_lds_fence();
+      if (wsz >= 4) {
+        // one pass: the 4-wide minima of this tile's positions 0..60 and of the previous tile's 61..63 (whose last elements
+        // have just arrived); the windows below read the previous tile's and this tile's first 57 (wsz <= 60)
+        const int pm4 = lane <= 60 ? pt : pt - 64;
+        if (pm4 >= 0) ring_min4(ring, pm4);
+        wave_lds_fence();
+      }
+      if (t == 0) continue;
+      const int p0 = 64 * (t - 1) + lane;  // this lane's window, relative to w0s
+      const bool v = w0s + p0 < w0e;
+      uint64_t h = 0;
+      bool keep = false;
+      if (MODE == 2) {
+        int pos = p0;
+        if (wsz > 0) {
+          uint64_t mv;
+          const int m = ring_argmin(ring, p0, wsz, &mv);
+          pos = (m - p0 < k - sm) ? m : m + sm - k;
+        }
+        h = ring.hk[pos & 127];
+        keep = v && h != 0 && (!scaled || h <= a.max_hash);
+      } else {
+        uint64_t mv;
+        const int m = ring_argmin(ring, p0, wsz, &mv);
+        if (t == 1 && w0s > 0) {  // (uniform branch) window w0s-1 = {k-mer w0s-1} + the first wsz-1 of window w0s
+          int pm0 = -1;
+          if (lane == 0) {
+            const uint64_t x = hash_at(s, w0s - 1, k, tab);
+            int m2 = -1;
+            uint64_t mv2 = ~0ULL;
+            for (int j = 0; j < wsz - 1; j++) {
+              const uint64_t y = ring.hk[j & 127];
+              if (m2 < 0 || y < mv2) {
+                mv2 = y;
+                m2 = j;
+              }
+            }
+            pm0 = (m2 < 0 || x <= mv2) ? -1 : m2;  // relative position; -1 = k-mer w0s-1 itself
+          }
+          pm_carry = __builtin_amdgcn_readfirstlane(pm0);
+        }
+        int pm = __shfl_up(m, 1);
+        if (lane == 0) pm = pm_carry;  // -2 at the very first window of the mate: always emitted
+        pm_carry = __builtin_amdgcn_readlane(m, 63);
+        h = mv;
+        keep = v && m != pm && h != 0 && (!scaled || h <= a.max_hash);
+      }
+      const uint64_t mk = __ballot(keep);
+      const uint64_t lower = mk & ((1ULL << lane) - 1ULL);
+      bool keep2 = keep;
+      if (ADJ) {
+        const int src = lower ? 63 - __clzll((unsigned long long)lower) : lane;
+        const uint64_t prev = __shfl(h, src);
+        const bool has_prev = lower != 0 || any;
+        keep2 = keep && !(has_prev && h == (lower ? prev : last));
+      }
+      if (mk) {
+        const int hi = 63 - __clzll((unsigned long long)mk), lo = __ffsll((unsigned long long)mk) - 1;
+        const uint64_t lastv = readfirst64(__shfl(h, hi));
+        if (!any) first = readfirst64(__shfl(h, lo));
+        last = lastv;
+        any = true;
+      }
+      const uint64_t mk2 = ADJ ? __ballot(keep2) : mk;
+      if (keep2) temp[w0s + cnt + __popcll(mk2 & ((1ULL << lane) - 1ULL))] = h;
+      cnt += __popcll(mk2);
+      raw += __popcll(mk);
+      wave_lds_fence();  // the next iteration's hashes and minima overwrite what these windows read
+    }
+  }
+  if (lane == 0) {
+    sh.cnt[w] = cnt;
+    sh.raw[w] = raw;
+    sh.first[w] = first;
+    sh.last[w] = last;
+  }
+  __threadfence_block();
+  __syncthreads();
+  // the segments' pieces move together, in order
+  int off = c.cnt, have = c.have, my_off = 0, my_drop = 0, rawsum = 0;
+  uint64_t plast = c.last;
+#pragma unroll
+  for (int j = 0; j < K1W_WAVES; j++) {
+    const int cj = sh.cnt[j];
+    rawsum += sh.raw[j];
+    const int drop = (ADJ && cj > 0 && have && sh.first[j] == plast) ? 1 : 0;
+    if (j == w) {
+      my_off = off;
+      my_drop = drop;
+    }
+    off += cj - drop;
+    if (sh.raw[j] > 0) {
+      plast = sh.last[j];
+      have = 1;
+    }
+  }
+  for (int i = lane + my_drop; i < cnt; i += 64) fin[my_off + i - my_drop] = temp[w0s + i];
+  c.cnt = __builtin_amdgcn_readfirstlane(off);
+  c.have = __builtin_amdgcn_readfirstlane(have);
+  c.last = readfirst64(plast);
+  c.raw += __builtin_amdgcn_readfirstlane(rawsum);
+  __syncthreads();
+}
+
+// the per-read loop of the barrier-free window kernel: same contract as wg_reads_windows (scratch[] + nk_adj[] for queries that
+// will be sorted, hashes[] for the others)
+template <int MODE>
+__global__ void __launch_bounds__(K1W_THREADS) k1_windows_wave(const K1Args a) {
+  __shared__ uint64_t tab[256];
+  __shared__ K1WRing rings[K1W_WAVES];
+  __shared__ K1WShared sh;
+  const int tid = threadIdx.x;
+  if (tid < 256) tab[tid] = seed_of(tid);
+  __syncthreads();
+  K1WRing& ring = rings[tid >> 6];
+  const int raw_bound = a.dedup_threshold > K1_WAVE_SORT_CAP ? a.dedup_threshold : K1_WAVE_SORT_CAP;
+  for (uint32_t r = blockIdx.x; r < a.n_reads; r += gridDim.x) {
+    const uint64_t o1 = a.offs[r];
+    const int len1 = (int)(a.offs[r + 1] - o1);
+    uint64_t o2 = 0;
+    int len2 = 0;
+    const bool pe = a.offs2 != nullptr;
+    if (pe) {
+      o2 = a.offs2[r];
+      len2 = (int)(a.offs2[r + 1] - o2);
+    }
+    const bool skip = len1 < a.min_qlen && !(pe && len2 >= a.min_qlen);
+    int raw = 0, raw1 = 0;
+    if (!skip) {
+      uint64_t* hs_out = a.hashes + o1 + o2;
+      uint64_t* sc_out = a.scratch + o1 + o2;
+      bool need_raw = true;
+      if (a.nk_adj && len1 + len2 > raw_bound) {  // (a mate emits at most one value per base)
+        SeqCarry c;
+        wgw_mate<MODE, true>(a, a.seqs + o1, len1, tab, ring, sh, hs_out, sc_out, c, tid);
+        raw1 = c.raw;
+        if (pe) wgw_mate<MODE, true>(a, a.seqs2 + o2, len2, tab, ring, sh, hs_out + len1, sc_out, c, tid);
+        raw = c.raw;
+        need_raw = raw <= raw_bound || raw > (int)HUGE_MIN;
+        if (!need_raw && tid == 0) a.nk_adj[r] = c.cnt;
+      }
+      if (need_raw) {
+        SeqCarry c;
+        wgw_mate<MODE, false>(a, a.seqs + o1, len1, tab, ring, sh, sc_out, hs_out, c, tid);
+        raw1 = c.raw;
+        if (pe) wgw_mate<MODE, false>(a, a.seqs2 + o2, len2, tab, ring, sh, sc_out + len1, hs_out, c, tid);
+        raw = c.raw;
+      }
+    }
+    if (tid == 0) {
+      a.nk_raw[r] = raw;
+      a.nk1[r] = raw1;
+      a.qlen[r] = len1 + len2;
+    }
   }
 }
 
@@ -849,11 +1154,16 @@ bool launch_k1(const K1Args& a, uint32_t max_read_len, hipStream_t st) {
   }
   if (max_read_len > 2048) {  // long queries: a whole workgroup per read
     unsigned blocks = a.n_reads > 65536 ? 65536 : a.n_reads;
+    if (a.mode != 0 && a.scratch && wave_windows_usable(a) && !(a.flags & 4)) {  // window sketches: the barrier-free form
+      if (a.mode == 2) hipLaunchKernelGGL(k1_windows_wave<2>, dim3(blocks), dim3(K1W_THREADS), 0, st, a);
+      else hipLaunchKernelGGL(k1_windows_wave<1>, dim3(blocks), dim3(K1W_THREADS), 0, st, a);
+      return a.nk_adj != nullptr;
+    }
     if (!wg_lds_usable(a)) hipLaunchKernelGGL(k1_kmers_wg_global, dim3(blocks), dim3(K1WG), 0, st, a);
     else if (a.mode == 2) hipLaunchKernelGGL(k1_kmers_wg<2>, dim3(blocks), dim3(K1WG), 0, st, a);
     else if (a.mode == 1) hipLaunchKernelGGL(k1_kmers_wg<1>, dim3(blocks), dim3(K1WG), 0, st, a);
     else hipLaunchKernelGGL(k1_kmers_wg<0>, dim3(blocks), dim3(K1WG), 0, st, a);
-    return wg_lds_usable(a) && a.mode != 0 && a.nk_adj && a.scratch;
+    return wg_lds_usable(a) && a.mode != 0 && a.nk_adj && a.scratch && (a.flags & 2);
   }
   unsigned blocks = (a.n_reads + 3) / 4;
   if (blocks > 32768) blocks = 32768;

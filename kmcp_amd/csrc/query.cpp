@@ -82,6 +82,7 @@ int run_kmers(kmcpg_db* db, const uint8_t* d_seqs, const uint64_t* d_offs, const
   }
   a.nk_adj = d_nk_search;
   a.dedup_threshold = p.dedup_threshold;
+  a.flags = getenv("KMCPG_K1_FLAGS") ? atoi(getenv("KMCPG_K1_FLAGS")) : 3;
   const bool adj_done = launch_k1(a, max_read_len, st);
   uint64_t ub = max_read_len >= (uint32_t)a.k ? (uint64_t)(max_read_len - a.k + 1) : 0;
   if (d_seqs2) ub *= 2;
@@ -99,6 +100,7 @@ int run_kmers(kmcpg_db* db, const uint8_t* d_seqs, const uint64_t* d_offs, const
     d.nk_search = d_nk_search;
     d.pre = a.mode != 0;
     d.pre_done = adj_done;
+    d.key_shift = (I.scaled && a.max_hash) ? __builtin_clzll(a.max_hash) : 0;
     launch_dedup(d, ub, st);
     if (ub > HUGE_MIN) {
       // whole-genome queries: which ones they are is only known on the device -> one small read-back, then a device-wide

@@ -17,7 +17,9 @@ pytestmark = pytest.mark.gpu
 @pytest.fixture(scope="module")
 def case(oracle_lib, tmp_path_factory):
     tmp = tmp_path_factory.mktemp("paged")
-    genomes = synth.random_genomes(48, 24000, seed=90)
+    # genomes of different lengths: every block gets a NumSigs of its own (equal ones would be laid side by side in one group)
+    lens = np.random.default_rng(9).integers(16000, 32000, size=48)
+    genomes = [g[:n] for g, n in zip(synth.random_genomes(48, 32000, seed=90), lens)]
     db_dir = synth.make_db(tmp / "db", genomes, k=21, n_chunks=2, overlap=150, threads=12)  # 96 columns in blocks of 8
     odb = oracle_lib.OracleDB(db_dir)
     yield tmp, genomes, db_dir, odb
@@ -47,7 +49,9 @@ def test_open_reports_needed_and_free_then_paged_search_equals_resident(oracle_l
     tmp, genomes, db_dir, odb = case
     with Database.open(db_dir, device=0) as db:
         assert db.paged_info() == (0, 0)
-        need_mb = sum(db.block_info(b)["num_sigs"] * db.block_info(b)["stride"] for b in range(db.info.n_blocks)) / 2**20
+        bi = [db.block_info(b) for b in range(db.info.n_blocks)]
+        assert len({b["num_sigs"] for b in bi}) == len(bi)  # nothing grouped: the sum below is what is resident
+        need_mb = sum(b["num_sigs"] * b["stride"] for b in bi) / 2**20
     assert need_mb > 4
     reads = synth.sample_reads(genomes, 3000, 150, sub_rate=0.01, seed=91, frac_random=0.1)
     reads2 = synth.sample_reads(genomes, 3000, 150, sub_rate=0.01, seed=92, frac_random=0.6)

@@ -48,15 +48,16 @@ def main():
     only = sys.argv[1] if len(sys.argv) > 1 else ""  # "gtdb": the two GTDB-scale shapes only
     # sigs_step 0: every block has the same NumSigs (equal-length chunks, as BASELINE configs[1] is built) and the 32 narrow
     # blocks share one group of 1248-byte rows; sigs_step 7: a different NumSigs per block, every block on its own (39-byte rows)
-    for tag, step in ((("", 0), ("_distinct_numsigs", 7)) if only != "gtdb" else ()):
+    for tag, step in ((("", 0), ("_distinct_numsigs", 7)) if only not in ("gtdb", "hifi") else ((("", 0),) if only == "hifi" else ())):
         # paired-end 2 x 150 against the 10k-chunk index
         spec = lib.SynthSpec(k=21, num_hashes=1, fpr=0.3, n_blocks=32, cols_per_block=312, num_sigs=1121470, kmers_per_col=400000, seed=1, sigs_step=step)
         with Database.open_synthetic(spec) as db:
-            n = 262144
-            lens = torch.full((n,), 150, dtype=torch.int64)
-            s1, o1, t1 = rand_reads(n, lens, 1)
-            s2, o2, t2 = rand_reads(n, lens, 2)
-            out["pe_2x150_vs_10k_chunks" + tag] = run(db, s1, o1, n, t1 + t2, 150, default_params(), s2, o2)
+            if only != "hifi":
+                n = 262144
+                lens = torch.full((n,), 150, dtype=torch.int64)
+                s1, o1, t1 = rand_reads(n, lens, 1)
+                s2, o2, t2 = rand_reads(n, lens, 2)
+                out["pe_2x150_vs_10k_chunks" + tag] = run(db, s1, o1, n, t1 + t2, 150, default_params(), s2, o2)
         # HiFi ~10 kb against a Closed-Syncmer (s=11) 10k-chunk index
         spec = lib.SynthSpec(k=21, num_hashes=1, fpr=0.3, n_blocks=32, cols_per_block=312, num_sigs=300000, kmers_per_col=100000, seed=2, syncmer_s=11,
                              sigs_step=step)
@@ -67,6 +68,9 @@ def main():
             lens = torch.clamp((torch.randn(n, generator=g) * 2000 + 10000).long(), 2000, 20000)
             s, o, t = rand_reads(n, lens, 4)
             out["hifi_10kb_syncmer_vs_10k_chunks" + tag] = run(db, s, o, n, t, int(lens.max()), default_params())
+    if only == "hifi":
+        print(json.dumps(out, indent=1))
+        return
     # genome search: 4-Mbp queries against a FracMinHash (scale 1000), 3-hash, fpr 0.001 index of 50 k references
     spec = lib.SynthSpec(k=21, num_hashes=3, fpr=0.001, n_blocks=8, cols_per_block=6256, num_sigs=431000, kmers_per_col=10000, seed=3, scale=1000, sigs_step=13)
     with Database.open_synthetic(spec) as db:
