@@ -83,6 +83,8 @@ struct DedupArgs {
   int32_t* nk_search;    // NumKmers after dedup, 0 if the read is not searched
 };
 
+constexpr int K2_GATHER_SLOTS = 256;
+
 struct K2Args {
   const BlockDev* blocks;  // groups
   const Seg* segs;
@@ -112,7 +114,7 @@ struct K2Args {
   kmcpg_hit* hits;
   uint64_t hit_cap;
   unsigned long long* counter;
-  unsigned long long* gathered;  // optional (profiling level 2): number of 16-byte row loads issued
+  unsigned long long* gathered;  // optional (profiling level 2): 16-byte row loads issued, K2_GATHER_SLOTS counters 128 B apart
   const uint16_t* cmin_fpr;      // optional: [n] = smallest count whose FPR(n, count) passes -f, n <= cmin_fpr_n (query.cpp fpr_bound)
   int32_t cmin_fpr_n;
 };

@@ -56,7 +56,9 @@ void give_owner(ResultOwner* o) {
   const size_t bytes = o->matches.capacity() * sizeof(kmcpg_match) + (o->qlen.capacity() + o->qkmers.capacity() + o->ksize.capacity()) * 4 + o->offs.capacity() * 8;
   {
     std::lock_guard<std::mutex> g(g_owner_mu);
-    if (g_owner_pool.size() < 4 && bytes <= (1ull << 30)) {
+    // (a database full of close relatives returns hundreds of matches per read: 1.7 GB of records for a batch of 131 072 reads;
+    // handing such a buffer back to the allocator means page-faulting it in again for the next batch, 0.2 s of every 0.4 s)
+    if (g_owner_pool.size() < 4 && bytes <= (4ull << 30)) {
       g_owner_pool.push_back(o);
       return;
     }

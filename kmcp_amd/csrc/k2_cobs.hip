@@ -166,6 +166,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, GR 
   for (int d = 0; d < 4; d++)
 #pragma unroll
     for (int p = 0; p < NPL; p++) pl[d][p] = 0;
+  uint32_t g_acc = 0;  // 16-byte row loads this wave issued (profiling level 2)
 
   for (int c0 = 0; c0 < nmax; c0 += CH) {
     // ---- row indices of this chunk: loc = h % NumSigs (:6811), multi-hash h_i = uint32(a + b*i) (util-hash.go:125-142)
@@ -215,10 +216,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, GR 
         }
         x[i] = v;
       }
-      if (a.gathered) {  // measurement runs only: what this wave asked the memory system for
-        const uint64_t lv = __ballot(live);
-        if (lane == 0 && lv) atomicAdd(a.gathered, (unsigned long long)__popcll(lv) * NR * (MULTI ? nh : 1));
-      }
+      if (a.gathered) g_acc += (uint32_t)__popcll(__ballot(live)) * NR * (MULTI ? nh : 1);  // measurement runs only
       if constexpr (NR == 8) {
         csa8<NPL>(pl[0], x[0].x, x[1].x, x[2].x, x[3].x, x[4].x, x[5].x, x[6].x, x[7].x);
         csa8<NPL>(pl[1], x[0].y, x[1].y, x[2].y, x[3].y, x[4].y, x[5].y, x[6].y, x[7].y);
@@ -261,6 +259,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, GR 
     wave_lds_fence();
     if (!SPLIT && a.prune && __ballot(live) == 0) break;
   }
+  // what this wave asked the memory system for: one atomic per wave, spread over K2_GATHER_SLOTS counters a cache line apart
+  // (one atomic per row group on a single counter made a GTDB-scale launch take 11 s instead of 0.49 s)
+  if (a.gathered && lane == 0 && g_acc) atomicAdd(a.gathered + (size_t)(blockIdx.x % K2_GATHER_SLOTS) * 16, (unsigned long long)g_acc);
 
   if (SPLIT) {
     if (!live) return;

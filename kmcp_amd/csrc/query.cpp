@@ -335,8 +335,8 @@ extern "C" int kmcpg_query_device(kmcpg_db* db, const uint8_t* d_seqs, const uin
   // from is ~1/64 of the index (GTDB scale: 575 -> 510 ms per 524 k reads; profiles/r02_order_exp.txt)
   a.slot_major = getenv("KMCPG_SLOT_MAJOR") ? atoi(getenv("KMCPG_SLOT_MAJOR")) : 1;
   if (db->profiling >= 2) {
-    if (db->w_gathered.ensure(1)) return kmcpg_fail(KMCPG_ENOMEM, "hipMalloc failed");
-    HIPCHK(hipMemsetAsync(db->w_gathered.p, 0, sizeof(uint64_t), st));
+    if (db->w_gathered.ensure((size_t)K2_GATHER_SLOTS * 16)) return kmcpg_fail(KMCPG_ENOMEM, "hipMalloc failed");
+    HIPCHK(hipMemsetAsync(db->w_gathered.p, 0, (size_t)K2_GATHER_SLOTS * 16 * sizeof(uint64_t), st));
     a.gathered = (unsigned long long*)db->w_gathered.p;
   }
   if (int rcb = fpr_bound(db, p.max_fpr, max_short, st, &a.cmin_fpr, &a.cmin_fpr_n)) return rcb;
@@ -396,8 +396,10 @@ extern "C" int kmcpg_last_gathered_bytes(kmcpg_db* db, uint64_t* bytes) {
   KMCPG_USE_DEVICE(db);
   hipEvent_t* pev = db->ev + 3 * ((db->ev_calls - 1) % 4);
   HIPCHK(hipEventSynchronize(pev[2]));
+  std::vector<uint64_t> slots((size_t)K2_GATHER_SLOTS * 16);
+  HIPCHK(hipMemcpy(slots.data(), db->w_gathered.p, slots.size() * sizeof(uint64_t), hipMemcpyDeviceToHost));
   uint64_t n = 0;
-  HIPCHK(hipMemcpy(&n, db->w_gathered.p, sizeof n, hipMemcpyDeviceToHost));
+  for (int i = 0; i < K2_GATHER_SLOTS; i++) n += slots[(size_t)i * 16];
   *bytes = n * 16;
   return 0;
 }

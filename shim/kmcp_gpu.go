@@ -104,6 +104,28 @@ func OpenGPUDBDevices(path string, devices []int32) (*GPUDB, error) {
 	return db, nil
 }
 
+// OpenGPUDBPaged is OpenGPUDB for an index larger than the GPU's memory: the counterpart of the reference's mmap /
+// --low-mem modes (util-db-search.go:1238-1280, search.go:80).  The index is searched one resident part after the other
+// (passes = 0: as few parts as fit); batches should then be large, RunGPUEngine's batchSize is raised by the caller.
+// OpenGPUDB reports an index that does not fit with an error that names the bytes needed and free (code -5).
+func OpenGPUDBPaged(path string, device int, passes int) (*GPUDB, error) {
+	cpath := C.CString(path)
+	defer C.free(unsafe.Pointer(cpath))
+	db := &GPUDB{}
+	if err := gpuCall(func() C.int { return C.kmcpg_open_paged(cpath, C.int32_t(device), C.int32_t(passes), &db.h) }); err != nil {
+		return nil, err
+	}
+	if err := db.finishOpen(); err != nil {
+		db.Close()
+		return nil, err
+	}
+	return db, nil
+}
+
+// ExchangeInfo says how a multi-GPU handle brings the shards' hit lists together ("RCCL gather over N device(s)" or
+// "host merge ... (reason)").
+func (db *GPUDB) ExchangeInfo() string { return C.GoString(C.kmcpg_exchange_info(db.h)) }
+
 // Close replaces UnikIndexDB.Close (util-db-search.go:1119-1150).
 func (db *GPUDB) Close() error { return gpuCall(func() C.int { return C.kmcpg_close(db.h) }) }
 

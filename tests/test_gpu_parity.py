@@ -408,28 +408,31 @@ def test_dedup_classes_at_their_boundaries(G, oracle_lib):
 
     sizes = [1, 9, 64, 255, 256, 257, 300, 511, 512, 513, 1000, 4095, 4096, 4097, 9000, 16384, 16385, 20000]
     reads = [repetitive(n) for n in sizes] + [synth.random_genomes(1, n + k - 1, seed=79 + n)[0] for n in (260, 512, 513, 4096, 4097)]
-    spec = lib.SynthSpec(k=k, num_hashes=1, fpr=0.3, n_blocks=1, cols_per_block=8, num_sigs=1000, kmers_per_col=10, seed=1)
-    cfg = O.sketch_cfg(k=k)
-    with G["Database"].open_synthetic(spec) as db:
-        for thr in (0, 256, 600):
-            for batch in (reads, reads[:9], reads + [repetitive(70000)]):  # max length decides which classes are launched
-                seqs, offs = lib.pack_reads(batch)
-                t_seqs = torch.from_numpy(seqs).to(dev)
-                t_offs = torch.from_numpy(offs.view(np.int64)).to(dev)
-                t_h = torch.zeros(len(seqs) + 8, dtype=torch.int64, device=dev)
-                t_nk = torch.zeros(len(batch), dtype=torch.int32, device=dev)
-                p = G["default_params"](min_qlen=0, min_matched=1, dedup_threshold=thr)
-                db.kmers_device(t_seqs.data_ptr(), t_offs.data_ptr(), len(batch), len(seqs), max(len(r) for r in batch),
-                                t_h.data_ptr(), t_h.numel(), None, t_nk.data_ptr(), params=p)
-                torch.cuda.synchronize()
-                h = t_h.cpu().numpy().view(np.uint64)
-                nk = t_nk.cpu().numpy()
-                for i, r in enumerate(batch):
-                    raw = O.generate_kmers(r, cfg)
-                    want = O.sort_unique(raw) if len(raw) > thr else raw
-                    got = h[int(offs[i]):int(offs[i]) + int(nk[i])]
-                    assert nk[i] == len(want), (thr, i, len(raw), nk[i], len(want))
-                    assert np.array_equal(got, want), (thr, i, len(raw))
+    # no spread at all: every k-mer of a homopolymer / short tandem repeat falls into one or two buckets of the distribution sort
+    reads += [b"A" * 3000, b"AC" * 1500, b"ACG" * 700, b"ACGTTGCA" * 500 + synth.random_genomes(1, 1500, seed=99)[0]]
+    for sk in (0, 11):  # plain k-mers, and Closed Syncmers (runs of equal emissions: the fused adjacent-repeat filter of long reads)
+        spec = lib.SynthSpec(k=k, num_hashes=1, fpr=0.3, n_blocks=1, cols_per_block=8, num_sigs=1000, kmers_per_col=10, seed=1, syncmer_s=sk)
+        cfg = O.sketch_cfg(k=k, syncmer_s=sk)
+        with G["Database"].open_synthetic(spec) as db:
+            for thr in (0, 256, 600):
+                for batch in (reads, reads[:9], reads + [repetitive(70000)]):  # max length decides which classes are launched
+                    seqs, offs = lib.pack_reads(batch)
+                    t_seqs = torch.from_numpy(seqs).to(dev)
+                    t_offs = torch.from_numpy(offs.view(np.int64)).to(dev)
+                    t_h = torch.zeros(len(seqs) + 8, dtype=torch.int64, device=dev)
+                    t_nk = torch.zeros(len(batch), dtype=torch.int32, device=dev)
+                    p = G["default_params"](min_qlen=0, min_matched=1, dedup_threshold=thr)
+                    db.kmers_device(t_seqs.data_ptr(), t_offs.data_ptr(), len(batch), len(seqs), max(len(r) for r in batch),
+                                    t_h.data_ptr(), t_h.numel(), None, t_nk.data_ptr(), params=p)
+                    torch.cuda.synchronize()
+                    h = t_h.cpu().numpy().view(np.uint64)
+                    nk = t_nk.cpu().numpy()
+                    for i, r in enumerate(batch):
+                        raw = O.generate_kmers(r, cfg)
+                        want = O.sort_unique(raw) if len(raw) > thr else raw
+                        got = h[int(offs[i]):int(offs[i]) + int(nk[i])]
+                        assert nk[i] == len(want), (sk, thr, i, len(raw), nk[i], len(want))
+                        assert np.array_equal(got, want), (sk, thr, i, len(raw))
 
 
 def test_batch_larger_than_one_launch(G):
