@@ -119,8 +119,15 @@ def main():
         dt = time.time() - t0
         assert p.returncode == 0, p.stderr
         rows = sum(1 for _ in open(tsv)) - 4
+        pipe = [ln for ln in p.stderr.split("\n") if "pipeline:" in ln]
+        # the same without a file system behind the writer: formatting + pipeline alone
+        t0 = time.time()
+        p2 = subprocess.run([CLI, "-d", d, fq, "-o", "/dev/null"], capture_output=True, text=True)
+        dt2 = time.time() - t0
+        assert p2.returncode == 0, p2.stderr
+        pipe2 = [ln for ln in p2.stderr.split("\n") if "pipeline:" in ln]
         r["cli"] = dict(reads=a.cli_reads, wall_s=dt, reads_per_s=a.cli_reads / dt, tsv_bytes=os.path.getsize(tsv), rows=rows, rows_per_read=rows / a.cli_reads,
-                        rows_per_s=rows / dt, log_tail=p.stderr.strip().split("\n")[-4:])
+                        rows_per_s=rows / dt, pipeline=pipe[-1] if pipe else "", to_dev_null=dict(wall_s=dt2, rows_per_s=rows / dt2, pipeline=pipe2[-1] if pipe2 else ""))
         out[f"uniform_sigs={mode}"] = r
         print(json.dumps({f"uniform_sigs={mode}": r}), file=sys.stderr)
     info["db_dirs"] = {m: os.path.join(a.out_dir, f"mode{m}", "R001") for m in a.modes.split(",")}
