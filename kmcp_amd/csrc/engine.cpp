@@ -425,6 +425,44 @@ int plan_passes(kmcpg_db* front, int device, uint64_t* largest_shard_bytes, uint
 }
 }  // namespace kmcpg
 
+namespace kmcpg {
+// kmcpg_open for another shard of a database whose headers `src` has already parsed (the shards of an in-process multi-GPU
+// handle, the passes of a paged one): __db.yml and the .uniki headers — hundreds of thousands of reference names at GTDB
+// scale — are read once, every further handle copies the parsed metadata and only makes its own blocks resident.
+int open_like(const kmcpg_db* src, const kmcpg_opts* opts, kmcpg_db** out) {
+  *out = nullptr;
+  DbPtr db(new kmcpg_db());
+  int rc = check_opts(opts, &db->opts);
+  if (rc) return rc;
+  const bool meta_only = db->opts.device < 0;
+  if (!meta_only) HIPCHK(hipSetDevice(db->opts.device));
+  db->db_dir = src->db_dir;
+  db->ks_desc = src->ks_desc;
+  db->info = src->info;
+  db->blocks = src->blocks;
+  for (auto& b : db->blocks) {
+    b.local = false;
+    b.local_idx = -1;
+    b.stride = 0;
+    b.d_rows = nullptr;
+    b.group = -1;
+    b.byte_off = 0;
+  }
+  assign_shards(db.get());
+  form_groups(db.get());
+  if (!meta_only) {
+    rc = alloc_groups(db.get());
+    if (rc) return rc;
+    rc = upload_blocks(db.get());
+    if (rc) return rc;
+  }
+  rc = finish_open(db.get());
+  if (rc) return rc;
+  *out = db.release();
+  return 0;
+}
+}  // namespace kmcpg
+
 extern "C" int kmcpg_open(const char* db_dir, const kmcpg_opts* opts, kmcpg_db** out) {
   if (!db_dir || !out) return kmcpg_fail(KMCPG_EINVAL, "null argument");
   *out = nullptr;

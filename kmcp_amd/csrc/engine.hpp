@@ -94,6 +94,7 @@ struct FprBoundTable {
 };
 void release_fpr_bounds(kmcpg_db* db);  // query.cpp
 int plan_passes(kmcpg_db* front, int device, uint64_t* largest_shard_bytes, uint64_t* free_bytes);  // engine.cpp
+int open_like(const kmcpg_db* src, const kmcpg_opts* opts, kmcpg_db** out);                           // engine.cpp
 struct AsyncState;
 void async_release(kmcpg_db* db);  // host.cpp
 int async_in_flight(kmcpg_db* db);

@@ -428,7 +428,7 @@ int search_paged(kmcpg_db* front, const uint8_t* seqs, const uint64_t* offs, con
       }
       kmcpg_opts so{front->paged_device, r, S, 0};
       kmcpg_db* sh = nullptr;
-      int rc = kmcpg_open(front->db_dir.c_str(), &so, &sh);
+      int rc = open_like(front, &so, &sh);  // (the front has parsed every header already)
       if (rc) return kmcpg_fail(rc, "pass %d of %d: %s", r + 1, S, std::string(kmcpg_err_ref()).c_str());
       front->paged_resident = sh;
       front->paged_rank = r;
@@ -694,7 +694,7 @@ extern "C" int kmcpg_open_devices(const char* db_dir, const int32_t* devices, in
   for (int32_t i = 0; i < n_devices; i++) {
     kmcpg_opts so{devices[i], i, n_devices, 0};
     kmcpg_db* sh = nullptr;
-    rc = kmcpg_open(db_dir, &so, &sh);
+    rc = open_like(front, &so, &sh);  // (the headers were parsed once, by the front)
     if (rc) {
       std::string keep = kmcpg_err_ref();
       kmcpg_close(front);

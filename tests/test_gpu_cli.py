@@ -96,6 +96,12 @@ def test_cli_single_end_gz_and_flags(oracle_lib, tmp_path):
     compare(run_cli(["-d", db_root, fq, "--gpu-batch", "100"], str(tmp_path / "o1.tsv.gz")), want, trailer)
     # one process driving several shards (here two on the same GPU)
     compare(run_cli(["-d", db_root, fq, "--gpu-ids", "0,0"], str(tmp_path / "o1b.tsv")), want, trailer)
+    # ... and the multi-GPU handle's RCCL exchange (one rank here: KMCPG_RCCL=force), announced in the log
+    r = subprocess.run([CLI, "-d", db_root, fq, "--gpu-ids", "0", "-o", str(tmp_path / "o1c.tsv")], capture_output=True, text=True, timeout=300,
+                       env=dict(os.environ, KMCPG_RCCL="force"))
+    assert r.returncode == 0, r.stderr
+    assert "exchange of the hit lists: RCCL gather over 1 device(s)" in r.stderr, r.stderr
+    compare(open(tmp_path / "o1c.tsv").read().split("\n"), want, trailer)
     # -K keeps unmatched rows; -H drops the header; thresholds + sort by jacc + top score
     p = O.default_params(min_qcov=0.4, min_matched=5, sort_by=2, top_n_scores=1)
     want, trailer = oracle_tsv(O, odb, ids, reads, params=p, keep_unmatched=True)

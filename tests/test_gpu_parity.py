@@ -387,6 +387,29 @@ def test_k1_all_forms_across_k(G, oracle_lib, k):
                     assert np.array_equal(got, want), (kw, i, len(r))
 
 
+@pytest.mark.parametrize("flags", ["3", "7", "4"])
+def test_window_sketch_kernel_forms_on_long_reads(G, oracle_lib, tmp_path, monkeypatch, flags):
+    """The three forms the window sketches of long reads can take — the barrier-free wave form (default; KMCPG_K1_FLAGS=3), the
+    1024-thread tile form with two-level arg-min and fused adjacent-repeat filter (7; what windows wider than 60 hashes get), the
+    tile form with plain scans and a separate k_adj_unique pass (4) — give the oracle's results: single and paired long reads,
+    low-complexity sequence, reads at and around the -u / wave-sort bounds, Closed Syncmer and Minimizer databases, and a window
+    too wide for the wave form (minimizer w = 100: tile form whatever the flags)."""
+    O = oracle_lib
+    monkeypatch.setenv("KMCPG_K1_FLAGS", flags)
+    genomes = synth.random_genomes(6, 40000, seed=300)
+    rng = np.random.default_rng(301)
+    lens = [2049, 2100, 2500, 3000, 4097, 6000, 9000, 12000, 20000, 300, 512 + 30, 150]
+    for name, kw in (("syn", dict(syncmer_s=11)), ("min", dict(minimizer_w=7)), ("minwide", dict(minimizer_w=100)), ("synscaled", dict(syncmer_s=13, scale=3))):
+        db_dir = synth.make_db(tmp_path / name, genomes, k=21, n_chunks=2, overlap=150, threads=2, **kw)
+        r1 = [synth.sample_reads(genomes, 1, L, sub_rate=0.005, seed=int(rng.integers(1 << 30)), frac_random=0.0)[0] for L in lens]
+        r1 += [b"ACGTTGCAAT" * 400, b"A" * 2600 + genomes[0][:2000], genomes[1][:5000] + b"N" * 300 + genomes[1][5000:9000]]
+        n, res = _run(G, O, db_dir, r1)
+        assert n >= 10, (name, n)
+        r2 = [synth.sample_reads(genomes, 1, int(rng.integers(100, 8000)), sub_rate=0.005, seed=int(rng.integers(1 << 30)), frac_random=0.3)[0] for _ in r1]
+        n, res = _run(G, O, db_dir, r1, r2, oracle_kw=dict(fpr_buf_size=499), gpu_kw=dict())
+        assert n >= 10, (name, n)
+
+
 def test_dedup_classes_at_their_boundaries(G, oracle_lib):
     """K1d: sort + unique of queries above -u in every size class — one wave (n <= 512), 256-thread workgroup (<= 4096),
     1024-thread workgroup (LDS <= 16384, global memory above), device-wide sort (> 65536) — at the class boundaries, on reads
