@@ -50,6 +50,11 @@ fi
 if want shapes; then
   stats shapes python $R/tools/bench_shapes.py
 fi
+if want hifi; then
+  # the long-read sketch kernel: kernel stats + the SQ counters behind "bound by VALU issue"
+  stats hifi python $R/tools/bench_shapes.py hifi
+  run hifi_pmc_sq --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAIT_INST_ANY --kernel-trace -d $OUT/_prof_hifi_pmc_sq -o hifi_pmc_sq -- python $R/tools/bench_shapes.py hifi
+fi
 if want sq; then
   run gtdb_pmc_sq --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU GRBM_GUI_ACTIVE --kernel-trace -d $OUT/_prof_gtdb_pmc_sq -o gtdb_pmc_sq -- $BENCH --steps 2 --warmup 1
   run gtdb_pmc_l2 --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum --kernel-trace -d $OUT/_prof_gtdb_pmc_l2 -o gtdb_pmc_l2 -- $BENCH --steps 2 --warmup 1
