@@ -173,7 +173,9 @@ def run_workload(name, ctx, steps, warmup, batch_reads=0, cpu_baseline=True, cpu
 
     cap = 4 * B + 4096
     main = torch.cuda.current_stream(dev)
-    side = torch.cuda.Stream(dev)  # D2H of a finished step while the next step's kernels run on `main`
+    # D2H (and, N > 1, the exchange) of a finished step while the next step's kernels run on `main`: a high-priority stream, so
+    # that its small copies / collectives are not queued behind a 60-500 ms kernel that fills the chip
+    side = torch.cuda.Stream(dev, priority=-1)
     stream = main.cuda_stream
 
     class Buf:  # device outputs of one step in flight + their pinned host copies
@@ -578,6 +580,7 @@ def main():
     ctx.collective = ctx.world > 1 or force
     if ctx.collective:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        os.environ.setdefault("TORCH_NCCL_HIGH_PRIORITY", "1")  # the collectives of step i run beside the kernels of step i+1
         if force:
             dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%s" % os.environ.get("MASTER_PORT", "29749"), world_size=1, rank=0, device_id=ctx.dev)
         elif ctx.same_gpu:
