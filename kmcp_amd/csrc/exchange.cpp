@@ -171,7 +171,10 @@ Exchange* exchange_create(const std::vector<int>& devices, std::string* why) {
     return nullptr;
   }
   for (size_t i = 0; i < devices.size(); i++) {
-    if (hipSetDevice(devices[i]) != hipSuccess || hipStreamCreateWithFlags(&x->streams[i], hipStreamNonBlocking) != hipSuccess) {
+    // highest priority: the few hundred KB of a batch's hit lists must not wait behind the next batch's chip-filling kernels
+    int prio_lo = 0, prio_hi = 0;
+    if (hipSetDevice(devices[i]) != hipSuccess || hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi) != hipSuccess ||
+        hipStreamCreateWithPriority(&x->streams[i], hipStreamNonBlocking, prio_hi) != hipSuccess) {
       *why = "stream creation failed";
       exchange_destroy(x);
       return nullptr;
