@@ -61,7 +61,13 @@ uint32_t device_stride(uint32_t row_bytes) {
   return (row_bytes + 63) / 64 * 64;
 }
 
-int lpr_for_stride(uint32_t stride) { return stride <= 64 ? 4 : (stride <= 256 ? 16 : 64); }
+// lanes per row tile (16 B each): the narrowest form that covers the row, so that no lane of a wave idles (a 128-byte row on the
+// 16-lane form left half of every wave without a row to load)
+int lpr_for_stride(uint32_t stride) {
+  if (const char* e = getenv("KMCPG_LPR8"))
+    if (atoi(e) == 0) return stride <= 64 ? 4 : (stride <= 256 ? 16 : 64);
+  return stride <= 64 ? 4 : (stride <= 128 ? 8 : (stride <= 256 ? 16 : 64));
+}
 
 void magic_for(uint64_t d, uint64_t* hi, uint64_t* lo) {
   unsigned __int128 m = (~(unsigned __int128)0) / d + 1;  // wraps to 0 for d == 1: then x % 1 == 0 falls out

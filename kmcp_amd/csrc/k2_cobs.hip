@@ -387,6 +387,7 @@ int launch_k2(const K2Args& a, int lpr, int npl, hipStream_t st) {
   const bool multi = a.num_hashes > 1;
   switch (lpr) {
     case 4: return launch_k2_l<4>(a, npl, multi, st);
+    case 8: return launch_k2_l<8>(a, npl, multi, st);
     case 16: return launch_k2_l<16>(a, npl, multi, st);
     case 64: return launch_k2_l<64>(a, npl, multi, st);
     default: return -1;
@@ -413,6 +414,7 @@ int launch_k2_split(const K2Args& a, int lpr, hipStream_t st) {
   const bool multi = a.num_hashes > 1;
   switch (lpr) {
     case 4: launch_k2_split_t<4>(a, multi, st); return 0;
+    case 8: launch_k2_split_t<8>(a, multi, st); return 0;
     case 16: launch_k2_split_t<16>(a, multi, st); return 0;
     case 64: launch_k2_split_t<64>(a, multi, st); return 0;
     default: return -1;
