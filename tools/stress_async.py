@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """Stress of the asynchronous boundary: several host threads hammer ONE handle with kmcpg_submit / kmcpg_wait /
 kmcpg_search_batch in random patterns (batch sizes 0 .. 3000, single-end, paired-end with --try-se, up to three tickets held per
-thread, waits out of order, KMCPG_EBUSY handled by waiting), on a single-GPU handle and on an in-process multi-device handle
-(two shards on GPU 0).  Every result must equal the one the same batch gives when it is searched alone.
+thread, waits out of order, KMCPG_EBUSY handled by waiting), on a single-GPU handle, on an in-process multi-device handle
+(two shards on GPU 0: host merge), on one whose hit lists go through the RCCL exchange, and on a paged handle (3 passes per batch).
+Every result must equal the one the same batch gives when it is searched alone.
 
 usage: stress_async.py [seconds=30] [threads=6]
 """
@@ -46,9 +47,20 @@ def main():
                 s1, o1 = lib.pack_reads(r1)
                 s2, o2 = lib.pack_reads(r2) if paired else (None, None)
                 pool.append((s1, o1, s2, o2, p, key(db.search_packed(s1, o1, s2, o2, p))))
-        for label, opener in (("one GPU", lambda: Database.open(db_dir)), ("two shards in one process", lambda: Database.open_devices(db_dir, [0, 0]))):
+        def open_rccl():
+            os.environ["KMCPG_RCCL"] = "force"  # one GPU here: the RCCL exchange with a one-rank communicator
+            try:
+                db = Database.open_devices(db_dir, [0])
+            finally:
+                os.environ.pop("KMCPG_RCCL", None)
+            assert db.exchange_info().startswith("RCCL gather"), db.exchange_info()
+            return db
+
+        openers = (("one GPU", lambda: Database.open(db_dir)), ("two shards in one process", lambda: Database.open_devices(db_dir, [0, 0])),
+                   ("RCCL exchange of an in-process multi-GPU handle (one rank)", open_rccl), ("paged in 3 passes", lambda: Database.open_paged(db_dir, 0, 3)))
+        for label, opener in openers:
             db = opener()
-            stop = time.time() + seconds / 2
+            stop = time.time() + seconds / len(openers)
             errors, done, busy = [], [0] * n_threads, [0] * n_threads
 
             def worker(t):
