@@ -85,7 +85,7 @@ __device__ __forceinline__ int block_unique(P src, int n, uint64_t* __restrict__
 // Queries of at most 512 k-mers (paired-end 2x150 / 2x250 reads just above -u 256): one WAVE per query, 8 elements per lane
 // in registers (element e = lane*8 + i).  The same all-ascending bitonic network: compare-exchanges at distance < 8 are
 // register moves, the others exchange registers with lane ^ mask (ds_bpermute); no LDS array, no barrier.
-constexpr int DW_CAP = 512;
+constexpr int DW_CAP = DEDUP_WAVE_CAP;
 
 __device__ __forceinline__ void cx64(uint64_t& lo, uint64_t& hi) {
   if (lo > hi) {

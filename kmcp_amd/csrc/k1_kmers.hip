@@ -288,7 +288,7 @@ __global__ void __launch_bounds__(256) k1_kmers(const K1Args a) {
 
 // ---- long queries (HiFi reads, -g whole genomes): one 1024-thread workgroup per read -------------------------
 constexpr int K1WG = 1024;
-constexpr int K1_WAVE_SORT_CAP = 512;  // queries of up to this many emissions are sorted by k_dedup_wave, which reads them from hashes[] (k1_dedup.hip DW_CAP)
+constexpr int K1_WAVE_SORT_CAP = DEDUP_WAVE_CAP;  // (kernels.hpp)
 
 // ordered compaction of one tile of K1WG candidates into out[cnt...]; returns the new (uniform) count
 __device__ __forceinline__ int wg_compact(bool keep, uint64_t h, uint64_t* __restrict__ out, int cnt, int* s_wave, int tid) {

@@ -29,6 +29,9 @@ void launch_plant_reads(const BlockDev* blocks, uint32_t nblocks, int num_hashes
 void launch_build_scatter(uint8_t* sigs, uint64_t num_sigs, uint64_t mh, uint64_t ml, uint32_t row_bytes, int num_hashes, const uint64_t* hashes,
                           const uint64_t* col_off, uint32_t col0, uint32_t n_cols, uint64_t n, hipStream_t st);
 
+// queries of up to this many emissions above -u are sorted by one wave (k_dedup_wave), which reads them from hashes[]; the
+// long-read sketch kernels keep the raw emissions of such queries for it (k1_kmers.hip)
+constexpr int DEDUP_WAVE_CAP = 512;
 // queries with more than HUGE_MIN k-mers: device-wide sort + unique (sort_huge.hip)
 constexpr uint32_t HUGE_MIN = 65536;
 size_t huge_dedup_temp_bytes(uint32_t max_n);
