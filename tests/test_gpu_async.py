@@ -175,8 +175,11 @@ def test_async_stress_short():
     assert r.returncode == 0 and "stress ok" in r.stdout, (r.stdout[-1000:], r.stderr[-2000:])
 
 
-def test_hit_heavy_batches_follow_the_data(oracle_lib, tmp_path):
-    """A database of 70 close relatives: every read matches ~60 columns.  The hit buffers of the lanes learn that from the first
+@pytest.mark.parametrize("budget_mb", [None, "0"])
+def test_hit_heavy_batches_follow_the_data(oracle_lib, tmp_path, monkeypatch, budget_mb):
+    """(budget_mb = "0": KMCPG_HIT_BUDGET_MB=0 — the lanes' hit buffers may not grow beyond the plain size, every heavy batch
+    overflows and is searched a second time with room for its hits: same results.)
+    A database of 70 close relatives: every read matches ~60 columns.  The hit buffers of the lanes learn that from the first
     large batch (kmcpg_wait reruns it once with room for every hit), later batches fit at once; the eager read-back stays
     bounded at 32 hits per read, so the rest of every batch's hits arrives through the late copy in kmcpg_wait.  Batches of
     2 000 reads in flight on all lanes, a small one (below the size that updates the estimate) and a hit-free one in between."""
@@ -196,6 +199,8 @@ def test_hit_heavy_batches_follow_the_data(oracle_lib, tmp_path):
     small = synth.sample_reads([base], 40, 150, sub_rate=0.0, seed=300, frac_random=0.0)
     empty = synth.sample_reads([base], 1500, 150, seed=301, frac_random=1.0)
     order = [heavy[0], heavy[1], small, heavy[2], empty, heavy[3], heavy[4], heavy[5]]
+    if budget_mb is not None:
+        monkeypatch.setenv("KMCPG_HIT_BUDGET_MB", budget_mb)
     with Database.open(db_dir) as db:
         alone = [db.search(b, params=default_params()) for b in order]  # one at a time (also the first overflow + rerun)
         assert alone[0].offs[-1] > 40 * len(order[0]) and alone[4].offs[-1] == 0
