@@ -64,6 +64,15 @@ WORKLOADS = {
     "config1_wide": dict(k=21, num_hashes=1, fpr=0.3, n_blocks=1, cols_per_block=9984, num_sigs=1121470, kmers_per_col=400000,
                          batch_reads=1048576, kernel="k2_cobs<64,8,false>",
                          name="10k-chunk synthetic as one block: 1 x 9984 cols x 1121470 sigs (1.4 GB), 150bp k=21"),
+    # The reference's own published short-read benchmark (benchmarks/searching/README.md:38-63, 180-229): GTDB r202 representatives
+    # UNCHUNKED (47 894 genomes), `kmcp compute -k 31`, `kmcp index -f 0.3 -n 1 -b 1024` => 47 blocks x 1024 columns (128-byte rows),
+    # 55.15 GB; 150-bp reads searched with `-t 0.8`: 1.14-1.41 M reads in 53.4-72.8 s on 40 threads = 18.9-21.3 k reads/s.  Blocks
+    # hold genomes of ascending size, so every block has its own NumSigs: 3.0 M + 267 k i rows (0.5-5.5 M k-mers per genome at
+    # fpr 0.3), 55.2 GB in total.
+    "gtdb_unchunked_k31": dict(k=31, num_hashes=1, fpr=0.3, n_blocks=47, cols_per_block=1024, num_sigs=3000000, sigs_step=267000,
+                               kmers_per_col=3200000, batch_reads=1048576, kernel="k2_cobs<8,8,false>", min_qcov=0.8,
+                               metric="reads/sec searched (150bp, k=31, -t 0.8) vs the unchunked GTDB index of the reference's published benchmark",
+                               name="gtdb r202 unchunked synthetic: 47 blocks x 1024 cols, 3.0-15.3 M sigs (55.2 GB), 150bp k=31, -t 0.8"),
 }
 READ_LEN = 150
 
@@ -149,7 +158,7 @@ def run_workload(name, ctx, steps, warmup, batch_reads=0, cpu_baseline=True, cpu
                          cols_per_block=wl["cols_per_block"], num_sigs=wl["num_sigs"], kmers_per_col=wl["kmers_per_col"], seed=42,
                          sigs_step=wl.get("sigs_step", 0))
     free_b, _ = torch.cuda.mem_get_info(dev)
-    need = wl["n_blocks"] * wl["num_sigs"] * ((wl["cols_per_block"] + 7) // 8 + 64) / world
+    need = wl["n_blocks"] * (wl["num_sigs"] + wl.get("sigs_step", 0) * (wl["n_blocks"] - 1) / 2) * ((wl["cols_per_block"] + 7) // 8 + 64) / world
     if need > 0.9 * free_b:
         raise SystemExit(f"workload needs {need/1e9:.1f} GB of HBM on this rank, {free_b/1e9:.1f} GB free")
     t0 = time.time()
@@ -158,6 +167,7 @@ def run_workload(name, ctx, steps, warmup, batch_reads=0, cpu_baseline=True, cpu
     info = db.info
     n_cols = int(info.n_cols)
     params = default_params()  # kmcp search defaults: -t 0.55 -c 10 -m 30 -f 0.01 -u 256
+    params.min_qcov = wl.get("min_qcov", params.min_qcov)
     db.set_profiling(True)
 
     # ---- batches resident in HBM; distinct data per step (cycled if K+W is large)
@@ -311,7 +321,7 @@ def run_workload(name, ctx, steps, warmup, batch_reads=0, cpu_baseline=True, cpu
             pmc = None
 
     out = {
-        "metric": "reads/sec searched (150bp, k=21) vs GTDB-scale index",
+        "metric": wl.get("metric", "reads/sec searched (150bp, k=21) vs GTDB-scale index"),
         "value": B * steps / elapsed,
         "unit": "reads/s",
         "n_gpus": world,
@@ -328,7 +338,7 @@ def run_workload(name, ctx, steps, warmup, batch_reads=0, cpu_baseline=True, cpu
         "config": {"workload": wl["name"], "batch_reads": B, "read_len": READ_LEN, "k": wl["k"], "num_hashes": wl["num_hashes"],
                    "index_bytes": int(info.matrix_bytes), "index_bytes_this_rank": int(info.matrix_bytes_local),
                    "blocks": int(info.n_blocks), "columns": n_cols, "parallelism": f"block-shard x{world}",
-                   "search_flags": "-t 0.55 -c 10 -m 30 -f 0.01 -u 256"},
+                   "search_flags": f"-t {params.min_qcov:g} -c 10 -m 30 -f 0.01 -u 256"},
         "roofline": {"bound": "hbm", "kernel": wl["kernel"], "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
                      "traffic_source": None,
                      "definition": "achieved = bytes the kernel moved per launch (traffic) / its mean HIP-event duration over the timed steps; "
@@ -372,7 +382,7 @@ def run_workload(name, ctx, steps, warmup, batch_reads=0, cpu_baseline=True, cpu
                 gpu_half(i, bufs[0])
                 torch.cuda.synchronize()
                 bufs[0].copied.record(main)
-                per_batch.append(db.last_gathered_bytes())
+                per_batch.append((db.last_gathered_bytes(), db.last_hash_bytes()))
         finally:
             db.set_profiling(True)
             for k_, v_ in old.items():
@@ -384,11 +394,16 @@ def run_workload(name, ctx, steps, warmup, batch_reads=0, cpu_baseline=True, cpu
 
     rf = out["roofline"]
     per_batch = measure_gathered()
-    gathered = float(np.mean([per_batch[(warmup + j) % n_batches] for j in range(steps)]))
+    row_b = float(np.mean([per_batch[(warmup + j) % n_batches][0] for j in range(steps)]))
+    hash_b = float(np.mean([per_batch[(warmup + j) % n_batches][1] for j in range(steps)]))
+    gathered = row_b + hash_b
     rf["gathered_bytes_per_launch"] = gathered
+    rf["row_bytes_per_launch"] = row_b
+    rf["hash_bytes_per_launch"] = hash_b
     rf["traffic"] = gathered
-    rf["traffic_source"] = ("live: row bytes the k2_cobs launches of the timed steps asked the memory system for (kernel-side counter, "
-                            "kmcpg_last_gathered_bytes); cross-check = traffic_pmc (rocprofv3 --pmc FETCH_SIZE pass of the same command)")
+    rf["traffic_source"] = ("live: bytes the k2_cobs launches of the timed steps asked the memory system for, counted by the kernel itself: its 16-byte "
+                            "row loads (kmcpg_last_gathered_bytes) + the 8-byte k-mer hashes it reads once per (read, slot) (kmcpg_last_hash_bytes); "
+                            "cross-check = traffic_pmc (rocprofv3 --pmc FETCH_SIZE pass of the same command)")
     rf["achieved"] = gathered / (k2_avg_ms * 1e-3) / 1e9
     rf["frac"] = rf["achieved"] / HBM_PEAK_GBS
     rf["traffic_over_algorithmic"] = gathered / alg_bytes
@@ -436,7 +451,7 @@ def run_workload(name, ctx, steps, warmup, batch_reads=0, cpu_baseline=True, cpu
         # sector pruning switched off: every row byte of every k-mer is fetched whatever the index holds (traffic = algorithmic
         # bytes + row padding), the data-independent figure of the same kernel
         _, k2_np = kernel_only(max(2, min(steps, 4)), {"KMCPG_PRUNE": "0"})
-        g_np = float(np.mean(measure_gathered({"KMCPG_PRUNE": "0"})))
+        g_np = float(np.mean([r_ + h_ for r_, h_ in measure_gathered({"KMCPG_PRUNE": "0"})]))
         rf["prune_off"] = {"kernel_ms": k2_np, "traffic": g_np, "achieved": g_np / (k2_np * 1e-3) / 1e9, "frac": g_np / (k2_np * 1e-3) / 1e9 / HBM_PEAK_GBS,
                            "effective_gbps": alg_bytes / (k2_np * 1e-3) / 1e9, "frac_algorithmic": alg_bytes / (k2_np * 1e-3) / 1e9 / HBM_PEAK_GBS,
                            "traffic_over_algorithmic": g_np / alg_bytes}
@@ -504,7 +519,7 @@ def run_workload(name, ctx, steps, warmup, batch_reads=0, cpu_baseline=True, cpu
             R = cpu_sample_reads or 256
             while True:  # grow the sample until it is several seconds of CPU work
                 t2 = time.perf_counter()
-                oqk, ohits = odb.search_batch(reads_h[:R * READ_LEN], offs_h[:R + 1], O.default_params(), threads=threads, refshape=refshape)
+                oqk, ohits = odb.search_batch(reads_h[:R * READ_LEN], offs_h[:R + 1], O.default_params(min_qcov=params.min_qcov), threads=threads, refshape=refshape)
                 tcpu = time.perf_counter() - t2
                 if cpu_sample_reads or tcpu >= target_s or R >= B:
                     return R, tcpu, oqk, ohits
@@ -601,6 +616,12 @@ def main():
         finally:
             os.environ.pop("KMCPG_FUSE", None)
         out["secondary"]["config1_ungrouped"] = {k: unf[k] for k in keys if k in unf}
+        # the configuration of the reference's own published short-read numbers (unchunked GTDB, k = 31, -b 1024, -t 0.8)
+        pub = run_workload("gtdb_unchunked_k31", ctx, min(max(args.steps, 5), 20), 2, cpu_baseline=not args.no_cpu_baseline, cpu_target_s=3.0)
+        out["secondary"]["gtdb_unchunked_k31"] = {k: pub[k] for k in keys + ("metric",) if k in pub}
+        out["secondary"]["gtdb_unchunked_k31"]["published"] = {
+            "value": [18.9e3, 21.3e3], "unit": "reads/s", "threads": 40,
+            "source": "reference benchmarks/searching/README.md:186-229 (1.14-1.41 M reads in 53.4-72.8 s, kmcp v0.9.0, hot page cache)"}
     if ctx.collective:
         dist.destroy_process_group()
     sys.stdout.flush()

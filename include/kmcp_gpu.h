@@ -235,6 +235,9 @@ int kmcpg_set_profiling(kmcpg_db* db, int enable);  /* 0 off, 1 timing, 2 timing
 /* Bytes the COBS kernel(s) of the last kmcpg_query_device call asked the memory system for (16 B per lane and row actually
  * loaded, row padding included, pruned rows not): a live cross-check of the FETCH_SIZE counter passes.  Level 2 only. */
 int kmcpg_last_gathered_bytes(kmcpg_db* db, uint64_t* bytes);
+/* ... and the bytes of k-mer hashes the same launches read (8 B per k-mer, once per (read, slot): 0.8 % of the row bytes for
+ * 1-KB row tiles, 6 % for 128-byte rows).  Rows + hashes is what FETCH_SIZE sees.  Level 2 only. */
+int kmcpg_last_hash_bytes(kmcpg_db* db, uint64_t* bytes);
 int kmcpg_last_timing(kmcpg_db* db, float* kmers_ms, float* cobs_ms);
 /* The same for an earlier call: age 0 = the last one, 1 = the one before ... (the last 4 are kept), so that a caller with
  * several batches in flight can read the times of a finished one without waiting for the newest. */

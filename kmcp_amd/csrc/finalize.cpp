@@ -1,6 +1,7 @@
 // finalize.cpp — the host half: float64 thresholds, FPR, Match values, sorting (util-db-search.go:7471-7489, :260-345).
 #include <hip/hip_runtime.h>
 #include <math.h>
+#include <stdint.h>
 #include <stdarg.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -81,11 +82,6 @@ bool match_less(const kmcpg_match& x, const kmcpg_match& y, int sort_by) {
   if (t1 != t2) return t1 > t2;
   return x.col < y.col;  // deterministic tie-break; the reference's order among exact ties is arbitrary
 }
-
-struct SortKey {
-  double s, t;  // score and tie score of match_less for the sort mode in force
-  uint32_t col, idx;
-};
 
 // Host cores this process may use: the affinity mask capped by the cgroup CPU quota (a GPU box shows 256 cores and grants 16).
 unsigned usable_cpus() {
@@ -348,6 +344,15 @@ extern "C" int kmcpg_finalize(const kmcpg_db* db, const kmcpg_hit* hits, uint64_
         }
         row = row_of_n;
       }
+      // A read with a handful of hits (the usual case) builds its matches in place and sorts the records; a read with many
+      // (a database full of close relatives: hundreds) builds them in a scratch array, orders 4-byte indices and writes every
+      // 64-byte record once, in its final position.
+      const bool in_place = s1 - s0 <= 8;
+      static thread_local std::vector<kmcpg_match> tmp;
+      if (!in_place && tmp.size() < s1 - s0) tmp.resize(s1 - s0);
+      kmcpg_match* const dst = in_place ? mbase + first : tmp.data();
+      uint64_t cnt2 = 0;
+      int c_lo = INT32_MAX, c_hi = 0;
       for (uint64_t i = s0; i < s1; i++) {
         const kmcpg_hit& h = sorted_p[i];
         const int count = (int)h.count;
@@ -368,39 +373,55 @@ extern "C" int kmcpg_finalize(const kmcpg_db* db, const kmcpg_hit* hits, uint64_
         m.qcov = c / nh;
         m.tcov = T;
         m.jacc = c / (nh + nt - c);
-        mbase[pos2++] = m;
+        dst[cnt2++] = m;
+        c_lo = std::min(c_lo, count);
+        c_hi = std::max(c_hi, count);
       }
-      uint64_t cnt2 = pos2 - first;
-      if (cnt2 > 1 && cnt2 <= 8) {  // the usual case: a handful of matches, sorted in place
-        if (!p.do_not_sort) {
-          const int sb = p.sort_by;
-          std::sort(mbase + first, mbase + pos2, [sb](const kmcpg_match& x, const kmcpg_match& y) { return match_less(x, y, sb); });
+      pos2 = first + cnt2;
+      if (in_place) {
+        if (cnt2 > 1) {
+          if (!p.do_not_sort) {
+            const int sb = p.sort_by;
+            std::sort(mbase + first, mbase + pos2, [sb](const kmcpg_match& x, const kmcpg_match& y) { return match_less(x, y, sb); });
+          } else {
+            std::sort(mbase + first, mbase + pos2, [](const kmcpg_match& x, const kmcpg_match& y) { return x.col < y.col; });
+          }
+        }
+      } else if (cnt2 > 0) {
+        static thread_local std::vector<uint32_t> order, bucket;
+        if (order.size() < cnt2) order.resize(cnt2);
+        uint32_t* const ord = order.data();
+        const kmcpg_match* const t = tmp.data();
+        if (!p.do_not_sort && p.sort_by == 0 && (uint64_t)(c_hi - c_lo) < 4 * cnt2 + 64) {
+          // -s qcov (the default): qcov = mkmers / n with one n per read, so the primary key is the integer mkmers (two
+          // counts that differ give quotients more than an ulp apart) — a counting sort over the counts present, descending;
+          // equal counts (a few per bucket) are then ordered by tcov descending, column ascending, as match_less does.
+          const size_t nb = (size_t)(c_hi - c_lo) + 1;
+          bucket.assign(nb + 1, 0);
+          for (uint64_t i = 0; i < cnt2; i++) bucket[(size_t)(c_hi - t[i].mkmers) + 1]++;
+          for (size_t b = 0; b < nb; b++) bucket[b + 1] += bucket[b];
+          for (uint64_t i = 0; i < cnt2; i++) ord[bucket[(size_t)(c_hi - t[i].mkmers)]++] = (uint32_t)i;
+          // bucket[b] is now the END of bucket b
+          uint32_t b0 = 0;
+          for (size_t b = 0; b < nb; b++) {
+            const uint32_t b1 = bucket[b];
+            if (b1 - b0 > 1)
+              std::sort(ord + b0, ord + b1, [t](uint32_t x, uint32_t y) {
+                if (t[x].tcov != t[y].tcov) return t[x].tcov > t[y].tcov;
+                return t[x].col < t[y].col;
+              });
+            b0 = b1;
+          }
         } else {
-          std::sort(mbase + first, mbase + pos2, [](const kmcpg_match& x, const kmcpg_match& y) { return x.col < y.col; });
+          for (uint64_t i = 0; i < cnt2; i++) ord[i] = (uint32_t)i;
+          if (!p.do_not_sort) {
+            const int sb = p.sort_by;
+            std::sort(ord, ord + cnt2, [t, sb](uint32_t x, uint32_t y) { return match_less(t[x], t[y], sb); });
+          } else {
+            std::sort(ord, ord + cnt2, [t](uint32_t x, uint32_t y) { return t[x].col < t[y].col; });
+          }
         }
-      } else if (cnt2 > 1) {
-        // many matches (a database full of close relatives): 24-byte keys are sorted instead of the 64-byte records, which
-        // are then put in place in one pass.  Same order as match_less: score and tie score descending, column ascending.
-        static thread_local std::vector<SortKey> keys;
-        static thread_local std::vector<kmcpg_match> tmp;
-        keys.resize(cnt2);
-        tmp.assign(mbase + first, mbase + pos2);
-        for (uint64_t i = 0; i < cnt2; i++) {
-          const kmcpg_match& m = tmp[i];
-          SortKey& k = keys[i];
-          k.idx = (uint32_t)i;
-          k.col = m.col;
-          if (p.do_not_sort) k.s = k.t = 0;
-          else if (p.sort_by == 1) { k.s = m.tcov; k.t = m.mkmers; }
-          else if (p.sort_by == 2) { k.s = m.jacc; k.t = m.mkmers; }
-          else { k.s = m.qcov; k.t = m.tcov; }
-        }
-        std::sort(keys.begin(), keys.end(), [](const SortKey& x, const SortKey& y) {
-          if (x.s != y.s) return x.s > y.s;
-          if (x.t != y.t) return x.t > y.t;
-          return x.col < y.col;
-        });
-        for (uint64_t i = 0; i < cnt2; i++) mbase[first + i] = tmp[keys[i].idx];
+        for (uint64_t i = 0; i < cnt2; i++) mbase[first + i] = t[ord[i]];
       }
       if (cnt2 > 0 && p.top_n_scores > 0 && !p.do_not_sort) {  // --keep-top-scores (:285-311), including its [:i+1]
         int nn = 0;

@@ -167,6 +167,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, GR 
 #pragma unroll
     for (int p = 0; p < NPL; p++) pl[d][p] = 0;
   uint32_t g_acc = 0;  // 16-byte row loads this wave issued (profiling level 2)
+  uint32_t h_acc = 0;  // ... and its 8-byte hash loads (a read's hashes are fetched once per slot: 8 B per 16*LPR B of row)
 
   for (int c0 = 0; c0 < nmax; c0 += CH) {
     // ---- row indices of this chunk: loc = h % NumSigs (:6811), multi-hash h_i = uint32(a + b*i) (util-hash.go:125-142)
@@ -180,6 +181,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, GR 
       const uint64_t ns = bq->num_sigs;
       const uint64_t s16 = bq->stride >> 4;  // rows are addressed in 16-byte units: 32 bits reach 64 GB per block
       const int kidx = c0 + j;
+      if (a.gathered) h_acc += (uint32_t)__popcll(__ballot(kidx < nq));  // measurement runs only
       if (kidx < nq) {
         const uint64_t h = a.hashes[koq + kidx];
         if (!MULTI) {
@@ -261,7 +263,10 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, GR 
   }
   // what this wave asked the memory system for: one atomic per wave, spread over K2_GATHER_SLOTS counters a cache line apart
   // (one atomic per row group on a single counter made a GTDB-scale launch take 11 s instead of 0.49 s)
-  if (a.gathered && lane == 0 && g_acc) atomicAdd(a.gathered + (size_t)(blockIdx.x % K2_GATHER_SLOTS) * 16, (unsigned long long)g_acc);
+  if (a.gathered && lane == 0 && (g_acc | h_acc)) {
+    atomicAdd(a.gathered + (size_t)(blockIdx.x % K2_GATHER_SLOTS) * 16, (unsigned long long)g_acc);
+    atomicAdd(a.gathered + (size_t)(blockIdx.x % K2_GATHER_SLOTS) * 16 + 1, (unsigned long long)h_acc);  // same cache line
+  }
 
   if (SPLIT) {
     if (!live) return;

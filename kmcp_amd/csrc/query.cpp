@@ -389,7 +389,8 @@ extern "C" int kmcpg_set_profiling(kmcpg_db* db, int enable) {
   return 0;
 }
 
-extern "C" int kmcpg_last_gathered_bytes(kmcpg_db* db, uint64_t* bytes) {
+// word 0 of every counter slot: 16-byte row loads; word 1: 8-byte hash loads
+static int read_gather_slots(kmcpg_db* db, int word, uint64_t unit, uint64_t* bytes) {
   if (!db || !bytes) return kmcpg_fail(KMCPG_EINVAL, "null argument");
   std::lock_guard<std::mutex> g(db->mu);
   if (db->profiling < 2 || !db->w_gathered.p || db->ev_calls == 0) return kmcpg_fail(KMCPG_EINVAL, "no kmcpg_query_device call at profiling level 2 yet");
@@ -399,10 +400,13 @@ extern "C" int kmcpg_last_gathered_bytes(kmcpg_db* db, uint64_t* bytes) {
   std::vector<uint64_t> slots((size_t)K2_GATHER_SLOTS * 16);
   HIPCHK(hipMemcpy(slots.data(), db->w_gathered.p, slots.size() * sizeof(uint64_t), hipMemcpyDeviceToHost));
   uint64_t n = 0;
-  for (int i = 0; i < K2_GATHER_SLOTS; i++) n += slots[(size_t)i * 16];
-  *bytes = n * 16;
+  for (int i = 0; i < K2_GATHER_SLOTS; i++) n += slots[(size_t)i * 16 + (size_t)word];
+  *bytes = n * unit;
   return 0;
 }
+
+extern "C" int kmcpg_last_gathered_bytes(kmcpg_db* db, uint64_t* bytes) { return read_gather_slots(db, 0, 16, bytes); }
+extern "C" int kmcpg_last_hash_bytes(kmcpg_db* db, uint64_t* bytes) { return read_gather_slots(db, 1, 8, bytes); }
 
 extern "C" int kmcpg_timing_at(kmcpg_db* db, uint32_t age, float* kmers_ms, float* cobs_ms) {
   if (!db) return kmcpg_fail(KMCPG_EINVAL, "null argument");

@@ -59,4 +59,13 @@ if want sq; then
   run gtdb_pmc_sq --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU GRBM_GUI_ACTIVE --kernel-trace -d $OUT/_prof_gtdb_pmc_sq -o gtdb_pmc_sq -- $BENCH --steps 2 --warmup 1
   run gtdb_pmc_l2 --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum --kernel-trace -d $OUT/_prof_gtdb_pmc_l2 -o gtdb_pmc_l2 -- $BENCH --steps 2 --warmup 1
 fi
+if want pub; then
+  # the reference's published benchmark configuration: unchunked GTDB, k = 31, 47 blocks of 128-byte rows, -t 0.8
+  PUB="$BENCH --workload gtdb_unchunked_k31"
+  stats pub $PUB --steps 3 --warmup 1
+  pmc pub $PUB --steps 2 --warmup 1
+  KMCPG_PRUNE=0 pmc pub_pruneoff $PUB --steps 2 --warmup 1
+  KMCPG_PRUNE=0 run pub_pruneoff_pmc_sq --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAIT_INST_ANY --kernel-trace -d $OUT/_prof_pub_pruneoff_pmc_sq -o pub_pruneoff_pmc_sq -- $PUB --steps 2 --warmup 1
+  KMCPG_PRUNE=0 run pub_pruneoff_pmc_l2 --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum --kernel-trace -d $OUT/_prof_pub_pruneoff_pmc_l2 -o pub_pruneoff_pmc_l2 -- $PUB --steps 2 --warmup 1
+fi
 ls $OUT | grep "^${TAG}_" | head -60

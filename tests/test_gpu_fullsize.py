@@ -156,7 +156,7 @@ def test_pruning_keeps_boundary_columns(oracle_lib):
                     c = np.unpackbits(rows, axis=1)[:, :cols_per_block].sum(axis=0)
                     for col in np.nonzero(c >= cmin)[0]:
                         want.add((i, b * cols_per_block + int(col), int(c[col])))
-            got, gathered = {}, {}
+            got, gathered, hashed = {}, {}, {}
             db.set_profiling(2)  # the kernel counts the 16-byte row loads it issues
             for prune in ("1", "0"):
                 os.environ["KMCPG_PRUNE"] = prune
@@ -169,12 +169,17 @@ def test_pruning_keeps_boundary_columns(oracle_lib):
                 h = hits[:int(cnt[0].item())].cpu().numpy()
                 got[prune] = {(int(r), int(c), int(k)) for r, c, k in h}
                 gathered[prune] = db.last_gathered_bytes()
+                hashed[prune] = db.last_hash_bytes()
             assert got["1"] == got["0"] == want
             # without pruning every (k-mer, group) costs one padded row (k-mers rounded up to whole groups of 8 rows: the tail
             # reads the all-zero row); the three equal-NumSigs blocks form one group.  With pruning the kernel asks for less.
             stride = db.block_info(0)["stride"]
             assert gathered["0"] == sum((len(km) + 7) // 8 * 8 for km in kms) * stride
             assert gathered["1"] <= gathered["0"]
+            # ... and a read's hashes are fetched once per slot (every whole KiB of the row is a tile, the rest one more)
+            nslots = stride // 1024 + (1 if stride % 1024 else 0)
+            assert hashed["0"] == 8 * sum(len(km) for km in kms) * nslots
+            assert 0 < hashed["1"] <= hashed["0"]
             if cols_per_block == 14976:
                 assert gathered["1"] < 0.8 * gathered["0"]  # 2 % density: almost every sector dies early (narrow rows share one sector with the planted columns)
             assert len(want) >= 2 * len(reads)  # the end-loaded and the start-loaded column of every read

@@ -54,6 +54,29 @@ def test_family_database_reduced(oracle_lib, tmp_path, uniform_sigs):
         odb.close()
 
 
+def test_many_matches_every_sort_mode(oracle_lib, tmp_path):
+    """Dozens of matches per read (30 strains of one species): kmcpg_finalize's paths for reads with many matches — the counting
+    sort by mKmers of `-s qcov`, the index sorts of `-s tcov` / `-s jacc` / `-S`, `-n`, `-T` — give the oracle's matches in the
+    oracle's order."""
+    import family_db
+    from kmcp_amd import Database, default_params
+    O = oracle_lib
+    info, reads = family_db.build(str(tmp_path / "db"), ecoli_strains=30, small_strains=1, n_reads=1200, threads=8)
+    rl = _reads_list(reads)
+    odb = O.OracleDB(info["db_dir"])
+    try:
+        with Database.open(info["db_dir"], device=0) as db:
+            for kw in (dict(), dict(sort_by=1), dict(sort_by=2), dict(do_not_sort=1), dict(top_n_scores=3), dict(sort_by=2, top_n_scores=2),
+                       dict(min_tcov=0.0002), dict(min_qcov=0.3, min_matched=5)):
+                res = db.search(rl, params=default_params(**kw))
+                n = synth.assert_parity(odb, res, rl, oparams=O.default_params(**kw))
+                if not kw:
+                    per_read = np.diff(np.asarray(res.offs, dtype=np.int64))
+                    assert per_read.max() > 30 and np.count_nonzero(per_read > 8) > len(rl) // 4, (per_read.max(), n)
+    finally:
+        odb.close()
+
+
 def test_strain_columns_equal_the_oracles_compute(oracle_lib):
     """The generator's columns (K1 on the GPU + torch sort/unique) are what the oracle's `kmcp compute` restatement yields for the
     same sequence: k-mers of 10 overlapping chunks of a real genome with N's and several records."""
