@@ -14,6 +14,7 @@
 #include <vector>
 
 #include "fpr.hpp"
+#include "fastmod.hpp"
 #include "kernels.hpp"
 
 using namespace kmcpg;
@@ -74,7 +75,6 @@ int build_block(const std::string& path, const kmcpg_build_cfg& cfg, const std::
   }
   const uint32_t row_bytes = (n + 7) / 8;
   const uint64_t bytes = num_sigs * (uint64_t)row_bytes;
-  unsigned __int128 m = (~(unsigned __int128)0) / num_sigs + 1;
   uint8_t* d_sigs = nullptr;
   uint64_t *d_hashes = nullptr, *d_off = nullptr;
   std::vector<uint8_t> host;
@@ -97,7 +97,7 @@ int build_block(const std::string& path, const kmcpg_build_cfg& cfg, const std::
     if (!stage.empty()) {
       BHIP(hipMemcpy(d_hashes, stage.data(), stage.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
       BHIP(hipMemcpy(d_off, off.data(), off.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
-      launch_build_scatter(d_sigs, num_sigs, (uint64_t)(m >> 64), (uint64_t)m, row_bytes, cfg.num_hashes, d_hashes, d_off, c0, c1 - c0, stage.size(), nullptr);
+      launch_build_scatter(d_sigs, num_sigs, fastmod_magic(num_sigs), row_bytes, cfg.num_hashes, d_hashes, d_off, c0, c1 - c0, stage.size(), nullptr);
       BHIP(hipDeviceSynchronize());
     }
     c0 = c1;

@@ -16,8 +16,7 @@ namespace kmcpg {
 struct BlockDev {
   const uint8_t* rows;  // device pointer, (num_sigs + 1) * stride bytes
   uint64_t num_sigs;    // Header.NumSigs: modulus of the row address (util-db-search.go:6811)
-  uint64_t magic_hi;    // M = floor((2^128-1)/num_sigs)+1, exact 64-bit fastmod (replaces fastdiv, :6611)
-  uint64_t magic_lo;
+  uint64_t magic_hi;    // fastmod_magic(num_sigs): exact h % num_sigs with one 64-bit high multiply (fastmod.hpp; replaces fastdiv, :6611)
   uint32_t stride;      // bytes per row in HBM (multiple of 16)
   uint32_t row_bytes;   // Header.NumRowBytes = (ncols+7)/8 (group: sum over the members)
   uint32_t ncols;

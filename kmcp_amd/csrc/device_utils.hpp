@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "fastmod.hpp"
+
 namespace kmcpg {
 
 __device__ __forceinline__ uint64_t rol1(uint64_t v) { return (v << 1) | (v >> 63); }
@@ -23,18 +25,6 @@ __device__ __forceinline__ uint64_t seed_of(int b) {
     case 'T': case 't': case 'U': case 'u': return T;
     default: return 0;
   }
-}
-
-// exact a % d for any 64-bit a, d (Lemire fastmod with a 128-bit magic): replaces fastdiv.Uint64.Mod
-// (util-db-search.go:6611,6811).
-__device__ __forceinline__ uint64_t fastmod_u64(uint64_t a, uint64_t d, uint64_t mh, uint64_t ml) {
-  uint64_t lo = ml * a;
-  uint64_t hi = __umul64hi(ml, a) + mh * a;
-  uint64_t p_hi = __umul64hi(lo, d);
-  uint64_t q_lo = hi * d;
-  uint64_t q_hi = __umul64hi(hi, d);
-  uint64_t sum = q_lo + p_hi;
-  return q_hi + (sum < q_lo ? 1ULL : 0ULL);
 }
 
 __device__ __forceinline__ void wave_lds_fence() {

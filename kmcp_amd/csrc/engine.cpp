@@ -25,6 +25,7 @@
 #include "common.hpp"
 #include "dbformat.hpp"
 #include "engine.hpp"
+#include "fastmod.hpp"
 #include "exchange.hpp"
 #include "fpr.hpp"
 #include "kernels.hpp"
@@ -69,11 +70,6 @@ int lpr_for_stride(uint32_t stride) {
   return stride <= 64 ? 4 : (stride <= 128 ? 8 : (stride <= 256 ? 16 : 64));
 }
 
-void magic_for(uint64_t d, uint64_t* hi, uint64_t* lo) {
-  unsigned __int128 m = (~(unsigned __int128)0) / d + 1;  // wraps to 0 for d == 1: then x % 1 == 0 falls out
-  *hi = (uint64_t)(m >> 64);
-  *lo = (uint64_t)m;
-}
 
 // blocks are independent: greedy partition by bytes, largest first
 void assign_shards(kmcpg_db* db) {
@@ -197,7 +193,7 @@ int finish_open(kmcpg_db* db) {
     BlockDev bd{};
     bd.rows = b.d_rows;
     bd.num_sigs = b.h.num_sigs;
-    magic_for(b.h.num_sigs, &bd.magic_hi, &bd.magic_lo);
+    bd.magic_hi = fastmod_magic(b.h.num_sigs);
     bd.stride = b.stride;
     bd.row_bytes = b.h.row_bytes;
     bd.ncols = (uint32_t)b.h.names.size();
@@ -223,7 +219,7 @@ int finish_open(kmcpg_db* db) {
     BlockDev gd{};
     gd.rows = G.d_rows;
     gd.num_sigs = G.num_sigs;
-    magic_for(G.num_sigs, &gd.magic_hi, &gd.magic_lo);
+    gd.magic_hi = fastmod_magic(G.num_sigs);
     gd.stride = G.stride;
     gd.row_bytes = G.row_bytes;
     gd.col_base = db->blocks[(size_t)G.members[0]].col_base;

@@ -99,6 +99,13 @@ __device__ __forceinline__ void csa4(uint32_t (&pl)[NPL], uint32_t x0, uint32_t 
 // is bound by the L2->fabric path, not by latency (the 8-row form runs as fast at 2 waves per SIMD as at 5), and of the
 // occupancy targets tried for the 4-row form this one is the fastest (GTDB scale: 488 ms; 506-510 ms at 5-6 waves, 510 ms at 3,
 // starved at 2: profiles/r02_group_rows.txt).
+struct alignas(16) UnitConst {  // one (read, slot) unit as the index phase sees it
+  uint64_t ns, mh;  // NumSigs of the slot's block and its fastmod constant
+  uint64_t koff;    // first hash of the read (of this chunk of it: SPLIT)
+  uint32_t s16;     // row pitch in 16-byte units
+  int32_t n;        // k-mers of the read handled by this unit
+};
+
 template <int LPR, int NPL, bool MULTI, bool SPLIT, int GR = 8>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, GR == 4 ? 4 : 10))) k2_cobs(const K2Args a) {
   constexpr int G = 64 / LPR;
@@ -107,6 +114,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, GR 
   constexpr int NHMAX = MULTI ? 4 : 1;
   static_assert(CH % 8 == 0, "chunk must be a multiple of the CSA group");
   __shared__ uint32_t s_rows[4][NHMAX][G * CH];
+  __shared__ UnitConst s_unit[4][G];
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int g = lane / LPR, li = lane % LPR;
@@ -158,7 +166,6 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, GR 
   constexpr int GRP = LPR < 8 ? LPR : 8;  // lanes that share a sector
   bool live = active;
   const uint8_t* __restrict__ base = bd->rows + boff;
-  const uint64_t koff = a.offs[r] + (a.offs2 ? a.offs2[r] : 0) + (uint64_t)k0;
   const int nh = MULTI ? a.num_hashes : 1;
 
   uint32_t pl[4][NPL];
@@ -169,30 +176,52 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, GR 
   uint32_t g_acc = 0;  // 16-byte row loads this wave issued (profiling level 2)
   uint32_t h_acc = 0;  // ... and its 8-byte hash loads (a read's hashes are fetched once per slot: 8 B per 16*LPR B of row)
 
+  // ---- what the index phase needs to know about a unit — its block's modulus, fastmod constant (fastmod.hpp) and row pitch,
+  //      the read's k-mer count and where its hashes start — goes to LDS once (32 B per unit).  With the block constants
+  //      loaded from global memory inside the loop, every (unit, chunk) paid two dependent round trips through a memory
+  //      system that the row gathers keep saturated: on 128-byte rows (8 units per wave) the waves spent as long there as
+  //      on their rows.  (LDS rather than registers: five more live VGPRs cost the 8-row forms a wave per SIMD.)
+  if (li == 0) {
+    UnitConst uc;
+    uc.ns = bd->num_sigs;
+    uc.mh = bd->magic_hi;
+    uc.koff = a.offs[r] + (a.offs2 ? a.offs2[r] : 0) + (uint64_t)k0;
+    uc.s16 = stride >> 4;  // rows are addressed in 16-byte units: 32 bits reach 64 GB per block
+    uc.n = n;
+    s_unit[wave][g] = uc;
+  }
+  wave_lds_fence();
+  constexpr int IT = G * CH / 64;  // (unit, k-mer) pairs of a chunk per lane
+
   for (int c0 = 0; c0 < nmax; c0 += CH) {
-    // ---- row indices of this chunk: loc = h % NumSigs (:6811), multi-hash h_i = uint32(a + b*i) (util-hash.go:125-142)
-    for (int p = lane; p < G * CH; p += 64) {
+    // ---- row indices of this chunk: loc = h % NumSigs (:6811), multi-hash h_i = uint32(a + b*i) (util-hash.go:125-142).
+    //      First every hash load of the chunk (IT per lane, all in flight together), then the arithmetic.
+    uint64_t hv[IT];
+    uint32_t has_mask = 0;
+#pragma unroll
+    for (int it = 0; it < IT; it++) {
+      const int p = lane + 64 * it;
       const int q = p / CH, j = p % CH;
-      const int srcl = q * LPR;
-      const int nq = __shfl(n, srcl);
-      const uint64_t koq = __shfl((unsigned long long)koff, srcl);
-      const uint32_t bi = __shfl(slot.block, srcl);
-      const BlockDev* __restrict__ bq = a.blocks + bi;
-      const uint64_t ns = bq->num_sigs;
-      const uint64_t s16 = bq->stride >> 4;  // rows are addressed in 16-byte units: 32 bits reach 64 GB per block
-      const int kidx = c0 + j;
-      if (a.gathered) h_acc += (uint32_t)__popcll(__ballot(kidx < nq));  // measurement runs only
-      if (kidx < nq) {
-        const uint64_t h = a.hashes[koq + kidx];
+      const bool has = c0 + j < s_unit[wave][q].n;
+      if (a.gathered) h_acc += (uint32_t)__popcll(__ballot(has));  // measurement runs only
+      hv[it] = has ? a.hashes[s_unit[wave][q].koff + (uint64_t)(c0 + j)] : 0;
+      has_mask |= (has ? 1u : 0u) << it;
+    }
+#pragma unroll
+    for (int it = 0; it < IT; it++) {
+      const int p = lane + 64 * it;
+      const uint64_t ns = s_unit[wave][p / CH].ns, mh = s_unit[wave][p / CH].mh;
+      const uint32_t s16 = s_unit[wave][p / CH].s16;
+      if ((has_mask >> it) & 1u) {
+        const uint64_t h = hv[it];
         if (!MULTI) {
-          s_rows[wave][0][p] = (uint32_t)(fastmod_u64(h, ns, bq->magic_hi, bq->magic_lo) * s16);
+          s_rows[wave][0][p] = (uint32_t)fastmod_u64(h, ns, mh) * s16;
         } else {
           const uint32_t ha = (uint32_t)(h >> 32), hb = (uint32_t)h;
-          for (int i = 0; i < nh; i++)
-            s_rows[wave][i][p] = (uint32_t)(fastmod_u64((uint64_t)(uint32_t)(ha + hb * (uint32_t)i), ns, bq->magic_hi, bq->magic_lo) * s16);
+          for (int i = 0; i < nh; i++) s_rows[wave][i][p] = (uint32_t)fastmod_u64((uint64_t)(uint32_t)(ha + hb * (uint32_t)i), ns, mh) * s16;
         }
       } else {
-        for (int i = 0; i < nh; i++) s_rows[wave][i][p] = (uint32_t)(ns * s16);  // the appended all-zero row
+        for (int i = 0; i < nh; i++) s_rows[wave][i][p] = (uint32_t)ns * s16;  // the appended all-zero row
       }
     }
     wave_lds_fence();

@@ -26,7 +26,7 @@ void launch_plant(const BlockDev& bd, uint32_t col, int num_hashes, const uint64
 void launch_plant_reads(const BlockDev* blocks, uint32_t nblocks, int num_hashes, const uint64_t* hashes, const uint64_t* offs,
                         const int32_t* nk, const uint32_t* cols, uint32_t n_reads, hipStream_t st);
 
-void launch_build_scatter(uint8_t* sigs, uint64_t num_sigs, uint64_t mh, uint64_t ml, uint32_t row_bytes, int num_hashes, const uint64_t* hashes,
+void launch_build_scatter(uint8_t* sigs, uint64_t num_sigs, uint64_t mh, uint32_t row_bytes, int num_hashes, const uint64_t* hashes,
                           const uint64_t* col_off, uint32_t col0, uint32_t n_cols, uint64_t n, hipStream_t st);
 
 // queries of up to this many emissions above -u are sorted by one wave (k_dedup_wave), which reads them from hashes[]; the

@@ -134,7 +134,7 @@ __global__ void k_plant(BlockDev bd, uint32_t col, int num_hashes, const uint64_
     const uint32_t ha = (uint32_t)(h >> 32), hb = (uint32_t)h;
     for (int t = 0; t < num_hashes; t++) {
       const uint64_t hv = num_hashes == 1 ? h : (uint64_t)(uint32_t)(ha + hb * (uint32_t)t);
-      const uint64_t row = fastmod_u64(hv, bd.num_sigs, bd.magic_hi, bd.magic_lo);
+      const uint64_t row = fastmod_u64(hv, bd.num_sigs, bd.magic_hi);
       // bd.rows is the block's first byte inside its group's row: any alignment
       const uintptr_t byte = (uintptr_t)bd.rows + row * bd.stride + (col >> 3);
       atomicOr(reinterpret_cast<uint32_t*>(byte & ~(uintptr_t)3), (uint32_t)(1u << (7 - (col & 7))) << (8 * (byte & 3)));
@@ -170,7 +170,7 @@ __global__ void __launch_bounds__(256) k_plant_reads(const BlockDev* __restrict_
       const uint32_t ha = (uint32_t)(h >> 32), hb = (uint32_t)h;
       for (int t = 0; t < num_hashes; t++) {
         const uint64_t hv = num_hashes == 1 ? h : (uint64_t)(uint32_t)(ha + hb * (uint32_t)t);
-        const uint64_t row = fastmod_u64(hv, bd.num_sigs, bd.magic_hi, bd.magic_lo);
+        const uint64_t row = fastmod_u64(hv, bd.num_sigs, bd.magic_hi);
         const uintptr_t byte = (uintptr_t)bd.rows + row * bd.stride + (col >> 3);
         atomicOr(reinterpret_cast<uint32_t*>(byte & ~(uintptr_t)3), (uint32_t)(1u << (7 - (col & 7))) << (8 * (byte & 3)));
       }
@@ -193,7 +193,7 @@ namespace kmcpg {
 // index building: sigs[h_i % NumSigs][col] = 1 for every hash of every column of one block (index.go:1107-1309).
 // hashes = the block's columns back to back, col_off[c] = first hash of column c (n_cols+1 entries); the matrix is row-major
 // with the on-disk row width (no padding), bit 7 - col%8 of byte col/8 (index.go:1157).
-__global__ void k_build_scatter(uint8_t* __restrict__ sigs, uint64_t num_sigs, uint64_t mh, uint64_t ml, uint32_t row_bytes, int num_hashes,
+__global__ void k_build_scatter(uint8_t* __restrict__ sigs, uint64_t num_sigs, uint64_t mh, uint32_t row_bytes, int num_hashes,
                                 const uint64_t* __restrict__ hashes, const uint64_t* __restrict__ col_off, uint32_t col0, uint32_t n_cols, uint64_t n) {
   for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
     uint32_t lo = 0, hi = n_cols;  // column of hash i: last c with col_off[c] <= i
@@ -206,18 +206,18 @@ __global__ void k_build_scatter(uint8_t* __restrict__ sigs, uint64_t num_sigs, u
     const uint32_t ha = (uint32_t)(h >> 32), hb = (uint32_t)h;
     for (int t = 0; t < num_hashes; t++) {
       const uint64_t hv = num_hashes == 1 ? h : (uint64_t)(uint32_t)(ha + hb * (uint32_t)t);
-      const uint64_t byte = fastmod_u64(hv, num_sigs, mh, ml) * row_bytes + (col >> 3);
+      const uint64_t byte = fastmod_u64(hv, num_sigs, mh) * row_bytes + (col >> 3);
       uint32_t* w = reinterpret_cast<uint32_t*>(sigs + (byte & ~3ULL));
       atomicOr(w, (uint32_t)(1u << (7 - (col & 7))) << (8 * (byte & 3)));
     }
   }
 }
 
-void launch_build_scatter(uint8_t* sigs, uint64_t num_sigs, uint64_t mh, uint64_t ml, uint32_t row_bytes, int num_hashes, const uint64_t* hashes,
+void launch_build_scatter(uint8_t* sigs, uint64_t num_sigs, uint64_t mh, uint32_t row_bytes, int num_hashes, const uint64_t* hashes,
                           const uint64_t* col_off, uint32_t col0, uint32_t n_cols, uint64_t n, hipStream_t st) {
   if (n == 0) return;
   unsigned blocks = (unsigned)((n + 255) / 256 > 65536 ? 65536 : (n + 255) / 256);
-  hipLaunchKernelGGL(k_build_scatter, dim3(blocks), dim3(256), 0, st, sigs, num_sigs, mh, ml, row_bytes, num_hashes, hashes, col_off, col0, n_cols, n);
+  hipLaunchKernelGGL(k_build_scatter, dim3(blocks), dim3(256), 0, st, sigs, num_sigs, mh, row_bytes, num_hashes, hashes, col_off, col0, n_cols, n);
 }
 
 }  // namespace kmcpg

@@ -44,6 +44,13 @@ def oracle_tsv(O, odb, ids, reads, reads2=None, params=None, keep_unmatched=Fals
     return lines, trailer
 
 
+def _free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
 def run_cli(args, out_path, env=None):
     r = subprocess.run([CLI] + args + ["-o", out_path, "-q"], capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode == 0, r.stderr
@@ -170,7 +177,7 @@ def test_dist_search_module_matches_oracle(oracle_lib, tmp_path):
     out3 = str(tmp_path / "d3.tsv")
     env["KMCP_DIST_SAME_GPU"] = "1"
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "3", "--master-addr", "127.0.0.1",
-                        "--master-port", "29731", "-m", "kmcp_amd.dist_search", "-d", os.path.dirname(db_dir), fq, "-o", out3, "-t", "0.45", "-s", "tcov",
+                        "--master-port", str(_free_port()), "-m", "kmcp_amd.dist_search", "-d", os.path.dirname(db_dir), fq, "-o", out3, "-t", "0.45", "-s", "tcov",
                         "-K", "--gpu-batch", "128"], capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-3000:]
     assert open(out3).read() == open(out).read()

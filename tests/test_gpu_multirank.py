@@ -31,7 +31,16 @@ def _env(same_gpu_var):
     return env, multi
 
 
+def _free_port():
+    """A TCP port nobody listens on right now (tests of this file may run side by side under pytest-xdist)."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
 def _launch(n, port, args, env):
+    port = port or _free_port()
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1", "--master-port", str(port)] + args
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
     if r.returncode != 0:  # the ranks' tracebacks sit in the middle of torchrun's stderr: keep all of it where gpurun brings it back
@@ -58,7 +67,7 @@ def test_bench_two_ranks_equal_one_rank():
     one = subprocess.run([sys.executable, "bench.py", "--gpus", "1"] + args, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
     assert one.returncode == 0, one.stderr[-3000:]
     j1 = _bench_line(one.stdout)
-    j2 = _bench_line(_launch(2, 29741, ["bench.py", "--gpus", "2"] + args, env).stdout)
+    j2 = _bench_line(_launch(2, None, ["bench.py", "--gpus", "2"] + args, env).stdout)
     assert j1["n_gpus"] == 1 and j2["n_gpus"] == 2 and j2["scaling"] == "strong"
     assert j2["config"]["parallelism"] == "block-shard x2"
     assert j2["config"]["index_bytes"] == j1["config"]["index_bytes"]
@@ -72,7 +81,7 @@ def test_bench_two_ranks_equal_one_rank():
     assert ("nccl" if multi else "gloo")  # which exchange ran is decided by the GPUs visible; both go through gather_hits
     # the same N > 1 code path of bench.py over RCCL itself: a one-rank nccl group (all_gather_into_tensor, gather, barrier,
     # all_reduce on device tensors) must reproduce the plain one-rank numbers
-    env_f = dict(env, KMCP_BENCH_FORCE_DIST="1", MASTER_PORT="29745")
+    env_f = dict(env, KMCP_BENCH_FORCE_DIST="1", MASTER_PORT=str(_free_port()))
     env_f.pop("KMCP_BENCH_SAME_GPU", None)
     forced = subprocess.run([sys.executable, "bench.py", "--gpus", "1"] + args, capture_output=True, text=True, timeout=900, env=env_f, cwd=ROOT)
     assert forced.returncode == 0, forced.stderr[-3000:]
@@ -97,7 +106,7 @@ def test_sharded_searcher_overflow_loop(oracle_lib, tmp_path):
     assert len(want) > 50 * len(reads)
     env, _ = _env("KMCP_DIST_SAME_GPU")
     out = str(tmp_path / "o.tsv")
-    _launch(2, 29743, ["-m", "kmcp_amd.dist_search", "-d", os.path.dirname(db_dir), fq, "-o", out, "-t", "0.31", "-f", "1", "-c", "1"], env)
+    _launch(2, None, ["-m", "kmcp_amd.dist_search", "-d", os.path.dirname(db_dir), fq, "-o", out, "-t", "0.31", "-f", "1", "-c", "1"], env)
     compare(open(out).read().split("\n"), want, trailer)
 
 
@@ -144,7 +153,7 @@ def test_sharded_searcher_walks_the_k_sizes_of_a_multi_k_database(oracle_lib, tm
     assert ks == {21, 31}
     env, _ = _env("KMCP_DIST_SAME_GPU")
     out = str(tmp_path / "o.tsv")
-    _launch(2, 29741, ["-m", "kmcp_amd.dist_search", "-d", os.path.dirname(db_dir), fq, "-o", out, "-t", "0.2", "--gpu-batch", "100"], env)
+    _launch(2, None, ["-m", "kmcp_amd.dist_search", "-d", os.path.dirname(db_dir), fq, "-o", out, "-t", "0.2", "--gpu-batch", "100"], env)
     compare(open(out).read().split("\n"), want, trailer)
     # in process, one rank: the same walk through the per-shard pair == the library's own
     seqs, offs = lib.pack_reads(reads)
