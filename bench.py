@@ -5,7 +5,7 @@ One "step" = one pass of the hot path over one batch of synthetic 150-bp reads t
 k-mer generation + K2 COBS query on the GPU, hit hand-over, and the host half (float64 thresholds, FPR, sort) that turns
 the hit tuples into finalized matches in host memory; the host half of step i overlaps the kernels of step i+1.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload gtdb|config1] [--batch-reads B]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload gtdb|config1|gtdb_unchunked_k31|...] [--batch-reads B]
 
 N>1 is launched by the driver as `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`:
 one rank per GPU; the index's independent blocks are partitioned over the ranks (libkmcpgpu shards by
@@ -18,7 +18,8 @@ The synthetic index is generated directly in HBM: 32 b
 were planted into a random column, 10 % are uniform random.
 
 The JSON line reports the GTDB-scale workload (the configuration BASELINE.json's metric is quoted on).  At N=1 the
-same line carries, under "secondary", the numbers of BASELINE.json configs[1] (10 k chunks, 39-byte rows).
+same line carries, under "secondary", the numbers of BASELINE.json configs[1] (10 k chunks, 39-byte rows) and of the
+configuration the reference's own published short-read numbers are quoted on (unchunked GTDB, k = 31, -b 1024, -t 0.8).
 """
 import argparse
 import json
