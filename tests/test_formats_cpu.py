@@ -180,7 +180,8 @@ def test_finalize_worker_threads_agree(small_db):
         assert np.array_equal(o.matches, whole.matches) and np.array_equal(o.offs, whole.offs)
 
 
-def test_finalize_orders_many_matches_per_read(small_db):
+@pytest.mark.parametrize("spread", [False, True])
+def test_finalize_orders_many_matches_per_read(small_db, spread):
     """Reads with dozens of matches (a database of close relatives) take kmcpg_finalize's key-sort path: the order must be
     Matches.Less / SortByTCov / SortByJacc (util-db-search.go:105-145) — score, then tie score, both descending — with the
     column as the last resort, for every sort mode; -S/--do-not-sort lists by column; --keep-top-scores keeps a prefix."""
@@ -192,9 +193,12 @@ def test_finalize_orders_many_matches_per_read(small_db):
     h = np.zeros(n_reads * per, dtype=HIT_DTYPE)
     h["read"] = np.repeat(np.arange(n_reads, dtype=np.uint32), per)
     h["col"] = cols.reshape(-1)
-    h["count"] = rng.integers(20, 26, n_reads * per)  # few distinct counts: ties in qcov everywhere
-    h = h[rng.permutation(len(h))]
+    h["count"] = rng.integers(20, 26, n_reads * per)  # few distinct counts: ties in qcov everywhere (-s qcov: counting sort)
     qk = rng.choice([130, 97], n_reads).astype(np.int32)
+    if spread:  # long queries, counts all over the place: more distinct counts than matches (-s qcov: the general index sort)
+        h["count"] = rng.integers(800, 6000, n_reads * per)
+        qk = rng.choice([6000, 7001], n_reads).astype(np.int32)
+    h = h[rng.permutation(len(h))]
     ql = np.full(n_reads, 150, dtype=np.int32)
     with Database.open(db_dir, device=-1) as db:
         for flags in (dict(sort_by=0), dict(sort_by=1), dict(sort_by=2), dict(do_not_sort=1)):
