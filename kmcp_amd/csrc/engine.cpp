@@ -250,15 +250,11 @@ int finish_open(kmcpg_db* db) {
     HIPCHK(hipMemcpy(c.d_slots, c.slots.data(), c.slots.size() * sizeof(Slot), hipMemcpyHostToDevice));
   }
   db->col_block.clear();
-  db->col_size.clear();
-  db->col_gsize.clear();
-  db->col_tidx.clear();
+  db->col_meta.clear();
   for (size_t i = 0; i < db->blocks.size(); i++)
     for (size_t c = 0; c < db->blocks[i].h.names.size(); c++) {
       db->col_block.push_back((uint32_t)i);
-      db->col_size.push_back(db->blocks[i].h.sizes[c]);
-      db->col_gsize.push_back(db->blocks[i].h.gsizes[c]);
-      db->col_tidx.push_back(db->blocks[i].h.indices[c]);
+      db->col_meta.push_back(kmcpg_db::ColMeta{db->blocks[i].h.sizes[c], db->blocks[i].h.gsizes[c], db->blocks[i].h.indices[c], 0});
     }
   db->fpr.reset(new QueryFpr(db->info.fpr));
   return 0;

@@ -1,6 +1,7 @@
 // engine.hpp — internals shared by the host-side translation units of libkmcpgpu.so (engine.cpp: residency;
 // query.cpp: GPU half; finalize.cpp: host half; host.cpp: the whole pipeline on host buffers).  Not part of the ABI.
 #pragma once
+#include <stdlib.h>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -114,8 +115,13 @@ struct kmcpg_db {
   kmcpg::Seg* d_segs = nullptr;
   std::vector<kmcpg::SlotClass> classes;
   std::vector<uint32_t> col_block;  // global column -> block index
-  std::vector<uint64_t> col_size, col_gsize;  // Header.Sizes / GSizes per global column (flat copies for the host half)
-  std::vector<uint32_t> col_tidx;             // Header.Indices
+  struct ColMeta {   // per global column, side by side for the host half (one cache line per hit instead of three)
+    uint64_t size;   // Header.Sizes: k-mers of the column
+    uint64_t gsize;  // Header.GSizes
+    uint32_t tidx;   // Header.Indices: chunk index | #chunks << 16
+    uint32_t pad;
+  };
+  std::vector<ColMeta> col_meta;
   std::unique_ptr<kmcpg::QueryFpr> fpr;
   std::mutex mu;      // serialises the enqueueing of GPU-half calls (their kernels share the workspace below, in stream order;
                       // calls on different streams are ordered by ws_ev)
@@ -177,7 +183,22 @@ struct NoInitAlloc : std::allocator<T> {
     else ::new ((void*)q) U(std::forward<A>(a)...);
   }
 };
-typedef std::vector<kmcpg_match, NoInitAlloc<kmcpg_match>> MatchVec;
+// ... and whose storage starts on a cache line: a kmcpg_match is 64 bytes, so every record is exactly one line and the host
+// half can write the records of match-heavy batches with streaming stores (finalize.cpp)
+template <class T>
+struct LineAlloc : NoInitAlloc<T> {
+  template <class U>
+  struct rebind {
+    using other = LineAlloc<U>;
+  };
+  T* allocate(size_t n) {
+    void* q = nullptr;
+    if (posix_memalign(&q, 64, std::max<size_t>(64, n * sizeof(T))) != 0) throw std::bad_alloc();
+    return (T*)q;
+  }
+  void deallocate(T* q, size_t) { free(q); }
+};
+typedef std::vector<kmcpg_match, LineAlloc<kmcpg_match>> MatchVec;
 
 struct ResultOwner {
   std::vector<int32_t> qlen, qkmers, ksize;

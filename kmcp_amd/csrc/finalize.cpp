@@ -1,6 +1,9 @@
 // finalize.cpp — the host half: float64 thresholds, FPR, Match values, sorting (util-db-search.go:7471-7489, :260-345).
 #include <hip/hip_runtime.h>
 #include <math.h>
+#if defined(__SSE2__)
+#include <emmintrin.h>
+#endif
 #include <stdint.h>
 #include <stdarg.h>
 #include <stdio.h>
@@ -70,6 +73,26 @@ void give_owner(ResultOwner* o) {
 struct OwnerReturn {
   void operator()(ResultOwner* o) const { give_owner(o); }
 };
+
+// One record into the result array with streaming stores (seven 8-byte pieces; consecutive records fill whole cache lines in
+// the write-combining buffers), so that the gigabyte of records a match-heavy batch produces is written once instead of read
+// (for ownership) and written.
+inline void store_record(kmcpg_match* dst, const kmcpg_match& src) {
+#if defined(__x86_64__) && defined(__SSE2__)
+  static_assert(sizeof(kmcpg_match) == 56 && alignof(kmcpg_match) == 8, "seven 8-byte pieces");
+  long long w[7];
+  memcpy(w, &src, sizeof w);
+  long long* d = reinterpret_cast<long long*>(dst);
+  for (int i = 0; i < 7; i++) _mm_stream_si64(d + i, w[i]);
+#else
+  *dst = src;
+#endif
+}
+inline void records_visible() {
+#if defined(__SSE2__)
+  _mm_sfence();
+#endif
+}
 
 bool match_less(const kmcpg_match& x, const kmcpg_match& y, int sort_by) {
   double s1, s2, t1, t2;
@@ -221,10 +244,10 @@ extern "C" int kmcpg_finalize(const kmcpg_db* db, const kmcpg_hit* hits, uint64_
   o->qkmers.assign(qkmers, qkmers + n_reads);
   const int k_used = p.k > 0 ? p.k : db->info.k;
   o->ksize.assign(n_reads, k_used);
-  // Reads are independent, so the batch is cut into W contiguous ranges of reads, one per worker thread:
+  // Reads are independent, so the batch is cut into R contiguous ranges of reads (up to four per worker):
   //  A. every worker takes a slice of the hit list (it arrives in no particular order) and counts its hits per range;
   //  B. ... and scatters them into the ranges' areas of `parted`;
-  //  C. worker w owns range w: counting sort of its hits by read, float64 thresholds, Match values, sort per read.  A hit
+  //  C. one range at a time per worker: counting sort of its hits by read, float64 thresholds, Match values, sort per read.  A hit
   //     yields at most one match, so the worker writes its matches straight into the result array from the position of its
   //     range's first hit on; the gaps the filters leave are closed afterwards.
   static thread_local std::vector<kmcpg_hit, NoInitAlloc<kmcpg_hit>> parted;
@@ -235,36 +258,39 @@ extern "C" int kmcpg_finalize(const kmcpg_db* db, const kmcpg_hit* hits, uint64_
   if ((uint64_t)W > n_reads) W = n_reads ? (int)n_reads : 1;
   if (const char* e = getenv("KMCPG_FINALIZE_THREADS")) W = std::max(1, std::min(atoi(e), 64));
   if ((uint64_t)W > std::max<uint32_t>(1, n_reads)) W = (int)std::max<uint32_t>(1, n_reads);
-  const uint32_t per_range = n_reads ? (n_reads + (uint32_t)W - 1) / (uint32_t)W : 1;
-  auto range_lo = [&](int w) { return (uint32_t)std::min<uint64_t>((uint64_t)w * per_range, n_reads); };
+  // ranges of 2^shift reads (a shift, not a division, per hit in phases A and B), up to four per worker: the pool hands them
+  // out one at a time, so uneven ranges even out, and a range's hits (phase C sorts them by read) stay cache-sized
+  uint64_t range_hits = 131072;
+  if (const char* e = getenv("KMCPG_FIN_RANGE_HITS")) range_hits = std::max<uint64_t>(1024, strtoull(e, nullptr, 10));
+  const uint64_t r_max = W > 1 ? std::min<uint64_t>(2048, std::max<uint64_t>(4ull * (uint64_t)W, n_hits / range_hits)) : 1ull;
+  int shift = 0;
+  while (shift < 32 && (((uint64_t)n_reads + (1ull << shift) - 1) >> shift) > r_max) shift++;
+  const int R = (int)std::max<uint64_t>(1, ((uint64_t)n_reads + (1ull << shift) - 1) >> shift);
+  auto range_lo = [&](int w) { return (uint32_t)std::min<uint64_t>((uint64_t)w << shift, n_reads); };
   const size_t n_cols = db->col_block.size();
   parted.resize(n_hits);
   per_read.assign((size_t)n_reads, 0);
   // thread_local objects are per thread: the workers get at this thread's buffers through plain pointers
   kmcpg_hit* const parted_p = parted.data();
   o->matches.resize(n_hits);
-  std::vector<uint64_t> cnt((size_t)W * W, 0);  // cnt[slice a][range b]
+  std::vector<uint64_t> cnt((size_t)W * R, 0);  // cnt[slice a][range b]
   std::atomic<int> bad{0};
   auto run = [&](auto&& fn) { pool.parallel_for(W, fn); };  // W pieces of work on the process-wide workers (+ this thread)
   auto slice = [&](int a, uint64_t* lo, uint64_t* hi) {
     *lo = n_hits * (uint64_t)a / (uint64_t)W;
     *hi = n_hits * (uint64_t)(a + 1) / (uint64_t)W;
   };
-  // ... and notes the NumKmers values of the queries that have hits: their FPR rows are fetched once, before phase C
-  std::vector<char> seen((size_t)W * (QueryFpr::kCachedMaxN + 1), 0);
+  const double t_00 = now();
   run([&](int a) {
     uint64_t lo, hi;
     slice(a, &lo, &hi);
-    uint64_t* c = cnt.data() + (size_t)a * W;
-    char* sn = seen.data() + (size_t)a * (QueryFpr::kCachedMaxN + 1);
+    uint64_t* c = cnt.data() + (size_t)a * R;
     for (uint64_t i = lo; i < hi; i++) {
       if (hits[i].read >= n_reads || hits[i].col >= n_cols) {
         bad.store(1);
         return;
       }
-      c[hits[i].read / per_range]++;
-      const int n = qkmers[hits[i].read];
-      if (n > 0 && n <= QueryFpr::kCachedMaxN) sn[n] = 1;
+      c[(uint64_t)hits[i].read >> shift]++;
     }
   });
   if (bad.load()) {
@@ -273,40 +299,42 @@ extern "C" int kmcpg_finalize(const kmcpg_db* db, const kmcpg_hit* hits, uint64_
       if (hits[i].col >= n_cols) return kmcpg_fail(KMCPG_EINVAL, "hit names column %u of %zu", hits[i].col, n_cols);
     }
   }
-  std::vector<uint64_t> range_start((size_t)W + 1, 0), pos((size_t)W * W, 0);
-  for (int b2 = 0; b2 < W; b2++) {
+  const double t_a = now();
+  std::vector<uint64_t> range_start((size_t)R + 1, 0), pos((size_t)W * R, 0);
+  for (int b2 = 0; b2 < R; b2++) {
     uint64_t p0 = range_start[(size_t)b2];
     for (int a = 0; a < W; a++) {
-      pos[(size_t)a * W + b2] = p0;
-      p0 += cnt[(size_t)a * W + b2];
+      pos[(size_t)a * R + b2] = p0;
+      p0 += cnt[(size_t)a * R + b2];
     }
     range_start[(size_t)b2 + 1] = p0;
   }
   run([&](int a) {
     uint64_t lo, hi;
     slice(a, &lo, &hi);
-    uint64_t* q = pos.data() + (size_t)a * W;
+    uint64_t* q = pos.data() + (size_t)a * R;
     kmcpg_hit* dst = parted_p;
-    for (uint64_t i = lo; i < hi; i++) dst[q[hits[i].read / per_range]++] = hits[i];
+    for (uint64_t i = lo; i < hi; i++) dst[q[(uint64_t)hits[i].read >> shift]++] = hits[i];
   });
   t_1 = now();
-  // FPR rows of the NumKmers values present (a handful for short reads), fetched once so that the workers below never lock
+  // FPR rows of the NumKmers values present in the batch (a handful for short reads; one O(n) pass each, kept by the database
+  // handle), fetched once so that the workers below never lock.  (Looked up per read here, not per hit in phase A: a random
+  // access into qkmers for every hit was a third of that phase.)
   QueryFpr* F = db->fpr.get();
   std::unordered_map<int, const std::vector<double>*> fpr_rows;
-  for (int n = 1; n <= QueryFpr::kCachedMaxN; n++)
-    for (int a = 0; a < W; a++)
-      if (seen[(size_t)a * (QueryFpr::kCachedMaxN + 1) + (size_t)n]) {
-        fpr_rows.emplace(n, F->ensure_row(n));
-        break;
-      }
+  if (n_hits) {
+    std::vector<char> seen((size_t)QueryFpr::kCachedMaxN + 1, 0);
+    for (uint32_t r = 0; r < n_reads; r++)
+      if (qkmers[r] > 0 && qkmers[r] <= QueryFpr::kCachedMaxN) seen[(size_t)qkmers[r]] = 1;
+    for (int n = 1; n <= QueryFpr::kCachedMaxN; n++)
+      if (seen[(size_t)n]) fpr_rows.emplace(n, F->ensure_row(n));
+  }
   t_2 = now();
   kmcpg_match* const mbase = o->matches.data();
   uint64_t* const per_read_p = per_read.data();
-  std::vector<uint64_t> wcount((size_t)W, 0);
-  const uint64_t* const col_size = db->col_size.data();
-  const uint64_t* const col_gsize = db->col_gsize.data();
-  const uint32_t* const col_tidx = db->col_tidx.data();
-  run([&](int w) {
+  std::vector<uint64_t> wcount((size_t)R, 0);
+  const kmcpg_db::ColMeta* const col_meta = db->col_meta.data();
+  pool.parallel_for(R, [&](int w) {
     const uint32_t lo = range_lo(w), hi = range_lo(w + 1);
     const uint64_t h0 = range_start[(size_t)w], h1 = range_start[(size_t)w + 1];
     if (hi <= lo) return;
@@ -359,15 +387,16 @@ extern "C" int kmcpg_finalize(const kmcpg_db* db, const kmcpg_hit* hits, uint64_
         if (count < p.min_matched) continue;
         const double c = (double)count;
         if (!(c > thr)) continue;
-        const double nt = (double)col_size[h.col];
+        const kmcpg_db::ColMeta cm = col_meta[h.col];
+        const double nt = (double)cm.size;
         const double T = c / nt;
         if (!(T >= p.min_tcov)) continue;
         const double fpr = row ? (*row)[(size_t)std::min(count, n)] : F->get(n, count);
         if (!(fpr <= p.max_fpr)) continue;
         kmcpg_match m{};
         m.col = h.col;
-        m.target_idx = col_tidx[h.col];
-        m.gsize = col_gsize[h.col];
+        m.target_idx = cm.tidx;
+        m.gsize = cm.gsize;
         m.mkmers = count;
         m.fpr = fpr;
         m.qcov = c / nh;
@@ -405,11 +434,20 @@ extern "C" int kmcpg_finalize(const kmcpg_db* db, const kmcpg_hit* hits, uint64_
           uint32_t b0 = 0;
           for (size_t b = 0; b < nb; b++) {
             const uint32_t b1 = bucket[b];
-            if (b1 - b0 > 1)
-              std::sort(ord + b0, ord + b1, [t](uint32_t x, uint32_t y) {
-                if (t[x].tcov != t[y].tcov) return t[x].tcov > t[y].tcov;
-                return t[x].col < t[y].col;
-              });
+            auto before = [t](uint32_t x, uint32_t y) {
+              if (t[x].tcov != t[y].tcov) return t[x].tcov > t[y].tcov;
+              return t[x].col < t[y].col;
+            };
+            if (b1 - b0 > 16) {
+              std::sort(ord + b0, ord + b1, before);
+            } else {  // the usual bucket: a handful of equal counts
+              for (uint32_t i = b0 + 1; i < b1; i++) {
+                const uint32_t v = ord[i];
+                uint32_t j = i;
+                for (; j > b0 && before(v, ord[j - 1]); j--) ord[j] = ord[j - 1];
+                ord[j] = v;
+              }
+            }
             b0 = b1;
           }
         } else {
@@ -421,7 +459,7 @@ extern "C" int kmcpg_finalize(const kmcpg_db* db, const kmcpg_hit* hits, uint64_
             std::sort(ord, ord + cnt2, [t](uint32_t x, uint32_t y) { return t[x].col < t[y].col; });
           }
         }
-        for (uint64_t i = 0; i < cnt2; i++) mbase[first + i] = t[ord[i]];
+        for (uint64_t i = 0; i < cnt2; i++) store_record(mbase + first + i, t[ord[i]]);
       }
       if (cnt2 > 0 && p.top_n_scores > 0 && !p.do_not_sort) {  // --keep-top-scores (:285-311), including its [:i+1]
         int nn = 0;
@@ -441,12 +479,13 @@ extern "C" int kmcpg_finalize(const kmcpg_db* db, const kmcpg_hit* hits, uint64_
       }
       per_read_p[r] = pos2 - first;
     }
+    records_visible();
     wcount[(size_t)w] = pos2 - h0;
     if (timing && w == 0) fprintf(stderr, "finalize worker 0: counting sort %.2f, matches %.2f ms (%llu hits)\n", tw1 - t_2, now() - tw1, (unsigned long long)(h1 - h0));
   });
   t_3 = now();
   uint64_t total = 0;
-  for (int w = 0; w < W; w++) {  // close the gaps the filters left between the workers' ranges
+  for (int w = 0; w < R; w++) {  // close the gaps the filters left between the ranges
     if (range_start[(size_t)w] != total && wcount[(size_t)w]) memmove(mbase + total, mbase + range_start[(size_t)w], wcount[(size_t)w] * sizeof(kmcpg_match));
     total += wcount[(size_t)w];
   }
@@ -455,6 +494,7 @@ extern "C" int kmcpg_finalize(const kmcpg_db* db, const kmcpg_hit* hits, uint64_
   o->offs[0] = 0;
   for (uint32_t r = 0; r < n_reads; r++) o->offs[r + 1] = o->offs[r] + per_read[r];
   t_4 = now();
+  if (timing) fprintf(stderr, "finalize: prep %.2f count %.2f scatter %.2f (W %d R %d)\n", t_00 - t_0, t_a - t_00, t_1 - t_a, W, R);
   if (timing) fprintf(stderr, "finalize: bucket %.2f fprrows %.2f workers %.2f close %.2f ms\n", t_1 - t_0, t_2 - t_1, t_3 - t_2, t_4 - t_3);
   out->n_reads = n_reads;
   out->k = k_used;
