@@ -98,7 +98,8 @@ __device__ __forceinline__ void csa4(uint32_t (&pl)[NPL], uint32_t x0, uint32_t 
 // short form is its own instantiation (4 rows in flight; 97 VGPRs, the 8-row form 91) built for at most 4 waves per SIMD: the kernel
 // is bound by the L2->fabric path, not by latency (the 8-row form runs as fast at 2 waves per SIMD as at 5), and of the
 // occupancy targets tried for the 4-row form this one is the fastest (GTDB scale: 488 ms; 506-510 ms at 5-6 waves, 510 ms at 3,
-// starved at 2: profiles/r02_group_rows.txt).
+// starved at 2: profiles/r02_group_rows.txt).  That cap is for the 1-KB tiles only: with several units per wave (narrow rows, where
+// a unit's lanes idle once its sector is dead) a fifth wave is worth 1-2 % (128-byte rows at 55 GB: 63.2 -> 62.3 ms).
 struct alignas(16) UnitConst {  // one (read, slot) unit as the index phase sees it
   uint64_t ns, mh;  // NumSigs of the slot's block and its fastmod constant
   uint64_t koff;    // first hash of the read (of this chunk of it: SPLIT)
@@ -107,7 +108,7 @@ struct alignas(16) UnitConst {  // one (read, slot) unit as the index phase sees
 };
 
 template <int LPR, int NPL, bool MULTI, bool SPLIT, int GR = 8>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, GR == 4 ? 4 : 10))) k2_cobs(const K2Args a) {
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, (GR == 4 && LPR == 64) ? 4 : 10))) k2_cobs(const K2Args a) {
   constexpr int G = 64 / LPR;
   constexpr int PAIRS = MULTI ? 256 : 1024;
   constexpr int CH = (PAIRS / G) > 64 ? 64 : (PAIRS / G);
