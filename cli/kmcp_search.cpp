@@ -458,7 +458,7 @@ struct RowFormatter {
     return w_u64(p, (uint64_t)v);
   }
   static char* w_f4(char* p, double v) {  // "%.4f"
-    if (v >= 0 && v < 1e9) {
+    if (v >= 0 && v < 1e5) {  // v * 10000 < 1e9: its rounding error (< 2e-7) cannot carry the fraction across the 1e-6 guard below
       const double sc = v * 10000.0;
       const double fl = floor(sc);
       const double fr = sc - fl;
@@ -488,7 +488,17 @@ struct RowFormatter {
     char t[64];
     b.append(t, (size_t)(w_f4(t, v) - t));
   }
+  // FPR strings of short queries by (n, c) in a table, the rest in a map
+  std::vector<std::vector<std::string>> fpr_tab;
   const std::string& fpr(int n, int c, double v) {
+    if (n > 0 && n <= 4096 && c >= 0 && c <= n) {
+      if (fpr_tab.empty()) fpr_tab.resize(4097);
+      std::vector<std::string>& row_of_n = fpr_tab[(size_t)n];
+      if (row_of_n.empty()) row_of_n.resize((size_t)n + 1);
+      std::string& e = row_of_n[(size_t)c];
+      if (e.empty()) e.assign(tmp, (size_t)snprintf(tmp, sizeof tmp, "%.4e", v));
+      return e;
+    }
     const uint64_t key = ((uint64_t)(uint32_t)n << 32) | (uint32_t)c;
     auto it = fpr_cache.find(key);
     if (it != fpr_cache.end()) return it->second;
@@ -526,6 +536,59 @@ struct RowFormatter {
     p = w_f4(p, m.jacc); *p++ = '\t';
     p = w_u64(p, qidx); *p++ = '\n';
     b.append(line, (size_t)(p - line));
+  }
+  // All rows of one query.  With many matches (a database full of close relatives: hundreds per read) what is the same in every
+  // row — ID, qLen, qKmers in front, hits, kSize, queryIdx — is formatted once, and what depends on the column only (target,
+  // chunkIdx, chunks, tLen) once per column and formatter thread; a row then costs one integer, three fixed-point numbers and
+  // a few copies.
+  std::vector<std::string> col_text;  // "target\tchunkIdx\tchunks\ttLen\t" by column, filled on first use
+  void rows(std::string& b, std::string_view id, int qlen, int qkmers, const kmcpg_match* ms, uint64_t cnt, const std::vector<std::string>& target,
+            int k, uint64_t qidx) {
+    if (cnt < 4 || id.size() > 1024) {
+      for (uint64_t j = 0; j < cnt; j++) row(b, id, qlen, qkmers, cnt, target[ms[j].col], ms[j], k, qidx);
+      return;
+    }
+    char pre[1024 + 64], mid[32], ks[24], suf[32];
+    char* q = pre;
+    memcpy(q, id.data(), id.size()); q += id.size(); *q++ = '\t';
+    q = w_i(q, qlen); *q++ = '\t';
+    q = w_i(q, qkmers); *q++ = '\t';
+    const size_t pre_n = (size_t)(q - pre);
+    q = w_u64(mid, cnt); *q++ = '\t';
+    const size_t mid_n = (size_t)(q - mid);
+    q = w_i(ks, k); *q++ = '\t';
+    const size_t ks_n = (size_t)(q - ks);
+    q = w_u64(suf, qidx); *q++ = '\n';
+    const size_t suf_n = (size_t)(q - suf);
+    if (col_text.size() < target.size()) col_text.resize(target.size());
+    for (uint64_t j = 0; j < cnt; j++) {
+      const kmcpg_match& m = ms[j];
+      std::string& ct = col_text[m.col];
+      if (ct.empty()) {
+        ct = target[m.col];
+        ct.push_back('\t'); put_u64(ct, (uint16_t)m.target_idx);
+        ct.push_back('\t'); put_u64(ct, m.target_idx >> 16);
+        ct.push_back('\t'); put_u64(ct, m.gsize);
+        ct.push_back('\t');
+      }
+      const std::string& f = fpr(qkmers, m.mkmers, m.fpr);
+      if (pre_n + f.size() + ct.size() + 400 > LINE) {
+        row(b, id, qlen, qkmers, cnt, target[m.col], m, k, qidx);
+        continue;
+      }
+      char* p = line;
+      memcpy(p, pre, pre_n); p += pre_n;
+      memcpy(p, f.data(), f.size()); p += f.size(); *p++ = '\t';
+      memcpy(p, mid, mid_n); p += mid_n;
+      memcpy(p, ct.data(), ct.size()); p += ct.size();
+      memcpy(p, ks, ks_n); p += ks_n;
+      p = w_i(p, m.mkmers); *p++ = '\t';
+      p = w_f4(p, m.qcov); *p++ = '\t';
+      p = w_f4(p, m.tcov); *p++ = '\t';
+      p = w_f4(p, m.jacc); *p++ = '\t';
+      memcpy(p, suf, suf_n); p += suf_n;
+      b.append(line, (size_t)(p - line));
+    }
   }
   void unmatched(std::string& b, std::string_view id, int qlen, int qkmers, int k, uint64_t qidx) {
     b += id; b.push_back('\t'); put_i(b, qlen); b.push_back('\t'); put_i(b, qkmers);
@@ -980,10 +1043,21 @@ int main(int argc, char** argv) {
     FormatPool pool(nfmt);
     // the formatted text of a batch goes to the file on a thread of its own, while the next batch is being formatted
     Queue<std::unique_ptr<std::vector<std::string>>> q_flush(4);
+    // text buffers go round: a match-heavy batch is hundreds of megabytes of rows, and fresh strings would be page-faulted in
+    // (and grown by doubling) again for every batch
+    std::mutex free_mu;
+    std::vector<std::string> free_bufs;
     std::thread flusher([&] {
       std::unique_ptr<std::vector<std::string>> parts;
-      while (q_flush.pop(&parts))
+      while (q_flush.pop(&parts)) {
         for (const auto& p : *parts) out.write_raw(p);
+        std::lock_guard<std::mutex> g(free_mu);
+        for (auto& p : *parts)
+          if (free_bufs.size() < 64 && p.capacity() <= (1ull << 30)) {
+            p.clear();
+            free_bufs.push_back(std::move(p));
+          }
+      }
     });
     std::unique_ptr<Batch> b, got;
     std::map<uint64_t, std::unique_ptr<Batch>> pending;  // batches that finished ahead of their turn
@@ -1005,14 +1079,34 @@ int main(int argc, char** argv) {
       const auto tf0 = std::chrono::steady_clock::now();
       const kmcpg_result& r = b->res;
       const uint32_t n = r.n_reads;
-      const int parts = (int)std::max<uint32_t>(1, std::min<uint32_t>((uint32_t)nfmt, (n + 4095) / 4096));
+      // parts of about equal work: a query costs one unit, a row one more (reads of a family database carry hundreds of rows)
+      const uint64_t rows = n ? r.match_offs[n] : 0;
+      const int parts = (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)nfmt, std::max<uint64_t>((n + 4095) / 4096, rows / 32768)));
+      std::vector<uint32_t> cut((size_t)parts + 1, n);
+      cut[0] = 0;
+      for (int pi = 1; pi < parts; pi++) {
+        const uint64_t want = (rows + n) * (uint64_t)pi / (uint64_t)parts;
+        uint32_t a = cut[(size_t)pi - 1], z = n;  // first query i with match_offs[i] + i >= want
+        while (a < z) {
+          const uint32_t mid = a + (z - a) / 2;
+          if (r.match_offs[mid] + mid < want) a = mid + 1; else z = mid;
+        }
+        cut[(size_t)pi] = a;
+      }
       std::unique_ptr<std::vector<std::string>> chunk_p(new std::vector<std::string>((size_t)parts));
       std::vector<std::string>& chunk = *chunk_p;
+      {
+        std::lock_guard<std::mutex> g(free_mu);
+        for (int pi = 0; pi < parts && !free_bufs.empty(); pi++) {
+          chunk[(size_t)pi] = std::move(free_bufs.back());
+          free_bufs.pop_back();
+        }
+      }
       std::vector<uint64_t> part_matched((size_t)parts, 0);
       const std::function<void(int, RowFormatter&)> work = [&](int pi, RowFormatter& F) {
         std::string& buf = chunk[(size_t)pi];
-        const uint32_t lo = (uint32_t)((uint64_t)n * pi / parts), hi = (uint32_t)((uint64_t)n * (pi + 1) / parts);
-        buf.reserve((size_t)(hi - lo) * 96);
+        const uint32_t lo = cut[(size_t)pi], hi = cut[(size_t)pi + 1];
+        buf.reserve((size_t)(r.match_offs[hi] - r.match_offs[lo]) * 112 + (size_t)(hi - lo) * (o.keep_unmatched ? 64 : 8) + 256);
         for (uint32_t i = lo; i < hi; i++) {
           const uint64_t qidx = b->first_idx + i;
           const uint64_t m0 = r.match_offs[i], m1 = r.match_offs[i + 1];
@@ -1021,7 +1115,7 @@ int main(int argc, char** argv) {
             continue;
           }
           part_matched[(size_t)pi]++;
-          for (uint64_t j = m0; j < m1; j++) F.row(buf, b->id(i), r.qlen[i], r.qkmers[i], m1 - m0, target[r.matches[j].col], r.matches[j], r.ksize[i], qidx);
+          F.rows(buf, b->id(i), r.qlen[i], r.qkmers[i], r.matches + m0, m1 - m0, target, r.ksize[i], qidx);
         }
         if (out.gz()) buf = gzip_member(buf);
       };
