@@ -16,16 +16,16 @@ namespace kmcpg {
 // K2: the COBS query.
 //
 // Work unit = (read, slot) with slot = (group of resident blocks that share NumSigs, tile of LPR*16 bytes of its rows).  LPR
-// lanes serve one unit, so a wave carries G = 64/LPR units: LPR = 64 for every whole KiB of a row (GTDB-scale: 1872 B), 16 or 4
-// for what is left of it or for narrow rows (a lone 312-column block has 39-byte rows).  Units are numbered slot-major: all
+// lanes serve one unit, so a wave carries G = 64/LPR units: LPR = 64 for every whole KiB of a row (GTDB-scale: 1872 B), 16, 8 or 4
+// for what is left of it or for narrow rows (a lone 312-column block has 39-byte rows, `kmcp index -b 1024` gives 128-byte ones).  Units are numbered slot-major: all
 // waves in flight gather from one (group, tile) slice of the index.  Each lane owns 16 bytes = 128 columns of its unit's rows
 // and keeps their match counts as NPL bit-sliced planes (vertical counters): the rows of a group of GR = 8 (or 4) are reduced
 // with a carry-save adder tree and the carry word rippled into the upper planes, ~4 VALU ops per loaded dword, which keeps the
 // kernel memory-bound; after every group the sectors whose columns cannot reach the threshold any more stop
 // loading (exact branch and bound).
-// Row indices of a chunk of CH k-mers are computed cooperatively (one exact fastmod per (k-mer,
-// block)) into a per-wave LDS table; k-mers past the end of a read map to the all-zero row appended to
-// each block, so the inner loop has no tail code.
+// Row indices of a chunk of CH k-mers are computed cooperatively (one exact fastmod per (k-mer, block), fastmod.hpp) into a
+// per-wave LDS table — hash loads of the whole chunk first, block constants from LDS: no dependent global loads in that loop;
+// k-mers past the end of a read map to the all-zero row appended to each block, so the inner loop has no tail code.
 // ------------------------------------------------------------------------------------------------
 #define CSA(h, l, a_, b_, c_)              \
   {                                        \
