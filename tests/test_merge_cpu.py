@@ -5,6 +5,7 @@ import gzip
 import os
 import subprocess
 
+import numpy as np
 import pytest
 
 from tests import synth
@@ -169,6 +170,47 @@ def test_merge_three_inputs_with_ties(tmp_path):
             row("r5", 5, "A", "0.6000", 2), row("r5", 5, "F", "0.6000", 2), row("r9", 9, "F", "1.0000", 1)]
     assert got == [HEADER] + want + ["# input queries: 10", "# matched queries: 4", "# matched percentage: 40.0000%", ""]
     assert want == merge_restated([f1, f2, f3], [10, 10, 10])[0]
+
+
+def test_merge_random_inputs_any_block_size_gz_or_not(tmp_path):
+    """Random inputs (runs of 1-40 rows per query, ties, CRLF, a last line without newline) against the restatement above, read in
+    blocks of 16 bytes ... 4 MB (lines and runs of one queryIdx across block boundaries: the inputs are parsed in place, block by
+    block, on threads of their own), plain and gzip in, plain and multi-member gzip out."""
+    import gzip
+    rng = np.random.default_rng(3)
+
+    def row(q, idx, target, score, hits=9):
+        return f"{q}\t150\t130\t1.0000e-05\t{hits}\t{target}\t0\t1\t1000\t21\t80\t{score}\t0.1000\t0.0900\t{idx}"
+    for it in range(12):
+        n_in = int(rng.integers(2, 5))
+        inputs, paths = [], []
+        for k in range(n_in):
+            rows = []
+            for idx in sorted(rng.choice(400, int(rng.integers(0, 120)), replace=False)):
+                for j in range(int(rng.integers(1, 41)) if rng.random() < 0.1 else int(rng.integers(1, 4))):
+                    rows.append(row(f"read_{idx}/1", int(idx), f"T{k}_{j}", "%.4f" % (rng.integers(0, 11) / 10.0)))
+            inputs.append(rows)
+            p = str(tmp_path / f"i{it}_{k}.tsv")
+            text = "\n".join([HEADER] + rows + ["# input queries: 400", "# matched queries: 1", "# matched percentage: 0.2500%"])
+            if rng.random() < 0.5:
+                text += "\n"
+            if rng.random() < 0.3:
+                text = text.replace("\n", "\r\n")
+            if rng.random() < 0.5:
+                p += ".gz"
+                with gzip.open(p, "wb") as fh:
+                    fh.write(text.encode())
+            else:
+                open(p, "wb").write(text.encode())
+            paths.append(p)
+        want_rows, trailer = merge_restated(inputs, [400] * n_in)
+        out = str(tmp_path / f"o{it}.tsv") + (".gz" if it % 2 else "")
+        env = dict(os.environ, KMCP_MERGE_BLOCK=str(int(rng.choice([16, 33, 100, 1000, 65536, 4 << 20]))))
+        r = subprocess.run([MERGE, "-o", out] + paths, capture_output=True, text=True, timeout=120, env=env)
+        assert r.returncode == 0, r.stderr
+        got = (gzip.open(out, "rt") if out.endswith(".gz") else open(out)).read().split("\n")
+        assert got[0] == HEADER and got[1:1 + len(want_rows)] == want_rows, (it, env["KMCP_MERGE_BLOCK"])
+        assert got[1 + len(want_rows):] == trailer + [""]
 
 
 def test_merge_equals_search_of_the_joint_database(oracle_lib, tmp_path):
