@@ -21,6 +21,8 @@
 #include <thread>
 #include <vector>
 
+#include "fast_gunzip.hpp"
+
 [[noreturn]] void die(const char* fmt, ...);  // log the message and exit(255), like the reference's checkError
 
 // ------------------------------------------------------------------------------------------------
@@ -236,7 +238,8 @@ class FastxReader {
         if (const char* e = getenv("KMCP_BGZF_THREADS")) w = std::max(1, atoi(e));
         bgzf_.reset(new BgzfInflater(fd_, path, w));
         fd_ = -1;  // owned by the inflater now
-      } else if (got < 0 || (got >= 2 && magic[0] == 0x1f && magic[1] == 0x8b)) {  // gzip, or not seekable (a pipe): let zlib look
+      } else if (got >= 2 && magic[0] == 0x1f && magic[1] == 0x8b && map_gzip()) {  // a gzip file: the in-memory decoder (fast_gunzip.hpp)
+      } else if (got < 0 || (got >= 2 && magic[0] == 0x1f && magic[1] == 0x8b)) {  // gzip that cannot be mapped, or not seekable (a pipe): let zlib look
         gz_ = gzdopen(fd_, "rb");
         if (!gz_) die("%s: %s", path.c_str(), strerror(errno));
         fd_ = -1;  // owned by zlib now
@@ -244,8 +247,8 @@ class FastxReader {
         die("%s: %s", path.c_str(), strerror(errno));
       }
     }
-    if (gz_) {
-      gzbuffer(gz_, 1 << 20);
+    if (gz_ || fgz_) {
+      if (gz_) gzbuffer(gz_, 1 << 20);
       // inflate runs ahead on its own thread (4 chunks of 4 MB in flight) while this thread parses
       for (int i = 0; i < 4; i++) spare_.emplace_back(new Chunk());
       inflater_ = std::thread([this] {
@@ -258,14 +261,18 @@ class FastxReader {
             c = std::move(spare_.front());
             spare_.pop_front();
           }
-          const int n = gzread(gz_, c->data.data(), (unsigned)c->data.size());
+          const ssize_t n = fgz_ ? fgz_->read(c->data.data(), c->data.size()) : (ssize_t)gzread(gz_, c->data.data(), (unsigned)c->data.size());
           std::lock_guard<std::mutex> l(im_);
           if (n <= 0) {
             // a truncated or corrupt stream must not look like a short input (the reference's gzip reader aborts with
             // "unexpected EOF"): zlib reports Z_BUF_ERROR for a stream that ends inside a member, Z_DATA_ERROR for a bad CRC
-            int errnum = Z_OK;
-            const char* msg = gzerror(gz_, &errnum);
-            if (n < 0 || (errnum != Z_OK && errnum != Z_STREAM_END)) ierr_ = errnum == Z_ERRNO ? strerror(errno) : (msg && *msg ? msg : "corrupt gzip stream");
+            if (fgz_) {
+              if (n < 0) ierr_ = fgz_->error().empty() ? "corrupt gzip stream" : fgz_->error();
+            } else {
+              int errnum = Z_OK;
+              const char* msg = gzerror(gz_, &errnum);
+              if (n < 0 || (errnum != Z_OK && errnum != Z_STREAM_END)) ierr_ = errnum == Z_ERRNO ? strerror(errno) : (msg && *msg ? msg : "corrupt gzip stream");
+            }
             idone_ = true;
             icv_.notify_all();
             return;
@@ -287,6 +294,8 @@ class FastxReader {
       inflater_.join();
     }
     if (gz_) gzclose(gz_);
+    fgz_.reset();
+    if (gzmap_) munmap((void*)gzmap_, gzmap_size_);
     if (fd_ >= 0) close(fd_);
     if (child_ > 0) {  // reader dropped before the stream ended
       kill(child_, SIGTERM);
@@ -396,11 +405,11 @@ class FastxReader {
       const size_t room = std::min<size_t>(buf_.size() - end_, 1u << 30);
       ssize_t got;
       if (bgzf_) got = (ssize_t)bgzf_->read(&buf_[end_], room);
-      else if (gz_) got = (ssize_t)take_inflated(&buf_[end_], room);
+      else if (gz_ || fgz_) got = (ssize_t)take_inflated(&buf_[end_], room);
       else
         do got = read(fd_, &buf_[end_], room);
         while (got < 0 && errno == EINTR);
-      if (got < 0 && !bgzf_ && !gz_) die("%s: %s", path_.c_str(), strerror(errno));
+      if (got < 0 && !bgzf_ && !gz_ && !fgz_) die("%s: %s", path_.c_str(), strerror(errno));
       if (got <= 0 && child_ > 0) {  // the decompressor's verdict on the file
         int st = 0;
         waitpid(child_, &st, 0);
@@ -438,6 +447,19 @@ class FastxReader {
     std::vector<char> data = std::vector<char>(4u << 20);
     size_t n = 0;
   };
+  // maps a regular gzip file for FastGunzip; false (nothing changed) if it cannot be mapped or KMCP_ZLIB_GUNZIP asks for zlib
+  bool map_gzip() {
+    if (getenv("KMCP_ZLIB_GUNZIP")) return false;
+    struct stat st;
+    if (fstat(fd_, &st) != 0 || !S_ISREG(st.st_mode) || st.st_size < 18) return false;
+    void* m = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd_, 0);
+    if (m == MAP_FAILED) return false;
+    madvise(m, (size_t)st.st_size, MADV_SEQUENTIAL);
+    gzmap_ = (const uint8_t*)m;
+    gzmap_size_ = (size_t)st.st_size;
+    fgz_.reset(new FastGunzip(gzmap_, gzmap_size_));
+    return true;
+  }
   // `tool -dc path` with its stdout on a pipe; returns the read end
   int spawn_decompressor(const char* tool, const std::string& path) {
     int pfd[2];
@@ -462,6 +484,9 @@ class FastxReader {
   pid_t child_ = -1;
   std::string ierr_;  // set by the inflate thread
   gzFile gz_ = nullptr;
+  std::unique_ptr<FastGunzip> fgz_;  // ... or the in-memory decoder over the mapped file
+  const uint8_t* gzmap_ = nullptr;
+  size_t gzmap_size_ = 0;
   int fd_ = -1;
   std::unique_ptr<BgzfInflater> bgzf_;
   std::thread inflater_;
