@@ -23,6 +23,14 @@ for i in 1 2; do
   e=$(date +%s%N)
   echo "paired run $i: $(( (e - s) / 1000000 )) ms wall; $(grep -o 'pipeline:.*' $D/log.txt)"
 done
+# gzip input: the first million reads through kmcp-search's own decoder, through zlib, and end to end
+head -n 4000000 $D/reads.fq | gzip -6 > $D/reads1m.fq.gz
+kmcp_amd/kmcp-search --parse-only $D/reads1m.fq.gz 2>&1 >/dev/null | tail -n 1 | sed 's/$/ (gzip -6, fast_gunzip)/'
+KMCP_ZLIB_GUNZIP=1 kmcp_amd/kmcp-search --parse-only $D/reads1m.fq.gz 2>&1 >/dev/null | tail -n 1 | sed 's/$/ (gzip -6, zlib)/'
+s=$(date +%s%N)
+kmcp_amd/kmcp-search -d $D/db $D/reads1m.fq.gz -o $D/out_gz.tsv.gz 2> $D/log.txt
+e=$(date +%s%N)
+echo "gz in, gz out, 1 M reads: $(( (e - s) / 1000000 )) ms wall; $(grep -o 'pipeline:.*' $D/log.txt)"
 kmcp_amd/kmcp-search -d $D/db $D/reads.fq -o $D/out2.tsv --gpu-batch 100000 -q
 cmp $D/out.tsv $D/out2.tsv && echo "batch size does not change the output"
 tail -3 $D/out.tsv
