@@ -213,7 +213,7 @@ class FastGunzip {
   // canonical Huffman code of lens[0..n) -> two-level table (tb first-level bits); base/extra describe the symbols from `first`
   // on (length or distance codes), symbols below are literals, `eob` is the end-of-block symbol (-1: none)
   bool build(const uint8_t* lens, int n, int tb, std::vector<uint32_t>& tab, int first, int eob, const uint16_t* base, const uint8_t* extra,
-             int n_coded, bool is_codes) {
+             int n_coded, bool is_codes, bool pairs = false) {
     int count[16] = {0};
     for (int i = 0; i < n; i++) count[lens[i]]++;
     count[0] = 0;
@@ -270,6 +270,21 @@ class FastGunzip {
         for (size_t i = r >> tb; i < ((size_t)1 << sb); i += (size_t)1 << (l - tb)) tab[start + i] = e;
       }
     }
+    if (pairs) {
+      // two literals in one look-up where both codes fit the first-level index: the entry of index i starts with literal a of
+      // l1 bits; the tb - l1 bits after it select entry i >> l1 (entries repeat over the bits they do not use), and if that is a
+      // literal b of at most tb - l1 bits, index i decodes "ab" (value a | b << 8, l1 + l2 bits, extra field 1 = one more byte)
+      const std::vector<uint32_t> single(tab.begin(), tab.begin() + ((size_t)1 << tb));
+      for (size_t i = 0; i < ((size_t)1 << tb); i++) {
+        const uint32_t e1 = single[i];
+        if (((e1 >> 8) & 7) != LIT) continue;
+        const uint32_t l1 = e1 & 255;
+        if (l1 >= (uint32_t)tb) continue;
+        const uint32_t e2 = single[i >> l1];
+        if (((e2 >> 8) & 7) != LIT || (e2 & 255) > (uint32_t)tb - l1) continue;
+        tab[i] = entry(l1 + (e2 & 255), LIT, 1, (e1 >> 16) | ((e2 >> 16) << 8));
+      }
+    }
     return true;
   }
   bool fixed_tables() {
@@ -279,7 +294,7 @@ class FastGunzip {
     for (int i = 256; i < 280; i++) l[i] = 7;
     for (int i = 280; i < 288; i++) l[i] = 8;
     for (int i = 0; i < 32; i++) d[i] = 5;
-    return build(l, 288, LB, lt_, 257, 256, kLenBase, kLenExtra, 29, false) && build(d, 32, DB, dt_, 0, -1, kDistBase, kDistExtra, 30, false);
+    return build(l, 288, LB, lt_, 257, 256, kLenBase, kLenExtra, 29, false, true) && build(d, 32, DB, dt_, 0, -1, kDistBase, kDistExtra, 30, false);
   }
   bool dynamic_tables() {
     refill();
@@ -323,7 +338,7 @@ class FastGunzip {
       }
     }
     if (lens[256] == 0) return fail("invalid code -- missing end-of-block");
-    return build(lens, hlit, LB, lt_, 257, 256, kLenBase, kLenExtra, 29, false) && build(lens + hlit, hdist, DB, dt_, 0, -1, kDistBase, kDistExtra, 30, false);
+    return build(lens, hlit, LB, lt_, 257, 256, kLenBase, kLenExtra, 29, false, true) && build(lens + hlit, hdist, DB, dt_, 0, -1, kDistBase, kDistExtra, 30, false);
   }
 
   // ---- the stream ----
@@ -470,20 +485,27 @@ class FastGunzip {
         if (pad_ > 64) { why = "unexpected end of file"; break; }  // far past the end of the input and still no end of block
       }
       uint32_t e = lt[bb & ((1u << LB) - 1)];
-      if (((e >> 8) & 7) == LIT) {  // up to three literals per top-up: 3 x 15 bits fit the 56 that are there
+      // a literal entry holds one byte or two (build: pairs): both are stored, the position moves by 1 + its extra field
+#define FASTGZ_PUT_LITERALS(e)                      \
+  do {                                              \
+    out0[op] = (uint8_t)((e) >> 16);                \
+    out0[op + 1] = (uint8_t)((e) >> 24);            \
+    op += 1 + (((e) >> 11) & 1);                    \
+  } while (0)
+      if (((e >> 8) & 7) == LIT) {  // up to three literal look-ups per top-up: 3 x 15 bits fit the 56 that are there
         bb >>= (e & 255);
         bc -= (int)(e & 255);
-        out0[op++] = (uint8_t)(e >> 16);
+        FASTGZ_PUT_LITERALS(e);
         e = lt[bb & ((1u << LB) - 1)];
         if (((e >> 8) & 7) == LIT) {
           bb >>= (e & 255);
           bc -= (int)(e & 255);
-          out0[op++] = (uint8_t)(e >> 16);
+          FASTGZ_PUT_LITERALS(e);
           e = lt[bb & ((1u << LB) - 1)];
           if (((e >> 8) & 7) == LIT) {
             bb >>= (e & 255);
             bc -= (int)(e & 255);
-            out0[op++] = (uint8_t)(e >> 16);
+            FASTGZ_PUT_LITERALS(e);
             continue;
           }
         }
@@ -494,9 +516,10 @@ class FastGunzip {
       bc -= (int)(e & 255);
       const uint32_t kind = (e >> 8) & 7;
       if (kind == LIT) {
-        out0[op++] = (uint8_t)(e >> 16);
+        FASTGZ_PUT_LITERALS(e);
         continue;
       }
+#undef FASTGZ_PUT_LITERALS
       if (kind == LEN) {
         const uint32_t xl = (e >> 11) & 31;
         const size_t len = (e >> 16) + (uint32_t)(bb & ((1ull << xl) - 1));
