@@ -231,8 +231,10 @@ class FastGunzip {
     next[1] = 0;
     for (int l = 1; l < 15; l++) next[l + 1] = (uint16_t)((next[l] + count[l]) << 1);
     // second-level tables: bits needed per first-level prefix
-    std::vector<uint8_t> sub_bits;
-    std::vector<uint16_t> code((size_t)n);
+    std::vector<uint8_t>& sub_bits = sub_bits_;  // scratch kept between blocks (a block header should not cost heap calls)
+    std::vector<uint16_t>& code = code_;
+    code.assign((size_t)n, 0);
+    sub_bits.clear();
     if (maxlen > tb) sub_bits.assign((size_t)1 << tb, 0);
     for (int s = 0; s < n; s++) {
       const int l = lens[s];
@@ -274,7 +276,8 @@ class FastGunzip {
       // two literals in one look-up where both codes fit the first-level index: the entry of index i starts with literal a of
       // l1 bits; the tb - l1 bits after it select entry i >> l1 (entries repeat over the bits they do not use), and if that is a
       // literal b of at most tb - l1 bits, index i decodes "ab" (value a | b << 8, l1 + l2 bits, extra field 1 = one more byte)
-      const std::vector<uint32_t> single(tab.begin(), tab.begin() + ((size_t)1 << tb));
+      std::vector<uint32_t>& single = single_;
+      single.assign(tab.begin(), tab.begin() + ((size_t)1 << tb));
       for (size_t i = 0; i < ((size_t)1 << tb); i++) {
         const uint32_t e1 = single[i];
         if (((e1 >> 8) & 7) != LIT) continue;
@@ -307,7 +310,7 @@ class FastGunzip {
       cl[order[i]] = (uint8_t)bits(3);
     }
     // the code-length code: at most 7 bits, one level
-    std::vector<uint32_t> pt;
+    std::vector<uint32_t>& pt = pt_;
     static const uint16_t nob[19] = {0};
     static const uint8_t noe[19] = {0};
     {
@@ -586,5 +589,8 @@ class FastGunzip {
   bool final_ = false, done_ = false, first_member_ = true;
   State state_ = HEADER;
   std::vector<uint32_t> lt_, dt_;
+  std::vector<uint8_t> sub_bits_;   // scratch of build()
+  std::vector<uint16_t> code_;
+  std::vector<uint32_t> single_, pt_;
   std::string err_;
 };
