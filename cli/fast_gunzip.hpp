@@ -16,92 +16,67 @@
 #include <string>
 #include <vector>
 
-// CRC-32 (the gzip polynomial) by carry-less multiplication where the CPU has it: four 128-bit lanes folded per 64 bytes, then
-// down to 128, 64 and 32 bits (Gopal et al., "Fast CRC Computation for Generic Polynomials Using PCLMULQDQ", 2009; constants
-// for the reflected polynomial 0xEDB88320).  zlib 1.2.11's table-driven crc32 runs at 1 GB/s — a quarter of the time of the
-// whole decoder; this runs at 10-20 GB/s.  Checked against zlib's crc32 once at start-up (and in tests/gunzip_check.cpp): on a
-// mismatch, or without the instruction, zlib's is used.
+// CRC-32 (the gzip polynomial) by carry-less multiplication where the CPU has it.  The method is the folding step of Gopal et
+// al., "Fast CRC Computation for Generic Polynomials Using PCLMULQDQ" (Intel, 2009), written down from the paper's algebra:
+// a 128-bit accumulator A that stands D bits ahead of the data it is about to meet is replaced by
+//     lo64(A) * (x^(D+32) mod P)  xor  hi64(A) * (x^(D-32) mod P)  xor  data
+// (bit-reflected arithmetic: the low half of the register holds the EARLIER bytes; the product of two reflected operands comes
+// out one bit low, hence the constants are kept shifted left by one).  The constants are not copied from anywhere: xpow_mod()
+// below derives x^n mod P for the reflected polynomial 0xEDB88320 at compile time.  Four accumulators fold 64 bytes per turn
+// (D = 512), are then folded into one (D = 128), which swallows the remaining 16-byte pieces; the paper's Barrett reduction of
+// the last 128 bits is not used — those 16 bytes are simply handed to zlib's crc32 with an all-zero register, which is the same
+// number (the accumulator IS a message whose CRC equals that of everything folded into it).  zlib 1.2.11's table-driven crc32
+// runs at 1 GB/s — a quarter of the time of the whole decoder; this runs at 10-20 GB/s.  Checked against zlib's crc32 once at
+// start-up (and in tests/gunzip_check.cpp): on a mismatch, or without the instruction, zlib's is used.
 #if defined(__x86_64__)
 #include <immintrin.h>
 #include <wmmintrin.h>
 namespace fastgz {
+// x^n mod P, reflected (bit 31 = x^0 ... bit 0 = x^31), shifted left by one for the carry-less multiplier
+constexpr uint64_t xpow_mod(unsigned n) {
+  uint32_t v = 0x80000000u;  // x^0
+  for (unsigned i = 0; i < n; i++) v = (v >> 1) ^ ((v & 1u) ? 0xEDB88320u : 0u);
+  return (uint64_t)v << 1;
+}
+template <unsigned D>
+struct FoldBy {  // multipliers of an accumulator D bits ahead of its data
+  static constexpr uint64_t lo = xpow_mod(D + 32), hi = xpow_mod(D - 32);
+};
+template <unsigned D>
+__attribute__((target("pclmul,sse4.1"))) static inline __m128i fold_step(__m128i acc, __m128i data) {
+  const __m128i k = _mm_set_epi64x((long long)FoldBy<D>::hi, (long long)FoldBy<D>::lo);
+  const __m128i early = _mm_clmulepi64_si128(acc, k, 0x00);  // lo64(acc) * x^(D+32)
+  const __m128i late = _mm_clmulepi64_si128(acc, k, 0x11);   // hi64(acc) * x^(D-32)
+  return _mm_xor_si128(_mm_xor_si128(early, late), data);
+}
 // len >= 64 and a multiple of 16; crc is the raw register (the complement of the public value)
 __attribute__((target("pclmul,sse4.1"))) inline uint32_t crc32_fold(const unsigned char* buf, size_t len, uint32_t crc) {
-  alignas(16) static const uint64_t k1k2[] = {0x0154442bd4, 0x01c6e41596};
-  alignas(16) static const uint64_t k3k4[] = {0x01751997d0, 0x00ccaa009e};
-  alignas(16) static const uint64_t k5k0[] = {0x0163cd6124, 0x0000000000};
-  alignas(16) static const uint64_t poly[] = {0x01db710641, 0x01f7011641};
-  __m128i x0, x1, x2, x3, x4, x5, x6, x7, x8, y5, y6, y7, y8;
-  x1 = _mm_loadu_si128((const __m128i*)(buf + 0x00));
-  x2 = _mm_loadu_si128((const __m128i*)(buf + 0x10));
-  x3 = _mm_loadu_si128((const __m128i*)(buf + 0x20));
-  x4 = _mm_loadu_si128((const __m128i*)(buf + 0x30));
-  x1 = _mm_xor_si128(x1, _mm_cvtsi32_si128((int)crc));
-  x0 = _mm_load_si128((const __m128i*)k1k2);
-  buf += 64;
-  len -= 64;
-  while (len >= 64) {
-    x5 = _mm_clmulepi64_si128(x1, x0, 0x00);
-    x6 = _mm_clmulepi64_si128(x2, x0, 0x00);
-    x7 = _mm_clmulepi64_si128(x3, x0, 0x00);
-    x8 = _mm_clmulepi64_si128(x4, x0, 0x00);
-    x1 = _mm_clmulepi64_si128(x1, x0, 0x11);
-    x2 = _mm_clmulepi64_si128(x2, x0, 0x11);
-    x3 = _mm_clmulepi64_si128(x3, x0, 0x11);
-    x4 = _mm_clmulepi64_si128(x4, x0, 0x11);
-    y5 = _mm_loadu_si128((const __m128i*)(buf + 0x00));
-    y6 = _mm_loadu_si128((const __m128i*)(buf + 0x10));
-    y7 = _mm_loadu_si128((const __m128i*)(buf + 0x20));
-    y8 = _mm_loadu_si128((const __m128i*)(buf + 0x30));
-    x1 = _mm_xor_si128(_mm_xor_si128(x1, x5), y5);
-    x2 = _mm_xor_si128(_mm_xor_si128(x2, x6), y6);
-    x3 = _mm_xor_si128(_mm_xor_si128(x3, x7), y7);
-    x4 = _mm_xor_si128(_mm_xor_si128(x4, x8), y8);
-    buf += 64;
-    len -= 64;
-  }
-  x0 = _mm_load_si128((const __m128i*)k3k4);
-  x5 = _mm_clmulepi64_si128(x1, x0, 0x00);
-  x1 = _mm_clmulepi64_si128(x1, x0, 0x11);
-  x1 = _mm_xor_si128(_mm_xor_si128(x1, x2), x5);
-  x5 = _mm_clmulepi64_si128(x1, x0, 0x00);
-  x1 = _mm_clmulepi64_si128(x1, x0, 0x11);
-  x1 = _mm_xor_si128(_mm_xor_si128(x1, x3), x5);
-  x5 = _mm_clmulepi64_si128(x1, x0, 0x00);
-  x1 = _mm_clmulepi64_si128(x1, x0, 0x11);
-  x1 = _mm_xor_si128(_mm_xor_si128(x1, x4), x5);
-  while (len >= 16) {
-    x2 = _mm_loadu_si128((const __m128i*)buf);
-    x5 = _mm_clmulepi64_si128(x1, x0, 0x00);
-    x1 = _mm_clmulepi64_si128(x1, x0, 0x11);
-    x1 = _mm_xor_si128(_mm_xor_si128(x1, x2), x5);
-    buf += 16;
-    len -= 16;
-  }
-  x2 = _mm_clmulepi64_si128(x1, x0, 0x10);
-  x3 = _mm_setr_epi32(~0, 0, ~0, 0);
-  x1 = _mm_srli_si128(x1, 8);
-  x1 = _mm_xor_si128(x1, x2);
-  x0 = _mm_loadl_epi64((const __m128i*)k5k0);
-  x2 = _mm_srli_si128(x1, 4);
-  x1 = _mm_and_si128(x1, x3);
-  x1 = _mm_clmulepi64_si128(x1, x0, 0x00);
-  x1 = _mm_xor_si128(x1, x2);
-  x0 = _mm_load_si128((const __m128i*)poly);
-  x2 = _mm_and_si128(x1, x3);
-  x2 = _mm_clmulepi64_si128(x2, x0, 0x10);
-  x2 = _mm_and_si128(x2, x3);
-  x2 = _mm_clmulepi64_si128(x2, x0, 0x00);
-  x1 = _mm_xor_si128(x1, x2);
-  return (uint32_t)_mm_extract_epi32(x1, 1);
+  const __m128i* p = (const __m128i*)buf;
+  __m128i acc[4];
+  for (int j = 0; j < 4; j++) acc[j] = _mm_loadu_si128(p + j);
+  acc[0] = _mm_xor_si128(acc[0], _mm_cvtsi32_si128((int)crc));  // the register meets the first four bytes
+  p += 4;
+  size_t left = len - 64;
+  for (; left >= 64; left -= 64, p += 4)
+    for (int j = 0; j < 4; j++) acc[j] = fold_step<512>(acc[j], _mm_loadu_si128(p + j));
+  __m128i a = acc[0];
+  for (int j = 1; j < 4; j++) a = fold_step<128>(a, acc[j]);
+  for (; left >= 16; left -= 16, p++) a = fold_step<128>(a, _mm_loadu_si128(p));
+  alignas(16) unsigned char tail[16];
+  _mm_store_si128((__m128i*)tail, a);
+  // raw register 0 in = public value 0xFFFFFFFF in; raw register out = complement of the public value out
+  return ~(uint32_t)crc32(0xFFFFFFFFu, tail, 16);
 }
 inline bool fold_usable() {
   static const bool ok = [] {
     if (!__builtin_cpu_supports("pclmul") || !__builtin_cpu_supports("sse4.1")) return false;
-    unsigned char t[208];
-    for (size_t i = 0; i < sizeof t; i++) t[i] = (unsigned char)(i * 151 + 7);
     const uint32_t seed = 0x12345678u;
-    return (uint32_t)crc32(seed, t, (uInt)sizeof t) == ~crc32_fold(t, sizeof t, ~seed);
+    for (size_t n : {64u, 80u, 128u, 208u, 1040u}) {
+      unsigned char t[1040];
+      for (size_t i = 0; i < n; i++) t[i] = (unsigned char)(i * 151 + 7 + n);
+      if ((uint32_t)crc32(seed, t, (uInt)n) != ~crc32_fold(t, n, ~seed)) return false;
+    }
+    return true;
   }();
   return ok;
 }
