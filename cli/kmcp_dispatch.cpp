@@ -10,6 +10,7 @@
 // cobra accepts the root command's persistent flags (-j/--threads, -q/--quiet, -i/--infile-list, --log; root.go:62-82) before
 // the sub-command: they are handed on behind it.
 #include <limits.h>
+#include <errno.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>

@@ -926,7 +926,12 @@ int main(int argc, char** argv) {
   Queue<std::unique_ptr<Batch>> q_in(3), q_out(3);
   uint64_t total = 0, matched = 0;
   // a batch also closes at 64 Mbases (long queries); paged indexes want the largest batches the host can hold
-  const size_t max_bases = paged_passes > 1 ? std::min<size_t>((size_t)o.batch * 512, (size_t)2 << 30) : (size_t)64 << 20;
+  // (a batch's device workspace is up to 24 B per base: the library says how many bases fit beside the resident index)
+  size_t max_bases = paged_passes > 1 ? std::min<size_t>((size_t)o.batch * 512, (size_t)2 << 30) : (size_t)64 << 20;
+  {
+    uint64_t hint = 0;
+    if (kmcpg_batch_hint(db, &hint) == 0 && hint > 0) max_bases = std::max<size_t>((size_t)1 << 20, std::min<size_t>(max_bases, (size_t)hint));
+  }
 
   double t_reader_blocked = 0, t_reader_total = 0;  // the reader thread: waiting for a free queue slot / its whole life
   std::thread reader([&] {

@@ -141,6 +141,11 @@ const char* kmcpg_exchange_info(const kmcpg_db* db);
 int kmcpg_open_paged(const char* db_dir, int32_t device, int32_t passes, kmcpg_db** out);
 /* passes of a paged handle (0 for every other handle) and how many shard uploads it has done so far */
 int kmcpg_paged_info(const kmcpg_db* db, int32_t* passes, uint64_t* uploads);
+/* How many bases (read 1 + read 2) one batch may hold on this handle so that its device workspace fits beside the resident index
+ * (K1 and the sort + unique of long queries take up to 24 B per base, query.cpp): a paged handle answers from the HBM it kept
+ * free beside its largest shard, every other handle from what is free now; 0 = unknown.  A batch that does not fit is not an
+ * error of kmcpg_search_batch either: it is searched as two halves (recursively) and answered as one result. */
+int kmcpg_batch_hint(const kmcpg_db* db, uint64_t* max_bases);
 int kmcpg_close(kmcpg_db* db);
 const char* kmcpg_last_error(void);
 int kmcpg_db_info(const kmcpg_db* db, kmcpg_info* info);

@@ -124,11 +124,12 @@ void form_groups(kmcpg_db* db) {
 
 // HBM this process may still take on the current device.  KMCPG_HBM_LIMIT_MB caps it (tests of the larger-than-HBM path; a
 // host that shares the GPU).
+// ~0 = the device would not say: callers skip their fit checks and let hipMalloc decide.
 uint64_t hbm_free_bytes() {
   size_t free_b = 0, total_b = 0;
   if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) {
     (void)hipGetLastError();
-    return 0;
+    return ~0ull;
   }
   uint64_t f = free_b;
   if (const char* e = getenv("KMCPG_HBM_LIMIT_MB")) f = std::min<uint64_t>(f, (uint64_t)std::max(0ll, atoll(e)) << 20);
@@ -153,7 +154,7 @@ int alloc_groups(kmcpg_db* db) {
   // local blocks must be resident.  Say so with numbers before the first allocation fails half-way: the caller can then split
   // the index over more GPUs (shard_count) or search it in passes (kmcpg_open_paged).
   const uint64_t need = resident_bytes(db), free_b = hbm_free_bytes(), kWorkspaceReserve = workspace_reserve();
-  if (need + kWorkspaceReserve > free_b)
+  if (free_b != ~0ull && need + kWorkspaceReserve > free_b)
     return kmcpg_fail(KMCPG_ENOMEM, "index does not fit in HBM: shard %d/%d needs %.2f GB for its %zu block group(s) + %.1f GB of workspace, %.2f GB free on device %d "
                       "(more GPUs: kmcpg_open_devices / --gpus; one GPU: kmcpg_open_paged / --gpu-passes)",
                       db->opts.shard_rank, db->opts.shard_count, need / 1e9, db->groups.size(), kWorkspaceReserve / 1e9, free_b / 1e9, db->opts.device);
@@ -394,13 +395,15 @@ namespace kmcpg {
 // Passes a paged handle needs (kmcpg_open_paged): the smallest number S of shards (same byte-balanced partition as
 // kmcpg_open with shard_count = S) whose largest shard fits the free HBM of `device` next to the workspace.  `front` is a
 // metadata-only handle of the whole database; its own partition is restored before returning.  0 = not even one block fits.
-int plan_passes(kmcpg_db* front, int device, uint64_t* largest_shard_bytes, uint64_t* free_bytes) {
+int plan_passes(kmcpg_db* front, int device, uint64_t* largest_shard_bytes, uint64_t* free_bytes, uint64_t* reserve_bytes) {
   if (hipSetDevice(device) != hipSuccess) return 0;
   // a paged handle lives on large batches (every batch pays passes - 1 uploads): room for the k-mer workspace of a few million
   // reads (8-25 B per base) is kept free beside the resident shard
-  const uint64_t free_b = hbm_free_bytes();
+  uint64_t free_b = hbm_free_bytes();
+  if (free_b == ~0ull) free_b = 0;  // paging needs a number: an unknown device plans nothing
   const uint64_t reserve = getenv("KMCPG_WORKSPACE_RESERVE_MB") ? workspace_reserve() : std::max<uint64_t>(workspace_reserve(), std::min<uint64_t>(free_b / 8, 24ull << 30));
   if (free_bytes) *free_bytes = free_b;
+  if (reserve_bytes) *reserve_bytes = reserve;
   const kmcpg_opts keep = front->opts;
   int found = 0;
   const int nb = (int)front->blocks.size();

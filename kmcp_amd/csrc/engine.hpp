@@ -94,7 +94,7 @@ struct FprBoundTable {
   uint16_t* h = nullptr;
 };
 void release_fpr_bounds(kmcpg_db* db);  // query.cpp
-int plan_passes(kmcpg_db* front, int device, uint64_t* largest_shard_bytes, uint64_t* free_bytes);  // engine.cpp
+int plan_passes(kmcpg_db* front, int device, uint64_t* largest_shard_bytes, uint64_t* free_bytes, uint64_t* reserve_bytes = nullptr);  // engine.cpp
 int open_like(const kmcpg_db* src, const kmcpg_opts* opts, kmcpg_db** out);                           // engine.cpp
 struct AsyncState;
 void async_release(kmcpg_db* db);  // host.cpp
@@ -148,6 +148,7 @@ struct kmcpg_db {
   kmcpg_db* paged_resident = nullptr;
   std::mutex paged_mu;
   uint64_t paged_uploads = 0;  // shards made resident so far (tests / logs)
+  uint64_t paged_reserve = 0;  // HBM plan_passes() kept free beside the largest shard: what a batch's workspace may take
   // optional HIP-event timing of the last kmcpg_query_device call
   int profiling = 0;  // 1: HIP-event timing of the kernels; 2: + count the row loads k2_cobs issues
   kmcpg::DevBuf<uint64_t> w_gathered;
@@ -183,8 +184,9 @@ struct NoInitAlloc : std::allocator<T> {
     else ::new ((void*)q) U(std::forward<A>(a)...);
   }
 };
-// ... and whose storage starts on a cache line: a kmcpg_match is 64 bytes, so every record is exactly one line and the host
-// half can write the records of match-heavy batches with streaming stores (finalize.cpp)
+// ... and whose storage starts on a cache line.  A kmcpg_match is 56 bytes (seven 8-byte words, finalize.cpp asserts it), so
+// records straddle lines; the host half writes them with 8-byte streaming stores, which only need 8-byte alignment — the
+// aligned start merely keeps the first write-combining buffer of an array whole (finalize.cpp)
 template <class T>
 struct LineAlloc : NoInitAlloc<T> {
   template <class U>

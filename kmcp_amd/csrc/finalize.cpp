@@ -374,7 +374,7 @@ extern "C" int kmcpg_finalize(const kmcpg_db* db, const kmcpg_hit* hits, uint64_
       }
       // A read with a handful of hits (the usual case) builds its matches in place and sorts the records; a read with many
       // (a database full of close relatives: hundreds) builds them in a scratch array, orders 4-byte indices and writes every
-      // 64-byte record once, in its final position.
+      // 56-byte record once, in its final position.
       const bool in_place = s1 - s0 <= 8;
       static thread_local std::vector<kmcpg_match> tmp;
       if (!in_place && tmp.size() < s1 - s0) tmp.resize(s1 - s0);

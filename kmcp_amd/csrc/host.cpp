@@ -742,8 +742,8 @@ extern "C" int kmcpg_open_paged(const char* db_dir, int32_t device, int32_t pass
   kmcpg_db* front = nullptr;
   int rc = kmcpg_open(db_dir, &mo, &front);  // metadata of every block: names, sizes, FPR table
   if (rc) return rc;
-  uint64_t largest = 0, free_b = 0;
-  const int fit = plan_passes(front, device, &largest, &free_b);
+  uint64_t largest = 0, free_b = 0, reserve = 0;
+  const int fit = plan_passes(front, device, &largest, &free_b, &reserve);
   if (passes == 0) passes = fit;
   if (fit == 0 || passes < fit) {
     kmcpg_close(front);
@@ -760,6 +760,9 @@ extern "C" int kmcpg_open_paged(const char* db_dir, int32_t device, int32_t pass
   }
   front->paged_passes = passes;
   front->paged_device = device;
+  // what stays free beside the largest shard of the tightest partition that fits (>= the reserve plan_passes asked for; more
+  // passes than needed leave more than this: the hint stays on the safe side)
+  front->paged_reserve = std::max<uint64_t>(reserve, free_b > largest ? free_b - largest : 0);
   front->info.n_blocks_local = front->info.n_blocks;
   front->info.matrix_bytes_local = front->info.matrix_bytes;
   *out = front;
@@ -812,8 +815,67 @@ extern "C" int kmcpg_search_batch(kmcpg_db* db, const uint8_t* seqs, const uint6
   memset(out, 0, sizeof *out);
   kmcpg_ticket* t = nullptr;
   int rc = submit_checked(db, seqs, offs, seqs2, offs2, n_reads, params, true, &t);
-  if (rc) return rc;
-  return kmcpg_wait(t, out);
+  if (rc == 0) rc = kmcpg_wait(t, out);
+  if (rc != KMCPG_ENOMEM || n_reads < 2) return rc;
+  // The batch's workspace (8-24 B per base next to the resident index) or its hit buffers did not fit: the two halves of the
+  // batch one after the other, their results joined — a caller that sized its batches for an emptier GPU gets its answer
+  // instead of an error (the reference has no such limit: it searches query by query).  The halves split again if they must.
+  const std::string why = kmcpg_err_ref();
+  const uint32_t h = n_reads / 2;
+  kmcpg_result part[2];
+  for (int i = 0; i < 2; i++) {
+    const uint32_t lo = i ? h : 0, cnt = i ? n_reads - h : h;
+    // offsets of a half start at its first read: a rebased copy (the sequences themselves are addressed in place)
+    std::vector<uint64_t> o1((size_t)cnt + 1), o2;
+    for (uint32_t r = 0; r <= cnt; r++) o1[r] = offs[lo + r] - offs[lo];
+    if (offs2) {
+      o2.resize((size_t)cnt + 1);
+      for (uint32_t r = 0; r <= cnt; r++) o2[r] = offs2[lo + r] - offs2[lo];
+    }
+    rc = kmcpg_search_batch(db, seqs + offs[lo], o1.data(), seqs2 ? seqs2 + offs2[lo] : nullptr, offs2 ? o2.data() : nullptr, cnt, params, &part[i]);
+    if (rc) {
+      if (i) kmcpg_result_free(&part[0]);
+      return rc;
+    }
+  }
+  ResultOwner* a = (ResultOwner*)part[0].owner;
+  const ResultOwner* b = (const ResultOwner*)part[1].owner;
+  const uint64_t base = a->offs.back();
+  a->qlen.insert(a->qlen.end(), b->qlen.begin(), b->qlen.end());
+  a->qkmers.insert(a->qkmers.end(), b->qkmers.begin(), b->qkmers.end());
+  a->ksize.insert(a->ksize.end(), b->ksize.begin(), b->ksize.end());
+  for (size_t r = 1; r < b->offs.size(); r++) a->offs.push_back(base + b->offs[r]);
+  a->matches.insert(a->matches.end(), b->matches.begin(), b->matches.end());
+  *out = part[0];
+  out->n_reads = n_reads;
+  out->qlen = a->qlen.data();
+  out->qkmers = a->qkmers.data();
+  out->ksize = a->ksize.data();
+  out->match_offs = a->offs.data();
+  out->matches = a->matches.data();
+  kmcpg_result_free(&part[1]);
+  if (getenv("KMCPG_VERBOSE")) fprintf(stderr, "kmcpg_search_batch: %u queries searched as two halves (%s)\n", n_reads, why.c_str());
+  return 0;
+}
+
+// How many bases a batch may hold on this handle so that its workspace fits beside the resident index: K1/K1d take up to 24 B
+// per base (8 B of hashes, 16 B of sort scratch for queries above -u and for window sketches; query.cpp), the lanes another few
+// bytes per base of staging.  A paged handle answers from the reserve plan_passes() kept free beside its largest shard, every
+// other handle from the HBM free right now.  *max_bases = 0: unknown (the device would not say).
+extern "C" int kmcpg_batch_hint(const kmcpg_db* db, uint64_t* max_bases) {
+  if (!db || !max_bases) return kmcpg_fail(KMCPG_EINVAL, "null argument");
+  uint64_t room = 0;
+  if (db->paged_passes > 1) room = db->paged_reserve;
+  else if (db->opts.device >= 0) {
+    int cur = -1;
+    (void)hipGetDevice(&cur);
+    size_t fr = 0, tot = 0;
+    if (hipSetDevice(db->opts.device) == hipSuccess && hipMemGetInfo(&fr, &tot) == hipSuccess) room = fr;
+    else (void)hipGetLastError();
+    if (cur >= 0) (void)hipSetDevice(cur);
+  }
+  *max_bases = room / 40;  // 24 B/base of workspace + staging of the lanes in flight + headroom for the hit buffers
+  return 0;
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -262,6 +262,10 @@ extern "C" int kmcpg_query_device(kmcpg_db* db, const uint8_t* d_seqs, const uin
     return kmcpg_fail(KMCPG_EINVAL, "k=%d is not a k-mer size of this database", p.k);
   const int k_used = p.k > 0 ? p.k : db->info.k;
   hipStream_t st = (hipStream_t)stream;
+  // test hook: behave as if the k-mer workspace of a batch above this many bases could not be allocated (the batch-halving path
+  // of kmcpg_search_batch, tests/test_gpu_paged.py)
+  if (const char* e = getenv("KMCPG_TEST_MAX_BASES"))
+    if (total_bases > (uint64_t)atoll(e)) return kmcpg_fail(KMCPG_ENOMEM, "hipMalloc failed (KMCPG_TEST_MAX_BASES)");
   if (int rc0 = ws_begin(db, st)) return rc0;
   WsGuard wsg{db, st};
   if (db->w_hashes.ensure(total_bases + 1) || db->w_nk_raw.ensure(n_reads + 1) || db->w_nk1.ensure(n_reads + 1)) return kmcpg_fail(KMCPG_ENOMEM, "hipMalloc failed");

@@ -16,7 +16,7 @@ EXPORTS = [
     "kmcpg_result_free", "kmcpg_query_device", "kmcpg_finalize", "kmcpg_open_synthetic", "kmcpg_plant",
     "kmcpg_read_rows", "kmcpg_block_info", "kmcpg_kmers_device", "kmcpg_plant_reads_device", "kmcpg_set_profiling",
     "kmcpg_last_timing", "kmcpg_open_devices", "kmcpg_build_db", "kmcpg_submit", "kmcpg_wait", "kmcpg_read_row_range", "kmcpg_timing_at", "kmcpg_last_gathered_bytes", "kmcpg_last_hash_bytes",
-    "kmcpg_db_ks", "kmcpg_open_paged", "kmcpg_paged_info", "kmcpg_exchange_info",
+    "kmcpg_db_ks", "kmcpg_open_paged", "kmcpg_paged_info", "kmcpg_exchange_info", "kmcpg_batch_hint",
 ]
 
 
@@ -123,6 +123,7 @@ def load():
     L.kmcpg_open_paged.argtypes = [C.c_char_p, C.c_int32, C.c_int32, C.POINTER(vp)]
     L.kmcpg_paged_info.argtypes = [vp, i32p, u64p]
     L.kmcpg_exchange_info.argtypes = [vp]
+    L.kmcpg_batch_hint.argtypes = [vp, u64p]
     L.kmcpg_exchange_info.restype = C.c_char_p
     L.kmcpg_close.argtypes = [vp]
     L.kmcpg_db_info.argtypes = [vp, C.POINTER(Info)]
@@ -260,6 +261,12 @@ class Database:
         p, u = C.c_int32(0), C.c_uint64(0)
         _check(load().kmcpg_paged_info(self._h, C.byref(p), C.byref(u)))
         return int(p.value), int(u.value)
+
+    def batch_hint(self):
+        """bases one batch may hold so that its device workspace fits beside the resident index (0 = unknown)"""
+        n = C.c_uint64(0)
+        _check(load().kmcpg_batch_hint(self._h, C.byref(n)))
+        return int(n.value)
 
     @classmethod
     def open_synthetic(cls, spec: SynthSpec, device=0, shard_rank=0, shard_count=1):

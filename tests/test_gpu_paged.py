@@ -110,3 +110,33 @@ def test_cli_falls_back_to_passes(oracle_lib, case):
     r = subprocess.run([CLI, "-d", db_root, fq, "-o", str(tmp / "p3.tsv"), "--gpu-passes", "3", "-q"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr
     assert open(tmp / "p3.tsv").read().split("\n") == one
+
+
+def test_a_batch_whose_workspace_does_not_fit_is_searched_in_halves(oracle_lib, case):
+    """a batch whose device workspace cannot be allocated is not an error of kmcpg_search_batch — it is
+    searched as two halves (recursively) and answered as one result; kmcpg_batch_hint tells a host how large a batch may be.
+    KMCPG_TEST_MAX_BASES makes kmcpg_query_device refuse larger batches with KMCPG_ENOMEM, as a failed hipMalloc would."""
+    from kmcp_amd import Database, default_params
+    O = oracle_lib
+    tmp, genomes, db_dir, odb = case
+    reads = synth.sample_reads(genomes, 1500, 150, sub_rate=0.01, seed=95, frac_random=0.1)
+    reads2 = synth.sample_reads(genomes, 1500, 150, sub_rate=0.01, seed=96, frac_random=0.5)
+    with Database.open(db_dir, device=0) as db:
+        hint = db.batch_hint()
+        assert hint > 1 << 20  # an (almost) empty MI355X: gigabases
+        whole = db.search(reads, params=default_params())
+        whole_pe = db.search(reads, reads2, params=default_params(try_se=1, fpr_buf_size=499))
+        os.environ["KMCPG_TEST_MAX_BASES"] = str(150 * 200)  # 1500 reads -> 8 pieces; pairs -> 16
+        try:
+            res = db.search(reads, params=default_params())
+            res_pe = db.search(reads, reads2, params=default_params(try_se=1, fpr_buf_size=499))
+        finally:
+            os.environ.pop("KMCPG_TEST_MAX_BASES")
+    for a, b in ((whole, res), (whole_pe, res_pe)):
+        assert np.array_equal(a.qlen, b.qlen) and np.array_equal(a.qkmers, b.qkmers) and np.array_equal(a.offs, b.offs)
+        assert np.array_equal(a.ksize, b.ksize) and a.matches.tobytes() == b.matches.tobytes()
+    assert synth.assert_parity(odb, res, reads) > 1000
+    assert synth.assert_parity(odb, res_pe, reads, reads2, O.default_params(try_se=1, fpr_buf_size=499)) > 500
+    with small_gpu(64):
+        with Database.open_paged(db_dir, device=0, passes=4) as db:
+            assert 0 < db.batch_hint() <= (64 << 20) // 40 + 1
