@@ -74,6 +74,34 @@ WORKLOADS = {
                                kmers_per_col=3200000, batch_reads=1048576, kernel="k2_cobs<8,8,false>", min_qcov=0.8,
                                metric="reads/sec searched (150bp, k=31, -t 0.8) vs the unchunked GTDB index of the reference's published benchmark",
                                name="gtdb r202 unchunked synthetic: 47 blocks x 1024 cols, 3.0-15.3 M sigs (55.2 GB), 150bp k=31, -t 0.8"),
+    # BASELINE.json configs[2] — genome search (reference: benchmarks/searching/README.md:382-432): whole
+    # assemblies as queries (`kmcp search -g --sort-by jacc -t 0.4`) against a FracMinHash (scale 1000) index of 50 048 references
+    # with 3 hash functions at fpr 0.001, `index -j 8` => 8 blocks x 6 256 columns (782-byte rows).  The references come in
+    # families: every query genome has `relatives` mutated copies in the index (substitution rate 0, 0.5 %, ... 4.5 %: the
+    # shared-21-mer fraction falls from 1 to 0.38, so ~9 of the 10 pass -t 0.4 — with decreasing qCov/jacc, the threshold
+    # cutting through the family); the query itself is a 0.5 %-mutated, randomly reverse-complemented copy; 10 % of the queries
+    # are unrelated genomes.  ~8 000 sketch k-mers per query: the sort+unique path and 16 counter planes.
+    "config2_genome_search": dict(k=21, num_hashes=3, fpr=0.001, n_blocks=8, cols_per_block=6256, num_sigs=431000, sigs_step=13, kmers_per_col=10000,
+                                  scale=1000, batch_reads=128, read_len=4000000, relatives=10, rel_step=0.005, sub_rate=0.005, distinct_batches=2,
+                                  min_qcov=0.4, sort_by=2, unit="queries/s", cpu_sample_start=16, kernel="k2_cobs (16 planes) / k1 segments",
+                                  metric="genomes/sec searched (4-Mbp assemblies, FracMinHash scale 1000, k=21, 3 hashes, -t 0.4) vs a 50 k-reference index",
+                                  name="genome search, synthetic: 8 blocks x 6256 cols x 431 k sigs (2.7 GB), 3 hashes, fpr 0.001, scale 1000; "
+                                       "queries = 4-Mbp genomes with 10 relatives each in the index"),
+    # BASELINE.json configs[4] — HiFi long reads (reference: benchmarks/mock-hifi-zymo/README.md:52-53): reads
+    # of ~N(10 kb, 2 kb) with 0.1 % errors sampled from the chunks of a Closed-Syncmer (k=21, s=11) 10 k-chunk database.  A
+    # database built by `kmcp compute -S 11` + `kmcp index -j 32` has a NumSigs of its own in every block (the number of syncmers
+    # differs from chunk to chunk, the block takes the maximum: index.go:936-946) => sigs_step > 0, 39-byte rows, nothing grouped.
+    "config4_hifi": dict(k=21, num_hashes=1, fpr=0.3, n_blocks=32, cols_per_block=312, num_sigs=300000, sigs_step=7, kmers_per_col=100000, syncmer_s=11,
+                         batch_reads=16384, read_len=("normal", 10000, 2000, 2000, 20000), sub_rate=0.001, unit="reads/s", cpu_sample_start=64,
+                         kernel="k2_cobs<4,16> / k1_windows_wave<2>",
+                         metric="reads/sec searched (HiFi ~10 kb, Closed Syncmer s=11, k=21) vs a 10k-chunk index",
+                         name="HiFi synthetic: 32 blocks x 312 cols x ~300 k sigs (0.37 GB), closed syncmer s=11 k=21, reads ~N(10 kb, 2 kb) 0.1 % errors"),
+    # ... and the same database built with kmcpg_build_cfg.uniform_sigs = 1 (one NumSigs for all blocks: one 1248-byte gather per k-mer)
+    "config4_hifi_uniform_sigs": dict(k=21, num_hashes=1, fpr=0.3, n_blocks=32, cols_per_block=312, num_sigs=300000, sigs_step=0, kmers_per_col=100000,
+                                      syncmer_s=11, batch_reads=16384, read_len=("normal", 10000, 2000, 2000, 20000), sub_rate=0.001, unit="reads/s",
+                                      cpu_sample_start=64, kernel="k2_cobs<64,16> + k2_cobs<16,16> / k1_windows_wave<2>",
+                                      metric="reads/sec searched (HiFi ~10 kb, Closed Syncmer s=11, k=21) vs a 10k-chunk index with one NumSigs",
+                                      name="HiFi synthetic, blocks with equal NumSigs (grouped rows): 32 x 312 cols x 300 k sigs, closed syncmer s=11 k=21"),
 }
 READ_LEN = 150
 
@@ -96,24 +124,73 @@ def effective_cpus():
     return n
 
 
-def make_batch(dev, n_reads, n_cols, seed):
-    """(fragments to plant, their target columns, the reads actually searched), all uint8/int32 on device."""
+class Batch:
+    """One batch of synthetic queries resident in HBM: `reads` (uint8 ASCII), CSR `offs` (int64[n+1]), the column each query was
+    sampled from (`cols`, -1 = unrelated), total bases and the longest query."""
+    pass
+
+
+def _read_lengths(spec, n, seed):
+    if isinstance(spec, int):
+        return torch.full((n,), spec, dtype=torch.int64)
+    kind, mean, sd, lo, hi = spec
+    assert kind == "normal"
+    g = torch.Generator()
+    g.manual_seed(seed)
+    return torch.clamp((torch.randn(n, generator=g) * sd + mean).long(), lo, hi)
+
+
+def _mutate(code, rate, g, chunk=1 << 28):
+    """substitutions at `rate` per base (the substitute is uniform over ACGT, as in SURVEY.md 8d's read models)"""
+    if rate <= 0:
+        return code
+    out = code.clone()
+    for a in range(0, code.numel(), chunk):  # chunked: a 4-Mbp-genome batch is 0.5 G bases
+        v = out[a:a + chunk]
+        sub = torch.rand(v.numel(), generator=g, device=v.device) < rate
+        v[sub] = torch.randint(0, 4, (int(sub.sum().item()),), generator=g, device=v.device, dtype=torch.uint8)
+    return out
+
+
+def make_batch(dev, wl, n_reads, n_cols, seed, plant):
+    """Builds one batch and plants what its queries were sampled from: plant(ascii, offs, n, total, maxlen, cols) ORs the Bloom
+    bits of every (sketched) k-mer of fragment i into column cols[i] (kmcpg_plant_reads_device: same K1 as a query, so the index
+    holds exactly what `kmcp compute` + `kmcp index` would have put there for these sequences).  With `relatives` = R each
+    fragment is planted R times, as copies with substitution rates 0, rel_step, 2 rel_step ... into R different columns."""
     g = torch.Generator(device=dev)
     g.manual_seed(seed)
     acgt = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=dev)
-    code = torch.randint(0, 4, (n_reads, READ_LEN), generator=g, device=dev)
+    lens = _read_lengths(wl.get("read_len", READ_LEN), n_reads, seed).to(dev)
+    offs = torch.zeros(n_reads + 1, dtype=torch.int64, device=dev)
+    offs[1:] = torch.cumsum(lens, 0)
+    total, maxlen = int(offs[-1].item()), int(lens.max().item())
+    code = torch.randint(0, 4, (total,), generator=g, device=dev, dtype=torch.uint8)
     cols = torch.randint(0, n_cols, (n_reads,), generator=g, device=dev).to(torch.int32)
     is_random = torch.rand(n_reads, generator=g, device=dev) < 0.10
     cols[is_random] = -1  # 0xFFFFFFFF: not planted
-    # the read: 1 % substitutions, then half of them reverse-complemented
-    sub = torch.rand(n_reads, READ_LEN, generator=g, device=dev) < 0.01
-    rcode = torch.where(sub, torch.randint(0, 4, (n_reads, READ_LEN), generator=g, device=dev), code)
+    R = int(wl.get("relatives", 1))
+    for r in range(R):
+        rel = _mutate(code, r * wl.get("rel_step", 0.0), g)
+        # relative r of a query lives 7919 r columns further (another block for most of them)
+        cr = torch.where(cols >= 0, (cols.to(torch.int64) + 7919 * r) % n_cols, torch.full_like(cols, -1, dtype=torch.int64)).to(torch.int32).contiguous()
+        frag = acgt[rel.long()] if rel.numel() < (1 << 28) else torch.cat([acgt[rel[a:a + (1 << 28)].long()] for a in range(0, rel.numel(), 1 << 28)])
+        plant(frag, offs, n_reads, total, maxlen, cr)
+        torch.cuda.synchronize()
+        del rel, frag
+    # the query: substitutions, then half of them reverse-complemented (A<->T, C<->G = 3 - code)
+    q = _mutate(code, wl.get("sub_rate", 0.01), g)
     rc = torch.rand(n_reads, generator=g, device=dev) < 0.5
-    rcode = torch.where(rc[:, None], 3 - rcode.flip(1), rcode)  # A<->T, C<->G under the ACGT code
-    frag = acgt[code].contiguous().view(-1)
-    reads = acgt[rcode].contiguous().view(-1)
-    offs = (torch.arange(n_reads + 1, device=dev, dtype=torch.int64) * READ_LEN).contiguous()
-    return frag, cols.contiguous(), reads, offs
+    if isinstance(wl.get("read_len", READ_LEN), int) and maxlen <= 4096:
+        q2 = q.view(n_reads, maxlen)
+        q = torch.where(rc[:, None], 3 - q2.flip(1), q2).contiguous().view(-1)
+    else:
+        o = offs.cpu().tolist()
+        for i in torch.nonzero(rc).flatten().cpu().tolist():
+            q[o[i]:o[i + 1]] = 3 - q[o[i]:o[i + 1]].flip(0)
+    bt = Batch()
+    bt.reads = (acgt[q.long()] if q.numel() < (1 << 28) else torch.cat([acgt[q[a:a + (1 << 28)].long()] for a in range(0, q.numel(), 1 << 28)])).contiguous()
+    bt.offs, bt.cols, bt.total, bt.maxlen, bt.n = offs.contiguous(), cols.contiguous(), total, maxlen, n_reads
+    return bt
 
 
 class Ctx:
@@ -149,7 +226,7 @@ def run_workload(name, ctx, steps, warmup, batch_reads=0, cpu_baseline=True, cpu
     kmcpg_finalize on the host (float64 thresholds, FPR, sort): finalized matches in host memory.  The host half of step i runs
     while the GPU works on step i+1 (it is inside the timed region for every one of the K steps)."""
     from kmcp_amd import Database, default_params, lib
-    from kmcp_amd.dist import gather_hits
+    from kmcp_amd.dist import gather_hits, hits_checksum
 
     world, rank, dev, dev_index = ctx.world, ctx.rank, ctx.dev, ctx.dev_index
     coll = ctx.collective  # the N > 1 code path (also taken by a one-rank RCCL group under KMCP_BENCH_FORCE_DIST=1: tests)
@@ -157,7 +234,8 @@ def run_workload(name, ctx, steps, warmup, batch_reads=0, cpu_baseline=True, cpu
     B = batch_reads or wl["batch_reads"]
     spec = lib.SynthSpec(k=wl["k"], num_hashes=wl["num_hashes"], fpr=wl["fpr"], n_blocks=wl["n_blocks"],
                          cols_per_block=wl["cols_per_block"], num_sigs=wl["num_sigs"], kmers_per_col=wl["kmers_per_col"], seed=42,
-                         sigs_step=wl.get("sigs_step", 0))
+                         sigs_step=wl.get("sigs_step", 0), scale=wl.get("scale", 0), syncmer_s=wl.get("syncmer_s", 0),
+                         minimizer_w=wl.get("minimizer_w", 0))
     free_b, _ = torch.cuda.mem_get_info(dev)
     need = wl["n_blocks"] * (wl["num_sigs"] + wl.get("sigs_step", 0) * (wl["n_blocks"] - 1) / 2) * ((wl["cols_per_block"] + 7) // 8 + 64) / world
     if need > 0.9 * free_b:
@@ -169,20 +247,21 @@ def run_workload(name, ctx, steps, warmup, batch_reads=0, cpu_baseline=True, cpu
     n_cols = int(info.n_cols)
     params = default_params()  # kmcp search defaults: -t 0.55 -c 10 -m 30 -f 0.01 -u 256
     params.min_qcov = wl.get("min_qcov", params.min_qcov)
+    params.sort_by = wl.get("sort_by", 0)
     db.set_profiling(True)
+    unit = wl.get("unit", "reads/s")
 
     # ---- batches resident in HBM; distinct data per step (cycled if K+W is large)
-    n_batches = max(1, min(steps + warmup, 4))
-    batches = []
-    for i in range(n_batches):
-        frag, cols, reads, offs = make_batch(dev, B, n_cols, seed=1000 + i)
-        db.plant_reads_device(frag.data_ptr(), offs.data_ptr(), B, B * READ_LEN, READ_LEN, cols.data_ptr())
-        batches.append((reads, offs, cols))
-        del frag
+    n_batches = max(1, min(steps + warmup, wl.get("distinct_batches", 4)))
+
+    def plant(frag, offs, n, total, maxlen, cols):
+        db.plant_reads_device(frag.data_ptr(), offs.data_ptr(), n, total, maxlen, cols.data_ptr())
+
+    batches = [make_batch(dev, wl, B, n_cols, 1000 + i, plant) for i in range(n_batches)]
     torch.cuda.synchronize()
     setup_s = time.time() - t0
 
-    cap = 4 * B + 4096
+    cap = (4 + 2 * int(wl.get("relatives", 1))) * B + 4096
     main = torch.cuda.current_stream(dev)
     # D2H (and, N > 1, the exchange) of a finished step while the next step's kernels run on `main`: a high-priority stream, so
     # that its small copies / collectives are not queued behind a 60-500 ms kernel that fills the chip
@@ -207,10 +286,10 @@ def run_workload(name, ctx, steps, warmup, batch_reads=0, cpu_baseline=True, cpu
 
     def gpu_half(i, bf):
         """Enqueues K1+K2 of batch i on this rank's blocks (nothing waits here)."""
-        reads, offs, _ = batches[i % n_batches]
+        bt = batches[i % n_batches]
         if bf.used:
             main.wait_event(bf.copied)  # the previous step that used these buffers has left them
-        db.query_device(reads.data_ptr(), offs.data_ptr(), B, B * READ_LEN, READ_LEN, bf.d_hits.data_ptr(), cap, bf.d_cnt.data_ptr(),
+        db.query_device(bt.reads.data_ptr(), bt.offs.data_ptr(), B, bt.total, bt.maxlen, bf.d_hits.data_ptr(), cap, bf.d_cnt.data_ptr(),
                         bf.d_qk.data_ptr(), bf.d_ql.data_ptr(), params=params, stream=stream)
         bf.h_cnt.copy_(bf.d_cnt, non_blocking=True)
         bf.kernels_done.record(main)
@@ -306,7 +385,8 @@ def run_workload(name, ctx, steps, warmup, batch_reads=0, cpu_baseline=True, cpu
     last = (warmup + steps - 1) % n_batches
     qk = bufs[(steps - 1) % len(bufs)].d_qk.cpu().numpy().astype(np.int64)
     kmers_per_launch = int(qk.sum())
-    alg_bytes = kmers_per_launch * int(info.row_bytes_sum_local) * int(info.num_hashes) + B * READ_LEN + 12 * (n_hits_total // max(1, steps))
+    bases_per_launch = float(np.mean([batches[(warmup + j) % n_batches].total for j in range(steps)]))
+    alg_bytes = kmers_per_launch * int(info.row_bytes_sum_local) * int(info.num_hashes) + int(bases_per_launch) + 12 * (n_hits_total // max(1, steps))
     k2_avg_ms = float(np.mean(k2_ms))
     effective = alg_bytes / (k2_avg_ms * 1e-3) / 1e9
     pmc, pmc_src = None, None
@@ -321,10 +401,18 @@ def run_workload(name, ctx, steps, warmup, batch_reads=0, cpu_baseline=True, cpu
         except Exception:
             pmc = None
 
+    # DRAM-side vs Infinity-Cache-side share of the fabric traffic, from the committed counter passes of the same command
+    # (profiles/traffic.json "mall": {...})
+    mall = None
+    try:
+        mall = json.load(open(tfile)).get("mall", {}).get(f"{name}{'_ungrouped' if os.environ.get('KMCPG_FUSE') == '0' else ''}:{B}:{world}")
+    except Exception:
+        mall = None
+
     out = {
         "metric": wl.get("metric", "reads/sec searched (150bp, k=21) vs GTDB-scale index"),
         "value": B * steps / elapsed,
-        "unit": "reads/s",
+        "unit": unit,
         "n_gpus": world,
         "steps": steps,
         "warmup": warmup,
@@ -334,17 +422,25 @@ def run_workload(name, ctx, steps, warmup, batch_reads=0, cpu_baseline=True, cpu
         "vs_baseline": None,
         "dtype": "u32 bitwise (bit-sliced counters), u64 hashes",
         "data": "synthetic",
-        "value_definition": "reads resident in HBM -> finalized (target, mKmers, qCov, tCov, jacc, FPR) tuples in host memory; the host half "
-                            "of a step overlaps the next step's kernels; see host_boundary for reads starting in host memory",
-        "config": {"workload": wl["name"], "batch_reads": B, "read_len": READ_LEN, "k": wl["k"], "num_hashes": wl["num_hashes"],
+        "value_definition": "queries resident in HBM -> finalized (target, mKmers, qCov, tCov, jacc, FPR) tuples in host memory (the bench contract: "
+                            "inputs are in HBM when the timed region starts; the host half of a step overlaps the next step's kernels).  SURVEY.md 8(d)'s "
+                            "number - batch bytes in HOST memory -> hit tuples in HOST memory, PCIe both ways included - is `value_host_to_host` "
+                            "(details under host_boundary); it is measured in the same run at N = 1",
+        "value_host_to_host": None,
+        "config": {"workload": wl["name"], "batch_reads": B, "read_len": wl.get("read_len", READ_LEN), "bases_per_batch": int(bases_per_launch),
+                   "mean_kmers_per_query": kmers_per_launch / B, "k": wl["k"], "num_hashes": wl["num_hashes"],
                    "index_bytes": int(info.matrix_bytes), "index_bytes_this_rank": int(info.matrix_bytes_local),
                    "blocks": int(info.n_blocks), "columns": n_cols, "parallelism": f"block-shard x{world}",
-                   "search_flags": f"-t {params.min_qcov:g} -c 10 -m 30 -f 0.01 -u 256"},
+                   "search_flags": f"-t {params.min_qcov:g} -c 10 -m 30 -f 0.01 -u 256 -s {('qcov', 'tcov', 'jacc')[params.sort_by]}"},
         "roofline": {"bound": "hbm", "kernel": wl["kernel"], "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
                      "traffic_source": None,
+                     "bound_detail": "L2->fabric read traffic (what FETCH_SIZE counts): requests that miss the XCD's L2 and are served by the Infinity "
+                                     "Cache (MALL, 256 MiB) or by HBM.  `peak` is the HBM3E spec peak; `frac` therefore compares fabric-side bytes with "
+                                     "the DRAM peak and part of those bytes never left the die - see mall_split for how many",
                      "definition": "achieved = bytes the kernel moved per launch (traffic) / its mean HIP-event duration over the timed steps; "
                                    "frac = achieved / peak.  effective_gbps = ALGORITHMIC bytes (SURVEY 8d) / the same duration: larger than "
                                    "achieved, and possibly than peak, by what exact sector pruning never fetches",
+                     "mall_split": mall,
                      "algorithmic_bytes_per_launch": alg_bytes, "effective_gbps": effective, "frac_algorithmic": effective / HBM_PEAK_GBS,
                      "traffic_pmc": pmc, "traffic_pmc_source": pmc_src,
                      "measured_ceiling": {"gbps": FABRIC_CEILING_GBS, "what": "random 128-B gathers that miss L2 (L2->fabric path), tools/ubench_cache.cpp",
@@ -363,10 +459,26 @@ def run_workload(name, ctx, steps, warmup, batch_reads=0, cpu_baseline=True, cpu
     hh = None
     if rank == 0:
         hh = bufs[0].h_hits[:n_last].numpy().astype(np.int64)
-        cols_last = batches[last][2].cpu().numpy().astype(np.int64)
+        cols_last = batches[last].cols.cpu().numpy().astype(np.int64)
         got = set(zip(hh[:, 0].tolist(), hh[:, 1].tolist()))
         planted = np.nonzero(cols_last >= 0)[0]
         out["planted_recall"] = sum((int(r), int(cols_last[r])) in got for r in planted[:20000]) / max(1, min(len(planted), 20000))
+        # the merged hit list of this batch is a function of the seeds only: same number at every N (checked against the CPU oracle
+        # below, on a sample, at every N)
+        out["sanity_batch"] = {"hits": int(len(hh)), "hits_checksum": hits_checksum(hh), "batch_seed": 1000 + last,
+                               "note": "order-independent 64-bit checksum of the merged (read, column, count) list of one batch: identical at N = 1, 2, 4, 8"}
+    # who ran: world size, backend, and every rank's own kernel time / traffic (the slowest rank sets the step)
+    out["ranks"] = {"world_size": dist.get_world_size() if coll else 1, "backend": dist.get_backend() if coll else None,
+                    "exchange": ("torch.distributed all_gather_into_tensor(counts) + gather(hit buffers) on a side stream" if coll else "none (one rank)")}
+    mine = {"rank": rank, "device": torch.cuda.get_device_name(dev), "blocks": int(info.n_blocks_local), "index_bytes": int(info.matrix_bytes_local),
+            "k1_ms": float(np.mean(k1_ms)), "k2_ms": k2_avg_ms, "hits_last_batch": int(bufs[0].h_cnt[0])}
+    if coll:
+        per = [None] * dist.get_world_size()
+        dist.all_gather_object(per, mine)
+    else:
+        per = [mine]
+    out["ranks"]["per_rank"] = per
+    out["ranks"]["k2_ms_min_max"] = [min(p_["k2_ms"] for p_ in per), max(p_["k2_ms"] for p_ in per)]
 
     # ---- what the kernel moved: every distinct batch of the timed steps once more with the kernel counting its own row loads
     #      (profiling level 2: one atomic per wave and row group, 16 B per lane and row actually loaded, row padding included,
@@ -438,7 +550,7 @@ def run_workload(name, ctx, steps, warmup, batch_reads=0, cpu_baseline=True, cpu
                         os.environ[k_] = v_
             return dt / nsteps, float(np.mean(ms))
         per_step, _ = kernel_only(max(2, min(steps, 8)))
-        out["device_only"] = {"value": B / per_step, "unit": "reads/s", "ms_per_step": per_step * 1e3,
+        out["device_only"] = {"value": B / per_step, "unit": unit, "ms_per_step": per_step * 1e3,
                               "note": "reads in HBM -> raw (read, column, count) hit tuples in host memory, no host half (round 1's `value`)"}
         local_strides = [bi["stride"] for bi in (db.block_info(b_) for b_ in range(int(info.n_blocks))) if bi["local"]]
         stride0 = max(local_strides) if local_strides else 0
@@ -461,7 +573,7 @@ def run_workload(name, ctx, steps, warmup, batch_reads=0, cpu_baseline=True, cpu
     #      kmcpg_submit / kmcpg_wait — reads in host memory in; H2D, K1, K2, D2H of the hits, float64 thresholds, FPR, sort;
     #      finalized matches in host memory out — three batches in flight, and one batch alone through kmcpg_search_batch
     if rank == 0 and world == 1 and extras:
-        hb = [(b_[0].cpu().numpy(), b_[1].cpu().numpy().astype(np.uint64)) for b_ in batches]
+        hb = [(b_.reads.cpu().numpy(), b_.offs.cpu().numpy().astype(np.uint64)) for b_ in batches]
         db.search_packed_count(hb[0][0], hb[0][1], params=params)  # first calls size the staging buffers
         tk = [db.submit(*hb[i % len(hb)], params=params) for i in range(3)]
         for t_ in tk:
@@ -487,70 +599,114 @@ def run_workload(name, ctx, steps, warmup, batch_reads=0, cpu_baseline=True, cpu
         [x.start() for x in th]
         [x.join() for x in th]
         dt = (time.perf_counter() - t1) / NB
-        out["host_boundary"] = {"value": B / dt, "unit": "reads/s", "ms_per_batch": dt * 1e3, "batches": NB, "host_threads": HT, "in_flight": 2 * HT,
+        out["value_host_to_host"] = B / dt
+        out["host_boundary"] = {"value": B / dt, "unit": unit, "ms_per_batch": dt * 1e3, "batches": NB, "host_threads": HT, "in_flight": 2 * HT,
                                 "single_batch_ms": single * 1e3, "single_batch_reads_per_s": B / single, "matches": n_matches,
                                 "note": "kmcpg_submit/kmcpg_wait: host buffers in, finalized matches out (staging copy, PCIe both ways and "
                                         "the host half included); single_batch = one kmcpg_search_batch call with nothing overlapped"}
         del hb
 
-    # ---- CPU baseline: the oracle (C restatement of the reference algorithm), timed on this box's host cores on a bounded
-    #      sample: ALL blocks copied back from HBM (when host memory allows) x the first R reads of the last batch.
-    if rank == 0 and world == 1 and cpu_baseline:
+    # ---- CPU oracle on a bounded sample.  N = 1: the cpu_baseline leg (timed, ALL blocks copied back from HBM when host memory
+    #      allows) + parity of the GPU hits on that sample.  N > 1: the same parity check on rank 0 over rows fetched from every
+    #      rank (each owner reads its blocks back, rank 0 receives them), untimed: the merged hit list of a multi-GPU run is
+    #      checked against the CPU restatement in the very run that produced it.
+    want_oracle = cpu_baseline and (world == 1 or os.environ.get("KMCP_BENCH_PARITY_N", "1") != "0")
+    if want_oracle:
         import shutil
-        from oracle import oracle as O
         index_bytes = int(info.matrix_bytes)
-        avail = host_memory_available()
-        S = wl["n_blocks"] if index_bytes * 1.15 + (8 << 30) < avail else max(1, min(wl["n_blocks"], int((avail - (8 << 30)) * 0.8 / (index_bytes / wl["n_blocks"]))))
+        S = wl["n_blocks"]
+        if rank == 0:
+            avail = host_memory_available()
+            if not index_bytes * 1.15 + (8 << 30) < avail:
+                S = max(1, min(wl["n_blocks"], int((avail - (8 << 30)) * 0.8 / (index_bytes / wl["n_blocks"]))))
+        if coll:
+            t_s = torch.tensor([S], dtype=torch.int64, device="cpu" if ctx.same_gpu else dev)
+            dist.broadcast(t_s, src=0)
+            S = int(t_s.item())
         t1 = time.perf_counter()
         blocks = []
+        owners = None
+        if coll:
+            loc = torch.tensor([1 if db.block_info(b)["local"] else 0 for b in range(S)], dtype=torch.int64, device="cpu" if ctx.same_gpu else dev)
+            allloc = [torch.zeros_like(loc) for _ in range(world)]
+            dist.all_gather(allloc, loc)
+            owners = [next(r_ for r_ in range(world) if int(allloc[r_][b].item())) for b in range(S)]
         for b in range(S):
             bi = db.block_info(b)
-            rows = np.empty((bi["num_sigs"], bi["row_bytes"]), dtype=np.uint8)
-            chunk = 262144
-            for r0 in range(0, bi["num_sigs"], chunk):
-                db.read_row_range(b, r0, rows[r0:r0 + chunk])
-            blocks.append((bi["num_sigs"], bi["n_cols"], bi["col_base"], rows))
+            own = owners[b] if owners else 0
+            rows = None
+            if rank == own or rank == 0:
+                rows = np.empty((bi["num_sigs"], bi["row_bytes"]), dtype=np.uint8)
+            if rank == own:
+                chunk = 262144
+                for r0 in range(0, bi["num_sigs"], chunk):
+                    db.read_row_range(b, r0, rows[r0:r0 + chunk])
+            if own != 0:  # block b travels owner -> rank 0 (RCCL send/recv of device tensors; host tensors over gloo)
+                if rank == own:
+                    t_ = torch.from_numpy(rows)
+                    dist.send(t_ if ctx.same_gpu else t_.to(dev), dst=0)
+                elif rank == 0:
+                    t_ = torch.empty(rows.shape, dtype=torch.uint8, device="cpu" if ctx.same_gpu else dev)
+                    dist.recv(t_, src=own)
+                    rows[...] = t_.cpu().numpy()
+                if rank != 0:
+                    rows = None
+            if rank == 0:
+                blocks.append((bi["num_sigs"], bi["n_cols"], bi["col_base"], rows))
         copy_s = time.perf_counter() - t1
-        odb = O.OracleDB.from_memory(O.sketch_cfg(k=wl["k"]), wl["num_hashes"], wl["fpr"], blocks, wl["kmers_per_col"])
+    if want_oracle and rank == 0:
+        from oracle import oracle as O
+        odb = O.OracleDB.from_memory(O.sketch_cfg(k=wl["k"], scale=max(1, wl.get("scale", 1)), minimizer_w=wl.get("minimizer_w", 0), syncmer_s=wl.get("syncmer_s", 0)),
+                                     wl["num_hashes"], wl["fpr"], blocks, wl["kmers_per_col"])
         threads = effective_cpus()
-        reads_h = batches[last][0].cpu().numpy()
-        offs_h = batches[last][1].cpu().numpy().astype(np.uint64)
+        reads_h = batches[last].reads.cpu().numpy()
+        offs_h = batches[last].offs.cpu().numpy().astype(np.uint64)
+        oparams = O.default_params(min_qcov=params.min_qcov)
 
-        def timed(refshape, target_s):
-            R = cpu_sample_reads or 256
+        def timed(refshape, target_s, fixed=0):
+            R = fixed or cpu_sample_reads or wl.get("cpu_sample_start", 256)
             while True:  # grow the sample until it is several seconds of CPU work
                 t2 = time.perf_counter()
-                oqk, ohits = odb.search_batch(reads_h[:R * READ_LEN], offs_h[:R + 1], O.default_params(min_qcov=params.min_qcov), threads=threads, refshape=refshape)
+                oqk, ohits = odb.search_batch(reads_h[:int(offs_h[R])], offs_h[:R + 1], oparams, threads=threads, refshape=refshape)
                 tcpu = time.perf_counter() - t2
-                if cpu_sample_reads or tcpu >= target_s or R >= B:
+                if fixed or cpu_sample_reads or tcpu >= target_s or R >= B:
                     return R, tcpu, oqk, ohits
                 R = min(B, int(R * max(2.0, 1.5 * target_s / max(tcpu, 1e-3))))
 
-        R, tcpu, oqk, ohits = timed(False, cpu_target_s)
+        # N > 1: a fixed small sample (a check, not a baseline); N = 1: sized to `cpu_target_s` seconds of CPU work
+        R, tcpu, oqk, ohits = timed(False, cpu_target_s, fixed=0 if world == 1 else min(B, 8 * wl.get("cpu_sample_start", 256)))
         # same-run parity on the sample: GPU hits of these reads restricted to the sampled blocks == oracle hits
         hi_col = blocks[-1][2] + blocks[-1][1]
         g = hh[(hh[:, 0] < R) & (hh[:, 1] < hi_col)]
         g = g[np.lexsort((g[:, 1], g[:, 0]))]
         parity = bool(np.array_equal(g, ohits.astype(np.int64))) and bool(np.array_equal(oqk[:R], qk[:R]))
         frac_blocks = S / wl["n_blocks"]
-        R2, tcpu2, oqk2, ohits2 = timed(True, cpu_target_s)
-        same = bool(np.array_equal(ohits2, ohits[ohits[:, 0] < R2])) if R2 <= R else bool(np.array_equal(ohits2[ohits2[:, 0] < R], ohits))
-        out["cpu_baseline"] = {
-            "value": R / tcpu * frac_blocks, "unit": "reads/s", "cores": threads, "kind": "port",
-            "sample": f"{R} reads x {S} of {wl['n_blocks']} blocks ({sum(b_[3].nbytes for b_ in blocks)/1e9:.1f} GB of index rows copied back from HBM "
-                      f"in {copy_s:.1f} s) in {tcpu:.2f} s on {threads} threads: oracle ko_search_batch (OpenMP over reads, LUT vertical counters)"
-                      + ("" if S == wl["n_blocks"] else f"; host memory holds only {S} blocks: value scaled by {frac_blocks:.4f}"),
-            "parity_on_sample": parity, "sample_hits": int(len(ohits)),
-            "reference_shaped": {"value": R2 / tcpu2 * frac_blocks, "unit": "reads/s", "cores": threads,
-                                 "sample": f"{R2} reads x {S} blocks in {tcpu2:.2f} s: one worker per block, 64 buffered rows, byte transposition + "
-                                           "Count8 per column byte (util-db-search.go:6811-6972, :213-219), AVX2 movemask Count8",
-                                 "same_hits_as_port": same},
-            "reference_binary": {"kmcp": shutil.which("kmcp"), "go": shutil.which("go"),
-                                 "note": "BASELINE.md 3.1 probe: the Go reference is timed instead when a kmcp binary is on PATH (none in this image)"},
-        }
+        sample_txt = (f"{R} queries ({int(offs_h[R])} bases) x {S} of {wl['n_blocks']} blocks ({sum(b_[3].nbytes for b_ in blocks)/1e9:.1f} GB of index rows "
+                      f"copied back from HBM in {copy_s:.1f} s) in {tcpu:.2f} s on {threads} threads: oracle ko_search_batch (OpenMP over queries, LUT vertical counters)"
+                      + ("" if S == wl["n_blocks"] else f"; host memory holds only {S} blocks: value scaled by {frac_blocks:.4f}"))
+        if world == 1:
+            out["cpu_baseline"] = {
+                "value": R / tcpu * frac_blocks, "unit": unit, "cores": threads, "kind": "port", "sample": sample_txt,
+                "parity_on_sample": parity, "sample_hits": int(len(ohits)),
+                "reference_binary": {"kmcp": shutil.which("kmcp"), "go": shutil.which("go"),
+                                     "note": "BASELINE.md 3.1 probe: the Go reference is timed instead when a kmcp binary is on PATH (none in this image)"},
+            }
+            if wl["num_hashes"] == 1:  # the reference-shaped leg restates the single-hash worker (util-db-search.go:6811-6972)
+                R2, tcpu2, oqk2, ohits2 = timed(True, cpu_target_s)
+                same = bool(np.array_equal(ohits2, ohits[ohits[:, 0] < R2])) if R2 <= R else bool(np.array_equal(ohits2[ohits2[:, 0] < R], ohits))
+                out["cpu_baseline"]["reference_shaped"] = {
+                    "value": R2 / tcpu2 * frac_blocks, "unit": unit, "cores": threads,
+                    "sample": f"{R2} queries x {S} blocks in {tcpu2:.2f} s: one worker per block, 64 buffered rows, byte transposition + "
+                              "Count8 per column byte (util-db-search.go:6811-6972, :213-219), AVX2 movemask Count8",
+                    "same_hits_as_port": same}
+        else:
+            out["parity_at_n"] = {"parity_on_sample": parity, "sample": sample_txt, "sample_hits": int(len(ohits)),
+                                  "note": "rank 0 ran the CPU oracle on rows fetched from every rank's shard and compared the merged multi-GPU hit list of the sample with it"}
         odb.close()
         del blocks
         assert parity, "GPU hits differ from the CPU oracle on the sample"
+    if coll:
+        dist.barrier()
 
     db.close()
     del bufs, batches
@@ -608,7 +764,8 @@ def main():
                        cpu_sample_reads=args.cpu_sample_reads, extras=not args.no_extras)
     if ctx.world == 1 and args.workload == "gtdb" and not args.no_secondary and not args.batch_reads:
         sec = run_workload("config1", ctx, min(max(args.steps, 5), 20), 2, cpu_baseline=not args.no_cpu_baseline, cpu_target_s=3.0)
-        keys = ("value", "unit", "ms_per_step", "config", "roofline", "planted_recall", "device_only", "host_boundary", "cpu_baseline")
+        keys = ("value", "value_host_to_host", "unit", "ms_per_step", "config", "roofline", "planted_recall", "sanity_batch", "device_only", "host_boundary",
+                "cpu_baseline", "hits_per_step", "matches_per_step", "setup_s")
         out["secondary"] = {"config1": {k: sec[k] for k in keys if k in sec}}
         # the same index with every block on its own (what a database with a different NumSigs per block gets): KMCPG_FUSE=0
         os.environ["KMCPG_FUSE"] = "0"
@@ -623,6 +780,14 @@ def main():
         out["secondary"]["gtdb_unchunked_k31"]["published"] = {
             "value": [18.9e3, 21.3e3], "unit": "reads/s", "threads": 40,
             "source": "reference benchmarks/searching/README.md:186-229 (1.14-1.41 M reads in 53.4-72.8 s, kmcp v0.9.0, hot page cache)"}
+        # BASELINE.json configs[2] and configs[4] with queries that MATCH (families of relatives / reads sampled from planted chunks)
+        for nm, st_ in (("config2_genome_search", 6), ("config4_hifi", 10), ("config4_hifi_uniform_sigs", 6)):
+            r_ = run_workload(nm, ctx, min(max(args.steps, 3), st_), 2, cpu_baseline=not args.no_cpu_baseline and nm != "config4_hifi_uniform_sigs",
+                              cpu_target_s=3.0)
+            out["secondary"][nm] = {k: r_[k] for k in keys + ("metric",) if k in r_}
+        out["secondary"]["config2_genome_search"]["published"] = {
+            "value": [1.6, 1.9], "unit": "queries/s", "threads": 8,
+            "source": "reference benchmarks/searching/README.md:382-432 (genome search against GTDB, FracMinHash scale 1000: 0.53-0.62 s per query, 8 threads)"}
     if ctx.collective:
         dist.destroy_process_group()
     sys.stdout.flush()

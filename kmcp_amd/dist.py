@@ -50,6 +50,23 @@ def hits_to_numpy(parts):
     return np.ascontiguousarray(cat).view(np.uint32).reshape(-1, 3).copy().view(HIT_DTYPE).reshape(-1)
 
 
+def hits_checksum(h):
+    """Order-independent 64-bit checksum of a hit list (int array [n, 3] of (read, column, count)): the sum mod 2^64 of a mixed
+    64-bit word per tuple.  The synthetic index and the batches are functions of the seeds only, so the merged list — and this
+    number — must be the same at N = 1, 2, 4, 8 GPUs."""
+    if len(h) == 0:
+        return "0000000000000000"
+    a = np.ascontiguousarray(h).astype(np.uint64)
+    with np.errstate(over="ignore"):
+        x = a[:, 0] * np.uint64(0x9E3779B97F4A7C15) + a[:, 1] * np.uint64(0xC2B2AE3D27D4EB4F) + a[:, 2] * np.uint64(0x165667B19E3779F9)
+        x ^= x >> np.uint64(30)
+        x *= np.uint64(0xBF58476D1CE4E5B9)
+        x ^= x >> np.uint64(27)
+        x *= np.uint64(0x94D049BB133111EB)
+        x ^= x >> np.uint64(31)
+        return "%016x" % int(np.add.reduce(x, dtype=np.uint64))
+
+
 def _take_reads(seqs, offs, idx):
     """the reads `idx` of a packed batch as a packed batch of their own"""
     o = offs.astype(np.int64)

@@ -52,7 +52,7 @@ def _worker(rank, world, db_dir, port, reads, ret):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        from kmcp_amd.dist import gather_hits, hits_to_numpy
+        from kmcp_amd.dist import gather_hits, hits_checksum, hits_to_numpy
         from kmcp_amd.lib import Database, default_params
         from oracle import oracle as O
         odb = O.OracleDB(db_dir)
@@ -74,6 +74,14 @@ def _worker(rank, world, db_dir, port, reads, ret):
             n = synth.assert_parity(odb, res, reads)
             ret["hits"] = n
             ret["per_rank"] = [int(x.shape[0]) for x in parts]
+            # the N-invariant the bench line prints (bench.py sanity_batch.hits_checksum): the merged list of `world` shards has
+            # the checksum of the one-shard list, in whatever order the shards' pieces arrive
+            merged = torch.cat(parts).numpy().astype(np.int64)
+            ret["checksum"] = hits_checksum(merged)
+            ret["checksum_shuffled"] = hits_checksum(merged[np.random.default_rng(rank).permutation(len(merged))])
+            with Database.open(db_dir, device=-1, shard_rank=0, shard_count=1) as one:  # N = 1: every block on one rank
+                h1 = _shard_hits(O, odb, one, reads, p)[0]
+            ret["checksum_one_rank"] = hits_checksum(np.array(h1, dtype=np.int64).reshape(-1, 3))
         else:
             assert parts is None
         # GPU entry points must refuse a metadata-only handle
@@ -105,6 +113,7 @@ def test_sharded_gather_finalize_gloo(oracle_lib, tmp_path, world):
         mp.spawn(_worker, args=(world, db_dir, _free_port(), reads, ret), nprocs=world, join=True)
         assert ret["hits"] > 100
         assert sum(1 for x in ret["per_rank"] if x > 0) >= 2  # the hits really came from several shards
+        assert ret["checksum"] == ret["checksum_one_rank"] == ret["checksum_shuffled"] != "0000000000000000"
 
 
 def test_shard_balance_by_bytes(oracle_lib, tmp_path):

@@ -76,6 +76,10 @@ def test_bench_two_ranks_equal_one_rank():
     assert j2["hits_per_step"] == j1["hits_per_step"] > 10000
     assert j2["matches_per_step"] == j1["matches_per_step"] > 10000
     assert j2["planted_recall"] == j1["planted_recall"] > 0.99
+    # the N-invariant of the bench line: the merged hit list of one batch, as an order-independent checksum
+    assert j2["sanity_batch"]["hits_checksum"] == j1["sanity_batch"]["hits_checksum"] and j2["sanity_batch"]["hits"] == j1["sanity_batch"]["hits"] > 10000
+    assert j2["ranks"]["world_size"] == 2 and len(j2["ranks"]["per_rank"]) == 2 and {p_["rank"] for p_ in j2["ranks"]["per_rank"]} == {0, 1}
+    assert j2["ranks"]["backend"] == ("nccl" if multi else "gloo")
     assert j2["roofline"]["algorithmic_bytes_per_launch"] * 2 == pytest.approx(j1["roofline"]["algorithmic_bytes_per_launch"], rel=0.02)
     assert j2["value"] > 0 and "host_boundary" not in j2  # per-rank extras ride along only at N = 1
     assert ("nccl" if multi else "gloo")  # which exchange ran is decided by the GPUs visible; both go through gather_hits
@@ -87,6 +91,22 @@ def test_bench_two_ranks_equal_one_rank():
     assert forced.returncode == 0, forced.stderr[-3000:]
     jf = _bench_line(forced.stdout)
     assert jf["hits_per_step"] == j1["hits_per_step"] and jf["matches_per_step"] == j1["matches_per_step"] and jf["planted_recall"] == j1["planted_recall"]
+    assert jf["sanity_batch"]["hits_checksum"] == j1["sanity_batch"]["hits_checksum"] and jf["ranks"]["backend"] == "nccl"
+
+
+def test_bench_two_ranks_hit_list_equals_the_cpu_oracle():
+    """At N > 1 rank 0 fetches the rows of every rank's shard (owner reads them back, send/recv to rank 0), runs the CPU oracle
+    on a sample of the batch and compares the MERGED multi-GPU hit list with it (bench.py `parity_at_n`): the first run on real
+    multi-GPU hardware checks itself.  Here: BASELINE configs[1] (32 blocks, 1.4 GB) on two ranks."""
+    env, multi = _env("KMCP_BENCH_SAME_GPU")
+    args = ["--steps", "2", "--warmup", "1", "--workload", "config1", "--batch-reads", "32768", "--no-secondary", "--no-extras"]
+    one = subprocess.run([sys.executable, "bench.py", "--gpus", "1"] + args, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert one.returncode == 0, one.stderr[-3000:]
+    j1 = _bench_line(one.stdout)
+    j2 = _bench_line(_launch(2, None, ["bench.py", "--gpus", "2"] + args, env).stdout)
+    assert j1["cpu_baseline"]["parity_on_sample"] is True and "parity_at_n" not in j1
+    assert j2["parity_at_n"]["parity_on_sample"] is True and j2["parity_at_n"]["sample_hits"] > 1000 and "cpu_baseline" not in j2
+    assert j2["sanity_batch"] == j1["sanity_batch"]
 
 
 def test_sharded_searcher_overflow_loop(oracle_lib, tmp_path):
