@@ -278,20 +278,41 @@ def run_workload(name, ctx, steps, warmup, batch_reads=0, cpu_baseline=True, cpu
             self.h_hits = torch.empty((cap * world, 3), dtype=torch.int32).pin_memory()
             self.h_qk = torch.empty(B, dtype=torch.int32).pin_memory()
             self.h_ql = torch.empty(B, dtype=torch.int32).pin_memory()
+            # K3 (device half of finalize): matches grouped by read, filtered by -T, in final order — 8 bytes each + the reads' offsets
+            self.d_pairs = torch.empty((cap * (world if rank == 0 else 1), 2), dtype=torch.int32, device=dev)
+            self.d_roffs = torch.zeros(B + 2, dtype=torch.int64, device=dev)
+            self.d_cat = torch.empty((cap * world, 3), dtype=torch.int32, device=dev) if (coll and rank == 0) else None
+            self.d_ncat = torch.zeros(1, dtype=torch.int64, device=dev)
+            self.h_pairs = torch.empty((cap * world, 2), dtype=torch.int32).pin_memory()
+            self.h_roffs = torch.zeros(B + 2, dtype=torch.int64).pin_memory()
+            self.k3_start = torch.cuda.Event(enable_timing=True)
+            self.k3_end = torch.cuda.Event(enable_timing=True)
             self.kernels_done = torch.cuda.Event()
             self.copied = torch.cuda.Event()
             self.used = False
+            self.grouped = False
 
     bufs = [Buf(), Buf()]  # two steps in flight, with and without a collective
 
-    def gpu_half(i, bf):
-        """Enqueues K1+K2 of batch i on this rank's blocks (nothing waits here)."""
+    use_k3 = os.environ.get("KMCP_BENCH_K3", "1") != "0"  # 0: the round-3 host half (kmcpg_finalize on the raw hit list)
+    k3_ms = []
+
+    def gpu_half(i, bf, raw=False):
+        """Enqueues K1 + K2 of batch i on this rank's blocks and, at N = 1, K3 behind them (nothing waits here).
+        raw: leave the hit list as K2 emitted it (the sanity step: checksum and oracle diff work on the raw tuples)."""
         bt = batches[i % n_batches]
         if bf.used:
             main.wait_event(bf.copied)  # the previous step that used these buffers has left them
         db.query_device(bt.reads.data_ptr(), bt.offs.data_ptr(), B, bt.total, bt.maxlen, bf.d_hits.data_ptr(), cap, bf.d_cnt.data_ptr(),
                         bf.d_qk.data_ptr(), bf.d_ql.data_ptr(), params=params, stream=stream)
         bf.h_cnt.copy_(bf.d_cnt, non_blocking=True)
+        bf.grouped = use_k3 and not raw
+        if bf.grouped and not coll:
+            bf.k3_start.record(main)
+            db.group_device(bf.d_hits.data_ptr(), bf.d_cnt.data_ptr(), cap, bf.d_qk.data_ptr(), B, bf.d_pairs.data_ptr(), bf.d_roffs.data_ptr(),
+                            params=params, stream=stream)
+            bf.k3_end.record(main)
+            bf.h_roffs.copy_(bf.d_roffs, non_blocking=True)
         bf.kernels_done.record(main)
         bf.used = True
 
@@ -304,7 +325,11 @@ def run_workload(name, ctx, steps, warmup, batch_reads=0, cpu_baseline=True, cpu
             assert n <= cap, "hit buffer overflow"
             side.wait_event(bf.kernels_done)
             with torch.cuda.stream(side):
-                bf.h_hits[:n].copy_(bf.d_hits[:n], non_blocking=True)
+                if bf.grouped:
+                    kept = int(bf.h_roffs[B])
+                    bf.h_pairs[:kept].copy_(bf.d_pairs[:kept], non_blocking=True)
+                else:
+                    bf.h_hits[:n].copy_(bf.d_hits[:n], non_blocking=True)
                 bf.h_qk.copy_(bf.d_qk, non_blocking=True)
                 bf.h_ql.copy_(bf.d_ql, non_blocking=True)
                 bf.copied.record(side)
@@ -317,10 +342,25 @@ def run_workload(name, ctx, steps, warmup, batch_reads=0, cpu_baseline=True, cpu
         with torch.cuda.stream(side):
             parts = gather_hits(bf.d_hits, bf.d_cnt[:1], dst=0, force_collectives=True)  # all_gather(counts) + gather(hit buffers)
             if rank == 0:
-                for part in parts:
-                    c = part.shape[0]
-                    bf.h_hits[n:n + c].copy_(part, non_blocking=True)
-                    n += c
+                if bf.grouped:
+                    # the shards' lists side by side on this GPU, then K3 over the concatenation: grouped, filtered, ordered here,
+                    # 8 bytes per match to the host
+                    for part in parts:
+                        c = part.shape[0]
+                        bf.d_cat[n:n + c].copy_(part, non_blocking=True)
+                        n += c
+                    bf.d_ncat.fill_(n)
+                    bf.k3_start.record(side)
+                    db.group_device(bf.d_cat.data_ptr(), bf.d_ncat.data_ptr(), cap * world, bf.d_qk.data_ptr(), B, bf.d_pairs.data_ptr(),
+                                    bf.d_roffs.data_ptr(), params=params, stream=side.cuda_stream)
+                    bf.k3_end.record(side)
+                    bf.h_roffs.copy_(bf.d_roffs, non_blocking=True)
+                    bf.h_pairs[:n].copy_(bf.d_pairs[:n], non_blocking=True)  # (at most n survive -T; h_roffs says how many)
+                else:
+                    for part in parts:
+                        c = part.shape[0]
+                        bf.h_hits[n:n + c].copy_(part, non_blocking=True)
+                        n += c
                 bf.h_qk.copy_(bf.d_qk, non_blocking=True)
                 bf.h_ql.copy_(bf.d_ql, non_blocking=True)
             bf.copied.record(side)
@@ -331,6 +371,10 @@ def run_workload(name, ctx, steps, warmup, batch_reads=0, cpu_baseline=True, cpu
         if rank != 0:
             return 0
         bf.copied.synchronize()
+        if bf.grouped:
+            k3_ms.append(bf.k3_start.elapsed_time(bf.k3_end))
+            kept = int(bf.h_roffs[B])
+            return db.finalize_grouped(bf.h_pairs[:kept].numpy(), bf.h_roffs.numpy(), bf.h_qk.numpy(), bf.h_ql.numpy(), params=params, count_only=True)
         return db.finalize_count(bf.h_hits[:n].numpy(), bf.h_qk.numpy(), bf.h_ql.numpy(), params=params)
 
     def barrier():
@@ -445,7 +489,8 @@ def run_workload(name, ctx, steps, warmup, batch_reads=0, cpu_baseline=True, cpu
                      "traffic_pmc": pmc, "traffic_pmc_source": pmc_src,
                      "measured_ceiling": {"gbps": FABRIC_CEILING_GBS, "what": "random 128-B gathers that miss L2 (L2->fabric path), tools/ubench_cache.cpp",
                                           "source": "profiles/r02_ubench_cache.txt"},
-                     "kernel_ms": k2_avg_ms, "kmers_kernel_ms": float(np.mean(k1_ms))},
+                     "kernel_ms": k2_avg_ms, "kmers_kernel_ms": float(np.mean(k1_ms)),
+                     "finalize_kernels_ms": (float(np.mean(k3_ms[-steps:])) if k3_ms else None)},
         "hits_per_step": n_hits_total / max(1, steps),
         "matches_per_step": n_matches_total / max(1, steps),
         "setup_s": setup_s,
@@ -453,7 +498,7 @@ def run_workload(name, ctx, steps, warmup, batch_reads=0, cpu_baseline=True, cpu
 
     # ---- sanity on the last batch: planted reads must come back with their column (the step holds collectives: every
     #      rank takes part, rank 0 evaluates the merged hit list)
-    gpu_half(last, bufs[0])
+    gpu_half(last, bufs[0], raw=True)
     n_last = exchange(bufs[0])
     torch.cuda.synchronize()
     hh = None

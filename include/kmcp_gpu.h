@@ -209,6 +209,27 @@ int kmcpg_query_device(kmcpg_db* db, const uint8_t* d_seqs, const uint64_t* d_of
 int kmcpg_finalize(const kmcpg_db* db, const kmcpg_hit* hits, uint64_t n_hits, const int32_t* qkmers,
                    const int32_t* qlen, uint32_t n_reads, const kmcpg_params* params, kmcpg_result* out);
 
+/* -- the host half split in two (round 4): its grouping, -T filter and per-query ordering run on the GPU, the host only expands
+ *    (column, count) pairs to Match records.  kmcpg_search_batch / kmcpg_submit use this by themselves (KMCPG_DEVICE_FINALIZE=0
+ *    keeps the hits on the round-3 path through kmcpg_finalize); a host that drives kmcpg_query_device per shard gathers the
+ *    shards' hit lists on one GPU (RCCL) and calls kmcpg_group_device there.
+ *    kmcpg_group_device: d_hits[0 .. min(*d_n_hits, hit_cap)) as kmcpg_query_device left them (any order, any number of shards
+ *    concatenated) -> d_pairs: the matches of read i at [d_read_offs[i], d_read_offs[i+1]), those failing -T (count / size <
+ *    min_tcov in float64, util-db-search.go:7471-7473) dropped, ordered as handleQuerySingleDB orders them (:260-283, :105-145:
+ *    -s qcov/tcov/jacc, ties by column; -S: column order).  Segments longer than 4096 matches come back grouped but unordered
+ *    (kmcpg_finalize_grouped sorts those).  d_pairs needs room for hit_cap pairs, d_read_offs for n_reads + 2 words: the last
+ *    one receives the number of hits that named a read or column that does not exist (must be 0).  Only enqueues on `stream`.
+ *    kmcpg_finalize_grouped: the float64 Match values (qCov, tCov, jacc :7487-7489), the FPR column and its -f test (:7474-7478),
+ *    --keep-top-scores (:285-311) and the name-independent metadata; same result as kmcpg_finalize on the same hits. */
+typedef struct {
+  uint32_t col;   /* global column */
+  uint32_t count; /* matched k-mers */
+} kmcpg_pair;
+int kmcpg_group_device(kmcpg_db* db, const kmcpg_hit* d_hits, const uint64_t* d_n_hits, uint64_t hit_cap, const int32_t* d_qkmers,
+                       uint32_t n_reads, const kmcpg_params* params, kmcpg_pair* d_pairs, uint64_t* d_read_offs, void* stream);
+int kmcpg_finalize_grouped(const kmcpg_db* db, const kmcpg_pair* pairs, const uint64_t* read_offs, const int32_t* qkmers,
+                           const int32_t* qlen, uint32_t n_reads, const kmcpg_params* params, kmcpg_result* out);
+
 /* -- benchmarking / full-size parity support (no counterpart in the reference) ------------------ */
 typedef struct {
   int32_t k;            /* 21 */

@@ -118,4 +118,24 @@ struct K2Args {
   int32_t cmin_fpr_n;
 };
 
+// K3 (k3_finalize.hip): hit list -> per-read segments of (column, count), filtered by -T, ordered as the reference orders a
+// query's matches.  Segments of more than K3_WG_CAP matches are grouped but left unordered (the host sorts those).
+constexpr int K3_WAVE_CAP = 512, K3_WG_CAP = 4096;
+struct K3Args {
+  const kmcpg_hit* hits;
+  const unsigned long long* n_hits;  // device word: hits produced (may exceed hit_cap: then only hit_cap are there)
+  uint64_t hit_cap;
+  const int32_t* nk;        // NumKmers per read
+  uint32_t n_reads;
+  uint32_t n_cols;
+  const uint64_t* col_size; // Header.Sizes per global column
+  double min_tcov;          // -T
+  int32_t sort_mode;        // 0 qcov, 1 tcov, 2 jacc (-s), 3 column order (-S)
+  uint32_t* cnt;            // [n_reads + 1], zero on entry and on exit
+  uint64_t* offs;           // [n_reads + 1] out: CSR offsets of the reads' segments
+  uint64_t* sums;           // scan scratch, one word per 4096 reads
+  kmcpg_pair* pairs;        // out: offs[n_reads] pairs
+  uint32_t* bad;            // hits naming a read / column that does not exist (an internal error: the caller reports it)
+};
+
 }  // namespace kmcpg

@@ -258,6 +258,12 @@ int finish_open(kmcpg_db* db) {
       db->col_meta.push_back(kmcpg_db::ColMeta{db->blocks[i].h.sizes[c], db->blocks[i].h.gsizes[c], db->blocks[i].h.indices[c], 0});
     }
   db->fpr.reset(new QueryFpr(db->info.fpr));
+  if (db->opts.device >= 0 && !db->col_meta.empty()) {  // K3 reads the columns' k-mer counts (-T, the tcov / jacc sort keys)
+    std::vector<uint64_t> sz(db->col_meta.size());
+    for (size_t c = 0; c < sz.size(); c++) sz[c] = db->col_meta[c].size;
+    HIPCHK(hipMalloc((void**)&db->d_col_size, sz.size() * sizeof(uint64_t)));
+    HIPCHK(hipMemcpy(db->d_col_size, sz.data(), sz.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
+  }
   return 0;
 }
 
@@ -623,6 +629,9 @@ extern "C" int kmcpg_close(kmcpg_db* db) {
   db->w_huge_info.release();
   db->w_huge_temp.release();
   db->w_gathered.release();
+  db->w_fin_cnt.release();
+  db->w_fin_sums.release();
+  if (db->d_col_size) (void)hipFree(db->d_col_size);
   kmcpg::release_fpr_bounds(db);
   kmcpg::async_release(db);
   if (db->ws_ev) (void)hipEventDestroy(db->ws_ev);

@@ -152,6 +152,10 @@ struct kmcpg_db {
   // optional HIP-event timing of the last kmcpg_query_device call
   int profiling = 0;  // 1: HIP-event timing of the kernels; 2: + count the row loads k2_cobs issues
   kmcpg::DevBuf<uint64_t> w_gathered;
+  // K3 (device half of finalize): Header.Sizes of every global column on the device, per-read counters and scan scratch
+  uint64_t* d_col_size = nullptr;
+  kmcpg::DevBuf<uint32_t> w_fin_cnt;
+  kmcpg::DevBuf<uint64_t> w_fin_sums;
   std::vector<kmcpg::FprBoundTable> fpr_bounds;  // -f bound tables (query.cpp fpr_bound): one per (max_fpr, size), never rewritten
   hipEvent_t ev[12] = {};   // ring of 4 calls x (start, k-mers done, COBS done)
   uint64_t ev_calls = 0;    // profiled calls so far

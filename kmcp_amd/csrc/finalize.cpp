@@ -323,11 +323,8 @@ extern "C" int kmcpg_finalize(const kmcpg_db* db, const kmcpg_hit* hits, uint64_
   QueryFpr* F = db->fpr.get();
   std::unordered_map<int, const std::vector<double>*> fpr_rows;
   if (n_hits) {
-    std::vector<char> seen((size_t)QueryFpr::kCachedMaxN + 1, 0);
     for (uint32_t r = 0; r < n_reads; r++)
-      if (qkmers[r] > 0 && qkmers[r] <= QueryFpr::kCachedMaxN) seen[(size_t)qkmers[r]] = 1;
-    for (int n = 1; n <= QueryFpr::kCachedMaxN; n++)
-      if (seen[(size_t)n]) fpr_rows.emplace(n, F->ensure_row(n));
+      if (qkmers[r] > 0 && !fpr_rows.count(qkmers[r])) fpr_rows.emplace(qkmers[r], F->ensure_row(qkmers[r]));
   }
   t_2 = now();
   kmcpg_match* const mbase = o->matches.data();
@@ -365,7 +362,7 @@ extern "C" int kmcpg_finalize(const kmcpg_db* db, const kmcpg_hit* hits, uint64_
       const double nh = (double)n;
       const double thr = nh * p.min_qcov;
       const std::vector<double>* row = nullptr;
-      if (n > 0 && n <= QueryFpr::kCachedMaxN) {
+      if (n > 0) {
         if (n != row_n) {
           row_n = n;
           row_of_n = fpr_rows.find(n)->second;
@@ -391,7 +388,7 @@ extern "C" int kmcpg_finalize(const kmcpg_db* db, const kmcpg_hit* hits, uint64_
         const double nt = (double)cm.size;
         const double T = c / nt;
         if (!(T >= p.min_tcov)) continue;
-        const double fpr = row ? (*row)[(size_t)std::min(count, n)] : F->get(n, count);
+        const double fpr = row ? QueryFpr::value(*row, n, count) : F->get(n, count);
         if (!(fpr <= p.max_fpr)) continue;
         kmcpg_match m{};
         m.col = h.col;
@@ -496,6 +493,165 @@ extern "C" int kmcpg_finalize(const kmcpg_db* db, const kmcpg_hit* hits, uint64_
   t_4 = now();
   if (timing) fprintf(stderr, "finalize: prep %.2f count %.2f scatter %.2f (W %d R %d)\n", t_00 - t_0, t_a - t_00, t_1 - t_a, W, R);
   if (timing) fprintf(stderr, "finalize: bucket %.2f fprrows %.2f workers %.2f close %.2f ms\n", t_1 - t_0, t_2 - t_1, t_3 - t_2, t_4 - t_3);
+  out->n_reads = n_reads;
+  out->k = k_used;
+  out->qlen = o->qlen.data();
+  out->qkmers = o->qkmers.data();
+  out->ksize = o->ksize.data();
+  out->match_offs = o->offs.data();
+  out->matches = o->matches.data();
+  out->owner = o.release();
+  return 0;
+}
+
+// The host half behind K3 (k3_finalize.hip): the hit list arrives grouped by read, filtered by -T and in final order, 8 bytes per
+// match; what is left is the float64 arithmetic of a Match (util-db-search.go:7487-7489), the FPR column with its -f test
+// (:7474-7478; for queries of up to 1 024 k-mers K2 has applied it already through the bound table — the running value of
+// util-fpr.go:32-50 only ever falls, so "count >= smallest passing count" IS the test), --keep-top-scores (:285-311) and the
+// columns' metadata.  Every threshold is applied again (a no-op on lists K2 + K3 produced): a list from elsewhere is finalized
+// correctly too, and segments longer than K3 orders (K3_WG_CAP) are sorted here.
+extern "C" int kmcpg_finalize_grouped(const kmcpg_db* db, const kmcpg_pair* pairs, const uint64_t* read_offs, const int32_t* qkmers, const int32_t* qlen,
+                                      uint32_t n_reads, const kmcpg_params* params, kmcpg_result* out) {
+  if (!db || !out || !read_offs || (n_reads && (!qkmers || !qlen))) return kmcpg_fail(KMCPG_EINVAL, "null argument");
+  const kmcpg_params p = params ? *params : default_params();
+  const uint64_t n_pairs = read_offs[n_reads];
+  if (n_pairs && !pairs) return kmcpg_fail(KMCPG_EINVAL, "null argument");
+  if (read_offs[0] != 0) return kmcpg_fail(KMCPG_EINVAL, "read_offs[0] must be 0");
+  if (read_offs[(size_t)n_reads + 1] != 0)
+    return kmcpg_fail(KMCPG_EINVAL, "%llu hit(s) named a read or column that does not exist", (unsigned long long)read_offs[(size_t)n_reads + 1]);
+  std::unique_ptr<ResultOwner, OwnerReturn> o(take_owner());
+  o->qlen.assign(qlen, qlen + n_reads);
+  o->qkmers.assign(qkmers, qkmers + n_reads);
+  const int k_used = p.k > 0 ? p.k : db->info.k;
+  o->ksize.assign(n_reads, k_used);
+  o->matches.resize(n_pairs);
+  o->offs.resize((size_t)n_reads + 1);
+  WorkerPool& pool = WorkerPool::get();
+  // contiguous ranges of reads holding ~64 k matches each (the offsets are at hand: a binary search per boundary)
+  const uint64_t per_range = 65536;
+  const int R = (int)std::max<uint64_t>(1, std::min<uint64_t>(std::min<uint64_t>(n_reads, 4096), (n_pairs + per_range - 1) / per_range));
+  std::vector<uint32_t> lo_of((size_t)R + 1, n_reads);
+  lo_of[0] = 0;
+  for (int w = 1; w < R; w++) {
+    const uint64_t target = n_pairs * (uint64_t)w / (uint64_t)R;
+    lo_of[(size_t)w] = std::max<uint32_t>(lo_of[(size_t)w - 1], (uint32_t)(std::lower_bound(read_offs, read_offs + n_reads, target) - read_offs));
+  }
+  QueryFpr* F = db->fpr.get();
+  const size_t n_cols = db->col_meta.size();
+  const kmcpg_db::ColMeta* const col_meta = db->col_meta.data();
+  kmcpg_match* const mbase = o->matches.data();
+  uint64_t* const per_read = o->offs.data() + 1;  // counts first, offsets after the ranges are closed
+  std::vector<uint64_t> wcount((size_t)R, 0);
+  std::atomic<int> bad{0};
+  pool.parallel_for(R, [&](int w) {
+    const uint32_t lo = lo_of[(size_t)w], hi = lo_of[(size_t)w + 1];
+    uint64_t pos = lo < n_reads ? read_offs[lo] : n_pairs;
+    const uint64_t pos0 = pos;
+    int row_n = -1;
+    const std::vector<double>* row = nullptr;
+    static thread_local std::vector<kmcpg_match> tmp;
+    for (uint32_t r = lo; r < hi; r++) {
+      const uint64_t s0 = read_offs[r], s1 = read_offs[r + 1];
+      per_read[r] = 0;
+      if (s1 == s0) continue;
+      if (s1 < s0 || s1 > n_pairs) {
+        bad.store(1);
+        return;
+      }
+      const int n = qkmers[r];
+      const double nh = (double)n, thr = nh * p.min_qcov;
+      if (n > 0 && n != row_n) {
+        row_n = n;
+        row = F->ensure_row(n);
+      }
+      const uint64_t m = s1 - s0;
+      const bool host_sort = m > (uint64_t)K3_WG_CAP;  // K3 left this segment unordered
+      if (host_sort && tmp.size() < m) tmp.resize(m);
+      const uint64_t first = pos;
+      uint64_t kept = 0;
+      // --keep-top-scores while the records go out: matches arrive by descending score
+      int nn = 0;
+      double pscore = 1024;
+      const bool top = p.top_n_scores > 0 && !p.do_not_sort;
+      bool cut = false;
+      for (uint64_t i = s0; i < s1 && !cut; i++) {
+        const kmcpg_pair h = pairs[i];
+        if (h.col >= n_cols) {
+          bad.store(1);
+          return;
+        }
+        const int count = (int)h.count;
+        if (count < p.min_matched) continue;
+        const double c = (double)count;
+        if (!(c > thr)) continue;
+        const kmcpg_db::ColMeta cm = col_meta[h.col];
+        const double nt = (double)cm.size;
+        const double T = c / nt;
+        if (!(T >= p.min_tcov)) continue;
+        const double fpr = n > 0 ? QueryFpr::value(*row, n, count) : 1.0;
+        if (!(fpr <= p.max_fpr)) continue;
+        kmcpg_match mm{};
+        mm.col = h.col;
+        mm.target_idx = cm.tidx;
+        mm.gsize = cm.gsize;
+        mm.mkmers = count;
+        mm.fpr = fpr;
+        mm.qcov = c / nh;
+        mm.tcov = T;
+        mm.jacc = c / (nh + nt - c);
+        if (host_sort) {
+          tmp[kept++] = mm;
+          continue;
+        }
+        if (top) {
+          const double score = p.sort_by == 1 ? mm.tcov : (p.sort_by == 2 ? mm.jacc : mm.qcov);
+          if (score < pscore) {
+            nn++;
+            if (nn > p.top_n_scores) cut = true;  // the reference keeps this one too (its [:i+1], :305-309) and stops
+            pscore = score;
+          }
+        }
+        store_record(mbase + first + kept, mm);
+        kept++;
+      }
+      if (host_sort && kept) {
+        const int sb = p.sort_by;
+        if (!p.do_not_sort) std::sort(tmp.begin(), tmp.begin() + (ptrdiff_t)kept, [sb](const kmcpg_match& x, const kmcpg_match& y) { return match_less(x, y, sb); });
+        else std::sort(tmp.begin(), tmp.begin() + (ptrdiff_t)kept, [](const kmcpg_match& x, const kmcpg_match& y) { return x.col < y.col; });
+        uint64_t keep = kept;
+        if (top) {
+          uint64_t i = 0;
+          for (; i < kept; i++) {
+            const kmcpg_match& x = tmp[i];
+            const double score = p.sort_by == 1 ? x.tcov : (p.sort_by == 2 ? x.jacc : x.qcov);
+            if (score < pscore) {
+              nn++;
+              if (nn > p.top_n_scores) break;
+              pscore = score;
+            }
+          }
+          if (i >= kept) i = kept - 1;
+          keep = i + 1;
+        }
+        for (uint64_t i = 0; i < keep; i++) store_record(mbase + first + i, tmp[i]);
+        kept = keep;
+      }
+      per_read[r] = kept;
+      pos = first + kept;
+    }
+    records_visible();
+    wcount[(size_t)w] = pos - pos0;
+  });
+  if (bad.load()) return kmcpg_fail(KMCPG_EINVAL, "grouped hit list: offsets or columns out of range");
+  uint64_t total = 0;
+  for (int w = 0; w < R; w++) {  // close the gaps the filters / --keep-top-scores left between the ranges
+    const uint64_t start = lo_of[(size_t)w] < n_reads ? read_offs[lo_of[(size_t)w]] : n_pairs;
+    if (start != total && wcount[(size_t)w]) memmove(mbase + total, mbase + start, wcount[(size_t)w] * sizeof(kmcpg_match));
+    total += wcount[(size_t)w];
+  }
+  o->matches.resize(total);
+  o->offs[0] = 0;
+  for (uint32_t r = 0; r < n_reads; r++) o->offs[(size_t)r + 1] += o->offs[r];  // counts -> offsets
   out->n_reads = n_reads;
   out->k = k_used;
   out->qlen = o->qlen.data();

@@ -3,6 +3,8 @@
 
 #include <math.h>
 
+#include <algorithm>
+
 #include <limits>
 
 namespace kmcpg {
@@ -60,66 +62,76 @@ double go_pow(double x, double y) {
   return ldexp(a1, ae);
 }
 
-// FPR(n, i) for i = 0..upto
+// FPR(n, i) for i = 0..upto.  The reference's running value r only ever decreases, and once it is clamped to 0 — the next term
+// pushed it below zero, or BinomialCoeff left the float64 range (util-fpr.go:40-47), which happens within ~1 030 terms whatever
+// n is — every later value is 0.  The row therefore ENDS at the first dead entry (value 0): FPR(n, k) for k beyond the row is 0.
+// A row has at most min(n, ~1 030) + 1 entries, so rows of long queries (thousands of k-mers) are as cheap to keep as those of
+// short reads.
 static std::vector<double> fpr_row(double p_, int n, int upto) {
-  std::vector<double> out((size_t)upto + 1, 0.0);
+  std::vector<double> out;
+  out.reserve((size_t)std::min(upto, 1100) + 1);
   // C(n,i) for i <= n/2 exactly as BinomialCoeff's product loop rounds it: a 53-bit mantissa with an
-  // unbounded exponent (big.Float), kept here as a normalised (mantissa, exponent) pair.
-  const int half = upto < n / 2 ? upto : n / 2;
-  std::vector<double> binom((size_t)half + 1);
+  // unbounded exponent (big.Float), kept here as a normalised (mantissa, exponent) pair, one step per term.
+  const int half = n / 2;
   double m = 0.5;
   int e = 1;
-  binom[0] = 1.0;
-  for (int i = 0; i < half; i++) {
-    int de;
-    m = frexp(m * (double)(n - i), &de);
-    e += de;
-    m = frexp(m / (double)(i + 1), &de);
-    e += de;
-    binom[(size_t)i + 1] = ldexp(m, e);
-  }
+  std::vector<double> binom;  // C(n, i) for the i <= n/2 reached so far (the terms beyond n/2 read them back: C(n,i) = C(n,n-i))
+  binom.push_back(1.0);
   const double q = 1 - p_;
   double r = 1;
-  bool dead = false;
   for (int i = 0; i <= upto; i++) {
-    if (!dead) {
-      const double coeff = binom[(size_t)(i > n - i ? n - i : i)];
-      if (coeff > std::numeric_limits<double>::max()) {
-        dead = true;
-        r = 0;
-      } else {
-        double t = coeff * go_pow(p_, (double)i);
-        t = t * go_pow(q, (double)(n - i));
-        r -= t;
-        if (r < 0) {
-          dead = true;
-          r = 0;
-        }
-      }
+    const int bi = i > n - i ? n - i : i;
+    while ((int)binom.size() <= bi && (int)binom.size() <= half) {
+      const int j = (int)binom.size() - 1;
+      int de;
+      m = frexp(m * (double)(n - j), &de);
+      e += de;
+      m = frexp(m / (double)(j + 1), &de);
+      e += de;
+      binom.push_back(ldexp(m, e));
     }
-    out[(size_t)i] = r;
+    const double coeff = binom[(size_t)bi];
+    bool dead = false;
+    if (coeff > std::numeric_limits<double>::max()) {
+      dead = true;
+    } else {
+      double t = coeff * go_pow(p_, (double)i);
+      t = t * go_pow(q, (double)(n - i));
+      r -= t;
+      if (r < 0) dead = true;
+    }
+    if (dead) {
+      out.push_back(0.0);
+      break;
+    }
+    out.push_back(r);
   }
   return out;
 }
 
 const std::vector<double>& QueryFpr::row(int n) {
   auto it = rows_.find(n);
-  if (it != rows_.end()) return it->second;
-  return rows_.emplace(n, fpr_row(p_, n, n)).first->second;
+  if (it != rows_.end()) return *it->second;
+  if (rows_.size() >= kMaxRows) {  // a host that feeds queries of ever new lengths: start over; the rows handed out so far stay
+    retired_.clear();              // readable until the NEXT reset (callers hold a row for the duration of one call)
+    for (auto& kv : rows_) retired_.push_back(std::move(kv.second));
+    rows_.clear();
+  }
+  return *rows_.emplace(n, std::make_unique<std::vector<double>>(fpr_row(p_, n, n))).first->second;
 }
 
 const std::vector<double>* QueryFpr::ensure_row(int n) {
   std::lock_guard<std::mutex> g(mu_);
-  return &row(n);  // unordered_map never moves its mapped values
+  return &row(n);  // the vector lives on the heap, owned by the map (or, after a reset, by retired_)
 }
 
 double QueryFpr::get(int n, int k) {
   if (n <= 0) return 1;
   if (k > n) k = n;
   if (k < 0) return 1;
-  if (n > kCachedMaxN) return fpr_row(p_, n, k)[(size_t)k];  // long queries: do not keep O(n) rows around
   std::lock_guard<std::mutex> g(mu_);
-  return row(n)[(size_t)k];
+  const std::vector<double>& r = row(n);
+  return (size_t)k < r.size() ? r[(size_t)k] : 0.0;
 }
 
 }  // namespace kmcpg

@@ -4,6 +4,7 @@
 #pragma once
 #include <stdint.h>
 
+#include <memory>
 #include <mutex>
 #include <unordered_map>
 #include <vector>
@@ -18,16 +19,23 @@ class QueryFpr {
   explicit QueryFpr(double p) : p_(p) {}
   // queryFPR(n, k): 1 - sum_{i<=k} C(n,i) p^i (1-p)^(n-i), clamped at 0
   double get(int n, int k);
-  // rows are cached for n <= kCachedMaxN; ensure_row builds row n (FPR(n, 0..n)) if needed and returns it — the pointer
-  // stays valid for the life of the object, so readers need no lock afterwards
-  static constexpr int kCachedMaxN = 4096;
+  // Rows are cached for every n (a row ends at its first dead entry, see fpr.cpp: at most ~1 030 + 1 values whatever n is; at
+  // most kMaxRows rows are kept).  ensure_row builds row n if needed and returns it: value(row, k) reads FPR(n, k) without a lock.
+  // The pointer stays valid until kMaxRows further distinct n have been asked for (never, for a read-length distribution).
+  static constexpr size_t kMaxRows = 65536;
   const std::vector<double>* ensure_row(int n);
+  static double value(const std::vector<double>& row, int n, int k) {
+    if (k > n) k = n;
+    if (k < 0) return 1;
+    return (size_t)k < row.size() ? row[(size_t)k] : 0.0;
+  }
 
  private:
   const std::vector<double>& row(int n);
   double p_;
   std::mutex mu_;
-  std::unordered_map<int, std::vector<double>> rows_;
+  std::unordered_map<int, std::unique_ptr<std::vector<double>>> rows_;
+  std::vector<std::unique_ptr<std::vector<double>>> retired_;  // rows of the generation before the last reset: still readable
 };
 
 }  // namespace kmcpg

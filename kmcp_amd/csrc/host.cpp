@@ -72,6 +72,12 @@ struct Lane {
   DevBuf<uint64_t> d_offs, d_offs2, d_cnt;
   DevBuf<int32_t> d_qk, d_ql;
   DevBuf<kmcpg_hit> d_hits;
+  // K3 (device half of finalize): the batch's matches grouped by read and in final order, 8 bytes each + CSR offsets of the reads
+  DevBuf<kmcpg_pair> d_pairs;
+  DevBuf<uint64_t> d_roffs;
+  PinBuf<kmcpg_pair> h_pairs;
+  PinBuf<uint64_t> h_roffs;
+  bool grouped = false;  // this batch went through K3: h_pairs / h_roffs hold its result, h_hits is not filled
   hipEvent_t done = nullptr, uploaded = nullptr;
   uint32_t n = 0;
   bool paired = false;
@@ -82,6 +88,7 @@ struct Lane {
   void release() {
     h_seqs.release(); h_seqs2.release(); h_offs.release(); h_offs2.release(); h_cnt.release(); h_qk.release(); h_ql.release(); h_hits.release();
     d_seqs.release(); d_seqs2.release(); d_offs.release(); d_offs2.release(); d_cnt.release(); d_qk.release(); d_ql.release(); d_hits.release();
+    d_pairs.release(); d_roffs.release(); h_pairs.release(); h_roffs.release();
     if (done) (void)hipEventDestroy(done);
     if (uploaded) (void)hipEventDestroy(uploaded);
     done = uploaded = nullptr;
@@ -95,6 +102,7 @@ struct AsyncState {
   std::atomic<uint64_t> hits_hint{0};  // hits per 1024 reads seen lately: sizes the hit buffers and the eager D2H of the next batches
   uint64_t lane_hit_budget = 0;        // entries a lane's device hit buffer may grow to beyond the plain size (from free HBM at first use)
   bool hits_stay_on_device = false;    // shard of a handle that gathers the hit lists over RCCL: no per-shard D2H of hits
+  bool device_finalize = true;         // K3 after K2: grouping, -T and the per-query order on the GPU (KMCPG_DEVICE_FINALIZE=0: host)
   std::vector<std::unique_ptr<Lane>> lanes;
   size_t max_lanes = 4;
   std::mutex mu;
@@ -164,6 +172,7 @@ int async_state(kmcpg_db* db, AsyncState** out) {
     HIPCHK(hipStreamCreateWithFlags(&a->copy_stream, hipStreamNonBlocking));
     HIPCHK(hipStreamCreateWithFlags(&a->up_stream, hipStreamNonBlocking));
     if (const char* e = getenv("KMCPG_INFLIGHT")) a->max_lanes = (size_t)std::max(1, std::min(atoi(e), 16));
+    if (const char* e = getenv("KMCPG_DEVICE_FINALIZE")) a->device_finalize = atoi(e) != 0;
     // Hit buffers follow the data (a database full of close relatives returns hundreds of hits per read) but must never crowd
     // out the k-mer workspace next to a large index: all lanes together may take a quarter of what is free now (the index is
     // resident already), at most 16 GB.
@@ -264,6 +273,12 @@ int enqueue_query(kmcpg_db* db, AsyncState* A, Lane* L, const kmcpg_params& p) {
                               L->maxlen, &p, L->d_hits.p, L->d_hits.cap, L->d_cnt.p, L->d_qk.p, L->d_ql.p, st);
   if (rc) return rc;
   HIPCHK(hipMemcpyAsync(L->h_cnt.p, L->d_cnt.p, 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+  if (L->grouped) {  // K3 right behind K2 (an overflowing hit buffer makes both run again, collect())
+    if (L->d_pairs.ensure(L->d_hits.cap) || L->d_roffs.ensure((size_t)L->n + 2) || L->h_roffs.ensure((size_t)L->n + 2)) return kmcpg_fail(KMCPG_ENOMEM, "hipMalloc failed");
+    rc = kmcpg_group_device(db, L->d_hits.p, L->d_cnt.p, L->d_hits.cap, L->d_qk.p, L->n, &p, L->d_pairs.p, L->d_roffs.p, st);
+    if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(L->h_roffs.p, L->d_roffs.p, ((size_t)L->n + 2) * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+  }
   return 0;
 }
 
@@ -297,7 +312,10 @@ int enqueue(kmcpg_db* db, AsyncState* A, Lane* L, const kmcpg_params& p) {
     if (L->d_hits.ensure(cap)) return kmcpg_fail(KMCPG_ENOMEM, "hipMalloc failed");
   }
   const uint64_t first = std::min<uint64_t>(cap, std::max<uint64_t>((uint64_t)n * 2 + 1024, std::min<uint64_t>(expect + expect / 4, (uint64_t)n * 32)));
-  if (L->h_cnt.ensure(2) || L->h_qk.ensure(n) || L->h_ql.ensure(n) || L->h_hits.ensure(first)) return kmcpg_fail(KMCPG_ENOMEM, "hipHostMalloc failed");
+  // K3 only where this handle holds the whole database: the lists of shards (several GPUs, passes of a paged handle) are merged first
+  L->grouped = A->device_finalize && !A->hits_stay_on_device && db->opts.shard_count == 1;
+  if (L->h_cnt.ensure(2) || L->h_qk.ensure(n) || L->h_ql.ensure(n) || (L->grouped ? L->h_pairs.ensure(first) : L->h_hits.ensure(first)))
+    return kmcpg_fail(KMCPG_ENOMEM, "hipHostMalloc failed");
   // the reads go up on a stream of their own (150 MB per million reads: 4 ms of PCIe that would otherwise sit between the
   // kernels of consecutive batches); the lane's device buffers are idle, its previous batch was waited for
   hipStream_t up = A->up_stream;
@@ -330,7 +348,8 @@ int enqueue(kmcpg_db* db, AsyncState* A, Lane* L, const kmcpg_params& p) {
   HIPCHK(hipMemcpyAsync(L->h_qk.p, L->d_qk.p, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, st));
   HIPCHK(hipMemcpyAsync(L->h_ql.p, L->d_ql.p, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, st));
   L->copied = A->hits_stay_on_device ? 0 : std::min<uint64_t>(first, L->d_hits.cap);
-  if (L->copied) HIPCHK(hipMemcpyAsync(L->h_hits.p, L->d_hits.p, L->copied * sizeof(kmcpg_hit), hipMemcpyDeviceToHost, st));
+  if (L->copied && L->grouped) HIPCHK(hipMemcpyAsync(L->h_pairs.p, L->d_pairs.p, L->copied * sizeof(kmcpg_pair), hipMemcpyDeviceToHost, st));
+  else if (L->copied) HIPCHK(hipMemcpyAsync(L->h_hits.p, L->d_hits.p, L->copied * sizeof(kmcpg_hit), hipMemcpyDeviceToHost, st));
   HIPCHK(hipEventRecord(L->done, st));
   return 0;
 }
@@ -356,7 +375,20 @@ int collect(kmcpg_db* db, AsyncState* A, Lane* L, const kmcpg_params& p, uint64_
   // the k-mer count the counter planes were sized for (the longest read) bounds every query's NumKmers
   const uint64_t bound = (uint64_t)L->maxlen * (L->paired ? 2 : 1);
   if (L->h_cnt.p[1] > bound) return kmcpg_fail(KMCPG_EDEVICE, "internal: a query reported %llu k-mers, more than its length allows", (unsigned long long)L->h_cnt.p[1]);
-  if (fetch && cnt > L->copied) {
+  if (fetch && L->grouped) {
+    // K3 ran behind K2: what comes to the host is its output — offsets (already here) and the pairs that passed -T, in final order
+    const uint64_t kept = L->h_roffs.p[L->n];
+    if (kept > cnt) return kmcpg_fail(KMCPG_EDEVICE, "internal: K3 kept %llu of %llu hits", (unsigned long long)kept, (unsigned long long)cnt);
+    if (kept > L->copied) {
+      if (kept > L->h_pairs.cap) {
+        if (L->h_pairs.ensure(kept)) return kmcpg_fail(KMCPG_ENOMEM, "hipHostMalloc failed");
+        L->copied = 0;
+      }
+      HIPCHK(hipMemcpyAsync(L->h_pairs.p + L->copied, L->d_pairs.p + L->copied, (kept - L->copied) * sizeof(kmcpg_pair), hipMemcpyDeviceToHost, A->copy_stream));
+      HIPCHK(hipStreamSynchronize(A->copy_stream));
+      L->copied = kept;
+    }
+  } else if (fetch && cnt > L->copied) {
     if (cnt > L->h_hits.cap) {
       if (L->h_hits.ensure(cnt)) return kmcpg_fail(KMCPG_ENOMEM, "hipHostMalloc failed");
       L->copied = 0;
@@ -530,6 +562,8 @@ int finish_raw(kmcpg_ticket* t, kmcpg_result* out) {
     auto& pt = t->parts[0];
     int rc = collect(pt.shard, pt.shard->async, pt.lane, t->p, &n_hits);
     if (rc) return rc;
+    if (pt.lane->grouped && t->n)
+      return kmcpg_finalize_grouped(t->db, pt.lane->h_pairs.p, pt.lane->h_roffs.p, pt.lane->h_qk.p, pt.lane->h_ql.p, t->n, &t->p, out);
     hits = pt.lane->h_hits.p;
   } else if (Exchange* x = t->db->exchange) {
     // the shards' lists meet on the first GPU (RCCL send/recv over xGMI, exactly the bytes each shard produced) and come to
@@ -935,7 +969,7 @@ extern "C" int kmcpg_read_row_range(kmcpg_db* db, uint32_t block, uint64_t first
   if (n_rows == 0) return 0;
   std::lock_guard<std::mutex> g(db->mu);
   KMCPG_USE_DEVICE(db);
-  if (b.h.row_bytes >= 512) {  // wide rows: one strided copy
+  if (b.h.row_bytes >= 512 && b.h.row_bytes % 16 == 0) {  // wide rows of a DMA-friendly width: one strided copy (782-byte rows took 23 s for 2.7 GB this way)
     HIPCHK(hipMemcpy2D(out, b.h.row_bytes, b.d_rows + first_row * b.stride, b.stride, b.h.row_bytes, n_rows, hipMemcpyDeviceToHost));
     return 0;
   }

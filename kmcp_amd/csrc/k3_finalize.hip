@@ -1,0 +1,247 @@
+// k3_finalize.hip — K3: the hit list of a batch grouped by read, filtered by -T and ordered per read ON THE DEVICE.
+//
+// Reference counterpart: the tail of the UnikIndex worker (the target-coverage test, util-db-search.go:7471-7473) and the per-query
+// sort of handleQuerySingleDB (:260-283, Matches.Less / SortByTCov / SortByJacc :105-145).  K2 emits (read, column, count) tuples in
+// no particular order; until round 4 the host partitioned them by read, filtered and sorted them (finalize.cpp) — on databases full of
+// close relatives (hundreds of matches per read) that host half was 3x the time of the kernels.  Here:
+//   k3_count    per surviving hit (count / size >= -T in float64, the reference's own division): one atomic on its read's counter
+//   k3_scan_*   exclusive scan of the counters -> CSR offsets of the reads (uint64)
+//   k3_scatter  (column, count) pairs into their read's segment
+//   k3_sort_*   every segment ordered as the reference orders a query's matches; one wave per read for up to 512 matches (bitonic
+//               network in a wave-private LDS tile, no workgroup barrier), one workgroup for up to 4096; longer segments are left to
+//               the host (kmcpg_finalize_grouped knows the same constant).
+// What goes back over PCIe is 8 bytes per match in final order plus the offsets; the host only expands pairs to Match records.
+//
+// Sort keys (ascending order of the 128-bit key (A, B) = the reference's order; ties broken by column, as finalize.cpp does):
+//   -s qcov: qcov = c / n with one n per read, so the order of qcov is the order of the integer c (two counts that differ give
+//            quotients far more than an ulp apart); ties by tcov = c / size descending = size ascending (equal c; sizes below 2^52
+//            give distinct quotients), then column:            A = ~c : size[63:32]      B = size[31:0] : column
+//   -s tcov: (c / size) descending as float64 bit patterns (positive doubles order like their bits), then c descending, column:
+//                                                              A = ~bits(c / size)       B = ~c : column
+//   -s jacc: c / (n + size - c) likewise:                      A = ~bits(jacc)           B = ~c : column
+//   -S     : column order (this build's deterministic stand-in for the reference's arrival order): A = column, B = ~c : column
+#include <hip/hip_runtime.h>
+
+#include "common.hpp"
+#include "device_utils.hpp"
+#include "kernels.hpp"
+
+namespace kmcpg {
+
+namespace {
+
+constexpr int SCAN_ITEMS = 16, SCAN_THREADS = 256, SCAN_TILE = SCAN_ITEMS * SCAN_THREADS;
+
+__device__ __forceinline__ uint64_t n_hits_of(const K3Args& a) {
+  const unsigned long long n = *a.n_hits;
+  return n < a.hit_cap ? n : a.hit_cap;
+}
+
+// the -T test exactly as the reference makes it: float64(count) / float64(size) >= minTCov (:7471-7473)
+__device__ __forceinline__ bool passes(const K3Args& a, const kmcpg_hit& h) {
+  if (h.read >= a.n_reads || h.col >= a.n_cols) return false;  // counted in k3_count
+  if (a.min_tcov <= 0.0) return true;
+  return (double)h.count / (double)a.col_size[h.col] >= a.min_tcov;
+}
+
+__global__ void k3_count(K3Args a) {
+  const uint64_t n = n_hits_of(a);
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+    const kmcpg_hit h = a.hits[i];
+    if (h.read >= a.n_reads || h.col >= a.n_cols) {
+      atomicAdd(a.bad, 1u);
+      continue;
+    }
+    if (passes(a, h)) atomicAdd(&a.cnt[h.read], 1u);
+  }
+}
+
+// exclusive scan of cnt[0 .. n) into offs, in three launches: tile-local scans + tile totals, the scan of the totals, the add
+__global__ void __launch_bounds__(SCAN_THREADS) k3_scan_tiles(const uint32_t* __restrict__ cnt, uint64_t* __restrict__ offs, uint64_t* __restrict__ sums, uint32_t n) {
+  __shared__ uint64_t wsum[SCAN_THREADS / 64];
+  const uint32_t base = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
+  uint32_t v[SCAN_ITEMS];
+  uint64_t t = 0;
+#pragma unroll
+  for (int i = 0; i < SCAN_ITEMS; i++) {
+    v[i] = base + i < n ? cnt[base + i] : 0u;
+    t += v[i];
+  }
+  // inclusive scan of the threads' totals: within the wave by shuffles, across the 4 waves through LDS
+  uint64_t inc = t;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint64_t o = __shfl_up(inc, d, 64);
+    if (lane >= d) inc += o;
+  }
+  if (lane == 63) wsum[wave] = inc;
+  __syncthreads();
+  uint64_t before = 0;
+  for (int w = 0; w < wave; w++) before += wsum[w];
+  uint64_t run = before + inc - t;
+#pragma unroll
+  for (int i = 0; i < SCAN_ITEMS; i++) {
+    if (base + i < n) offs[base + i] = run;
+    run += v[i];
+  }
+  if (threadIdx.x == SCAN_THREADS - 1) sums[blockIdx.x] = before + inc;
+}
+
+__global__ void __launch_bounds__(SCAN_THREADS) k3_scan_sums(uint64_t* __restrict__ sums, uint32_t n_tiles) {
+  __shared__ uint64_t wsum[SCAN_THREADS / 64];
+  __shared__ uint64_t carry_s;
+  if (threadIdx.x == 0) carry_s = 0;
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (uint32_t b0 = 0; b0 < n_tiles; b0 += SCAN_THREADS) {
+    const uint32_t i = b0 + threadIdx.x;
+    const uint64_t t = i < n_tiles ? sums[i] : 0;
+    uint64_t inc = t;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const uint64_t o = __shfl_up(inc, d, 64);
+      if (lane >= d) inc += o;
+    }
+    if (lane == 63) wsum[wave] = inc;
+    __syncthreads();
+    uint64_t before = carry_s;
+    for (int w = 0; w < wave; w++) before += wsum[w];
+    if (i < n_tiles) sums[i] = before + inc - t;
+    __syncthreads();
+    if (threadIdx.x == SCAN_THREADS - 1) carry_s = before + inc;
+    __syncthreads();
+  }
+}
+
+__global__ void __launch_bounds__(SCAN_THREADS) k3_scan_add(uint64_t* __restrict__ offs, const uint64_t* __restrict__ sums, uint32_t n) {
+  const uint64_t add = sums[blockIdx.x];
+  const uint32_t base = blockIdx.x * SCAN_TILE;
+  for (uint32_t i = threadIdx.x; i < SCAN_TILE && base + i < n; i += SCAN_THREADS) offs[base + i] += add;
+}
+
+// segments are filled from the back (the counter of a read runs down to zero): the order inside a segment is settled by the sort
+__global__ void k3_scatter(K3Args a) {
+  const uint64_t n = n_hits_of(a);
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+    const kmcpg_hit h = a.hits[i];
+    if (!passes(a, h)) continue;
+    const uint32_t left = atomicSub(&a.cnt[h.read], 1u);
+    a.pairs[a.offs[h.read] + left - 1] = kmcpg_pair{h.col, h.count};
+  }
+}
+
+struct Key {
+  uint64_t a, b;
+};
+__device__ __forceinline__ bool key_less(const Key& x, const Key& y) { return x.a < y.a || (x.a == y.a && x.b < y.b); }
+
+__device__ __forceinline__ Key make_key(const K3Args& a, kmcpg_pair p, double nh) {
+  const uint32_t inv = ~p.count;
+  Key k;
+  if (a.sort_mode == 0) {
+    const uint64_t s = a.col_size[p.col];
+    k.a = ((uint64_t)inv << 32) | (s >> 32);
+    k.b = (s << 32) | p.col;
+  } else {
+    const double c = (double)p.count;
+    if (a.sort_mode == 3) k.a = p.col;
+    else {
+      const double nt = (double)a.col_size[p.col];
+      const double score = a.sort_mode == 1 ? c / nt : c / (nh + nt - c);  // :7487-7489, left to right as Go evaluates it
+      k.a = ~(uint64_t)__double_as_longlong(score);
+    }
+    k.b = ((uint64_t)inv << 32) | p.col;
+  }
+  return k;
+}
+
+__device__ __forceinline__ kmcpg_pair pair_of(const K3Args& a, const Key& k) {
+  kmcpg_pair p;
+  p.col = (uint32_t)k.b;
+  p.count = ~(uint32_t)((a.sort_mode == 0 ? k.a : k.b) >> 32);
+  return p;
+}
+
+// one compare-exchange step of the bitonic network over P keys in `t`, done by `nthreads` threads (tid = this thread's index)
+__device__ __forceinline__ void bitonic_step(Key* t, uint32_t P, uint32_t k, uint32_t j, uint32_t tid, uint32_t nthreads) {
+  for (uint32_t q = tid; q < P / 2; q += nthreads) {
+    const uint32_t i = ((q & ~(j - 1)) << 1) | (q & (j - 1));
+    const uint32_t l = i | j;
+    const Key x = t[i], y = t[l];
+    const bool up = (i & k) == 0;
+    if (key_less(y, x) == up) {
+      t[i] = y;
+      t[l] = x;
+    }
+  }
+}
+
+constexpr int WAVE_CAP = K3_WAVE_CAP, WG_CAP = K3_WG_CAP;
+
+// one wave per read, 4 reads per workgroup: segments of 2 .. WAVE_CAP matches
+__global__ void __launch_bounds__(256) k3_sort_wave(K3Args a) {
+  __shared__ Key tile[4][WAVE_CAP];
+  const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const uint64_t r = (uint64_t)blockIdx.x * 4 + wave;
+  if (r >= a.n_reads) return;
+  const uint64_t s0 = a.offs[r], s1 = a.offs[r + 1];
+  const uint64_t m = s1 - s0;
+  if (m < 2 || m > WAVE_CAP) return;
+  uint32_t P = 2;
+  while (P < m) P <<= 1;
+  Key* t = tile[wave];
+  const double nh = (double)a.nk[r];
+  for (uint32_t i = lane; i < P; i += 64) t[i] = i < m ? make_key(a, a.pairs[s0 + i], nh) : Key{~0ull, ~0ull};
+  wave_lds_fence();
+  for (uint32_t k = 2; k <= P; k <<= 1)
+    for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+      bitonic_step(t, P, k, j, lane, 64);
+      wave_lds_fence();
+    }
+  for (uint32_t i = lane; i < m; i += 64) a.pairs[s0 + i] = pair_of(a, t[i]);
+}
+
+// one workgroup per read (a grid-stride walk over all reads: the long segments are few): WAVE_CAP < matches <= WG_CAP
+__global__ void __launch_bounds__(256) k3_sort_wg(K3Args a) {
+  extern __shared__ Key big[];
+  for (uint64_t r = blockIdx.x; r < a.n_reads; r += gridDim.x) {
+    const uint64_t s0 = a.offs[r], s1 = a.offs[r + 1];
+    const uint64_t m = s1 - s0;
+    if (m <= WAVE_CAP || m > WG_CAP) continue;  // uniform over the workgroup
+    uint32_t P = 2;
+    while (P < m) P <<= 1;
+    const double nh = (double)a.nk[r];
+    for (uint32_t i = threadIdx.x; i < P; i += 256) big[i] = i < m ? make_key(a, a.pairs[s0 + i], nh) : Key{~0ull, ~0ull};
+    __syncthreads();
+    for (uint32_t k = 2; k <= P; k <<= 1)
+      for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+        bitonic_step(big, P, k, j, threadIdx.x, 256);
+        __syncthreads();
+      }
+    for (uint32_t i = threadIdx.x; i < m; i += 256) a.pairs[s0 + i] = pair_of(a, big[i]);
+    __syncthreads();
+  }
+}
+
+}  // namespace
+
+uint32_t k3_scan_tiles_for(uint32_t n) { return (n + SCAN_TILE - 1) / SCAN_TILE; }
+
+// cnt[0 .. n_reads] must be zero on entry (it is again on exit); offs gets n_reads + 1 entries, offs[n_reads] = matches kept
+void launch_k3(const K3Args& a, uint64_t hits_hint, hipStream_t st) {
+  if (a.n_reads == 0) return;
+  const uint64_t work = hits_hint ? hits_hint : a.hit_cap;
+  const unsigned gblocks = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((work + 255) / 256, 16384));
+  hipLaunchKernelGGL(k3_count, dim3(gblocks), dim3(256), 0, st, a);
+  const uint32_t n = a.n_reads + 1, tiles = k3_scan_tiles_for(n);
+  hipLaunchKernelGGL(k3_scan_tiles, dim3(tiles), dim3(SCAN_THREADS), 0, st, a.cnt, a.offs, a.sums, n);
+  hipLaunchKernelGGL(k3_scan_sums, dim3(1), dim3(SCAN_THREADS), 0, st, a.sums, tiles);
+  hipLaunchKernelGGL(k3_scan_add, dim3(tiles), dim3(SCAN_THREADS), 0, st, a.offs, a.sums, n);
+  hipLaunchKernelGGL(k3_scatter, dim3(gblocks), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(k3_sort_wave, dim3((a.n_reads + 3) / 4), dim3(256), 0, st, a);
+  const unsigned wgb = (unsigned)std::min<uint32_t>(a.n_reads, 2048);
+  hipLaunchKernelGGL(k3_sort_wg, dim3(wgb), dim3(256), (size_t)WG_CAP * sizeof(Key), st, a);
+}
+
+}  // namespace kmcpg

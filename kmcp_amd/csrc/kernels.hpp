@@ -16,6 +16,9 @@ int launch_k2(const K2Args& a, int lpr, int npl, hipStream_t st);
 int launch_k2_split(const K2Args& a, int lpr, hipStream_t st);
 void launch_list_long(const int32_t* nk, uint32_t n_reads, int32_t split_min, uint32_t* list, uint32_t* meta, hipStream_t st);
 void launch_threshold_long(const K2Args& a, hipStream_t st);
+// K3: group + filter + order the hit list on the device (k3_finalize.hip); hits_hint = expected number of hits (grid sizing), 0 = hit_cap
+void launch_k3(const K3Args& a, uint64_t hits_hint, hipStream_t st);
+uint32_t k3_scan_tiles_for(uint32_t n);
 void launch_max_nk(const int32_t* nk, uint32_t n_reads, unsigned long long* out, hipStream_t st);
 void launch_repack(const uint8_t* src, uint8_t* dst, uint64_t n_rows, uint32_t row_bytes, uint32_t stride, uint32_t byte_off, uint32_t ncols, hipStream_t st);
 void launch_gather_rows(const uint8_t* rows, uint32_t stride, uint32_t row_bytes, const uint64_t* idx, uint64_t first, uint64_t n, uint8_t* out,

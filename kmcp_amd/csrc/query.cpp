@@ -212,7 +212,7 @@ int fpr_bound(kmcpg_db* db, double max_fpr, uint64_t max_kmers, hipStream_t st, 
   for (int n = 1; n <= want_n; n++) {
     const std::vector<double>& row = *F->ensure_row(n);
     int c = 0;
-    while (c <= n && !(row[(size_t)c] <= max_fpr)) c++;
+    while (c <= n && !(QueryFpr::value(row, n, c) <= max_fpr)) c++;
     t.h[n] = (uint16_t)c;  // n + 1: no count passes
   }
   db->fpr_bounds.push_back(t);
@@ -379,6 +379,47 @@ extern "C" int kmcpg_query_device(kmcpg_db* db, const uint8_t* d_seqs, const uin
   if (db->profiling) {
     HIPCHK(hipEventRecord(pev[2], st));
     db->ev_calls++;
+  }
+  if (int rc1 = wsg.finish()) return rc1;
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+// K3: the device half of finalize (k3_finalize.hip) — group by read, -T, per-query order.  Enqueue only.
+extern "C" int kmcpg_group_device(kmcpg_db* db, const kmcpg_hit* d_hits, const uint64_t* d_n_hits, uint64_t hit_cap, const int32_t* d_qkmers, uint32_t n_reads,
+                                  const kmcpg_params* params, kmcpg_pair* d_pairs, uint64_t* d_read_offs, void* stream) {
+  if (!db || !d_n_hits || !d_read_offs || (n_reads && !d_qkmers) || (hit_cap && (!d_hits || !d_pairs))) return kmcpg_fail(KMCPG_EINVAL, "null argument");
+  if (db->opts.device < 0 || !db->d_col_size) return kmcpg_fail(KMCPG_EDEVICE, "metadata-only handle (device -1): no GPU work possible");
+  std::lock_guard<std::mutex> g(db->mu);
+  KMCPG_USE_DEVICE(db);
+  const kmcpg_params p = params ? *params : default_params();
+  hipStream_t st = (hipStream_t)stream;
+  if (int rc0 = ws_begin(db, st)) return rc0;
+  WsGuard wsg{db, st};
+  if (db->w_fin_cnt.ensure((size_t)n_reads + 2) || db->w_fin_sums.ensure((size_t)k3_scan_tiles_for(n_reads + 1) + 1)) return kmcpg_fail(KMCPG_ENOMEM, "hipMalloc failed");
+  // counters of the reads + the word that counts hits naming a read / column that does not exist
+  HIPCHK(hipMemsetAsync(db->w_fin_cnt.p, 0, ((size_t)n_reads + 2) * sizeof(uint32_t), st));
+  K3Args a{};
+  a.hits = d_hits;
+  a.n_hits = (const unsigned long long*)d_n_hits;
+  a.hit_cap = hit_cap;
+  a.nk = d_qkmers;
+  a.n_reads = n_reads;
+  a.n_cols = (uint32_t)db->col_meta.size();
+  a.col_size = db->d_col_size;
+  a.min_tcov = p.min_tcov;
+  a.sort_mode = p.do_not_sort ? 3 : (p.sort_by == 1 ? 1 : (p.sort_by == 2 ? 2 : 0));
+  a.cnt = db->w_fin_cnt.p;
+  a.bad = db->w_fin_cnt.p + n_reads + 1;
+  a.offs = d_read_offs;
+  a.sums = db->w_fin_sums.p;
+  a.pairs = d_pairs;
+  if (n_reads == 0) HIPCHK(hipMemsetAsync(d_read_offs, 0, 2 * sizeof(uint64_t), st));
+  else {
+    launch_k3(a, 0, st);
+    // d_read_offs[n_reads + 1] = the bad-hit count (a 32-bit word widened on the device side of the copy: two words cleared first)
+    HIPCHK(hipMemsetAsync(d_read_offs + n_reads + 1, 0, sizeof(uint64_t), st));
+    HIPCHK(hipMemcpyAsync(d_read_offs + n_reads + 1, a.bad, sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
   }
   if (int rc1 = wsg.finish()) return rc1;
   HIPCHK(hipGetLastError());

@@ -16,7 +16,7 @@ EXPORTS = [
     "kmcpg_result_free", "kmcpg_query_device", "kmcpg_finalize", "kmcpg_open_synthetic", "kmcpg_plant",
     "kmcpg_read_rows", "kmcpg_block_info", "kmcpg_kmers_device", "kmcpg_plant_reads_device", "kmcpg_set_profiling",
     "kmcpg_last_timing", "kmcpg_open_devices", "kmcpg_build_db", "kmcpg_submit", "kmcpg_wait", "kmcpg_read_row_range", "kmcpg_timing_at", "kmcpg_last_gathered_bytes", "kmcpg_last_hash_bytes",
-    "kmcpg_db_ks", "kmcpg_open_paged", "kmcpg_paged_info", "kmcpg_exchange_info", "kmcpg_batch_hint",
+    "kmcpg_db_ks", "kmcpg_open_paged", "kmcpg_paged_info", "kmcpg_exchange_info", "kmcpg_batch_hint", "kmcpg_group_device", "kmcpg_finalize_grouped",
 ]
 
 
@@ -79,6 +79,7 @@ class BuildCol(C.Structure):
 
 
 HIT_DTYPE = np.dtype([("read", np.uint32), ("col", np.uint32), ("count", np.uint32)])
+PAIR_DTYPE = np.dtype([("col", np.uint32), ("count", np.uint32)])
 MATCH_DTYPE = np.dtype([("col", np.uint32), ("target_idx", np.uint32), ("gsize", np.uint64), ("mkmers", np.int32),
                         ("reserved", np.int32), ("fpr", np.float64), ("qcov", np.float64), ("tcov", np.float64),
                         ("jacc", np.float64)])
@@ -139,6 +140,8 @@ def load():
     L.kmcpg_query_device.argtypes = [vp, vp, vp, vp, vp, C.c_uint32, C.c_uint64, C.c_uint32, C.POINTER(Params), vp,
                                      C.c_uint64, vp, vp, vp, vp]
     L.kmcpg_finalize.argtypes = [vp, vp, C.c_uint64, vp, vp, C.c_uint32, C.POINTER(Params), C.POINTER(Result)]
+    L.kmcpg_group_device.argtypes = [vp, vp, vp, C.c_uint64, vp, C.c_uint32, C.POINTER(Params), vp, vp, vp]
+    L.kmcpg_finalize_grouped.argtypes = [vp, vp, vp, vp, vp, C.c_uint32, C.POINTER(Params), C.POINTER(Result)]
     L.kmcpg_plant.argtypes = [vp, C.c_uint32, vp, C.c_uint64]
     L.kmcpg_read_rows.argtypes = [vp, C.c_uint32, vp, C.c_uint64, vp]
     L.kmcpg_read_row_range.argtypes = [vp, C.c_uint32, C.c_uint64, C.c_uint64, vp]
@@ -378,6 +381,30 @@ class Database:
         m = int(r.match_offs[n]) if n else 0
         load().kmcpg_result_free(C.byref(r))
         return m
+
+    # ---- the host half split in two: K3 on the device (group, -T, order), expansion to Match records on the host ----------
+    def group_device(self, d_hits, d_n_hits, hit_cap, d_qkmers, n_reads, d_pairs, d_read_offs, params=None, stream=None):
+        """kmcpg_group_device on device pointers: hits as query_device left them -> (column, count) pairs grouped by read, filtered by
+        -T, ordered per read; d_read_offs needs n_reads + 2 uint64 words."""
+        p = params or default_params()
+        _check(load().kmcpg_group_device(self._h, d_hits, d_n_hits, hit_cap, d_qkmers, n_reads, C.byref(p), d_pairs, d_read_offs, stream))
+
+    def finalize_grouped(self, pairs, read_offs, qkmers, qlen, params=None, count_only=False):
+        """kmcpg_finalize_grouped: pairs uint32 [m, 2] (or PAIR_DTYPE [m]), read_offs uint64 [n + 2] as group_device wrote them."""
+        p = params or default_params()
+        pairs = np.ascontiguousarray(pairs)
+        read_offs = np.ascontiguousarray(read_offs, dtype=np.uint64)
+        qkmers = np.ascontiguousarray(qkmers, dtype=np.int32)
+        qlen = np.ascontiguousarray(qlen, dtype=np.int32)
+        assert pairs.dtype.itemsize in (4, 8) and len(read_offs) == len(qkmers) + 2
+        r = Result()
+        n = len(qkmers)
+        _check(load().kmcpg_finalize_grouped(self._h, pairs.ctypes.data, read_offs.ctypes.data, qkmers.ctypes.data, qlen.ctypes.data, n, C.byref(p), C.byref(r)))
+        if count_only:
+            m = int(r.match_offs[n]) if n else 0
+            load().kmcpg_result_free(C.byref(r))
+            return m
+        return _copy_result(r)
 
     # ---- bench / parity support -----------------------------------------------------------------------
     def read_row_range(self, block, first_row, out):
