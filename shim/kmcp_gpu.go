@@ -13,6 +13,10 @@
 // threads by tests/shim_replay.c (tests/test_gpu_shim_replay.py), which is compiled and run with every GPU test run.
 package cmd
 
+// Tree layout the #cgo lines assume (shim/build.sh puts the files there): this file and kmcp_gpu_test.go in
+// <kmcp source>/kmcp/cmd/, include/kmcp_gpu.h of this repository in <kmcp source>/include/; the library is found through
+// CGO_LDFLAGS="-L<this repository>/kmcp_amd -Wl,-rpath,<this repository>/kmcp_amd".
+
 /*
 #cgo CFLAGS: -I${SRCDIR}/../../include
 #cgo LDFLAGS: -lkmcpgpu
@@ -23,6 +27,7 @@ import "C"
 
 import (
 	"fmt"
+	"path/filepath"
 	"runtime"
 	"sync"
 	"unsafe"
@@ -310,4 +315,41 @@ func RunGPUEngine(sg *UnikIndexDBSearchEngine, db *GPUDB) {
 		wg.Wait()
 		sg.done <- 1
 	}()
+}
+
+// NewGPUSearchEngine takes the place of NewUnikIndexDBSearchEngine (util-db-search.go:222-584) for one database that is searched
+// on the GPU: search.go keeps talking to sg.InCh / sg.OutCh / sg.Wait() / sg.Close() and reading sg.DBs[0].Info (the
+// min-query-cov check :405-409, the k-mer sizes :790).  The UnikIndexDB it finds there is a stub that carries the parsed
+// __db.yml only: no index file is opened or mapped by Go, the matrices live in HBM behind `gdb`.
+// Wiring in search.go:400:
+//
+//	var sg *UnikIndexDBSearchEngine
+//	if os.Getenv("KMCP_GPU") != "" {
+//		var gdb *GPUDB
+//		sg, gdb, err = NewGPUSearchEngine(searchOpt, 0, dbDirs[0])
+//		if err == nil { defer gdb.Close() }
+//	} else {
+//		sg, err = NewUnikIndexDBSearchEngine(searchOpt, dbDirs...)
+//	}
+func NewGPUSearchEngine(opt SearchOptions, device int, dbPath string) (*UnikIndexDBSearchEngine, *GPUDB, error) {
+	info, err := UnikIndexDBInfoFromFile(filepath.Join(dbPath, dbInfoFile))
+	if err != nil {
+		return nil, nil, err
+	}
+	if err = info.Check(); err != nil {
+		return nil, nil, err
+	}
+	gdb, err := OpenGPUDB(dbPath, device)
+	if err != nil {
+		return nil, nil, err
+	}
+	// UnikIndexDB.Close (:1119-1150) closes InCh, waits for `done` and closes the (here: no) index files
+	stub := &UnikIndexDB{Options: opt, path: dbPath, Info: info, InCh: make(chan *Query), done: make(chan int, 1)}
+	stub.done <- 1
+	sg := &UnikIndexDBSearchEngine{Options: opt, DBs: []*UnikIndexDB{stub}, DBNames: []string{filepath.Base(dbPath)}}
+	sg.done = make(chan int)
+	sg.InCh = make(chan *Query, 2*GPUBatchSize)
+	sg.OutCh = make(chan *QueryResult, 2*GPUBatchSize)
+	RunGPUEngine(sg, gdb)
+	return sg, gdb, nil
 }

@@ -407,3 +407,11 @@ def test_kmcp_search_spelling_and_profile_contract(oracle_lib, tmp_path):
     got = [(m["query"], m["qlen"], m["qkmers"], m["hits"], m["target"], m["chunk_idx"], m["chunks"], m["gsize"], m["k"], m["mkmers"]) for m in ms]
     assert got == expect and len(got) > 500
     odb.close()
+
+
+def test_shim_fixture_through_kmcp_search(tmp_path):
+    """shim/testdata (the fixture of the Go-side test of the cgo binding, shim/kmcp_gpu_test.go): kmcp-search on the GPU prints
+    exactly the committed TSV — the file the Go test diffs its rows against (tests/test_shim_fixture_cpu.py ties it to the oracle)."""
+    fix = os.path.join(ROOT, "shim", "testdata")
+    got = run_cli(["-d", os.path.join(fix, "db"), os.path.join(fix, "reads.fq")], str(tmp_path / "o.tsv"))
+    assert got == open(os.path.join(fix, "expected.tsv")).read().split("\n")
