@@ -23,6 +23,7 @@
 #include <map>
 #include <memory>
 #include <mutex>
+#include <set>
 #include <string>
 #include <string_view>
 #include <thread>
@@ -876,6 +877,26 @@ int main(int argc, char** argv) {
   if (dbi.minimizer && !dbi.syncmer)
     warn("this is a minimizer database: the reference publishes no result for minimizer sketches to check against, so this mode is "
          "verified against a restatement of bio/sketches only (DESIGN.md section 2)");
+  if (verbose) {
+    // Narrow blocks (rows of up to 64 bytes: what `kmcp index -j 32` makes of a small database) cost one memory request per (k-mer,
+    // block) whatever their width; blocks that share NumSigs are laid side by side in GPU memory and served by ONE request.  Blocks
+    // with a NumSigs of their own cannot be: say so once, with the remedy (profiles/r04_narrow_rows.txt: ~3x).
+    std::set<uint64_t> sigs;
+    int narrow = 0;
+    for (int32_t b = 0; b < dbi.n_blocks; b++) {
+      uint64_t ns = 0;
+      uint32_t nc = 0, rb = 0, st = 0, cb = 0;
+      int32_t loc = 0;
+      if (kmcpg_block_info(db, (uint32_t)b, &ns, &nc, &rb, &st, &loc, &cb) == 0 && rb <= 64) {
+        narrow++;
+        sigs.insert(ns);
+      }
+    }
+    if (narrow > 1 && sigs.size() > 1)
+      info("  note: %zu distinct NumSigs over %d narrow blocks (rows <= 64 bytes): every k-mer costs %zu gathers; a database built with fewer, wider "
+           "blocks (`kmcp index -b`) or with equal NumSigs (kmcpg_build_db uniform_sigs = 1) is searched ~3x faster",
+           sigs.size(), narrow, sigs.size());
+  }
   if (o.min_qcov <= dbi.fpr)  // search.go:405-409
     die("query coverage threshold (%f) should not be smaller than FPR of single bloom filter of index database (%f)", o.min_qcov, dbi.fpr);
   if (verbose) {

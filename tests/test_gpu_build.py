@@ -154,3 +154,12 @@ def test_uniform_num_sigs_makes_blocks_groupable(oracle_lib, tmp_path, mode):
             if m["qcov"] >= 0.9:
                 assert int(m["col"]) in cols_p, (i, int(m["col"]))
     assert strong > 200
+    # kmcp-search says once at open when narrow blocks cannot share a gather, and what to do about it
+    import subprocess
+    from tests.test_gpu_cli import CLI, write_fastq
+    fq = str(tmp_path / "r.fq")
+    write_fastq(fq, [f"r{i}" for i in range(20)], reads[:20])
+    for db_dir, hint in ((plain, True), (uni, mode != 1)):
+        r = subprocess.run([CLI, "-d", os.path.dirname(db_dir), fq, "-o", str(tmp_path / "o.tsv")], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr
+        assert ("distinct NumSigs over 8 narrow blocks" in r.stderr) == hint, r.stderr

@@ -36,27 +36,29 @@ def _same(a, b):
     assert a.matches.tobytes() == b.matches.tobytes()
 
 
-def _family(O, tmp, n_cols, base_len, seed, extra_max):
+def _family(O, tmp, n_cols, base_len, seed, extra_max, second=0):
     """n_cols columns that all hold the k-mers of one sequence (+ a different number of private k-mers each: different sizes, so
-    tcov and jacc differ from column to column while mKmers ties abound), in blocks of 512 columns"""
+    tcov and jacc differ from column to column while mKmers ties abound), in blocks of 512 columns; `second` more columns hold a
+    second sequence (reads from it have that many matches)"""
     rng = np.random.default_rng(seed)
-    base = synth.random_genomes(1, base_len, seed=seed)[0]
+    bases = synth.random_genomes(2, base_len, seed=seed)
     cfg = O.sketch_cfg(k=21)
-    shared = O.sort_unique(O.generate_kmers(base, cfg))
     cols = []
-    for c in range(n_cols):
-        drop = rng.random(len(shared)) < (0.0 if c % 7 == 0 else rng.uniform(0, 0.3))  # some relatives lack part of the sequence
-        extra = rng.integers(1, 2**63, size=int(rng.integers(0, extra_max)), dtype=np.int64).astype(np.uint64)
-        cols.append((f"c{c}", base_len, c % 10, 10, O.sort_unique(np.concatenate([shared[~drop], extra]))))
+    for fam, (base, ncol) in enumerate(zip(bases, (n_cols, second))):
+        shared = O.sort_unique(O.generate_kmers(base, cfg))
+        for c in range(ncol):
+            drop = rng.random(len(shared)) < (0.0 if c % 7 == 0 else rng.uniform(0, 0.3))  # some relatives lack part of the sequence
+            extra = rng.integers(1, 2**63, size=int(rng.integers(0, extra_max)), dtype=np.int64).astype(np.uint64)
+            cols.append((f"f{fam}c{c}", base_len, c % 10, 10, O.sort_unique(np.concatenate([shared[~drop], extra]))))
     db_dir = O.build_db(str(tmp), cfg, cols, num_hashes=1, fpr=0.3, threads=8, block_size=512)
-    reads = synth.sample_reads([base], 300, 150, sub_rate=0.01, seed=seed + 1, frac_random=0.1)
+    reads = synth.sample_reads(bases if second else bases[:1], 300, 150, sub_rate=0.01, seed=seed + 1, frac_random=0.1)
     return db_dir, reads
 
 
 def test_device_finalize_equals_host_finalize_and_the_oracle(oracle_lib, tmp_path):
     from kmcp_amd import Database, default_params
     O = oracle_lib
-    db_dir, reads = _family(O, tmp_path / "db", 700, 4000, seed=31, extra_max=3000)  # up to 700 matches per read: wave and workgroup sorts
+    db_dir, reads = _family(O, tmp_path / "db", 700, 4000, seed=31, extra_max=3000, second=90)  # 700 / 90 matches per read: workgroup and wave sorts
     odb = O.OracleDB(db_dir)
     try:
         with Database.open(db_dir, device=0) as dev, Database.open(db_dir, device=0) as host:
@@ -72,7 +74,7 @@ def test_device_finalize_equals_host_finalize_and_the_oracle(oracle_lib, tmp_pat
                     per_read = np.diff(a.offs.astype(np.int64))
                     assert per_read.max() > 512 and np.count_nonzero((per_read > 1) & (per_read <= 512)) > 20, (per_read.max(), n)
             # paired reads, --try-se retries (the retry lane runs K3 too)
-            reads2 = synth.sample_reads([synth.random_genomes(1, 4000, seed=31)[0]], 300, 150, sub_rate=0.01, seed=77, frac_random=0.5)
+            reads2 = synth.sample_reads(synth.random_genomes(2, 4000, seed=31), 300, 150, sub_rate=0.01, seed=77, frac_random=0.5)
             pe = dict(try_se=1, fpr_buf_size=499)
             a = dev.search(reads, reads2, params=default_params(**pe))
             with host_finalize():

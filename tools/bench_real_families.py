@@ -105,13 +105,61 @@ def main():
                      algorithmic_bytes=alg, gathered_bytes=gathered, gathered_over_algorithmic=gathered / alg, effective_gbps=alg / (k2 * 1e-3) / 1e9,
                      achieved_gbps=gathered / (k2 * 1e-3) / 1e9, k2_ms_prune_off=k2_np, gathered_bytes_prune_off=gathered_np,
                      gathered_over_algorithmic_prune_off=gathered_np / alg, achieved_gbps_prune_off=gathered_np / (k2_np * 1e-3) / 1e9)
-            del d_hits
+            # K3 alone: the hit list of the last launch grouped by read, filtered, ordered on the device
+            d_pairs = torch.empty((n_hits + 16, 2), dtype=torch.int32, device=dev)
+            d_roffs = torch.zeros(B + 2, dtype=torch.int64, device=dev)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            k3 = []
+            for _ in range(3):
+                e0.record()
+                db.group_device(d_hits.data_ptr(), d_cnt.data_ptr(), cap, d_qk.data_ptr(), B, d_pairs.data_ptr(), d_roffs.data_ptr(), params=params,
+                                stream=torch.cuda.current_stream(dev).cuda_stream)
+                e1.record()
+                torch.cuda.synchronize()
+                k3.append(e0.elapsed_time(e1))
+            r.update(k3_ms=min(k3), k3_kept=int(d_roffs[B].item()))
+            del d_hits, d_pairs
             torch.cuda.empty_cache()
             db.search_packed_count(h_reads, h_offs, params=params)  # sizes staging and hit buffers
+            ts = []
+            for _ in range(3):
+                t0 = time.time()
+                nm = db.search_packed_count(h_reads, h_offs, params=params)
+                ts.append(time.time() - t0)
+            dt = min(ts)
+            r.update(search_batch_s=dt, search_batch_reads_per_s=B / dt, search_batch_s_all=ts, matches=nm, matches_per_read=nm / B)
+            # ... and pipelined: batches through kmcpg_submit / kmcpg_wait from two host threads (what kmcp-search does)
+            import threading
+            NB = 8
+
+            def pump(t_):
+                tk = []
+                for i in range(t_, NB, 2):
+                    if len(tk) == 2:
+                        db.wait(tk.pop(0), count_only=True)
+                    tk.append(db.submit(h_reads, h_offs, params=params))
+                while tk:
+                    db.wait(tk.pop(0), count_only=True)
+            th = [threading.Thread(target=pump, args=(t_,)) for t_ in range(2)]
             t0 = time.time()
-            nm = db.search_packed_count(h_reads, h_offs, params=params)
-            dt = time.time() - t0
-            r.update(search_batch_s=dt, search_batch_reads_per_s=B / dt, matches=nm, matches_per_read=nm / B)
+            [x.start() for x in th]
+            [x.join() for x in th]
+            dtp = (time.time() - t0) / NB
+            r.update(pipelined_s_per_batch=dtp, pipelined_reads_per_s=B / dtp)
+        # the round-3 host half on the same batch (KMCPG_DEVICE_FINALIZE=0 is read when a handle makes its first search)
+        os.environ["KMCPG_DEVICE_FINALIZE"] = "0"
+        try:
+            with Database.open(db_dir, device=0) as db2:
+                db2.search_packed_count(h_reads, h_offs, params=params)
+                ts = []
+                for _ in range(3):
+                    t0 = time.time()
+                    nm2 = db2.search_packed_count(h_reads, h_offs, params=params)
+                    ts.append(time.time() - t0)
+                assert nm2 == nm
+                r.update(search_batch_host_finalize_s=min(ts), search_batch_host_finalize_reads_per_s=B / min(ts))
+        finally:
+            os.environ.pop("KMCPG_DEVICE_FINALIZE", None)
         # end to end through the CLI: FASTQ in, TSV out
         tsv = os.path.join(a.out_dir, f"mode{mode}.tsv")
         t0 = time.time()
