@@ -83,7 +83,7 @@ WORKLOADS = {
     # are unrelated genomes.  ~8 000 sketch k-mers per query: the sort+unique path and 16 counter planes.
     "config2_genome_search": dict(k=21, num_hashes=3, fpr=0.001, n_blocks=8, cols_per_block=6256, num_sigs=431000, sigs_step=13, kmers_per_col=10000,
                                   scale=1000, batch_reads=128, read_len=4000000, relatives=10, rel_step=0.005, sub_rate=0.005, distinct_batches=2,
-                                  min_qcov=0.4, sort_by=2, unit="queries/s", cpu_sample_start=16, kernel="k2_cobs (16 planes) / k1 segments",
+                                  min_qcov=0.4, sort_by=2, unit="queries/s", cpu_sample_start=16, kernel="k2_cobs<64,16,true,true,8> (SPLIT form; k1_kmers_wg<0> + k1_seg_hash beside it)",
                                   metric="genomes/sec searched (4-Mbp assemblies, FracMinHash scale 1000, k=21, 3 hashes, -t 0.4) vs a 50 k-reference index",
                                   name="genome search, synthetic: 8 blocks x 6256 cols x 431 k sigs (2.7 GB), 3 hashes, fpr 0.001, scale 1000; "
                                        "queries = 4-Mbp genomes with 10 relatives each in the index"),
@@ -93,13 +93,13 @@ WORKLOADS = {
     # differs from chunk to chunk, the block takes the maximum: index.go:936-946) => sigs_step > 0, 39-byte rows, nothing grouped.
     "config4_hifi": dict(k=21, num_hashes=1, fpr=0.3, n_blocks=32, cols_per_block=312, num_sigs=300000, sigs_step=7, kmers_per_col=100000, syncmer_s=11,
                          batch_reads=16384, read_len=("normal", 10000, 2000, 2000, 20000), sub_rate=0.001, unit="reads/s", cpu_sample_start=64,
-                         kernel="k2_cobs<4,16> / k1_windows_wave<2>",
+                         kernel="k2_cobs<4,16,false,false,8> (k1_windows_wave<2> beside it)",
                          metric="reads/sec searched (HiFi ~10 kb, Closed Syncmer s=11, k=21) vs a 10k-chunk index",
                          name="HiFi synthetic: 32 blocks x 312 cols x ~300 k sigs (0.37 GB), closed syncmer s=11 k=21, reads ~N(10 kb, 2 kb) 0.1 % errors"),
     # ... and the same database built with kmcpg_build_cfg.uniform_sigs = 1 (one NumSigs for all blocks: one 1248-byte gather per k-mer)
     "config4_hifi_uniform_sigs": dict(k=21, num_hashes=1, fpr=0.3, n_blocks=32, cols_per_block=312, num_sigs=300000, sigs_step=0, kmers_per_col=100000,
                                       syncmer_s=11, batch_reads=16384, read_len=("normal", 10000, 2000, 2000, 20000), sub_rate=0.001, unit="reads/s",
-                                      cpu_sample_start=64, kernel="k2_cobs<64,16> + k2_cobs<16,16> / k1_windows_wave<2>",
+                                      cpu_sample_start=64, kernel="k2_cobs<64,16,false,false,8> + k2_cobs<16,16,false,false,8> (k1_windows_wave<2> beside them)",
                                       metric="reads/sec searched (HiFi ~10 kb, Closed Syncmer s=11, k=21) vs a 10k-chunk index with one NumSigs",
                                       name="HiFi synthetic, blocks with equal NumSigs (grouped rows): 32 x 312 cols x 300 k sigs, closed syncmer s=11 k=21"),
 }
@@ -166,7 +166,7 @@ def make_batch(dev, wl, n_reads, n_cols, seed, plant):
     total, maxlen = int(offs[-1].item()), int(lens.max().item())
     code = torch.randint(0, 4, (total,), generator=g, device=dev, dtype=torch.uint8)
     cols = torch.randint(0, n_cols, (n_reads,), generator=g, device=dev).to(torch.int32)
-    is_random = torch.rand(n_reads, generator=g, device=dev) < 0.10
+    is_random = torch.rand(n_reads, generator=g, device=dev) < float(os.environ.get("KMCP_BENCH_RANDOM_FRAC", "0.10"))  # (experiments: 1 = no read has a home)
     cols[is_random] = -1  # 0xFFFFFFFF: not planted
     R = int(wl.get("relatives", 1))
     for r in range(R):
@@ -184,9 +184,19 @@ def make_batch(dev, wl, n_reads, n_cols, seed, plant):
         q2 = q.view(n_reads, maxlen)
         q = torch.where(rc[:, None], 3 - q2.flip(1), q2).contiguous().view(-1)
     else:
-        o = offs.cpu().tolist()
-        for i in torch.nonzero(rc).flatten().cpu().tolist():
-            q[o[i]:o[i + 1]] = 3 - q[o[i]:o[i + 1]].flip(0)
+        # ragged reads: position p of a reverse-complemented read i takes 3 - base at offs[i] + offs[i+1] - 1 - p (one gather per
+        # 2^27 positions; a loop over the reads would be tens of thousands of tiny launches)
+        out = torch.empty_like(q)
+        for a in range(0, total, 1 << 27):
+            b = min(total, a + (1 << 27))
+            pos = torch.arange(a, b, device=dev, dtype=torch.int64)
+            rid = torch.searchsorted(offs, pos, right=True) - 1
+            flip = rc[rid]
+            src = torch.where(flip, offs[rid] + offs[rid + 1] - 1 - pos, pos)
+            v = q[src]
+            out[a:b] = torch.where(flip, 3 - v, v)
+            del pos, rid, flip, src, v
+        q = out
     bt = Batch()
     bt.reads = (acgt[q.long()] if q.numel() < (1 << 28) else torch.cat([acgt[q[a:a + (1 << 28)].long()] for a in range(0, q.numel(), 1 << 28)])).contiguous()
     bt.offs, bt.cols, bt.total, bt.maxlen, bt.n = offs.contiguous(), cols.contiguous(), total, maxlen, n_reads

@@ -85,7 +85,7 @@ const char* exchange_note(const Exchange* x) { return x ? x->note.c_str() : "hos
 
 // Brings parts[r] (count[r] bytes at device pointer src[r] on devices[r]) together on devices[0] and copies the concatenation to
 // `dst` (pinned host memory, sum of the counts) — rank order.  Every src[r] must be complete (its kernels waited for).
-int exchange_gather(Exchange* x, const std::vector<const void*>& src, const std::vector<uint64_t>& bytes, uint8_t* dst) {
+int exchange_gather(Exchange* x, const std::vector<const void*>& src, const std::vector<uint64_t>& bytes, uint8_t* dst, const ExchangeOnDevice& on_device) {
   const int n = (int)x->devices.size();
   if ((int)src.size() != n || (int)bytes.size() != n) return kmcpg_fail(KMCPG_EINVAL, "exchange: %zu parts for %d devices", src.size(), n);
   uint64_t total = 0;
@@ -93,7 +93,8 @@ int exchange_gather(Exchange* x, const std::vector<const void*>& src, const std:
   if (total == 0) return 0;
   std::lock_guard<std::mutex> g(x->mu);
   HIPCHK(hipSetDevice(x->devices[0]));
-  if (x->d_gather.ensure(total + 16)) return kmcpg_fail(KMCPG_ENOMEM, "hipMalloc failed");
+  if (x->d_gather.ensure(total + 32)) return kmcpg_fail(KMCPG_ENOMEM, "hipMalloc failed");
+  uint8_t* const d_cat = x->d_gather.p + 16;  // 16 bytes in front of the concatenation belong to on_device (a count word)
   auto chk = [&](ncclResult_t r, const char* what) { return r == 0 ? 0 : kmcpg_fail(KMCPG_EDEVICE, "RCCL %s: %s", what, x->api.GetErrorString(r)); };
   if (int rc = chk(x->api.GroupStart(), "ncclGroupStart")) return rc;
   int rc = 0;
@@ -106,15 +107,22 @@ int exchange_gather(Exchange* x, const std::vector<const void*>& src, const std:
     rc = chk(x->api.Send(src[r], bytes[r], kNcclUint8, 0, x->comms[(size_t)r], x->streams[(size_t)r]), "ncclSend");
     if (rc) break;
     (void)hipSetDevice(x->devices[0]);
-    rc = chk(x->api.Recv(x->d_gather.p + off, bytes[r], kNcclUint8, r, x->comms[0], x->streams[0]), "ncclRecv");
+    rc = chk(x->api.Recv(d_cat + off, bytes[r], kNcclUint8, r, x->comms[0], x->streams[0]), "ncclRecv");
     off += bytes[r];
   }
   const int rc_end = chk(x->api.GroupEnd(), "ncclGroupEnd");
   if (rc == 0) rc = rc_end;
   if (rc) return rc;
   HIPCHK(hipSetDevice(x->devices[0]));
-  HIPCHK(hipMemcpyAsync(dst, x->d_gather.p, total, hipMemcpyDeviceToHost, x->streams[0]));
-  HIPCHK(hipStreamSynchronize(x->streams[0]));
+  if (on_device) {
+    rc = on_device(d_cat, total, (void*)x->streams[0]);
+    const hipError_t e = hipStreamSynchronize(x->streams[0]);
+    if (rc) return rc;
+    HIPCHK(e);
+  } else {
+    HIPCHK(hipMemcpyAsync(dst, d_cat, total, hipMemcpyDeviceToHost, x->streams[0]));
+    HIPCHK(hipStreamSynchronize(x->streams[0]));
+  }
   for (int r = 1; r < n; r++) {  // the senders' buffers are free again once their streams have drained
     HIPCHK(hipSetDevice(x->devices[r]));
     HIPCHK(hipStreamSynchronize(x->streams[(size_t)r]));

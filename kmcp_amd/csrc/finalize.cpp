@@ -519,6 +519,9 @@ extern "C" int kmcpg_finalize_grouped(const kmcpg_db* db, const kmcpg_pair* pair
   if (read_offs[0] != 0) return kmcpg_fail(KMCPG_EINVAL, "read_offs[0] must be 0");
   if (read_offs[(size_t)n_reads + 1] != 0)
     return kmcpg_fail(KMCPG_EINVAL, "%llu hit(s) named a read or column that does not exist", (unsigned long long)read_offs[(size_t)n_reads + 1]);
+  const bool timing = getenv("KMCPG_FIN_TIMING") != nullptr;
+  auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  const double t_0 = now();
   std::unique_ptr<ResultOwner, OwnerReturn> o(take_owner());
   o->qlen.assign(qlen, qlen + n_reads);
   o->qkmers.assign(qkmers, qkmers + n_reads);
@@ -526,6 +529,7 @@ extern "C" int kmcpg_finalize_grouped(const kmcpg_db* db, const kmcpg_pair* pair
   o->ksize.assign(n_reads, k_used);
   o->matches.resize(n_pairs);
   o->offs.resize((size_t)n_reads + 1);
+  const double t_1 = now();
   WorkerPool& pool = WorkerPool::get();
   // contiguous ranges of reads holding ~64 k matches each (the offsets are at hand: a binary search per boundary)
   const uint64_t per_range = 65536;
@@ -566,7 +570,12 @@ extern "C" int kmcpg_finalize_grouped(const kmcpg_db* db, const kmcpg_pair* pair
       }
       const uint64_t m = s1 - s0;
       const bool host_sort = m > (uint64_t)K3_WG_CAP;  // K3 left this segment unordered
-      if (host_sort && tmp.size() < m) tmp.resize(m);
+      // A handful of matches (the usual read): plain stores, straight into the result.  Many: the records are built in a scratch
+      // array and then written in one tight loop of streaming stores — streaming stores interleaved with the loads and divisions
+      // of the loop below leave half-filled write-combining buffers behind, which the memory system pays for with partial
+      // writes (measured: 0.5 us per record instead of 0.03).
+      const bool via_tmp = host_sort || m > 8;
+      if (via_tmp && tmp.size() < m) tmp.resize(m);
       const uint64_t first = pos;
       uint64_t kept = 0;
       // --keep-top-scores while the records go out: matches arrive by descending score
@@ -603,6 +612,9 @@ extern "C" int kmcpg_finalize_grouped(const kmcpg_db* db, const kmcpg_pair* pair
           tmp[kept++] = mm;
           continue;
         }
+        if (via_tmp) tmp[kept] = mm;
+        else mbase[first + kept] = mm;
+        kept++;
         if (top) {
           const double score = p.sort_by == 1 ? mm.tcov : (p.sort_by == 2 ? mm.jacc : mm.qcov);
           if (score < pscore) {
@@ -611,9 +623,9 @@ extern "C" int kmcpg_finalize_grouped(const kmcpg_db* db, const kmcpg_pair* pair
             pscore = score;
           }
         }
-        store_record(mbase + first + kept, mm);
-        kept++;
       }
+      if (via_tmp && !host_sort)
+        for (uint64_t i = 0; i < kept; i++) store_record(mbase + first + i, tmp[i]);
       if (host_sort && kept) {
         const int sb = p.sort_by;
         if (!p.do_not_sort) std::sort(tmp.begin(), tmp.begin() + (ptrdiff_t)kept, [sb](const kmcpg_match& x, const kmcpg_match& y) { return match_less(x, y, sb); });
@@ -642,6 +654,8 @@ extern "C" int kmcpg_finalize_grouped(const kmcpg_db* db, const kmcpg_pair* pair
     records_visible();
     wcount[(size_t)w] = pos - pos0;
   });
+  const double t_2 = now();
+  if (timing) fprintf(stderr, "finalize_grouped: prep %.2f workers %.2f ms (R %d, %llu pairs)\n", t_1 - t_0, t_2 - t_1, R, (unsigned long long)n_pairs);
   if (bad.load()) return kmcpg_fail(KMCPG_EINVAL, "grouped hit list: offsets or columns out of range");
   uint64_t total = 0;
   for (int w = 0; w < R; w++) {  // close the gaps the filters / --keep-top-scores left between the ranges

@@ -579,7 +579,31 @@ int finish_raw(kmcpg_ticket* t, kmcpg_result* out) {
       n_hits += c;
     }
     Lane* L0 = t->parts[0].lane;
-    if (hipSetDevice(t->parts[0].shard->opts.device) != hipSuccess || L0->h_hits.ensure(n_hits + 1)) return kmcpg_fail(KMCPG_ENOMEM, "hipHostMalloc failed");
+    kmcpg_db* sh0 = t->parts[0].shard;
+    if (hipSetDevice(sh0->opts.device) != hipSuccess) return kmcpg_fail(KMCPG_EDEVICE, "hipSetDevice failed");
+    if (sh0->async->device_finalize && t->n && n_hits) {
+      // K3 on the gathering GPU, over the concatenation of all shards' lists (every shard knows every column's k-mer count):
+      // grouped by read, filtered by -T, in final order; 8 bytes per match and the reads' offsets come to the host
+      if (L0->d_pairs.ensure(n_hits) || L0->d_roffs.ensure((size_t)t->n + 2) || L0->h_pairs.ensure(n_hits) || L0->h_roffs.ensure((size_t)t->n + 2))
+        return kmcpg_fail(KMCPG_ENOMEM, "hipMalloc failed");
+      uint64_t* h_word = L0->h_cnt.p;  // pinned; the lane's counters have been read by collect()
+      h_word[0] = n_hits;
+      const kmcpg_params p = t->p;
+      const uint32_t n = t->n;
+      int rc = exchange_gather(x, src, bytes, nullptr, [&](uint8_t* d_cat, uint64_t, void* st) -> int {
+        uint64_t* d_word = (uint64_t*)(d_cat - 16);
+        HIPCHK(hipMemcpyAsync(d_word, h_word, sizeof(uint64_t), hipMemcpyHostToDevice, (hipStream_t)st));
+        int rc2 = kmcpg_group_device(sh0, (const kmcpg_hit*)d_cat, d_word, n_hits, L0->d_qk.p, n, &p, L0->d_pairs.p, L0->d_roffs.p, st);
+        if (rc2) return rc2;
+        HIPCHK(hipMemcpyAsync(L0->h_roffs.p, L0->d_roffs.p, ((size_t)n + 2) * sizeof(uint64_t), hipMemcpyDeviceToHost, (hipStream_t)st));
+        // (at most n_hits pairs survive -T; h_roffs says how many)
+        HIPCHK(hipMemcpyAsync(L0->h_pairs.p, L0->d_pairs.p, n_hits * sizeof(kmcpg_pair), hipMemcpyDeviceToHost, (hipStream_t)st));
+        return 0;
+      });
+      if (rc) return rc;
+      return kmcpg_finalize_grouped(t->db, L0->h_pairs.p, L0->h_roffs.p, L0->h_qk.p, L0->h_ql.p, t->n, &t->p, out);
+    }
+    if (L0->h_hits.ensure(n_hits + 1)) return kmcpg_fail(KMCPG_ENOMEM, "hipHostMalloc failed");
     int rc = exchange_gather(x, src, bytes, (uint8_t*)L0->h_hits.p);
     if (rc) return rc;
     hits = L0->h_hits.p;

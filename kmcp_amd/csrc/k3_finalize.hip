@@ -4,7 +4,8 @@
 // sort of handleQuerySingleDB (:260-283, Matches.Less / SortByTCov / SortByJacc :105-145).  K2 emits (read, column, count) tuples in
 // no particular order; until round 4 the host partitioned them by read, filtered and sorted them (finalize.cpp) — on databases full of
 // close relatives (hundreds of matches per read) that host half was 3x the time of the kernels.  Here:
-//   k3_count    per surviving hit (count / size >= -T in float64, the reference's own division): one atomic on its read's counter
+//   k3_count    surviving hits (count / size >= -T in float64, the reference's own division) per read: one atomic per RUN of hits
+//               of one read (K2 emits them side by side)
 //   k3_scan_*   exclusive scan of the counters -> CSR offsets of the reads (uint64)
 //   k3_scatter  (column, count) pairs into their read's segment
 //   k3_sort_*   every segment ordered as the reference orders a query's matches; a wave per 16 reads for segments of up to 512
@@ -44,15 +45,44 @@ __device__ __forceinline__ bool passes(const K3Args& a, const kmcpg_hit& h) {
   return (double)h.count / (double)a.col_size[h.col] >= a.min_tcov;
 }
 
+// Hits come in runs: K2 emits the hits of one (read, slot) unit side by side (k2_cobs.hip, wave-aggregated emission), so 64
+// consecutive hits name a handful of reads — dozens of hits each on a database of close relatives.  A wave therefore finds the
+// runs of equal reads among its 64 hits (ballots), and only the first lane of a run touches the read's counter, with the length of
+// the run: 26.6 M hits of a 203-matches-per-read batch cost ~4 M atomics instead of 26.6 M (twice: count, then scatter).
+struct Run {
+  bool pass;      // this lane's hit takes part
+  bool head;      // ... and is the first of its run
+  int hpos;       // lane of the run's first hit
+  uint32_t len;   // hits in the run (valid on every lane of it)
+};
+__device__ __forceinline__ Run find_run(bool pass, uint32_t read, int lane) {
+  const uint32_t key = pass ? read : 0xffffffffu;  // (a read index is below 2^32 - 1: n_reads is a uint32)
+  const uint32_t prev = __shfl_up(key, 1);
+  Run r;
+  r.pass = pass;
+  r.head = pass && (lane == 0 || key != prev);
+  const uint64_t H = __ballot(r.head), P = __ballot(pass);
+  const uint64_t upto = lane == 63 ? ~0ull : ((2ull << lane) - 1ull);
+  const uint64_t hm = H & upto;
+  r.hpos = hm ? 63 - __clzll((long long)hm) : 0;
+  // the run ends before the next head or the next hit that does not take part
+  const uint64_t above = (r.hpos == 63) ? 0ull : ((H | ~P) & ~((2ull << r.hpos) - 1ull));
+  const int end = above ? __ffsll((long long)above) - 1 : 64;
+  r.len = (uint32_t)(end - r.hpos);
+  return r;
+}
+
 __global__ void k3_count(K3Args a) {
   const uint64_t n = n_hits_of(a);
-  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
-    const kmcpg_hit h = a.hits[i];
-    if (h.read >= a.n_reads || h.col >= a.n_cols) {
-      atomicAdd(a.bad, 1u);
-      continue;
-    }
-    if (passes(a, h)) atomicAdd(&a.cnt[h.read], 1u);
+  const int lane = threadIdx.x & 63;
+  const uint64_t step = (uint64_t)gridDim.x * blockDim.x;
+  for (uint64_t i0 = (uint64_t)blockIdx.x * blockDim.x + (threadIdx.x & ~63u); i0 < n; i0 += step) {  // wave-uniform trip count
+    const uint64_t i = i0 + (uint64_t)lane;
+    kmcpg_hit h{0xffffffffu, 0, 0};
+    if (i < n) h = a.hits[i];
+    if (i < n && (h.read >= a.n_reads || h.col >= a.n_cols)) atomicAdd(a.bad, 1u);
+    const Run r = find_run(i < n && passes(a, h), h.read, lane);
+    if (r.head) atomicAdd(&a.cnt[h.read], r.len);
   }
 }
 
@@ -123,11 +153,17 @@ __global__ void __launch_bounds__(SCAN_THREADS) k3_scan_add(uint64_t* __restrict
 // segments are filled from the back (the counter of a read runs down to zero): the order inside a segment is settled by the sort
 __global__ void k3_scatter(K3Args a) {
   const uint64_t n = n_hits_of(a);
-  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
-    const kmcpg_hit h = a.hits[i];
-    if (!passes(a, h)) continue;
-    const uint32_t left = atomicSub(&a.cnt[h.read], 1u);
-    a.pairs[a.offs[h.read] + left - 1] = kmcpg_pair{h.col, h.count};
+  const int lane = threadIdx.x & 63;
+  const uint64_t step = (uint64_t)gridDim.x * blockDim.x;
+  for (uint64_t i0 = (uint64_t)blockIdx.x * blockDim.x + (threadIdx.x & ~63u); i0 < n; i0 += step) {
+    const uint64_t i = i0 + (uint64_t)lane;
+    kmcpg_hit h{0xffffffffu, 0, 0};
+    if (i < n) h = a.hits[i];
+    const Run r = find_run(i < n && passes(a, h), h.read, lane);
+    uint32_t left = 0;
+    if (r.head) left = atomicSub(&a.cnt[h.read], r.len);  // the run takes places left - len .. left - 1 of its read's segment
+    left = __shfl(left, r.hpos);
+    if (r.pass) a.pairs[a.offs[h.read] + left - 1 - (uint32_t)(lane - r.hpos)] = kmcpg_pair{h.col, h.count};
   }
 }
 
