@@ -232,6 +232,17 @@ static Options parse_args(int argc, char** argv) {
 // ------------------------------------------------------------------------------------------------
 // pipeline
 // ------------------------------------------------------------------------------------------------
+// one 64-bit word per (query, column, count) tuple, summed mod 2^64 over a run: bench.py's hits_checksum (kmcp_amd/dist.py) in C++
+static inline uint64_t tuple_mix(uint64_t query, uint32_t col, uint32_t count) {
+  uint64_t x = query * 0x9E3779B97F4A7C15ULL + (uint64_t)col * 0xC2B2AE3D27D4EB4FULL + (uint64_t)count * 0x165667B19E3779F9ULL;
+  x ^= x >> 30;
+  x *= 0xBF58476D1CE4E5B9ULL;
+  x ^= x >> 27;
+  x *= 0x94D049BB133111EBULL;
+  x ^= x >> 31;
+  return x;
+}
+
 struct Batch {
   uint64_t seq = 0;  // position in the input: the writer emits batches in this order
   uint64_t first_idx = 0;
@@ -1032,6 +1043,7 @@ int main(int argc, char** argv) {
   });
 
   double t_gpu = 0, t_fmt = 0, t_read_wait = 0;  // seconds spent inside libkmcpgpu / formatting+writing / waiting for input
+  uint64_t sum_matches = 0, sum_check = 0;       // matches of the run and their order-independent checksum (log line below)
   // two searchers: libkmcpgpu serialises their GPU halves and runs the host half (thresholds, FPR, sorting) outside that lock,
   // so one batch is finalized while the next one's kernels run
   const int n_search = 2;
@@ -1042,6 +1054,7 @@ int main(int argc, char** argv) {
     searchers.emplace_back([&] {
       std::unique_ptr<Batch> b;
       double my_gpu = 0, my_wait = 0;
+      uint64_t my_sum = 0, my_matches = 0;
       for (;;) {
         const auto tw = std::chrono::steady_clock::now();
         if (!q_in.pop(&b)) break;
@@ -1051,10 +1064,19 @@ int main(int argc, char** argv) {
                                     (uint32_t)b->size(), &params, &b->res);
         if (rc != 0) die("%s", kmcpg_last_error());
         my_gpu += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        if (verbose) {  // order-independent checksum of the (query, column, mKmers) tuples: the same on 1, 2, 4, 8 GPUs
+          const kmcpg_result& r = b->res;
+          for (uint32_t i = 0; i < r.n_reads; i++)
+            for (uint64_t j = r.match_offs[i]; j < r.match_offs[i + 1]; j++)
+              my_sum += tuple_mix(b->first_idx + i, r.matches[j].col, (uint32_t)r.matches[j].mkmers);
+          my_matches += r.match_offs[r.n_reads];
+        }
         q_out.push(std::move(b));
       }
       {
         std::lock_guard<std::mutex> g(t_mu);
+        sum_matches += my_matches;
+        sum_check += my_sum;
         t_gpu += my_gpu;
         t_read_wait += my_wait;
       }
@@ -1171,6 +1193,8 @@ int main(int argc, char** argv) {
     info("done searching (pipeline: %.3f s in the GPU library, %.3f s formatting/writing, %.3f s waiting for the reader; reader: %.3f s parsing, %.3f s "
          "blocked; %.3f s before the search started)",
          t_gpu, t_fmt, t_read_wait, t_reader_total - t_reader_blocked, t_reader_blocked, std::chrono::duration<double>(t_search - t_start).count());
+    info("matches: %llu, checksum %016llx (order-independent over (queryIdx, column, mKmers): the same on any number of GPUs)", (unsigned long long)sum_matches,
+         (unsigned long long)sum_check);
     if (o.out_file != "-") info("search results saved to: %s", o.out_file.c_str());
   }
   // trailer read by `kmcp profile` (profile.go:1945-1951)

@@ -246,24 +246,39 @@ __global__ void __launch_bounds__(256) k3_sort_wave(K3Args a) {
   }
 }
 
-// one workgroup per read (a grid-stride walk over all reads: the long segments are few): WAVE_CAP < matches <= WG_CAP
+// Segments of WAVE_CAP < matches <= WG_CAP: one workgroup sorts one of them in LDS.  They are rare, so the workgroups first LOOK
+// for them 256 reads at a time (one coalesced load of the offsets per thread; a walk of one read per iteration with its two dependent
+// loads made a million-read batch wait 0.5 ms for nothing) and sort what they find.
 __global__ void __launch_bounds__(256) k3_sort_wg(K3Args a) {
-  extern __shared__ Key big[];
-  for (uint64_t r = blockIdx.x; r < a.n_reads; r += gridDim.x) {
-    const uint64_t s0 = a.offs[r], s1 = a.offs[r + 1];
-    const uint64_t m = s1 - s0;
-    if (m <= WAVE_CAP || m > WG_CAP) continue;  // uniform over the workgroup
-    uint32_t P = 2;
-    while (P < m) P <<= 1;
-    const double nh = (double)a.nk[r];
-    for (uint32_t i = threadIdx.x; i < P; i += 256) big[i] = i < m ? make_key(a, a.pairs[s0 + i], nh) : Key{~0ull, ~0ull};
+  __shared__ Key big[WG_CAP];  // 64 KB of the CU's 160 KB
+  __shared__ uint32_t n_found, found[256];
+  for (uint64_t r0 = (uint64_t)blockIdx.x * 256; r0 < a.n_reads; r0 += (uint64_t)gridDim.x * 256) {
+    if (threadIdx.x == 0) n_found = 0;
     __syncthreads();
-    for (uint32_t k = 2; k <= P; k <<= 1)
-      for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-        bitonic_step(big, P, k, j, threadIdx.x, 256);
-        __syncthreads();
-      }
-    for (uint32_t i = threadIdx.x; i < m; i += 256) a.pairs[s0 + i] = pair_of(a, big[i]);
+    const uint64_t rr = r0 + threadIdx.x;
+    if (rr < a.n_reads) {
+      const uint64_t mm = a.offs[rr + 1] - a.offs[rr];
+      if (mm > WAVE_CAP && mm <= WG_CAP) found[atomicAdd(&n_found, 1u)] = threadIdx.x;
+    }
+    __syncthreads();
+    const uint32_t nf = n_found;
+    for (uint32_t f = 0; f < nf; f++) {
+      const uint64_t r = r0 + found[f];
+      const uint64_t s0 = a.offs[r], s1 = a.offs[r + 1];
+      const uint64_t m = s1 - s0;
+      uint32_t P = 2;
+      while (P < m) P <<= 1;
+      const double nh = (double)a.nk[r];
+      for (uint32_t i = threadIdx.x; i < P; i += 256) big[i] = i < m ? make_key(a, a.pairs[s0 + i], nh) : Key{~0ull, ~0ull};
+      __syncthreads();
+      for (uint32_t k = 2; k <= P; k <<= 1)
+        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+          bitonic_step(big, P, k, j, threadIdx.x, 256);
+          __syncthreads();
+        }
+      for (uint32_t i = threadIdx.x; i < m; i += 256) a.pairs[s0 + i] = pair_of(a, big[i]);
+      __syncthreads();
+    }
     __syncthreads();
   }
 }
@@ -284,8 +299,8 @@ void launch_k3(const K3Args& a, uint64_t hits_hint, hipStream_t st) {
   hipLaunchKernelGGL(k3_scan_add, dim3(tiles), dim3(SCAN_THREADS), 0, st, a.offs, a.sums, n);
   hipLaunchKernelGGL(k3_scatter, dim3(gblocks), dim3(256), 0, st, a);
   hipLaunchKernelGGL(k3_sort_wave, dim3((a.n_reads + 4 * RPW - 1) / (4 * RPW)), dim3(256), 0, st, a);
-  const unsigned wgb = (unsigned)std::min<uint32_t>(a.n_reads, 2048);
-  hipLaunchKernelGGL(k3_sort_wg, dim3(wgb), dim3(256), (size_t)WG_CAP * sizeof(Key), st, a);
+  const unsigned wgb = (unsigned)std::min<uint32_t>((a.n_reads + 255) / 256, 2048);
+  hipLaunchKernelGGL(k3_sort_wg, dim3(wgb), dim3(256), 0, st, a);
 }
 
 }  // namespace kmcpg

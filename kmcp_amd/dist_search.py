@@ -18,7 +18,7 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
-from .dist import ShardedSearcher
+from .dist import ShardedSearcher, hits_checksum
 from .lib import default_params
 
 HEADER = "#query\tqLen\tqKmers\tFPR\thits\ttarget\tchunkIdx\tchunks\ttLen\tkSize\tmKmers\tqCov\ttCov\tjacc\tqueryIdx\n"
@@ -105,10 +105,11 @@ def main(argv=None):
         out = sys.stdout if a.out_file == "-" else (gzip.open(a.out_file, "wt") if a.out_file.endswith(".gz") else open(a.out_file, "w"))
         if not a.no_header_row:
             out.write(HEADER)
-    total = matched = 0
+    total = matched = n_matches = 0
+    check = 0  # order-independent checksum of the (queryIdx, column, mKmers) tuples: the same on any number of ranks
 
     def flush(ids, seqs):
-        nonlocal total, matched
+        nonlocal total, matched, n_matches, check
         offs = np.zeros(len(seqs) + 1, dtype=np.uint64)
         offs[1:] = np.cumsum([len(s) for s in seqs], dtype=np.uint64)
         buf = np.frombuffer(b"".join(seqs), dtype=np.uint8).copy() if offs[-1] else np.zeros(1, dtype=np.uint8)
@@ -116,6 +117,11 @@ def main(argv=None):
         if rank != 0:
             total += len(ids)
             return
+        if len(res.matches):
+            owner = np.repeat(np.arange(len(ids), dtype=np.int64), np.diff(res.offs.astype(np.int64))) + total
+            tup = np.stack([owner, res.matches["col"].astype(np.int64), res.matches["mkmers"].astype(np.int64)], axis=1)
+            check = (check + int(hits_checksum(tup), 16)) & 0xFFFFFFFFFFFFFFFF
+            n_matches += len(res.matches)
         for i, qid in enumerate(ids):
             qidx = total + i
             k = int(res.ksize[i])  # the k-mer size that answered (multi-k databases, search.go:530)
@@ -149,6 +155,8 @@ def main(argv=None):
         out.write("# matched percentage: %s%%\n" % ("%.4f" % (matched / total * 100) if total else "NaN"))
         if out is not sys.stdout:
             out.close()
+        print(f"kmcp_amd.dist_search: {world} rank(s), backend {dist.get_backend() if world > 1 else 'none'}: matches: {n_matches}, checksum {check:016x} "
+              "(order-independent over (queryIdx, column, mKmers): the same on any number of GPUs, and the one kmcp-search logs)", file=sys.stderr)
     srch.close()
     if world > 1:
         dist.destroy_process_group()

@@ -109,6 +109,15 @@ def test_cli_single_end_gz_and_flags(oracle_lib, tmp_path):
     assert r.returncode == 0, r.stderr
     assert "exchange of the hit lists: RCCL gather over 1 device(s)" in r.stderr, r.stderr
     compare(open(tmp_path / "o1c.tsv").read().split("\n"), want, trailer)
+    # the log carries an order-independent checksum of the (queryIdx, column, mKmers) tuples: the same however the index is spread
+    # over GPUs and however the input is cut into batches — what a first run on real multi-GPU hardware is compared by
+    import re
+    sums = {re.search(r"matches: (\d+), checksum ([0-9a-f]{16})", r.stderr).groups()}
+    for extra in (["--gpu-ids", "0,0"], ["--gpu-batch", "64"], []):
+        r2 = subprocess.run([CLI, "-d", db_root, fq, "-o", str(tmp_path / "o1d.tsv")] + extra, capture_output=True, text=True, timeout=300)
+        assert r2.returncode == 0, r2.stderr
+        sums.add(re.search(r"matches: (\d+), checksum ([0-9a-f]{16})", r2.stderr).groups())
+    assert len(sums) == 1 and int(next(iter(sums))[0]) == len(want), sums
     # -K keeps unmatched rows; -H drops the header; thresholds + sort by jacc + top score
     p = O.default_params(min_qcov=0.4, min_matched=5, sort_by=2, top_n_scores=1)
     want, trailer = oracle_tsv(O, odb, ids, reads, params=p, keep_unmatched=True)

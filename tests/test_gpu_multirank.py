@@ -126,8 +126,18 @@ def test_sharded_searcher_overflow_loop(oracle_lib, tmp_path):
     assert len(want) > 50 * len(reads)
     env, _ = _env("KMCP_DIST_SAME_GPU")
     out = str(tmp_path / "o.tsv")
-    _launch(2, None, ["-m", "kmcp_amd.dist_search", "-d", os.path.dirname(db_dir), fq, "-o", out, "-t", "0.31", "-f", "1", "-c", "1"], env)
+    r = _launch(2, None, ["-m", "kmcp_amd.dist_search", "-d", os.path.dirname(db_dir), fq, "-o", out, "-t", "0.31", "-f", "1", "-c", "1"], env)
     compare(open(out).read().split("\n"), want, trailer)
+    # both hosts log the same order-independent checksum of the (queryIdx, column, mKmers) tuples: two ranks here, one GPU there
+    import re
+    from tests.test_gpu_cli import CLI
+    two = re.search(r"2 rank\(s\), backend (\w+): matches: (\d+), checksum ([0-9a-f]{16})", r.stderr)
+    assert two and int(two.group(2)) == len(want), r.stderr[-2000:]
+    one = subprocess.run([CLI, "-d", os.path.dirname(db_dir), fq, "-o", str(tmp_path / "cli.tsv"), "-t", "0.31", "-f", "1", "-c", "1"], capture_output=True, text=True,
+                         timeout=300)
+    assert one.returncode == 0, one.stderr
+    m1 = re.search(r"matches: (\d+), checksum ([0-9a-f]{16})", one.stderr)
+    assert m1 and (m1.group(1), m1.group(2)) == (two.group(2), two.group(3)), (m1.groups(), two.groups())
 
 
 def test_sharded_searcher_walks_the_k_sizes_of_a_multi_k_database(oracle_lib, tmp_path):
