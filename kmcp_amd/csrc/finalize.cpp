@@ -94,6 +94,8 @@ inline void records_visible() {
 #endif
 }
 
+inline bool is_tombstone(const kmcpg_hit& h) { return h.read == 0xffffffffu && h.col == 0xffffffffu; }
+
 bool match_less(const kmcpg_match& x, const kmcpg_match& y, int sort_by) {
   double s1, s2, t1, t2;
   switch (sort_by) {  // Matches.Less / SortByTCov.Less / SortByJacc.Less (:105-145)
@@ -287,6 +289,7 @@ extern "C" int kmcpg_finalize(const kmcpg_db* db, const kmcpg_hit* hits, uint64_
     uint64_t* c = cnt.data() + (size_t)a * R;
     for (uint64_t i = lo; i < hi; i++) {
       if (hits[i].read >= n_reads || hits[i].col >= n_cols) {
+        if (is_tombstone(hits[i])) continue;  // K2's stand-in for a set bit outside every column (k2_cobs.hip, epilogue): skipped
         bad.store(1);
         return;
       }
@@ -295,6 +298,7 @@ extern "C" int kmcpg_finalize(const kmcpg_db* db, const kmcpg_hit* hits, uint64_
   });
   if (bad.load()) {
     for (uint64_t i = 0; i < n_hits; i++) {
+      if (is_tombstone(hits[i])) continue;
       if (hits[i].read >= n_reads) return kmcpg_fail(KMCPG_EINVAL, "hit %llu names read %u of %u", (unsigned long long)i, hits[i].read, n_reads);
       if (hits[i].col >= n_cols) return kmcpg_fail(KMCPG_EINVAL, "hit names column %u of %zu", hits[i].col, n_cols);
     }
@@ -314,7 +318,8 @@ extern "C" int kmcpg_finalize(const kmcpg_db* db, const kmcpg_hit* hits, uint64_
     slice(a, &lo, &hi);
     uint64_t* q = pos.data() + (size_t)a * R;
     kmcpg_hit* dst = parted_p;
-    for (uint64_t i = lo; i < hi; i++) dst[q[(uint64_t)hits[i].read >> shift]++] = hits[i];
+    for (uint64_t i = lo; i < hi; i++)
+      if (!is_tombstone(hits[i])) dst[q[(uint64_t)hits[i].read >> shift]++] = hits[i];
   });
   t_1 = now();
   // FPR rows of the NumKmers values present in the batch (a handful for short reads; one O(n) pass each, kept by the database

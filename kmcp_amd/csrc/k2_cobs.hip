@@ -376,6 +376,10 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, (GR
         hit.read = r;
         hit.col = sg_col + (byte - sg_lo) * 8u + (7u - (uint32_t)(q & 7));
         hit.count = count;
+        // A set bit outside every member of the group cannot exist in a resident index (k_repack masks the padding bits of every
+        // member's last byte, rows are zero-filled beyond the members).  Should one ever appear, its reserved slot becomes a
+        // tombstone that K3 and kmcpg_finalize skip, instead of a hit with a made-up column.
+        if (byte < sg_lo || byte >= sg_hi) hit = kmcpg_hit{0xffffffffu, 0xffffffffu, 0u};
         a.hits[idx] = hit;
       }
       idx++;

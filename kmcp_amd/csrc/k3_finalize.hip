@@ -80,7 +80,7 @@ __global__ void k3_count(K3Args a) {
     const uint64_t i = i0 + (uint64_t)lane;
     kmcpg_hit h{0xffffffffu, 0, 0};
     if (i < n) h = a.hits[i];
-    if (i < n && (h.read >= a.n_reads || h.col >= a.n_cols)) atomicAdd(a.bad, 1u);
+    if (i < n && (h.read >= a.n_reads || h.col >= a.n_cols) && !(h.read == 0xffffffffu && h.col == 0xffffffffu)) atomicAdd(a.bad, 1u);  // (tombstones of K2 are skipped)
     const Run r = find_run(i < n && passes(a, h), h.read, lane);
     if (r.head) atomicAdd(&a.cnt[h.read], r.len);
   }

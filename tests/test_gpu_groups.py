@@ -126,3 +126,53 @@ def test_grouped_database_from_files(oracle_lib, tmp_path):
             res[fuse] = [[(int(m["col"]), int(m["mkmers"])) for m in r.read(i)] for i in range(len(reads))]
     odb.close()
     assert res[True] == res[False]
+
+
+def test_uniki_files_with_padding_bits_set_in_fused_groups(oracle_lib, tmp_path):
+    """the hit emission of k2_cobs no longer validates a set bit against the segment table — it relies on the load
+    (k_repack) clearing the padding bits of every member's last byte.  Files `kmcp index` writes never carry such bits
+    (index.go:1157); here they are set in every row of every block of a database whose blocks (12 columns: 4 spare bits each) share
+    NumSigs and are therefore laid side by side in one group: the results — grouped and ungrouped — are those of the clean files
+    and of the oracle, and no hit names a column that does not exist."""
+    import shutil
+    from kmcp_amd import default_params, lib
+    O = oracle_lib
+    genomes = synth.random_genomes(44, 5000, seed=61)
+    cols = synth.make_columns(genomes, O.sketch_cfg(k=21))
+    clean = lib.build_db(str(tmp_path / "clean"), cols, k=21, threads=4, block_size=12, uniform_sigs=1)  # blocks of 12, 12, 12, 8 columns
+    dirty = str(tmp_path / "dirty" / "R001")
+    shutil.copytree(os.path.dirname(clean), os.path.dirname(dirty))
+    reads = synth.sample_reads(genomes, 500, 150, sub_rate=0.01, seed=62, frac_random=0.2)
+    with _open(clean, True) as db:
+        nb = int(db.info.n_blocks)
+        bi = [db.block_info(b) for b in range(nb)]
+        assert len({b["num_sigs"] for b in bi}) == 1 and [b["n_cols"] for b in bi] == [12, 12, 12, 8]
+        assert len({b["stride"] for b in bi}) == 1 and bi[0]["stride"] >= 16  # one group: 2 + 2 + 2 + 1 bytes side by side
+        want = db.search(reads, params=default_params(min_qcov=0.31, min_matched=1))
+    files = sorted(f for f in os.listdir(dirty) if f.endswith(".uniki"))
+    assert len(files) == nb
+    touched = 0
+    for f, b in zip(files, bi):
+        spare = (8 - b["n_cols"] % 8) % 8
+        if not spare:
+            continue
+        path = os.path.join(dirty, f)
+        raw = bytearray(open(path, "rb").read())
+        hdr = len(raw) - b["num_sigs"] * b["row_bytes"]  # the rows are the tail of the file (serialization.go:140, :379)
+        rows = np.frombuffer(raw, dtype=np.uint8, offset=hdr).reshape(b["num_sigs"], b["row_bytes"])
+        rows[:, -1] |= np.uint8((1 << spare) - 1)  # columns n_cols .. 8 * row_bytes - 1: bits 0 .. spare-1 of the last byte
+        open(path, "wb").write(raw)
+        touched += 1
+    assert touched == 3
+    for fuse in (True, False):
+        with _open(dirty, fuse) as db:
+            got = db.search(reads, params=default_params(min_qcov=0.31, min_matched=1))
+            assert int(got.matches["col"].max()) < 44
+            for f in ("qlen", "qkmers", "offs"):
+                assert np.array_equal(getattr(got, f), getattr(want, f)), (fuse, f)
+            assert got.matches.tobytes() == want.matches.tobytes(), fuse
+    odb = O.OracleDB(clean)
+    try:
+        assert synth.assert_parity(odb, want, reads, None, O.default_params(min_qcov=0.31, min_matched=1)) > 300
+    finally:
+        odb.close()
