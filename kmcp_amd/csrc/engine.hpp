@@ -211,5 +211,12 @@ struct ResultOwner {
   std::vector<uint64_t> offs;
   MatchVec matches;
 };
+// finalize.cpp: a result assembled piece by piece (kmcpg_search_batch cuts large batches into pieces, host.cpp)
+ResultOwner* result_owner_take();
+void result_owner_give(ResultOwner* o);
+void result_owner_shape(ResultOwner* o, uint32_t n_reads);
+int finalize_grouped_into(const kmcpg_db* db, const kmcpg_pair* pairs, const uint64_t* read_offs, const int32_t* qkmers, const int32_t* qlen, uint32_t n_reads,
+                          const kmcpg_params& p, ResultOwner* o, uint32_t read_base, uint64_t match_base, uint64_t* kept_out);
+void result_publish(ResultOwner* o, uint32_t n_reads, int k_used, kmcpg_result* out);
 
 }  // namespace kmcpg

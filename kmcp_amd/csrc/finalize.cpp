@@ -515,10 +515,17 @@ extern "C" int kmcpg_finalize(const kmcpg_db* db, const kmcpg_hit* hits, uint64_
 // util-fpr.go:32-50 only ever falls, so "count >= smallest passing count" IS the test), --keep-top-scores (:285-311) and the
 // columns' metadata.  Every threshold is applied again (a no-op on lists K2 + K3 produced): a list from elsewhere is finalized
 // correctly too, and segments longer than K3 orders (K3_WG_CAP) are sorted here.
-extern "C" int kmcpg_finalize_grouped(const kmcpg_db* db, const kmcpg_pair* pairs, const uint64_t* read_offs, const int32_t* qkmers, const int32_t* qlen,
-                                      uint32_t n_reads, const kmcpg_params* params, kmcpg_result* out) {
-  if (!db || !out || !read_offs || (n_reads && (!qkmers || !qlen))) return kmcpg_fail(KMCPG_EINVAL, "null argument");
-  const kmcpg_params p = params ? *params : default_params();
+namespace kmcpg {
+ResultOwner* result_owner_take() { return take_owner(); }
+void result_owner_give(ResultOwner* o) { give_owner(o); }
+
+// The work of kmcpg_finalize_grouped for the reads [read_base, read_base + n_reads) of a result that is being assembled in `o`:
+// their records go to o->matches[match_base ...] (the vector grows here), their match COUNTS to o->offs[read_base + 1 + r] (the caller
+// turns counts into offsets once every piece is in), qlen / qkmers / ksize to their places.  *kept = records written.
+// kmcpg_search_batch cuts a large batch into pieces that follow each other through the GPU and lands them here one after the other,
+// so that the copy and the expansion of a piece overlap the kernels of the next (host.cpp).
+int finalize_grouped_into(const kmcpg_db* db, const kmcpg_pair* pairs, const uint64_t* read_offs, const int32_t* qkmers, const int32_t* qlen, uint32_t n_reads,
+                          const kmcpg_params& p, ResultOwner* o, uint32_t read_base, uint64_t match_base, uint64_t* kept_out) {
   const uint64_t n_pairs = read_offs[n_reads];
   if (n_pairs && !pairs) return kmcpg_fail(KMCPG_EINVAL, "null argument");
   if (read_offs[0] != 0) return kmcpg_fail(KMCPG_EINVAL, "read_offs[0] must be 0");
@@ -527,13 +534,13 @@ extern "C" int kmcpg_finalize_grouped(const kmcpg_db* db, const kmcpg_pair* pair
   const bool timing = getenv("KMCPG_FIN_TIMING") != nullptr;
   auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   const double t_0 = now();
-  std::unique_ptr<ResultOwner, OwnerReturn> o(take_owner());
-  o->qlen.assign(qlen, qlen + n_reads);
-  o->qkmers.assign(qkmers, qkmers + n_reads);
   const int k_used = p.k > 0 ? p.k : db->info.k;
-  o->ksize.assign(n_reads, k_used);
-  o->matches.resize(n_pairs);
-  o->offs.resize((size_t)n_reads + 1);
+  if (n_reads) {
+    memcpy(o->qlen.data() + read_base, qlen, (size_t)n_reads * sizeof(int32_t));
+    memcpy(o->qkmers.data() + read_base, qkmers, (size_t)n_reads * sizeof(int32_t));
+    std::fill(o->ksize.begin() + read_base, o->ksize.begin() + read_base + n_reads, k_used);
+  }
+  o->matches.resize(match_base + n_pairs);
   const double t_1 = now();
   WorkerPool& pool = WorkerPool::get();
   // contiguous ranges of reads holding ~64 k matches each (the offsets are at hand: a binary search per boundary)
@@ -548,8 +555,8 @@ extern "C" int kmcpg_finalize_grouped(const kmcpg_db* db, const kmcpg_pair* pair
   QueryFpr* F = db->fpr.get();
   const size_t n_cols = db->col_meta.size();
   const kmcpg_db::ColMeta* const col_meta = db->col_meta.data();
-  kmcpg_match* const mbase = o->matches.data();
-  uint64_t* const per_read = o->offs.data() + 1;  // counts first, offsets after the ranges are closed
+  kmcpg_match* const mbase = o->matches.data() + match_base;
+  uint64_t* const per_read = o->offs.data() + 1 + read_base;  // counts; the caller makes offsets of them
   std::vector<uint64_t> wcount((size_t)R, 0);
   std::atomic<int> bad{0};
   pool.parallel_for(R, [&](int w) {
@@ -668,9 +675,15 @@ extern "C" int kmcpg_finalize_grouped(const kmcpg_db* db, const kmcpg_pair* pair
     if (start != total && wcount[(size_t)w]) memmove(mbase + total, mbase + start, wcount[(size_t)w] * sizeof(kmcpg_match));
     total += wcount[(size_t)w];
   }
-  o->matches.resize(total);
+  o->matches.resize(match_base + total);
+  *kept_out = total;
+  return 0;
+}
+
+// counts in o->offs[1 ..] -> offsets, and the result's pointers
+void result_publish(ResultOwner* o, uint32_t n_reads, int k_used, kmcpg_result* out) {
   o->offs[0] = 0;
-  for (uint32_t r = 0; r < n_reads; r++) o->offs[(size_t)r + 1] += o->offs[r];  // counts -> offsets
+  for (uint32_t r = 0; r < n_reads; r++) o->offs[(size_t)r + 1] += o->offs[r];
   out->n_reads = n_reads;
   out->k = k_used;
   out->qlen = o->qlen.data();
@@ -678,7 +691,27 @@ extern "C" int kmcpg_finalize_grouped(const kmcpg_db* db, const kmcpg_pair* pair
   out->ksize = o->ksize.data();
   out->match_offs = o->offs.data();
   out->matches = o->matches.data();
-  out->owner = o.release();
+  out->owner = o;
+}
+
+void result_owner_shape(ResultOwner* o, uint32_t n_reads) {
+  o->qlen.resize(n_reads);
+  o->qkmers.resize(n_reads);
+  o->ksize.resize(n_reads);
+  o->offs.assign((size_t)n_reads + 1, 0);
+  o->matches.clear();
+}
+}  // namespace kmcpg
+
+extern "C" int kmcpg_finalize_grouped(const kmcpg_db* db, const kmcpg_pair* pairs, const uint64_t* read_offs, const int32_t* qkmers, const int32_t* qlen,
+                                      uint32_t n_reads, const kmcpg_params* params, kmcpg_result* out) {
+  if (!db || !out || !read_offs || (n_reads && (!qkmers || !qlen))) return kmcpg_fail(KMCPG_EINVAL, "null argument");
+  const kmcpg_params p = params ? *params : default_params();
+  std::unique_ptr<ResultOwner, OwnerReturn> o(take_owner());
+  result_owner_shape(o.get(), n_reads);
+  uint64_t kept = 0;
+  if (int rc = finalize_grouped_into(db, pairs, read_offs, qkmers, qlen, n_reads, p, o.get(), 0, 0, &kept)) return rc;
+  result_publish(o.release(), n_reads, p.k > 0 ? p.k : db->info.k, out);
   return 0;
 }
 

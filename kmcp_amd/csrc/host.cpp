@@ -867,13 +867,121 @@ extern "C" int kmcpg_wait(kmcpg_ticket* t, kmcpg_result* out) {
   return rc;
 }
 
+// One large batch, several pieces in flight.  kmcpg_search_batch is a synchronous call: upload, K1 + K2 + K3, the copy of the ordered
+// pairs and their expansion to Match records would follow each other with nothing overlapped (on a database of close relatives —
+// 200 matches per read — the copy and the expansion take as long as the kernels).  Here the batch is cut into up to 4 pieces of at
+// least 16 384 queries that go through the handle's lanes one behind the other: while the GPU works on piece j + 1, piece j comes
+// down and is written straight into its place in the ONE result of the call (finalize_grouped_into), so the result is exactly that of
+// the unsplit batch and nothing is copied twice.  Taken when the handle holds the whole database on one GPU with K3 on and no query can
+// need a second search (--try-se on pairs, several k-mer sizes: those splice sub-results and keep the plain path).
+// A thread only ever BLOCKS for a lane while it holds none (two threads in here at once share the lanes instead of waiting for each
+// other's).  *took = false: not applicable, nothing done.
+static int search_batch_pieces(kmcpg_db* db, const uint8_t* seqs, const uint64_t* offs, const uint8_t* seqs2, const uint64_t* offs2, uint32_t n,
+                               const kmcpg_params& p, kmcpg_result* out, bool* took) {
+  *took = false;
+  constexpr uint32_t kMinPiece = 16384;
+  int want = 4;
+  if (const char* e = getenv("KMCPG_PIECES")) want = atoi(e);
+  if (want < 2 || n < 2 * kMinPiece) return 0;
+  if (!db->shards.empty() || db->paged_passes > 0 || db->opts.device < 0 || db->opts.shard_count != 1) return 0;
+  if ((p.try_se && seqs2) || (p.k <= 0 && db->ks_desc.size() > 1)) return 0;
+  AsyncState* A = nullptr;
+  if (int rc = async_state(db, &A)) return rc;
+  if (!A->device_finalize || A->hits_stay_on_device) return 0;
+  const uint32_t S = (uint32_t)std::min<uint64_t>((uint64_t)want, std::min<uint64_t>(A->max_lanes, n / kMinPiece));
+  if (S < 2) return 0;
+  *took = true;
+  struct Piece {
+    Lane* lane = nullptr;
+    uint32_t lo = 0, cnt = 0;
+  };
+  std::vector<Piece> pc(S);
+  for (uint32_t j = 0; j < S; j++) {
+    pc[j].lo = (uint32_t)((uint64_t)n * j / S);
+    pc[j].cnt = (uint32_t)((uint64_t)n * (j + 1) / S) - pc[j].lo;
+  }
+  ResultOwner* o = result_owner_take();
+  result_owner_shape(o, n);
+  uint64_t match_base = 0;
+  uint32_t next_finish = 0, next_submit = 0;
+  int rc = 0;
+  std::vector<uint64_t> o1, o2;
+  auto finish_one = [&]() -> int {  // the oldest piece in flight: wait, bring its pairs down, expand them into their place
+    Piece& q = pc[next_finish];
+    uint64_t n_hits = 0;
+    int r = collect(db, A, q.lane, p, &n_hits);
+    uint64_t kept = 0;
+    if (r == 0)
+      r = finalize_grouped_into(db, q.lane->h_pairs.p, q.lane->h_roffs.p, q.lane->h_qk.p, q.lane->h_ql.p, q.cnt, p, o, q.lo, match_base, &kept);
+    if (r) {
+      (void)hipStreamSynchronize(A->up_stream);
+      (void)hipStreamSynchronize(A->stream);
+    }
+    release_lane(A, q.lane, false);
+    q.lane = nullptr;
+    next_finish++;
+    match_base += kept;
+    return r;
+  };
+  while (rc == 0 && next_submit < S) {
+    Lane* L = acquire_lane(A, false, next_finish == next_submit);  // block only while holding no lane
+    if (!L) {
+      rc = finish_one();
+      continue;
+    }
+    Piece& q = pc[next_submit];
+    q.lane = L;
+    o1.resize((size_t)q.cnt + 1);
+    for (uint32_t r = 0; r <= q.cnt; r++) o1[r] = offs[q.lo + r] - offs[q.lo];
+    if (offs2) {
+      o2.resize((size_t)q.cnt + 1);
+      for (uint32_t r = 0; r <= q.cnt; r++) o2[r] = offs2[q.lo + r] - offs2[q.lo];
+    }
+    rc = stage(L, seqs + offs[q.lo], o1.data(), seqs2 ? seqs2 + offs2[q.lo] : nullptr, offs2 ? o2.data() : nullptr, q.cnt);
+    if (rc == 0) rc = enqueue(db, A, L, p);
+    next_submit++;
+    if (rc) {  // this piece never got as far as a completion event: drain and give its lane back, the older ones below
+      const std::string keep = kmcpg_err_ref();
+      (void)hipStreamSynchronize(A->up_stream);
+      (void)hipStreamSynchronize(A->stream);
+      release_lane(A, L, false);
+      q.lane = nullptr;
+      next_submit--;
+      kmcpg_err_ref() = keep;
+    }
+  }
+  while (rc == 0 && next_finish < next_submit) rc = finish_one();
+  if (rc) {
+    const std::string keep = kmcpg_err_ref();
+    (void)hipStreamSynchronize(A->up_stream);
+    (void)hipStreamSynchronize(A->stream);
+    for (uint32_t j = next_finish; j < next_submit; j++)
+      if (pc[j].lane) release_lane(A, pc[j].lane, false);
+    result_owner_give(o);
+    kmcpg_err_ref() = keep;
+    return rc;
+  }
+  result_publish(o, n, p.k > 0 ? p.k : db->info.k, out);
+  return 0;
+}
+
 extern "C" int kmcpg_search_batch(kmcpg_db* db, const uint8_t* seqs, const uint64_t* offs, const uint8_t* seqs2, const uint64_t* offs2, uint32_t n_reads,
                                   const kmcpg_params* params, kmcpg_result* out) {
   if (!out) return kmcpg_fail(KMCPG_EINVAL, "null argument");
   memset(out, 0, sizeof *out);
   kmcpg_ticket* t = nullptr;
-  int rc = submit_checked(db, seqs, offs, seqs2, offs2, n_reads, params, true, &t);
-  if (rc == 0) rc = kmcpg_wait(t, out);
+  int rc = 0;
+  bool took = false;
+  if (db && n_reads && seqs && offs && (seqs2 == nullptr) == (offs2 == nullptr)) {
+    const kmcpg_params pp = params ? *params : default_params();
+    if (pp.min_matched >= 1 && offs[0] == 0 && (!offs2 || offs2[0] == 0)) rc = search_batch_pieces(db, seqs, offs, seqs2, offs2, n_reads, pp, out, &took);
+  }
+  if (took && rc == 0) return 0;
+  if (took) memset(out, 0, sizeof *out);
+  if (!took || rc == KMCPG_ENOMEM) {
+    rc = submit_checked(db, seqs, offs, seqs2, offs2, n_reads, params, true, &t);
+    if (rc == 0) rc = kmcpg_wait(t, out);
+  }
   if (rc != KMCPG_ENOMEM || n_reads < 2) return rc;
   // The batch's workspace (8-24 B per base next to the resident index) or its hit buffers did not fit: the two halves of the
   // batch one after the other, their results joined — a caller that sized its batches for an emptier GPU gets its answer

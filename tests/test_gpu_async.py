@@ -224,3 +224,67 @@ def test_hit_heavy_batches_follow_the_data(oracle_lib, tmp_path, monkeypatch, bu
         sub = order[3][:80]
         assert synth.assert_parity(odb, db.search(sub, params=default_params()), sub) > 40 * len(sub)
     odb.close()
+
+
+def test_search_batch_cuts_large_batches_into_pieces(oracle_lib, tmp_path):
+    """kmcpg_search_batch sends a batch of >= 32 768 queries through the lanes as up to 4 pieces (upload / kernels / copy / expansion
+    of consecutive pieces overlap) and assembles ONE result in place: byte for byte the result of the unsplit call (KMCPG_PIECES=0),
+    for single reads, pairs, every sort mode with --keep-top-scores, a hit buffer that overflows inside a piece (hundreds of chance
+    hits per read at -t 0.31 -f 1), and from two threads at once (a thread blocks for a lane only while it holds none)."""
+    import os
+    import threading
+    from kmcp_amd import Database, default_params
+    O = oracle_lib
+    genomes = synth.random_genomes(60, 6000, seed=171)
+    db_dir = synth.make_db(tmp_path / "db", genomes, k=21, n_chunks=2, overlap=150, threads=8)  # 120 columns in blocks of 16
+    rng = np.random.default_rng(172)
+    pool = synth.sample_reads(genomes, 3000, 150, sub_rate=0.01, seed=173, frac_random=0.2)
+    pool2 = synth.sample_reads(genomes, 3000, 150, sub_rate=0.01, seed=174, frac_random=0.5)
+    idx = rng.integers(0, len(pool), size=40000)
+    reads = [pool[i] for i in idx]
+    reads2 = [pool2[i] for i in idx]
+
+    def same(a, b):
+        for f in ("qlen", "qkmers", "ksize", "offs"):
+            assert np.array_equal(getattr(a, f), getattr(b, f)), f
+        assert a.matches.tobytes() == b.matches.tobytes()
+
+    cases = [(dict(), False), (dict(sort_by=2, top_n_scores=2), False), (dict(min_tcov=0.01, sort_by=1), False), (dict(fpr_buf_size=499), True),
+             (dict(min_qcov=0.31, max_fpr=1.0, min_matched=1), False)]
+    odb = O.OracleDB(db_dir)
+    try:
+        with Database.open(db_dir, device=0) as db:
+            for kw, paired in cases:
+                p = default_params(**kw)
+                os.environ["KMCPG_PIECES"] = "0"
+                try:
+                    whole = db.search(reads, reads2 if paired else None, params=p)
+                finally:
+                    os.environ.pop("KMCPG_PIECES")
+                pieces = db.search(reads, reads2 if paired else None, params=p)
+                same(whole, pieces)
+                os.environ["KMCPG_PIECES"] = "2"
+                try:
+                    same(whole, db.search(reads, reads2 if paired else None, params=p))
+                finally:
+                    os.environ.pop("KMCPG_PIECES")
+                if "max_fpr" in kw:
+                    assert len(whole.matches) > 8 * len(reads)  # more hits than the plain hit buffer of a piece holds: the rerun path
+            # the oracle on a sample of the default case
+            res = db.search(reads, params=default_params())
+            sample = slice(0, 600)
+            sub = type(res)(res.qlen[sample], res.qkmers[sample], res.offs[:601], res.matches[:int(res.offs[600])], res.k, res.ksize[sample])
+            assert synth.assert_parity(odb, sub, reads[sample]) > 300
+            # two threads at once
+            out = [None, None]
+
+            def work(i):
+                out[i] = db.search(reads[i * 3:] + reads[:i * 3], params=default_params())
+
+            th = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+            [t.start() for t in th]
+            [t.join() for t in th]
+            same(out[0], res)
+            assert np.array_equal(out[1].qkmers, np.concatenate([res.qkmers[3:], res.qkmers[:3]]))
+    finally:
+        odb.close()
