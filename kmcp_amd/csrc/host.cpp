@@ -12,6 +12,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <memory>
 #include <mutex>
@@ -78,6 +79,8 @@ struct Lane {
   PinBuf<kmcpg_pair> h_pairs;
   PinBuf<uint64_t> h_roffs;
   bool grouped = false;  // this batch went through K3: h_pairs / h_roffs hold its result, h_hits is not filled
+  hipEvent_t k3_ev = nullptr, eager_ev = nullptr;  // K3 done on the kernel stream -> the eager copy of the pairs on the copy stream
+  bool eager_aside = false;                        // ... when it was put there (pieces of a large kmcpg_search_batch call)
   hipEvent_t done = nullptr, uploaded = nullptr;
   uint32_t n = 0;
   bool paired = false;
@@ -91,13 +94,17 @@ struct Lane {
     d_pairs.release(); d_roffs.release(); h_pairs.release(); h_roffs.release();
     if (done) (void)hipEventDestroy(done);
     if (uploaded) (void)hipEventDestroy(uploaded);
-    done = uploaded = nullptr;
+    if (k3_ev) (void)hipEventDestroy(k3_ev);
+    if (eager_ev) (void)hipEventDestroy(eager_ev);
+    done = uploaded = k3_ev = eager_ev = nullptr;
   }
 };
 
 struct AsyncState {
   hipStream_t stream = nullptr;
   hipStream_t copy_stream = nullptr;  // late D2H of a finished batch's hits: must not queue behind the kernels of later batches
+  // (Exactly three streams per handle beside the null stream: the runtime multiplexes HIP streams onto 4 hardware queues, and a
+  // fifth stream — tried for the pieces' eager copies — made uploads and kernels share one: -8 % on the pipelined path, same-box A/B.)
   hipStream_t up_stream = nullptr;    // H2D of a batch's reads, beside the kernels of the batches before it
   std::atomic<uint64_t> hits_hint{0};  // hits per 1024 reads seen lately: sizes the hit buffers and the eager D2H of the next batches
   uint64_t lane_hit_budget = 0;        // entries a lane's device hit buffer may grow to beyond the plain size (from free HBM at first use)
@@ -169,7 +176,11 @@ int async_state(kmcpg_db* db, AsyncState** out) {
     std::unique_ptr<AsyncState> a(new AsyncState());
     HIPCHK(hipSetDevice(db->opts.device));
     HIPCHK(hipStreamCreateWithFlags(&a->stream, hipStreamNonBlocking));
-    HIPCHK(hipStreamCreateWithFlags(&a->copy_stream, hipStreamNonBlocking));
+    // the copies back run at the highest stream priority: where a copy is done by a blit kernel it must not queue behind the
+    // chip-filling kernels of the next batch (same-box A/B: the eager copy at default priority cost the pipelined path 10 %)
+    int prio_lo = 0, prio_hi = 0;
+    if (hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi) != hipSuccess) prio_lo = prio_hi = 0;
+    HIPCHK(hipStreamCreateWithPriority(&a->copy_stream, hipStreamNonBlocking, prio_hi));
     HIPCHK(hipStreamCreateWithFlags(&a->up_stream, hipStreamNonBlocking));
     if (const char* e = getenv("KMCPG_INFLIGHT")) a->max_lanes = (size_t)std::max(1, std::min(atoi(e), 16));
     if (const char* e = getenv("KMCPG_DEVICE_FINALIZE")) a->device_finalize = atoi(e) != 0;
@@ -282,8 +293,10 @@ int enqueue_query(kmcpg_db* db, AsyncState* A, Lane* L, const kmcpg_params& p) {
   return 0;
 }
 
-// H2D + K1 + K2 + D2H of one staged lane on the handle's stream; returns without waiting
-int enqueue(kmcpg_db* db, AsyncState* A, Lane* L, const kmcpg_params& p) {
+// H2D + K1 + K2 (+ K3) + D2H of one staged lane on the handle's streams; returns without waiting.  generous_eager: a piece of a
+// large kmcpg_search_batch call — its neighbours of the same batch have just shown how many matches to expect, so the eager copy
+// may take all of them (it runs on the copy stream, beside the next piece's kernels)
+int enqueue(kmcpg_db* db, AsyncState* A, Lane* L, const kmcpg_params& p, bool generous_eager = false) {
   KMCPG_USE_DEVICE(db);
   if (!L->done) HIPCHK(hipEventCreateWithFlags(&L->done, hipEventDisableTiming));
   if (!L->uploaded) HIPCHK(hipEventCreateWithFlags(&L->uploaded, hipEventDisableTiming));
@@ -301,7 +314,9 @@ int enqueue(kmcpg_db* db, AsyncState* A, Lane* L, const kmcpg_params& p) {
   const uint64_t want = std::max<uint64_t>(base_cap, std::min<uint64_t>(expect + expect / 2, std::max<uint64_t>(base_cap, A->lane_hit_budget)));
   // a buffer left over from a burst of hit-heavy batches goes back once the data has calmed down (hits_hint decays by 1/8 per
   // batch): HBM pinned for the life of the handle is HBM the workspace of a later, larger batch may need
-  if (L->d_hits.cap > 4 * want && L->d_hits.cap > (1u << 20)) L->d_hits.release();
+  // (16x, not 4x: a lane that serves whole batches and quarter-batch pieces in turn must not free and reallocate its buffer every time —
+  // hipFree waits for the device)
+  if (L->d_hits.cap > 16 * want && L->d_hits.cap > (1u << 20)) L->d_hits.release();
   uint64_t cap = std::max<uint64_t>(L->d_hits.cap, want);
   if (L->d_seqs.ensure(L->tb1 + 16) || L->d_offs.ensure((size_t)n + 1) || L->d_cnt.ensure(2) || L->d_qk.ensure(n) || L->d_ql.ensure(n) ||
       (L->paired && (L->d_seqs2.ensure(L->tb2 + 16) || L->d_offs2.ensure((size_t)n + 1))))
@@ -311,7 +326,7 @@ int enqueue(kmcpg_db* db, AsyncState* A, Lane* L, const kmcpg_params& p) {
     cap = base_cap;
     if (L->d_hits.ensure(cap)) return kmcpg_fail(KMCPG_ENOMEM, "hipMalloc failed");
   }
-  const uint64_t first = std::min<uint64_t>(cap, std::max<uint64_t>((uint64_t)n * 2 + 1024, std::min<uint64_t>(expect + expect / 4, (uint64_t)n * 32)));
+  const uint64_t first = std::min<uint64_t>(cap, std::max<uint64_t>((uint64_t)n * 2 + 1024, std::min<uint64_t>(expect + expect / 4, (uint64_t)n * (generous_eager ? 1024 : 32))));
   // K3 only where this handle holds the whole database: the lists of shards (several GPUs, passes of a paged handle) are merged first
   L->grouped = A->device_finalize && !A->hits_stay_on_device && db->opts.shard_count == 1;
   if (L->h_cnt.ensure(2) || L->h_qk.ensure(n) || L->h_ql.ensure(n) || (L->grouped ? L->h_pairs.ensure(first) : L->h_hits.ensure(first)))
@@ -348,8 +363,22 @@ int enqueue(kmcpg_db* db, AsyncState* A, Lane* L, const kmcpg_params& p) {
   HIPCHK(hipMemcpyAsync(L->h_qk.p, L->d_qk.p, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, st));
   HIPCHK(hipMemcpyAsync(L->h_ql.p, L->d_ql.p, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, st));
   L->copied = A->hits_stay_on_device ? 0 : std::min<uint64_t>(first, L->d_hits.cap);
-  if (L->copied && L->grouped) HIPCHK(hipMemcpyAsync(L->h_pairs.p, L->d_pairs.p, L->copied * sizeof(kmcpg_pair), hipMemcpyDeviceToHost, st));
-  else if (L->copied) HIPCHK(hipMemcpyAsync(L->h_hits.p, L->d_hits.p, L->copied * sizeof(kmcpg_hit), hipMemcpyDeviceToHost, st));
+  L->eager_aside = false;
+  if (L->copied && L->grouped && !generous_eager) {
+    // a small copy (<= 32 pairs per read), in stream order before the lane's completion event (same-box A/B: on a stream of its own it
+    // cost the pipelined submit / wait path 8 %)
+    HIPCHK(hipMemcpyAsync(L->h_pairs.p, L->d_pairs.p, L->copied * sizeof(kmcpg_pair), hipMemcpyDeviceToHost, st));
+  } else if (L->copied && L->grouped) {
+    // a piece of a large kmcpg_search_batch call: all of its ordered pairs leave on the copy stream, behind K3 only, while the
+    // next piece's kernels run
+    L->eager_aside = true;
+    if (!L->k3_ev) HIPCHK(hipEventCreateWithFlags(&L->k3_ev, hipEventDisableTiming));
+    if (!L->eager_ev) HIPCHK(hipEventCreateWithFlags(&L->eager_ev, hipEventDisableTiming));
+    HIPCHK(hipEventRecord(L->k3_ev, st));
+    HIPCHK(hipStreamWaitEvent(A->copy_stream, L->k3_ev, 0));
+    HIPCHK(hipMemcpyAsync(L->h_pairs.p, L->d_pairs.p, L->copied * sizeof(kmcpg_pair), hipMemcpyDeviceToHost, A->copy_stream));
+    HIPCHK(hipEventRecord(L->eager_ev, A->copy_stream));
+  } else if (L->copied) HIPCHK(hipMemcpyAsync(L->h_hits.p, L->d_hits.p, L->copied * sizeof(kmcpg_hit), hipMemcpyDeviceToHost, st));
   HIPCHK(hipEventRecord(L->done, st));
   return 0;
 }
@@ -365,6 +394,7 @@ int collect(kmcpg_db* db, AsyncState* A, Lane* L, const kmcpg_params& p, uint64_
   for (int attempt = 0; cnt > L->d_hits.cap; attempt++) {  // the hit buffer was too small: rerun with room for every hit
     if (attempt == 2) return kmcpg_fail(KMCPG_ENOMEM, "hit buffer overflow");
     HIPCHK(hipStreamSynchronize(A->stream));
+    HIPCHK(hipStreamSynchronize(A->copy_stream));  // (the eager copy of the attempt that overflowed)
     if (L->d_hits.ensure(cnt + cnt / 4)) return kmcpg_fail(KMCPG_ENOMEM, "hipMalloc failed");
     int rc = enqueue_query(db, A, L, p);
     if (rc) return rc;
@@ -377,6 +407,7 @@ int collect(kmcpg_db* db, AsyncState* A, Lane* L, const kmcpg_params& p, uint64_
   if (L->h_cnt.p[1] > bound) return kmcpg_fail(KMCPG_EDEVICE, "internal: a query reported %llu k-mers, more than its length allows", (unsigned long long)L->h_cnt.p[1]);
   if (fetch && L->grouped) {
     // K3 ran behind K2: what comes to the host is its output — offsets (already here) and the pairs that passed -T, in final order
+    if (L->copied && L->eager_aside) HIPCHK(hipEventSynchronize(L->eager_ev));
     const uint64_t kept = L->h_roffs.p[L->n];
     if (kept > cnt) return kmcpg_fail(KMCPG_EDEVICE, "internal: K3 kept %llu of %llu hits", (unsigned long long)kept, (unsigned long long)cnt);
     if (kept > L->copied) {
@@ -413,8 +444,12 @@ void drop_ticket(kmcpg_ticket* t, bool failed = false) {
     if (failed && pt.shard->async && pt.shard->async->stream) {
       if (pt.shard->async->up_stream) (void)hipStreamSynchronize(pt.shard->async->up_stream);
       (void)hipStreamSynchronize(pt.shard->async->stream);
+      if (pt.shard->async->copy_stream) (void)hipStreamSynchronize(pt.shard->async->copy_stream);
     }
-    else if (pt.lane->done && pt.lane->n) (void)hipEventSynchronize(pt.lane->done);
+    else if (pt.lane->done && pt.lane->n) {
+      (void)hipEventSynchronize(pt.lane->done);
+      if (pt.lane->grouped && pt.lane->copied && pt.lane->eager_aside && pt.lane->eager_ev) (void)hipEventSynchronize(pt.lane->eager_ev);
+    }
     release_lane(pt.shard->async, pt.lane, pt.retry);
   }
   delete t;
@@ -906,16 +941,25 @@ static int search_batch_pieces(kmcpg_db* db, const uint8_t* seqs, const uint64_t
   uint32_t next_finish = 0, next_submit = 0;
   int rc = 0;
   std::vector<uint64_t> o1, o2;
+  const bool timing = getenv("KMCPG_FIN_TIMING") != nullptr;
+  auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  const double t_begin = now();
   auto finish_one = [&]() -> int {  // the oldest piece in flight: wait, bring its pairs down, expand them into their place
     Piece& q = pc[next_finish];
     uint64_t n_hits = 0;
+    const double ta = now();
     int r = collect(db, A, q.lane, p, &n_hits);
+    const double tb = now();
     uint64_t kept = 0;
     if (r == 0)
       r = finalize_grouped_into(db, q.lane->h_pairs.p, q.lane->h_roffs.p, q.lane->h_qk.p, q.lane->h_ql.p, q.cnt, p, o, q.lo, match_base, &kept);
+    if (timing)
+      fprintf(stderr, "piece %u: collect from %.2f to %.2f ms, expanded by %.2f ms (%llu hits, %llu kept)\n", next_finish, ta - t_begin, tb - t_begin, now() - t_begin,
+              (unsigned long long)n_hits, (unsigned long long)kept);
     if (r) {
       (void)hipStreamSynchronize(A->up_stream);
       (void)hipStreamSynchronize(A->stream);
+      (void)hipStreamSynchronize(A->copy_stream);
     }
     release_lane(A, q.lane, false);
     q.lane = nullptr;
@@ -938,12 +982,14 @@ static int search_batch_pieces(kmcpg_db* db, const uint8_t* seqs, const uint64_t
       for (uint32_t r = 0; r <= q.cnt; r++) o2[r] = offs2[q.lo + r] - offs2[q.lo];
     }
     rc = stage(L, seqs + offs[q.lo], o1.data(), seqs2 ? seqs2 + offs2[q.lo] : nullptr, offs2 ? o2.data() : nullptr, q.cnt);
-    if (rc == 0) rc = enqueue(db, A, L, p);
+    if (rc == 0) rc = enqueue(db, A, L, p, true);
+    if (timing) fprintf(stderr, "piece %u: enqueued at %.2f ms\n", next_submit, now() - t_begin);
     next_submit++;
     if (rc) {  // this piece never got as far as a completion event: drain and give its lane back, the older ones below
       const std::string keep = kmcpg_err_ref();
       (void)hipStreamSynchronize(A->up_stream);
       (void)hipStreamSynchronize(A->stream);
+      (void)hipStreamSynchronize(A->copy_stream);
       release_lane(A, L, false);
       q.lane = nullptr;
       next_submit--;
@@ -955,6 +1001,7 @@ static int search_batch_pieces(kmcpg_db* db, const uint8_t* seqs, const uint64_t
     const std::string keep = kmcpg_err_ref();
     (void)hipStreamSynchronize(A->up_stream);
     (void)hipStreamSynchronize(A->stream);
+    (void)hipStreamSynchronize(A->copy_stream);
     for (uint32_t j = next_finish; j < next_submit; j++)
       if (pc[j].lane) release_lane(A, pc[j].lane, false);
     result_owner_give(o);
