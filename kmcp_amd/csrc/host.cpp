@@ -923,6 +923,11 @@ static int search_batch_pieces(kmcpg_db* db, const uint8_t* seqs, const uint64_t
   AsyncState* A = nullptr;
   if (int rc = async_state(db, &A)) return rc;
   if (!A->device_finalize || A->hits_stay_on_device) return 0;
+  // The first large batch of a handle goes through whole: it teaches the handle how many hits to expect per read (hits_hint), so that
+  // the pieces of later batches get hit buffers and eager copies of the right size at once.  (Cold, every piece would overflow its
+  // buffer and run twice, and four lanes would allocate their pinned buffers inside the call: kmcp-search on a 100 000-read file
+  // spent 0.34 s instead of 0.14 s in here.)
+  if (A->hits_hint.load() == 0) return 0;
   const uint32_t S = (uint32_t)std::min<uint64_t>((uint64_t)want, std::min<uint64_t>(A->max_lanes, n / kMinPiece));
   if (S < 2) return 0;
   *took = true;
