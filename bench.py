@@ -82,8 +82,8 @@ WORKLOADS = {
     # cutting through the family); the query itself is a 0.5 %-mutated, randomly reverse-complemented copy; 10 % of the queries
     # are unrelated genomes.  ~8 000 sketch k-mers per query: the sort+unique path and 16 counter planes.
     "config2_genome_search": dict(k=21, num_hashes=3, fpr=0.001, n_blocks=8, cols_per_block=6256, num_sigs=431000, sigs_step=13, kmers_per_col=10000,
-                                  scale=1000, batch_reads=128, read_len=4000000, relatives=10, rel_step=0.005, sub_rate=0.005, distinct_batches=2,
-                                  min_qcov=0.4, sort_by=2, unit="queries/s", cpu_sample_start=16, kernel="k2_cobs<64,16,true,true,8> (SPLIT form; k1_kmers_wg<0> + k1_seg_hash beside it)",
+                                  scale=1000, batch_reads=256, read_len=4000000, relatives=10, rel_step=0.005, sub_rate=0.005, distinct_batches=2,
+                                  min_qcov=0.4, sort_by=2, unit="queries/s", cpu_sample_start=16, kernel="k2_cobs<64,16,true,false,8> (k1_kmers_wg<0> + k1_seg_hash beside it; batches below ~190 genomes take the chunked form <64,16,true,true,8>)",
                                   metric="genomes/sec searched (4-Mbp assemblies, FracMinHash scale 1000, k=21, 3 hashes, -t 0.4) vs a 50 k-reference index",
                                   name="genome search, synthetic: 8 blocks x 6256 cols x 431 k sigs (2.7 GB), 3 hashes, fpr 0.001, scale 1000; "
                                        "queries = 4-Mbp genomes with 10 relatives each in the index"),

@@ -307,7 +307,10 @@ extern "C" int kmcpg_query_device(kmcpg_db* db, const uint8_t* d_seqs, const uin
   uint32_t n_long = long_meta[0];
   // splitting pays when the long queries alone would leave the chip idle (few (query, slot) pairs) or need more than 16
   // counter planes; a batch of thousands of 10-kb reads already fills it and keeps the plain kernel (unless forced by env)
-  if (n_long && !sm_env && (uint64_t)n_long * total_slots > 16384 && long_meta[1] <= 65535) n_long = 0;
+  // (round 4, genome search with 3 hash functions, same-box A/B over batch sizes: from ~1 500 (query, slot) units on — 1.5 waves per SIMD — the
+  // plain kernel wins, because it prunes (a third of the row bytes are never fetched for 8 000-k-mer sketches at -t 0.4) and needs no atomics:
+  // 192 queries x 8 slots 5.0 vs 6.0 ms, 512 x 8 11.1 vs 16.3 ms; at 128 x 8 the chunked form still leads, 4.1 vs 4.5 ms.)
+  if (n_long && !sm_env && (uint64_t)n_long * total_slots >= 1536 && long_meta[1] <= 65535) n_long = 0;
   // largest NumKmers the plain kernel will meet: bounded by the read length, and exactly known once the long ones were listed
   uint64_t max_short = maxn;
   if (ask)
