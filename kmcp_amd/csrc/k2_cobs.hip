@@ -120,12 +120,25 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, (GR
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int g = lane / LPR, li = lane % LPR;
   const uint64_t per_read = SPLIT ? (uint64_t)a.nslots * a.split_chunks : (uint64_t)a.nslots;
-  const uint64_t total_units = (SPLIT ? (uint64_t)a.n_long : (uint64_t)a.n_reads) * per_read;
+  // slot_major 2 (several units per wave only): the G units of a wave are ONE read on G consecutive slots — the read's hashes are
+  // fetched once per wave instead of once per unit (the other units find them in the vector cache) — and the waves are numbered
+  // slot-group-major.  For small indexes, where the slices the waves in flight gather from fit the TLB reach anyway.
+  const bool by_read = !SPLIT && G > 1 && a.slot_major == 2;
+  const uint64_t slot_groups = ((uint64_t)a.nslots + G - 1) / G;
+  const uint64_t total_units = by_read ? (uint64_t)a.n_reads * slot_groups * G : (SPLIT ? (uint64_t)a.n_long : (uint64_t)a.n_reads) * per_read;
   const uint64_t u = a.unit_base + ((uint64_t)blockIdx.x * 4 + wave) * G + g;
-  const bool valid = u < total_units;
+  bool valid = u < total_units;
   uint32_t r = 0, sidx = 0, li_long = 0;
   int k0 = 0;
-  if (valid) {
+  if (valid && by_read) {
+    const uint64_t wid = u / G;
+    sidx = (uint32_t)((wid / a.n_reads) * G + (uint64_t)g);
+    r = (uint32_t)(wid % a.n_reads);
+    if (sidx >= a.nslots) {
+      valid = false;
+      sidx = 0;
+    }
+  } else if (valid) {
     if (SPLIT) {
       li_long = (uint32_t)(u / per_read);
       const uint32_t rem = (uint32_t)(u % per_read);
@@ -406,7 +419,7 @@ constexpr uint64_t K2_MAX_BLOCKS = 1ull << 23;  // x 256 threads = 2^31
 template <int LPR, int NPL>
 static void launch_k2_t(const K2Args& a, bool multi, hipStream_t st) {
   constexpr int G = 64 / LPR;
-  const uint64_t units = (uint64_t)a.n_reads * a.nslots;
+  const uint64_t units = (G > 1 && a.slot_major == 2) ? (uint64_t)a.n_reads * (((uint64_t)a.nslots + G - 1) / G) * G : (uint64_t)a.n_reads * a.nslots;
   const uint64_t waves = (units + G - 1) / G;
   const uint64_t blocks = (waves + 3) / 4;
   K2Args b = a;
