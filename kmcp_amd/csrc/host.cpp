@@ -191,7 +191,7 @@ int async_state(kmcpg_db* db, AsyncState** out) {
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = 0;
     uint64_t budget = std::min<uint64_t>(free_b / 4, 16ull << 30);
     if (const char* e = getenv("KMCPG_HIT_BUDGET_MB")) budget = (uint64_t)std::max(0ll, atoll(e)) << 20;
-    a->lane_hit_budget = budget / sizeof(kmcpg_hit) / (a->max_lanes + 1);
+    a->lane_hit_budget = budget / (sizeof(kmcpg_hit) + sizeof(kmcpg_pair)) / (a->max_lanes + 1);  // a hit entry has its K3 pair beside it (d_pairs)
     db->async = a.release();
   }
   *out = db->async;
