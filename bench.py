@@ -2,15 +2,17 @@
 """bench.py — reads/s searched (150 bp, k=21) against a GTDB-scale COBS index on MI355X.
 
 One "step" = one pass of the hot path over one batch of synthetic 150-bp reads that is already resident in HBM: K1 ntHash
-k-mer generation + K2 COBS query on the GPU, hit hand-over, and the host half (float64 thresholds, FPR, sort) that turns
-the hit tuples into finalized matches in host memory; the host half of step i overlaps the kernels of step i+1.
+k-mer generation + K2 COBS query + K3 (hit list grouped by read, -T, per-query order) on the GPU, 8-byte pairs to the host, and the
+expansion to finalized matches in host memory (kmcpg_finalize_grouped); the host half of step i overlaps the kernels of step i+1.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload gtdb|config1|gtdb_unchunked_k31|...] [--batch-reads B]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload gtdb|config1|gtdb_unchunked_k31|config2_genome_search|config4_hifi|...]
 
 N>1 is launched by the driver as `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`:
 one rank per GPU; the index's independent blocks are partitioned over the ranks (libkmcpgpu shards by
-bytes), every rank searches the whole batch against its blocks and the per-read hit lists are gathered on
-rank 0 over RCCL.  Total work is fixed as N grows => "scaling": "strong".
+bytes), every rank searches the whole batch against its blocks, the per-read hit lists are gathered on
+rank 0 over RCCL and K3 runs there over the concatenation.  Total work is fixed as N grows => "scaling": "strong".
+Every line carries `sanity_batch.hits_checksum` (the same at every N by construction), `ranks` (who ran, per-rank kernel times) and,
+at N > 1, `parity_at_n` (the merged hit list of a sample against the CPU oracle over rows fetched from every rank).
 
 The synthetic index is generated directly in HBM: 32 blocks x 14 976 columns
 (NumRowBytes 1 872) x 968 700 rows = 58.03 GB, bits i.i.d. Bernoulli(0.30) like a Bloom filter at fpr 0.3;
@@ -18,8 +20,11 @@ The synthetic index is generated directly in HBM: 32 b
 were planted into a random column, 10 % are uniform random.
 
 The JSON line reports the GTDB-scale workload (the configuration BASELINE.json's metric is quoted on).  At N=1 the
-same line carries, under "secondary", the numbers of BASELINE.json configs[1] (10 k chunks, 39-byte rows) and of the
-configuration the reference's own published short-read numbers are quoted on (unchunked GTDB, k = 31, -b 1024, -t 0.8).
+same line carries, under "secondary", BASELINE.json configs[1] (10 k chunks, 39-byte rows; grouped and ungrouped), the
+configuration the reference's own published short-read numbers are quoted on (unchunked GTDB, k = 31, -b 1024, -t 0.8),
+configs[2] (genome search: FracMinHash scale 1000, 3 hashes, 50 k references, queries with ~9 relatives each in the index) and
+configs[4] (HiFi ~10 kb reads sampled from planted chunks of a Closed-Syncmer index), each with roofline, CPU baseline and
+same-run oracle parity.
 """
 import argparse
 import json
