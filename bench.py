@@ -208,6 +208,36 @@ def make_batch(dev, wl, n_reads, n_cols, seed, plant):
     return bt
 
 
+_D2D = {}
+
+
+def d2d_copy_gbps(dev):
+    """device-to-device copy rate of this box in GB/s (bytes read + bytes written over time), measured once per process"""
+    if dev in _D2D:
+        return _D2D[dev]
+    try:
+        n = 2 << 30
+        a = torch.empty(n, dtype=torch.uint8, device=dev)
+        b = torch.empty(n, dtype=torch.uint8, device=dev)
+        a.zero_()
+        b.copy_(a)
+        torch.cuda.synchronize()
+        best = 0.0
+        for _ in range(5):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            b.copy_(a)
+            e1.record()
+            torch.cuda.synchronize()
+            best = max(best, 2.0 * n / (e0.elapsed_time(e1) * 1e-3) / 1e9)
+        del a, b
+        torch.cuda.empty_cache()
+        _D2D[dev] = best
+    except Exception:
+        _D2D[dev] = None
+    return _D2D[dev]
+
+
 class Ctx:
     pass
 
@@ -581,6 +611,12 @@ def run_workload(name, ctx, steps, warmup, batch_reads=0, cpu_baseline=True, cpu
     rf["frac"] = rf["achieved"] / HBM_PEAK_GBS
     rf["traffic_over_algorithmic"] = gathered / alg_bytes
     rf["measured_ceiling"]["frac"] = rf["achieved"] / FABRIC_CEILING_GBS
+    # the device-to-device copy rate of THIS box beside the vendor peak (a streaming figure: half of the bytes are
+    # writes, all of them sequential; the kernel's gathers are reads of 1 KB at random rows)
+    d2d = d2d_copy_gbps(dev)
+    if d2d:
+        rf["d2d_copy"] = {"gbps": d2d, "what": "torch copy of 2 GiB device to device on this box, read + written bytes / time (best of 5)",
+                          "frac": rf["achieved"] / d2d}
     if pmc:
         rf["pmc_gbps"] = pmc / (k2_avg_ms * 1e-3) / 1e9
         rf["frac_pmc"] = rf["pmc_gbps"] / HBM_PEAK_GBS
