@@ -914,7 +914,8 @@ extern "C" int kmcpg_wait(kmcpg_ticket* t, kmcpg_result* out) {
 static int search_batch_pieces(kmcpg_db* db, const uint8_t* seqs, const uint64_t* offs, const uint8_t* seqs2, const uint64_t* offs2, uint32_t n,
                                const kmcpg_params& p, kmcpg_result* out, bool* took) {
   *took = false;
-  constexpr uint32_t kMinPiece = 16384;
+  uint32_t kMinPiece = 16384;
+  if (const char* e = getenv("KMCPG_PIECE_MIN")) kMinPiece = (uint32_t)std::max(1, atoi(e));  // tests and tools/stress_async.py: pieces of small batches
   int want = 4;
   if (const char* e = getenv("KMCPG_PIECES")) want = atoi(e);
   if (want < 2 || n < 2 * kMinPiece) return 0;
