@@ -1109,6 +1109,121 @@ __global__ void __launch_bounds__(K1WG) k1_seg_hash(const K1Args a) {
   if (tid == 0) a.seg_cnt[blockIdx.x] = cnt;
 }
 
+// The same segments with ROLLING hashes (round 4).  The prefix-XOR form above prices every k-mer at two 64-bit scans, four variable
+// rotates and eight workgroup barriers per 1024 positions — ~150 lane-operations per base, 250 Gbase/s, which had become 42 % of a
+// genome-search step.  A genome has what a read lacks: long runs.  Here every lane owns ROLL_L = 128 consecutive k-mer positions and
+// rolls ntHash along them as the recurrence is meant to be used,
+//     fh(i+1) = rol1(fh(i) ^ rol(F[i], k-1)) ^ F[i+k]        rh(i+1) = ror1(rh(i) ^ R[i] ^ rol(R[i+k], k)),
+// after k steps of start-up: two byte look-ups and four seed look-ups (LDS) per k-mer and no cross-lane traffic at all.  A wave takes
+// 64 x 128 = 8192 positions, a workgroup of 8 waves one K1SEG segment.  The bases of a wave's stretch are staged in LDS with the
+// lanes' runs 132 bytes apart (the lanes walk their runs in step: a 128-byte pitch would put all of them on one bank).  Kept hashes
+// must come out in position order, i.e. lane after lane: a first walk counts what each lane keeps (wave prefix sum, then the
+// workgroup's over its 8 waves) and holds on to the first two hashes; a lane that kept more walks its run again to write them.  Same outputs as k1_seg_hash (out[], seg_cnt).
+constexpr int ROLL_L = 128, ROLL_WAVES = 8, ROLL_PITCH = ROLL_L + 4, ROLL_HALO = 256;
+static_assert(64 * ROLL_L * ROLL_WAVES == K1SEG, "a workgroup covers one segment");
+
+__global__ void __launch_bounds__(64 * ROLL_WAVES) k1_seg_roll(const K1Args a) {
+  // seeds, and the two rotated copies the recurrence asks for (a look-up instead of two variable 64-bit rotates per k-mer):
+  // tab_out[b] = rol(F[b], k-1) leaves fh with the base that drops out, tab_in[b] = rol(R[b], k) enters rh with the new one
+  __shared__ uint64_t tab[256], tab_out[256], tab_in[8];
+  __shared__ __attribute__((aligned(16))) uint8_t bases[ROLL_WAVES][64 * ROLL_PITCH + ROLL_HALO];
+  __shared__ int s_cnt[ROLL_WAVES];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  if (tid < 256) {
+    const uint64_t sd = seed_of(tid);
+    tab[tid] = sd;
+    tab_out[tid] = rolv(sd, a.k - 1);
+    if (tid < 8) tab_in[tid] = rolv(sd, a.k);
+  }
+  const uint32_t r = blockIdx.x / a.segs_max, seg = blockIdx.x % a.segs_max;
+  const uint64_t o1 = a.offs[r];
+  const int len = (int)(a.offs[r + 1] - o1);
+  const int k = a.k;
+  const int npos = len - k + 1;
+  const int p_lo = (int)seg * K1SEG;
+  const bool on = len >= a.min_qlen && p_lo < npos;  // (:778-786 gate; ErrShortSeq => no k-mers) — uniform over the workgroup
+  const int P0 = p_lo + w * 64 * ROLL_L;             // first position of this wave
+  const int wpos = on ? max(0, min(npos - P0, 64 * ROLL_L)) : 0;  // positions of this wave
+  uint8_t* __restrict__ B = bases[w];
+  auto at = [&](int q) -> int { return (q / ROLL_L) * ROLL_PITCH + (q % ROLL_L); };
+  if (wpos > 0) {
+    const uint8_t* __restrict__ s = a.seqs + o1 + P0;
+    const int nb = wpos + k - 1;  // bases this wave needs (k <= 128, the launcher checks: they end inside the 65th run slot)
+    // 16 bases per lane and turn (a 16-byte piece at a multiple of 16 never crosses the end of a 128-byte run, so it stays in one
+    // piece in LDS too; the source is wherever the read starts: unaligned loads), then what is left byte by byte
+    typedef uint32_t u32x4_any __attribute__((ext_vector_type(4), aligned(1)));
+    const int nb16 = nb & ~15;
+    for (int g = lane * 16; g < nb16; g += 64 * 16) {
+      const u32x4_any v = *reinterpret_cast<const u32x4_any*>(s + g);
+      uint32_t* d = reinterpret_cast<uint32_t*>(B + at(g));
+      d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+    }
+    for (int g = nb16 + lane; g < nb; g += 64) B[at(g)] = s[g];
+  }
+  __syncthreads();  // tab[] and the staged bases
+  const bool scaled = a.scaled != 0;
+  const uint64_t max_hash = a.max_hash;
+  const int q0 = lane * ROLL_L;
+  const int mine = max(0, min(wpos - q0, ROLL_L));  // k-mer positions of this lane
+  // one walk over the lane's run; `emit(h)` sees the kept hashes in position order
+  auto walk = [&](auto&& emit) {
+    if (mine <= 0) return;
+    uint64_t fh = 0, rh = 0;
+    for (int j = 0; j < k; j++) {  // start-up (hash_at): fh = XOR_j rol(F[j], k-1-j), rh = XOR_j rol(R[j], j)
+      const uint8_t b = B[at(q0 + j)];
+      fh = rol1(fh) ^ tab[b];
+      rh ^= rolv(tab[b & 7], j);
+    }
+    const uint8_t* __restrict__ run = B + lane * ROLL_PITCH;  // the lane's own 128 bases; what follows them starts 4 bytes later
+    for (int t = 0;; t++) {
+      const uint64_t h = fh < rh ? fh : rh;
+      if (h != 0 && (!scaled || h <= max_hash)) emit(h);
+      if (t + 1 >= mine) break;
+      const int ti = t + k;  // < 256: k <= 128
+      const uint8_t bo = run[t], bi = run[ti + ((ti >> 7) << 2)];
+      fh = rol1(fh ^ tab_out[bo]) ^ tab[bi];
+      const uint64_t x = rh ^ tab[bo & 7] ^ tab_in[bi & 7];
+      rh = (x >> 1) | (x << 63);
+    }
+  };
+  // (a FracMinHash database keeps one hash in hundreds: the first two a lane keeps stay in registers, and the second walk is only
+  // taken by a lane that kept more — every lane of an unscaled query, hardly any of a scaled one)
+  int c = 0;
+  uint64_t h0 = 0, h1 = 0;
+  walk([&](uint64_t h) {
+    if (c == 0) h0 = h;
+    else if (c == 1) h1 = h;
+    c++;
+  });
+  // where this lane's hashes go: behind those of the lower lanes of its wave and of the lower waves of the workgroup
+  int incl = c;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const int t = __shfl_up(incl, off);
+    if (lane >= off) incl += t;
+  }
+  if (lane == 63) s_cnt[w] = incl;
+  __syncthreads();
+  int before = 0, total = 0;
+#pragma unroll
+  for (int i = 0; i < ROLL_WAVES; i++) {
+    const int ci = s_cnt[i];
+    if (i < w) before += ci;
+    total += ci;
+  }
+  if (c > 0) {
+    uint64_t* __restrict__ out = a.scratch + o1 + p_lo + before + (incl - c);
+    if (c <= 2) {
+      out[0] = h0;
+      if (c == 2) out[1] = h1;
+    } else {
+      int i = 0;
+      walk([&](uint64_t h) { out[i++] = h; });
+    }
+  }
+  if (tid == 0) a.seg_cnt[blockIdx.x] = total;
+}
+
 __global__ void __launch_bounds__(256) k1_seg_pack(const K1Args a) {
   const uint32_t r = blockIdx.x / a.segs_max, seg = blockIdx.x % a.segs_max;
   const uint64_t o1 = a.offs[r];
@@ -1148,7 +1263,9 @@ bool launch_k1(const K1Args& a, uint32_t max_read_len, hipStream_t st) {
   if (a.n_reads == 0) return false;
   if (a.seg_cnt && a.segs_max > 1) {  // whole genomes: one workgroup per 65536-position segment, then an ordered pack
     const unsigned blocks = a.n_reads * a.segs_max;
-    hipLaunchKernelGGL(k1_seg_hash, dim3(blocks), dim3(K1WG), 0, st, a);
+    // rolling hashes for every k the staging halo holds (flags bit 3 = 8: the prefix-XOR form, for A/B runs)
+    if (a.k <= 128 && !(a.flags & 8)) hipLaunchKernelGGL(k1_seg_roll, dim3(blocks), dim3(64 * ROLL_WAVES), 0, st, a);
+    else hipLaunchKernelGGL(k1_seg_hash, dim3(blocks), dim3(K1WG), 0, st, a);
     hipLaunchKernelGGL(k1_seg_pack, dim3(blocks), dim3(256), 0, st, a);
     return false;
   }
