@@ -100,6 +100,7 @@ struct K2Args {
   int32_t nt_loads;      // non-temporal row loads
   int32_t prune;         // stop loading sectors whose columns can no longer reach the threshold
   int32_t group_rows;    // rows gathered between two pruning tests: 4 or 8
+  int32_t prune_every;   // the pruning test runs after every prune_every-th row group (1, 2, 4 or 8) and at the end of a chunk of 64 rows
   int32_t split_min;     // >0: queries with more k-mers are handled by the SPLIT launch
   int32_t slot_major;    // unit order: 1 = slot-major (unit u -> slot u / n_reads, read u % n_reads), 0 = read-major
   // long-query (SPLIT) form

@@ -287,7 +287,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, (GR
         csa4<NPL>(pl[2], x[0].z, x[1].z, x[2].z, x[3].z);
         csa4<NPL>(pl[3], x[0].w, x[1].w, x[2].w, x[3].w);
       }
-      if (!SPLIT && a.prune) {
+      if (!SPLIT && a.prune && ((((j / NR) + 1) & (a.prune_every - 1)) == 0 || j + NR >= cnt)) {
         const int done = min(n, c0 + j + NR);
         const int need = (int)cmin - (n - done);  // a column must already hold this many to stay in the race
         bool lane_alive = live;
