@@ -436,6 +436,7 @@ def run_workload(name, ctx, steps, warmup, batch_reads=0, cpu_baseline=True, cpu
         gpu_half(first, bufs[0])
         for j in range(count):
             bf = bufs[j % 2]
+            t0 = time.perf_counter()
             if j + 1 < count:
                 gpu_half(first + j + 1, bufs[(j + 1) % 2])
             ta = time.perf_counter()
@@ -448,7 +449,7 @@ def run_workload(name, ctx, steps, warmup, batch_reads=0, cpu_baseline=True, cpu
             if times is not None:
                 times.append(db.last_timing(age=1 if j + 1 < count else 0))
             if os.environ.get("KMCP_BENCH_TRACE"):
-                print(f"rank {rank} step {j}: exchange {1e3*(tb-ta):.2f} ms, host half {1e3*(tc-tb):.2f} ms, timing {1e3*(time.perf_counter()-tc):.2f} ms", file=sys.stderr)
+                print(f"rank {rank} step {j}: enqueue of the next {1e3*(ta-t0):.2f} ms, exchange {1e3*(tb-ta):.2f} ms, host half {1e3*(tc-tb):.2f} ms, timing {1e3*(time.perf_counter()-tc):.2f} ms", file=sys.stderr)
         return hits, matches
 
     run_steps(0, warmup)

@@ -27,11 +27,21 @@ namespace kmcpg {
 // per-wave LDS table — hash loads of the whole chunk first, block constants from LDS: no dependent global loads in that loop;
 // k-mers past the end of a read map to the all-zero row appended to each block, so the inner loop has no tail code.
 // ------------------------------------------------------------------------------------------------
+// carry-save adder: h = majority, l = parity of three words.  CSA3 spells them as one v_bitop3_b32 each (gfx950) for the long-query
+// kernels, which run near their issue limits; the short-query kernels (8 / 10 planes) wait for HBM and keep the form and the
+// instruction schedule they were tuned with (same-box A/B, scratch/call14.sh: the GTDB-scale launch is 1.7 % slower with CSA3 and
+// the regrouped loads).
 #define CSA(h, l, a_, b_, c_)              \
   {                                        \
     uint32_t u_ = (a_) ^ (b_);             \
     h = ((a_) & (b_)) | (u_ & (c_));       \
     l = u_ ^ (c_);                         \
+  }
+#define CSA3(h, l, a_, b_, c_)                                  \
+  {                                                             \
+    const uint32_t a__ = (a_), b__ = (b_), c__ = (c_);          \
+    h = __builtin_amdgcn_bitop3_b32(a__, b__, c__, 0xE8);       \
+    l = __builtin_amdgcn_bitop3_b32(a__, b__, c__, 0x96);       \
   }
 
 // 16 bytes of a row.  Index rows are read once per launch and L2 cannot hold a slice (cache note): non-temporal
@@ -41,6 +51,33 @@ __device__ __forceinline__ uint4 load_row16(const uint8_t* p, int nt) {
   const u32x4* q = reinterpret_cast<const u32x4*>(p);
   const u32x4 v = nt ? __builtin_nontemporal_load(q) : *q;
   return make_uint4(v.x, v.y, v.z, v.w);
+}
+
+// a carry of plane FROM's weight rippling through the planes above
+template <int NPL, int FROM>
+__device__ __forceinline__ void ripple(uint32_t (&pl)[NPL], uint32_t e) {
+#pragma unroll
+  for (int p = FROM; p < NPL; p++) {
+    uint32_t t = pl[p] & e;
+    pl[p] ^= e;
+    e = t;
+  }
+}
+
+// 8 rows into the planes of weight 1, 2 and 4; returns the carry of weight 8 (the caller reduces the carries of several groups
+// before anything ripples, k2_cobs)
+template <int NPL>
+__device__ __forceinline__ uint32_t csa8_low(uint32_t (&pl)[NPL], uint32_t x0, uint32_t x1, uint32_t x2, uint32_t x3, uint32_t x4,
+                                             uint32_t x5, uint32_t x6, uint32_t x7) {
+  uint32_t ta, tb, fa, fb, e;
+  CSA3(ta, pl[0], pl[0], x0, x1);
+  CSA3(tb, pl[0], pl[0], x2, x3);
+  CSA3(fa, pl[1], pl[1], ta, tb);
+  CSA3(ta, pl[0], pl[0], x4, x5);
+  CSA3(tb, pl[0], pl[0], x6, x7);
+  CSA3(fb, pl[1], pl[1], ta, tb);
+  CSA3(e, pl[2], pl[2], fa, fb);
+  return e;
 }
 
 template <int NPL>
@@ -108,7 +145,7 @@ struct alignas(16) UnitConst {  // one (read, slot) unit as the index phase sees
 };
 
 template <int LPR, int NPL, bool MULTI, bool SPLIT, int GR = 8>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, (GR == 4 && LPR == 64) ? 4 : 10))) k2_cobs(const K2Args a) {
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((NPL == 16 && !SPLIT && LPR >= 16) ? 3 : 1, (GR == 4 && LPR == 64) ? 4 : 10))) k2_cobs(const K2Args a) {
   constexpr int G = 64 / LPR;
   constexpr int PAIRS = MULTI ? 256 : 1024;
   constexpr int CH = (PAIRS / G) > 64 ? 64 : (PAIRS / G);
@@ -241,18 +278,18 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, (GR
     wave_lds_fence();
 
     const int cnt = min(CH, nmax - c0);
-    // NR rows at a time: gather, AND (multi-hash), add to the counters, then the branch-and-bound test
-    auto group = [&](auto nr_tag, int j) -> bool {
+    // NR rows: gather and AND (multi-hash).  The row indices come from LDS first (dead lanes read them too: no harm), then one
+    // branch around all loads of the group.
+    auto gather = [&](auto nr_tag, int j, uint4* __restrict__ x) {
       constexpr int NR = decltype(nr_tag)::value;
-      uint4 x[NR];
+      uint32_t ri[NR];
 #pragma unroll
-      for (int i = 0; i < NR; i++) {
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (live) {
-          const uint32_t row = s_rows[wave][0][g * CH + j + i];
-          v = load_row16(base + ((uint64_t)row << 4), a.nt_loads);
-        }
-        x[i] = v;
+      for (int i = 0; i < NR; i++) ri[i] = s_rows[wave][0][g * CH + j + i];
+#pragma unroll
+      for (int i = 0; i < NR; i++) x[i] = make_uint4(0, 0, 0, 0);
+      if (live) {
+#pragma unroll
+        for (int i = 0; i < NR; i++) x[i] = load_row16(base + ((uint64_t)ri[i] << 4), a.nt_loads);
       }
       if (MULTI) {
         // AND of the h rows (pand.AndUnsafe, :6639-6646), one hash function at a time over all NR k-mers: the NR loads of a hash
@@ -262,12 +299,12 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, (GR
         for (int hh = 1; hh < nh; hh++) {
           uint4 w[NR];
 #pragma unroll
-          for (int i = 0; i < NR; i++) {
-            w[i] = make_uint4(0, 0, 0, 0);
-            if (live) {
-              const uint32_t row2 = s_rows[wave][hh][g * CH + j + i];
-              w[i] = load_row16(base + ((uint64_t)row2 << 4), a.nt_loads);
-            }
+          for (int i = 0; i < NR; i++) ri[i] = s_rows[wave][hh][g * CH + j + i];
+#pragma unroll
+          for (int i = 0; i < NR; i++) w[i] = make_uint4(0, 0, 0, 0);
+          if (live) {
+#pragma unroll
+            for (int i = 0; i < NR; i++) w[i] = load_row16(base + ((uint64_t)ri[i] << 4), a.nt_loads);
           }
 #pragma unroll
           for (int i = 0; i < NR; i++) {
@@ -276,45 +313,143 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, (GR
         }
       }
       if (a.gathered) g_acc += (uint32_t)__popcll(__ballot(live)) * NR * (MULTI ? nh : 1);  // measurement runs only
-      if constexpr (NR == 8) {
-        csa8<NPL>(pl[0], x[0].x, x[1].x, x[2].x, x[3].x, x[4].x, x[5].x, x[6].x, x[7].x);
-        csa8<NPL>(pl[1], x[0].y, x[1].y, x[2].y, x[3].y, x[4].y, x[5].y, x[6].y, x[7].y);
-        csa8<NPL>(pl[2], x[0].z, x[1].z, x[2].z, x[3].z, x[4].z, x[5].z, x[6].z, x[7].z);
-        csa8<NPL>(pl[3], x[0].w, x[1].w, x[2].w, x[3].w, x[4].w, x[5].w, x[6].w, x[7].w);
-      } else {
-        csa4<NPL>(pl[0], x[0].x, x[1].x, x[2].x, x[3].x);
-        csa4<NPL>(pl[1], x[0].y, x[1].y, x[2].y, x[3].y);
-        csa4<NPL>(pl[2], x[0].z, x[1].z, x[2].z, x[3].z);
-        csa4<NPL>(pl[3], x[0].w, x[1].w, x[2].w, x[3].w);
+    };
+    // the branch-and-bound test after `done` k-mers of the unit's read: true when the whole wave is done with these rows
+    auto prune_test = [&](int done) -> bool {
+      const int need = (int)cmin - (n - done);  // a column must already hold this many to stay in the race
+      bool lane_alive = live;
+      if (live && need > 0) {
+        uint32_t any = 0;
+        if (NPL >= 32 || ((uint32_t)need >> NPL) == 0) {
+#pragma unroll
+          for (int d = 0; d < 4; d++) {
+            uint32_t ge = 0xffffffffu;
+#pragma unroll
+            for (int p = 0; p < NPL; p++) ge = (((uint32_t)need >> p) & 1u) ? (ge & pl[d][p]) : (ge | pl[d][p]);
+            any |= ge;
+          }
+        }
+        lane_alive = any != 0;
       }
-      if (!SPLIT && a.prune && ((((j / NR) + 1) & (a.prune_every - 1)) == 0 || j + NR >= cnt)) {
-        const int done = min(n, c0 + j + NR);
-        const int need = (int)cmin - (n - done);  // a column must already hold this many to stay in the race
-        bool lane_alive = live;
-        if (live && need > 0) {
-          uint32_t any = 0;
-          if (NPL >= 32 || ((uint32_t)need >> NPL) == 0) {
+      const uint64_t alive = __ballot(lane_alive);
+      live = live && ((alive >> (lane & ~(GRP - 1))) & ((1ULL << GRP) - 1ULL)) != 0;
+      return alive == 0;
+    };
+    if constexpr (NPL >= 16) {
+      // Long queries, 16 / 24 planes: these kernels run near their issue limits, and most of their VALU work was the carry out of
+      // every 8-row group rippling through 13 (21) upper planes.  Here the weight-8 carries of FOUR groups are first reduced among
+      // themselves (two of weight 16, then one of weight 32) and a single carry ripples from plane 5 on: 32 rows cost
+      // 4 x 7 + 3 carry-save adders and one ripple instead of 4 x 7 and four ripples.  The planes are in canonical form after every
+      // 32 rows, which is where the pruning test runs (a sector dies <= 24 rows later than with a test per group: < 2 % of a HiFi
+      // sketch); groups past the end of the chunk contribute zero carries.
+      static_assert(GR == 8, "deferred carries are written for 8-row groups");
+      constexpr int GI_UNROLL = MULTI ? 1 : 4;  // rolled where registers decide about the third wave per SIMD (multi-hash: 166 VGPRs, unrolled 174)
+      for (int j = 0; j < cnt; j += 32) {
+        uint32_t e8[4] = {0, 0, 0, 0}, s16[4] = {0, 0, 0, 0};
+#pragma unroll GI_UNROLL
+        for (int gi = 0; gi < 4; gi++) {
+          uint32_t en[4] = {0, 0, 0, 0};
+          if (j + 8 * gi < cnt) {  // wave-uniform
+            uint4 x[8];
+            gather(std::integral_constant<int, 8>{}, j + 8 * gi, x);
+            en[0] = csa8_low(pl[0], x[0].x, x[1].x, x[2].x, x[3].x, x[4].x, x[5].x, x[6].x, x[7].x);
+            en[1] = csa8_low(pl[1], x[0].y, x[1].y, x[2].y, x[3].y, x[4].y, x[5].y, x[6].y, x[7].y);
+            en[2] = csa8_low(pl[2], x[0].z, x[1].z, x[2].z, x[3].z, x[4].z, x[5].z, x[6].z, x[7].z);
+            en[3] = csa8_low(pl[3], x[0].w, x[1].w, x[2].w, x[3].w, x[4].w, x[5].w, x[6].w, x[7].w);
+          }
 #pragma unroll
-            for (int d = 0; d < 4; d++) {
-              uint32_t ge = 0xffffffffu;
-#pragma unroll
-              for (int p = 0; p < NPL; p++) ge = (((uint32_t)need >> p) & 1u) ? (ge & pl[d][p]) : (ge | pl[d][p]);
-              any |= ge;
+          for (int d = 0; d < 4; d++) {
+            if (gi == 0 || gi == 2) {
+              e8[d] = en[d];
+            } else if (gi == 1) {
+              CSA3(s16[d], pl[d][3], pl[d][3], e8[d], en[d]);
+            } else {
+              uint32_t sb, t;
+              CSA3(sb, pl[d][3], pl[d][3], e8[d], en[d]);
+              CSA3(t, pl[d][4], pl[d][4], s16[d], sb);
+              ripple<NPL, 5>(pl[d], t);
             }
           }
-          lane_alive = any != 0;
         }
-        const uint64_t alive = __ballot(lane_alive);
-        live = live && ((alive >> (lane & ~(GRP - 1))) & ((1ULL << GRP) - 1ULL)) != 0;
-        if (alive == 0) return true;  // the whole wave is done with these rows
+        if (!SPLIT && a.prune && prune_test(min(n, c0 + min(cnt, j + 32)))) break;  // (a chunk can be shorter than 32 rows: multi-hash on 64-byte tiles)
       }
-      return false;
-    };
-    // Sectors die at the first test after their last column has fallen behind: with 8 rows between tests that point is
-    // overshot by ~3.5 rows on average, with 4 rows by ~1.5 — 2.3 % of a 130-k-mer read's row traffic, for ~15 % more VALU work
-    // (the host picks the group size by regime, query.cpp; profiles/r02_group_rows.txt).
-    for (int j = 0; j < cnt; j += GR)
-      if (group(std::integral_constant<int, GR>{}, j)) break;
+    } else {
+      // short queries (8 / 10 planes): the loop these kernels were tuned with, untouched
+      // NR rows at a time: gather, AND (multi-hash), add to the counters, then the branch-and-bound test
+      auto group = [&](auto nr_tag, int j) -> bool {
+        constexpr int NR = decltype(nr_tag)::value;
+        uint4 x[NR];
+  #pragma unroll
+        for (int i = 0; i < NR; i++) {
+          uint4 v = make_uint4(0, 0, 0, 0);
+          if (live) {
+            const uint32_t row = s_rows[wave][0][g * CH + j + i];
+            v = load_row16(base + ((uint64_t)row << 4), a.nt_loads);
+          }
+          x[i] = v;
+        }
+        if (MULTI) {
+          // AND of the h rows (pand.AndUnsafe, :6639-6646), one hash function at a time over all NR k-mers: the NR loads of a hash
+          // function are in flight together.  (With the hash loop inside the k-mer loop — a run-time trip count — the compiler waited for
+          // every row before it asked for the next: the 3-hash genome search ran at 3.8 TB/s with 24 dependent loads per group, now 5.0.
+          // Keeping the loads of TWO hash functions in flight changes nothing more: 4.12-4.17 vs 4.08 ms, same-box A/B.)
+          for (int hh = 1; hh < nh; hh++) {
+            uint4 w[NR];
+  #pragma unroll
+            for (int i = 0; i < NR; i++) {
+              w[i] = make_uint4(0, 0, 0, 0);
+              if (live) {
+                const uint32_t row2 = s_rows[wave][hh][g * CH + j + i];
+                w[i] = load_row16(base + ((uint64_t)row2 << 4), a.nt_loads);
+              }
+            }
+  #pragma unroll
+            for (int i = 0; i < NR; i++) {
+              x[i].x &= w[i].x; x[i].y &= w[i].y; x[i].z &= w[i].z; x[i].w &= w[i].w;
+            }
+          }
+        }
+        if (a.gathered) g_acc += (uint32_t)__popcll(__ballot(live)) * NR * (MULTI ? nh : 1);  // measurement runs only
+        if constexpr (NR == 8) {
+          csa8<NPL>(pl[0], x[0].x, x[1].x, x[2].x, x[3].x, x[4].x, x[5].x, x[6].x, x[7].x);
+          csa8<NPL>(pl[1], x[0].y, x[1].y, x[2].y, x[3].y, x[4].y, x[5].y, x[6].y, x[7].y);
+          csa8<NPL>(pl[2], x[0].z, x[1].z, x[2].z, x[3].z, x[4].z, x[5].z, x[6].z, x[7].z);
+          csa8<NPL>(pl[3], x[0].w, x[1].w, x[2].w, x[3].w, x[4].w, x[5].w, x[6].w, x[7].w);
+        } else {
+          csa4<NPL>(pl[0], x[0].x, x[1].x, x[2].x, x[3].x);
+          csa4<NPL>(pl[1], x[0].y, x[1].y, x[2].y, x[3].y);
+          csa4<NPL>(pl[2], x[0].z, x[1].z, x[2].z, x[3].z);
+          csa4<NPL>(pl[3], x[0].w, x[1].w, x[2].w, x[3].w);
+        }
+        if (!SPLIT && a.prune && ((((j / NR) + 1) & (a.prune_every - 1)) == 0 || j + NR >= cnt)) {
+          const int done = min(n, c0 + j + NR);
+          const int need = (int)cmin - (n - done);  // a column must already hold this many to stay in the race
+          bool lane_alive = live;
+          if (live && need > 0) {
+            uint32_t any = 0;
+            if (NPL >= 32 || ((uint32_t)need >> NPL) == 0) {
+  #pragma unroll
+              for (int d = 0; d < 4; d++) {
+                uint32_t ge = 0xffffffffu;
+  #pragma unroll
+                for (int p = 0; p < NPL; p++) ge = (((uint32_t)need >> p) & 1u) ? (ge & pl[d][p]) : (ge | pl[d][p]);
+                any |= ge;
+              }
+            }
+            lane_alive = any != 0;
+          }
+          const uint64_t alive = __ballot(lane_alive);
+          live = live && ((alive >> (lane & ~(GRP - 1))) & ((1ULL << GRP) - 1ULL)) != 0;
+          if (alive == 0) return true;  // the whole wave is done with these rows
+        }
+        return false;
+      };
+      // Sectors die at the first test after their last column has fallen behind: with 8 rows between tests that point is
+      // overshot by ~3.5 rows on average, with 4 rows by ~1.5 — 2.3 % of a 130-k-mer read's row traffic, for ~15 % more VALU work
+      // (the host picks the group size by regime, query.cpp; profiles/r02_group_rows.txt).
+      for (int j = 0; j < cnt; j += GR)
+        if (group(std::integral_constant<int, GR>{}, j)) break;
+    }
     wave_lds_fence();
     if (!SPLIT && a.prune && __ballot(live) == 0) break;
   }
