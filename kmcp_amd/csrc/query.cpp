@@ -337,11 +337,11 @@ extern "C" int kmcpg_query_device(kmcpg_db* db, const uint8_t* d_seqs, const uin
   // Infinity Cache: 17.8 -> 19.6 ms) — profiles/r02_group_rows.txt.
   a.group_rows = (a.prune && npl <= 10 && db->info.matrix_bytes_local >= (4ull << 30)) ? 4 : 8;
   if (const char* e = getenv("KMCPG_GROUP_ROWS")) a.group_rows = atoi(e) == 4 ? 4 : 8;
-  // How often the test runs.  On 16 and 24 planes it is a quarter of the kernel's VALU work and those kernels run near their issue limits: every 4th
-  // group (32 rows; a sector is dropped <= 24 rows later, < 2 % of a HiFi sketch, 0.3 % of a genome's) — same-box A/B scratch/call13.sh: equal-width
-  // HiFi index 3.88 -> 3.55 ms per 16 384 reads, genome search 5.73 -> 5.48 ms per 256 genomes, the reference's narrow HiFi blocks (bound by
-  // request count) unchanged.  8- and 10-plane kernels wait for HBM: every group.
-  a.prune_every = npl >= 16 ? 4 : 1;
+  // How often the test runs in the 8/10-plane kernels: after every group (they wait for HBM; KMCPG_PRUNE_EVERY = 2/4/8 for experiments).
+  // The 16/24-plane kernels resolve their carries every 32 rows and test there (k2_cobs.hip): the test was a quarter of their VALU
+  // work at one test per group, and they run near their issue limits — same-box A/B scratch/call13.sh: equal-width HiFi index
+  // 3.88 -> 3.55 ms per 16 384 reads, genome search 5.73 -> 5.48 ms per 256 genomes with a test every 4th group alone.
+  a.prune_every = 1;
   if (const char* e = getenv("KMCPG_PRUNE_EVERY")) {
     const int v = atoi(e);
     a.prune_every = (v == 2 || v == 4 || v == 8) ? v : 1;
