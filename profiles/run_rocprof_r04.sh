@@ -9,7 +9,7 @@
 #   config2  BASELINE configs[2] (genome search, FracMinHash, 3 hashes) with matching queries: kernel stats + FETCH_SIZE
 #   config4  BASELINE configs[4] (HiFi, Closed Syncmer) with matching reads, both index variants: kernel stats + FETCH_SIZE
 #   pubsq    the published configuration (128-byte rows) WITH pruning: SQ counters
-# The rocpd .db files are deleted after extraction.    usage: profiles/run_rocprof_r04.sh [tag=r04] [which="all"]
+# STATS_ONLY=1 skips the FETCH_SIZE passes.  The rocpd .db files are deleted after extraction.    usage: profiles/run_rocprof_r04.sh [tag=r04] [which="all"]
 set -u
 TAG=${1:-r04}
 WHICH=${2:-all}
@@ -29,7 +29,7 @@ run() {  # name, rocprof args..., -- command
   echo "$name: $(( $(date +%s) - t0 )) s"
 }
 stats() { local n=$1; shift; run ${n}_stats --kernel-trace --stats -d $OUT/_prof_${n}_stats -o ${n}_stats -- "$@"; }
-pmc() { local n=$1; shift; run ${n}_pmc --pmc FETCH_SIZE --kernel-trace -d $OUT/_prof_${n}_pmc -o ${n}_pmc -- "$@"; }
+pmc() { [ -n "${STATS_ONLY:-}" ] && return 0; local n=$1; shift; run ${n}_pmc --pmc FETCH_SIZE --kernel-trace -d $OUT/_prof_${n}_pmc -o ${n}_pmc -- "$@"; }
 ctr() { local n=$1; local c=$2; shift; shift; run ${n} --pmc $c --kernel-trace -d $OUT/_prof_${n} -o ${n} -- "$@"; }
 want() { [ "$WHICH" = all ] || [[ ",$WHICH," == *",$1,"* ]]; }
 
