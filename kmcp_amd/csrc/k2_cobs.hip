@@ -145,7 +145,7 @@ struct alignas(16) UnitConst {  // one (read, slot) unit as the index phase sees
 };
 
 template <int LPR, int NPL, bool MULTI, bool SPLIT, int GR = 8>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((NPL == 16 && !SPLIT && LPR >= 16) ? 3 : 1, (GR == 4 && LPR == 64) ? 4 : 10))) k2_cobs(const K2Args a) {
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((NPL == 16 && !SPLIT && !MULTI && LPR >= 16) ? 3 : 1, (GR == 4 && LPR == 64) ? 4 : 10))) k2_cobs(const K2Args a) {
   constexpr int G = 64 / LPR;
   constexpr int PAIRS = MULTI ? 256 : 1024;
   constexpr int CH = (PAIRS / G) > 64 ? 64 : (PAIRS / G);
@@ -343,7 +343,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((NPL =
       // 32 rows, which is where the pruning test runs (a sector dies <= 24 rows later than with a test per group: < 2 % of a HiFi
       // sketch); groups past the end of the chunk contribute zero carries.
       static_assert(GR == 8, "deferred carries are written for 8-row groups");
-      constexpr int GI_UNROLL = MULTI ? 1 : 4;  // rolled where registers decide about the third wave per SIMD (multi-hash: 166 VGPRs, unrolled 174)
+      constexpr int GI_UNROLL = 4;  // (multi-hash: 174 VGPRs = 2 waves per SIMD unrolled, 166 = 3 waves rolled — and the unrolled form is 2 % faster, scratch/call17.sh)
       for (int j = 0; j < cnt; j += 32) {
         uint32_t e8[4] = {0, 0, 0, 0}, s16[4] = {0, 0, 0, 0};
 #pragma unroll GI_UNROLL
