@@ -80,6 +80,16 @@ __device__ __forceinline__ uint32_t csa8_low(uint32_t (&pl)[NPL], uint32_t x0, u
   return e;
 }
 
+// the same through a pointer the compiler knows to be global memory (a row pointer read from a BlockDev record is a generic one to
+// it: flat_load, whose completions cannot be counted in order — every wait becomes "all loads").  With global_load the adders of
+// one row group wait for that group's loads only while the next group's are in flight.
+typedef const u32x4 __attribute__((address_space(1))) * global_row_ptr;
+__device__ __forceinline__ uint4 load_row16_global(const uint8_t* p, int nt) {
+  global_row_ptr q = (global_row_ptr)(uintptr_t)p;
+  const u32x4 v = nt ? __builtin_nontemporal_load(q) : *q;
+  return make_uint4(v.x, v.y, v.z, v.w);
+}
+
 template <int NPL>
 __device__ __forceinline__ void csa8(uint32_t (&pl)[NPL], uint32_t x0, uint32_t x1, uint32_t x2, uint32_t x3, uint32_t x4,
                                      uint32_t x5, uint32_t x6, uint32_t x7) {
@@ -289,7 +299,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((NPL =
       for (int i = 0; i < NR; i++) x[i] = make_uint4(0, 0, 0, 0);
       if (live) {
 #pragma unroll
-        for (int i = 0; i < NR; i++) x[i] = load_row16(base + ((uint64_t)ri[i] << 4), a.nt_loads);
+        for (int i = 0; i < NR; i++) x[i] = load_row16_global(base + ((uint64_t)ri[i] << 4), a.nt_loads);
       }
       if (MULTI) {
         // AND of the h rows (pand.AndUnsafe, :6639-6646), one hash function at a time over all NR k-mers: the NR loads of a hash
@@ -304,7 +314,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((NPL =
           for (int i = 0; i < NR; i++) w[i] = make_uint4(0, 0, 0, 0);
           if (live) {
 #pragma unroll
-            for (int i = 0; i < NR; i++) w[i] = load_row16(base + ((uint64_t)ri[i] << 4), a.nt_loads);
+            for (int i = 0; i < NR; i++) w[i] = load_row16_global(base + ((uint64_t)ri[i] << 4), a.nt_loads);
           }
 #pragma unroll
           for (int i = 0; i < NR; i++) {
@@ -346,12 +356,16 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((NPL =
       constexpr int GI_UNROLL = 4;  // (multi-hash: 174 VGPRs = 2 waves per SIMD unrolled, 166 = 3 waves rolled — and the unrolled form is 2 % faster, scratch/call17.sh)
       for (int j = 0; j < cnt; j += 32) {
         uint32_t e8[4] = {0, 0, 0, 0}, s16[4] = {0, 0, 0, 0};
+        // (single hash function: the loads of group gi + 1 are issued before the adders of group gi run — 16 rows in flight per lane)
+        uint4 xq[2][8];
+        if (!MULTI) gather(std::integral_constant<int, 8>{}, j, xq[0]);
 #pragma unroll GI_UNROLL
         for (int gi = 0; gi < 4; gi++) {
           uint32_t en[4] = {0, 0, 0, 0};
+          if (!MULTI && gi < 3 && j + 8 * (gi + 1) < cnt) gather(std::integral_constant<int, 8>{}, j + 8 * (gi + 1), xq[(gi + 1) & 1]);
           if (j + 8 * gi < cnt) {  // wave-uniform
-            uint4 x[8];
-            gather(std::integral_constant<int, 8>{}, j + 8 * gi, x);
+            uint4(&x)[8] = xq[gi & 1];
+            if (MULTI) gather(std::integral_constant<int, 8>{}, j + 8 * gi, x);
             en[0] = csa8_low(pl[0], x[0].x, x[1].x, x[2].x, x[3].x, x[4].x, x[5].x, x[6].x, x[7].x);
             en[1] = csa8_low(pl[1], x[0].y, x[1].y, x[2].y, x[3].y, x[4].y, x[5].y, x[6].y, x[7].y);
             en[2] = csa8_low(pl[2], x[0].z, x[1].z, x[2].z, x[3].z, x[4].z, x[5].z, x[6].z, x[7].z);
