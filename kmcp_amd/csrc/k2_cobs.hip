@@ -7,6 +7,7 @@
 #include <type_traits>
 
 #include "common.hpp"
+#include "csa.hpp"
 #include "device_utils.hpp"
 #include "kernels.hpp"
 
@@ -27,23 +28,6 @@ namespace kmcpg {
 // per-wave LDS table — hash loads of the whole chunk first, block constants from LDS: no dependent global loads in that loop;
 // k-mers past the end of a read map to the all-zero row appended to each block, so the inner loop has no tail code.
 // ------------------------------------------------------------------------------------------------
-// carry-save adder: h = majority, l = parity of three words.  CSA3 spells them as one v_bitop3_b32 each (gfx950) for the long-query
-// kernels, which run near their issue limits; the short-query kernels (8 / 10 planes) wait for HBM and keep the form and the
-// instruction schedule they were tuned with (same-box A/B, scratch/call14.sh: the GTDB-scale launch is 1.7 % slower with CSA3 and
-// the regrouped loads).
-#define CSA(h, l, a_, b_, c_)              \
-  {                                        \
-    uint32_t u_ = (a_) ^ (b_);             \
-    h = ((a_) & (b_)) | (u_ & (c_));       \
-    l = u_ ^ (c_);                         \
-  }
-#define CSA3(h, l, a_, b_, c_)                                  \
-  {                                                             \
-    const uint32_t a__ = (a_), b__ = (b_), c__ = (c_);          \
-    h = __builtin_amdgcn_bitop3_b32(a__, b__, c__, 0xE8);       \
-    l = __builtin_amdgcn_bitop3_b32(a__, b__, c__, 0x96);       \
-  }
-
 // 16 bytes of a row.  Index rows are read once per launch and L2 cannot hold a slice (cache note): non-temporal
 // loads keep them from displacing the hash/offset lines in L2 (no measurable difference either way in the kernel).
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -51,33 +35,6 @@ __device__ __forceinline__ uint4 load_row16(const uint8_t* p, int nt) {
   const u32x4* q = reinterpret_cast<const u32x4*>(p);
   const u32x4 v = nt ? __builtin_nontemporal_load(q) : *q;
   return make_uint4(v.x, v.y, v.z, v.w);
-}
-
-// a carry of plane FROM's weight rippling through the planes above
-template <int NPL, int FROM>
-__device__ __forceinline__ void ripple(uint32_t (&pl)[NPL], uint32_t e) {
-#pragma unroll
-  for (int p = FROM; p < NPL; p++) {
-    uint32_t t = pl[p] & e;
-    pl[p] ^= e;
-    e = t;
-  }
-}
-
-// 8 rows into the planes of weight 1, 2 and 4; returns the carry of weight 8 (the caller reduces the carries of several groups
-// before anything ripples, k2_cobs)
-template <int NPL>
-__device__ __forceinline__ uint32_t csa8_low(uint32_t (&pl)[NPL], uint32_t x0, uint32_t x1, uint32_t x2, uint32_t x3, uint32_t x4,
-                                             uint32_t x5, uint32_t x6, uint32_t x7) {
-  uint32_t ta, tb, fa, fb, e;
-  CSA3(ta, pl[0], pl[0], x0, x1);
-  CSA3(tb, pl[0], pl[0], x2, x3);
-  CSA3(fa, pl[1], pl[1], ta, tb);
-  CSA3(ta, pl[0], pl[0], x4, x5);
-  CSA3(tb, pl[0], pl[0], x6, x7);
-  CSA3(fb, pl[1], pl[1], ta, tb);
-  CSA3(e, pl[2], pl[2], fa, fb);
-  return e;
 }
 
 // the same through a pointer the compiler knows to be global memory (a row pointer read from a BlockDev record is a generic one to
@@ -88,25 +45,6 @@ __device__ __forceinline__ uint4 load_row16_global(const uint8_t* p, int nt) {
   global_row_ptr q = (global_row_ptr)(uintptr_t)p;
   const u32x4 v = nt ? __builtin_nontemporal_load(q) : *q;
   return make_uint4(v.x, v.y, v.z, v.w);
-}
-
-template <int NPL>
-__device__ __forceinline__ void csa8(uint32_t (&pl)[NPL], uint32_t x0, uint32_t x1, uint32_t x2, uint32_t x3, uint32_t x4,
-                                     uint32_t x5, uint32_t x6, uint32_t x7) {
-  uint32_t ta, tb, fa, fb, e;
-  CSA(ta, pl[0], pl[0], x0, x1);
-  CSA(tb, pl[0], pl[0], x2, x3);
-  CSA(fa, pl[1], pl[1], ta, tb);
-  CSA(ta, pl[0], pl[0], x4, x5);
-  CSA(tb, pl[0], pl[0], x6, x7);
-  CSA(fb, pl[1], pl[1], ta, tb);
-  CSA(e, pl[2], pl[2], fa, fb);
-#pragma unroll
-  for (int p = 3; p < NPL; p++) {
-    uint32_t t = pl[p] & e;
-    pl[p] ^= e;
-    e = t;
-  }
 }
 
 // byte `byte` of a group's row, bit `bit` (7 = first column of the byte, index.go:1157) -> global column; false for padding
@@ -120,21 +58,6 @@ __device__ __forceinline__ bool group_col(const Seg* __restrict__ segs, const Bl
     }
   }
   return false;
-}
-
-// the same for 4 rows (the short groups of the zone where sectors die, see k2_cobs)
-template <int NPL>
-__device__ __forceinline__ void csa4(uint32_t (&pl)[NPL], uint32_t x0, uint32_t x1, uint32_t x2, uint32_t x3) {
-  uint32_t ta, tb, e;
-  CSA(ta, pl[0], pl[0], x0, x1);
-  CSA(tb, pl[0], pl[0], x2, x3);
-  CSA(e, pl[1], pl[1], ta, tb);
-#pragma unroll
-  for (int p = 2; p < NPL; p++) {
-    uint32_t t = pl[p] & e;
-    pl[p] ^= e;
-    e = t;
-  }
 }
 
 // SPLIT = true is the long-query form: a unit is (long query, slot, chunk of a.split_chk <= 8192 k-mers); its counts are added to a
@@ -372,18 +295,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((NPL =
             en[3] = csa8_low(pl[3], x[0].w, x[1].w, x[2].w, x[3].w, x[4].w, x[5].w, x[6].w, x[7].w);
           }
 #pragma unroll
-          for (int d = 0; d < 4; d++) {
-            if (gi == 0 || gi == 2) {
-              e8[d] = en[d];
-            } else if (gi == 1) {
-              CSA3(s16[d], pl[d][3], pl[d][3], e8[d], en[d]);
-            } else {
-              uint32_t sb, t;
-              CSA3(sb, pl[d][3], pl[d][3], e8[d], en[d]);
-              CSA3(t, pl[d][4], pl[d][4], s16[d], sb);
-              ripple<NPL, 5>(pl[d], t);
-            }
-          }
+          for (int d = 0; d < 4; d++) carry_step<NPL>(pl[d], gi, en[d], e8[d], s16[d]);
         }
         if (!SPLIT && a.prune && prune_test(min(n, c0 + min(cnt, j + 32)))) break;  // (a chunk can be shorter than 32 rows: multi-hash on 64-byte tiles)
       }
@@ -445,9 +357,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((NPL =
   #pragma unroll
               for (int d = 0; d < 4; d++) {
                 uint32_t ge = 0xffffffffu;
-  #pragma unroll
-                for (int p = 0; p < NPL; p++) ge = (((uint32_t)need >> p) & 1u) ? (ge & pl[d][p]) : (ge | pl[d][p]);
-                any |= ge;
+#pragma unroll
+            for (int p = 0; p < NPL; p++) ge = (((uint32_t)need >> p) & 1u) ? (ge & pl[d][p]) : (ge | pl[d][p]);
+            any |= ge;
               }
             }
             lane_alive = any != 0;
@@ -499,7 +411,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((NPL =
   //      validated before room is reserved.  The byte -> column mapping of a lane's hits keeps the segment of the previous hit
   //      in registers: the dependent global loads of a table walk per hit (58 hits in one lane = 58 round trips to memory in a
   //      row, under a saturated memory system) were what made hit-heavy batches 5 % slower, not the atomics.
-  const bool emit = live && !(NPL < 32 && (cmin >> NPL) != 0);  // else: unreachable count / nothing left alive
+  const bool emit = live && !(NPL < 32 && (cmin >> NPL) != 0);  // else: nothing left alive (the host picks NPL with n + 1 < 2^NPL, so cmin always fits: query.cpp)
   uint32_t ge[4];
   uint32_t mine = 0;
 #pragma unroll

@@ -310,14 +310,18 @@ extern "C" int kmcpg_query_device(kmcpg_db* db, const uint8_t* d_seqs, const uin
   // (round 4, genome search with 3 hash functions, same-box A/B over batch sizes: from ~1 500 (query, slot) units on — 1.5 waves per SIMD — the
   // plain kernel wins, because it prunes (a third of the row bytes are never fetched for 8 000-k-mer sketches at -t 0.4) and needs no atomics:
   // 192 queries x 8 slots 5.0 vs 6.0 ms, 512 x 8 11.1 vs 16.3 ms; at 128 x 8 the chunked form still leads, 4.1 vs 4.5 ms.)
-  if (n_long && !sm_env && (uint64_t)n_long * total_slots >= 1536 && long_meta[1] <= 65535) n_long = 0;
+  if (n_long && !sm_env && (uint64_t)n_long * total_slots >= 1536 && long_meta[1] <= 65534) n_long = 0;
   // largest NumKmers the plain kernel will meet: bounded by the read length, and exactly known once the long ones were listed
   uint64_t max_short = maxn;
   if (ask)
     max_short = n_long ? (uint64_t)split_min : std::max<uint64_t>(long_meta[1], (uint64_t)split_min);
   // counter planes: 8 for single short reads, 10 for pairs (2 x 150 bp = 260 k-mers, up to 2 x 500 bp), 16 for long reads
-  const int npl = max_short <= 255 ? 8 : (max_short <= 1023 ? 10 : (max_short <= 65535 ? 16 : (max_short <= 16777215 ? 24 : 0)));
-  if (!npl) return kmcpg_fail(KMCPG_EUNSUPPORTED, "queries with more than 16777215 k-mers need KMCPG_SPLIT_MIN > 0");
+  // (one below the planes' range: the largest threshold a query of n k-mers can get is n + 1 — `-t 1`, or an FPR bound no count passes —
+  // and k2_cobs compares counts with it on NPL bits: n + 1 <= 2^NPL - 1 keeps that compare exact.  A threshold past the planes' range
+  // made the kernel's epilogue emit every column with a count above its low bits: filtered again by the host half, so no wrong
+  // match, but a hit list of the whole row for reads of exactly 255 / 1 023 k-mers at -t 1.)
+  const int npl = max_short <= 254 ? 8 : (max_short <= 1022 ? 10 : (max_short <= 65534 ? 16 : (max_short <= 16777214 ? 24 : 0)));
+  if (!npl) return kmcpg_fail(KMCPG_EUNSUPPORTED, "queries with more than 16777214 k-mers need KMCPG_SPLIT_MIN > 0");
   K2Args a{};
   a.blocks = db->d_groupdev;
   a.segs = db->d_segs;
