@@ -655,3 +655,42 @@ def test_fpr_bound_on_the_device_changes_nothing_but_the_raw_hit_list(G, oracle_
                         assert raw["1"] == raw["0"]  # -f 0.9: the coverage threshold is the stricter one again
     finally:
         odb.close()
+
+
+def test_threshold_at_the_top_of_a_plane_class(G, oracle_lib, tmp_path):
+    """Reads of exactly 254 / 255 / 256 and 1022 / 1023 / 1024 k-mers, searched with -t just below 1 (every k-mer has to match) and
+    with -t 1 (no count can pass: float64(count) > n * 1.0 never holds, util-db-search.go:7468-7470).  The thresholds are n and
+    n + 1: the kernel compares counts with them on NPL bits, so the host puts n = 255 / 1 023 into the next plane class
+    (query.cpp); with -t 1 the raw hit list must be empty, not "every column with a count"."""
+    import torch
+    O = oracle_lib
+    lib = G["lib"]
+    genomes = synth.random_genomes(12, 6000, seed=71)
+    db_dir = synth.make_db(tmp_path, genomes, k=21, threads=2)
+    reads = []
+    for n in (254, 255, 256, 1022, 1023, 1024):
+        for gi in (0, 5):
+            reads.append(genomes[gi][300:300 + n + 20])       # exact: count == n
+            a = bytearray(genomes[gi][900:900 + n + 20])
+            a[len(a) // 2] = ord("A") if a[len(a) // 2] != ord("A") else ord("C")  # one substitution: 21 k-mers short of n
+            reads.append(bytes(a))
+    for t in (0.9995, 1.0):
+        kw = dict(min_qcov=t)
+        n, res = _run(G, O, db_dir, reads, oracle_kw=kw, gpu_kw=kw)
+        assert [int(x) for x in res.qkmers[::2]] == [254, 254, 255, 255, 256, 256, 1022, 1022, 1023, 1023, 1024, 1024]
+        assert n == (12 if t < 1 else 0)
+    # the raw hit list of the GPU half at -t 1
+    dev = torch.device("cuda:0")
+    seqs, offs = lib.pack_reads(reads)
+    t_seqs = torch.from_numpy(seqs).to(dev)
+    t_offs = torch.from_numpy(offs.view(np.int64)).to(dev)
+    nr = len(reads)
+    with G["Database"].open(db_dir, device=0) as db:
+        hits = torch.zeros((4096, 3), dtype=torch.int32, device=dev)
+        cnt = torch.zeros(2, dtype=torch.int64, device=dev)
+        qk = torch.zeros(nr, dtype=torch.int32, device=dev)
+        ql = torch.zeros(nr, dtype=torch.int32, device=dev)
+        db.query_device(t_seqs.data_ptr(), t_offs.data_ptr(), nr, int(offs[-1]), max(len(r) for r in reads), hits.data_ptr(), 4096, cnt.data_ptr(),
+                        qk.data_ptr(), ql.data_ptr(), params=G["default_params"](min_qcov=1.0))
+        torch.cuda.synchronize()
+        assert int(cnt[0].item()) == 0
