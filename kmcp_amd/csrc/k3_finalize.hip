@@ -25,6 +25,7 @@
 
 #include "common.hpp"
 #include "device_utils.hpp"
+#include "k3_keys.hpp"
 #include "kernels.hpp"
 
 namespace kmcpg {
@@ -41,8 +42,7 @@ __device__ __forceinline__ uint64_t n_hits_of(const K3Args& a) {
 // the -T test exactly as the reference makes it: float64(count) / float64(size) >= minTCov (:7471-7473)
 __device__ __forceinline__ bool passes(const K3Args& a, const kmcpg_hit& h) {
   if (h.read >= a.n_reads || h.col >= a.n_cols) return false;  // counted in k3_count
-  if (a.min_tcov <= 0.0) return true;
-  return (double)h.count / (double)a.col_size[h.col] >= a.min_tcov;
+  return a.min_tcov <= 0.0 || passes_tcov(h.count, a.col_size[h.col], a.min_tcov);
 }
 
 // Hits come in runs: K2 emits the hits of one (read, slot) unit side by side (k2_cobs.hip, wave-aggregated emission), so 64
@@ -167,38 +167,6 @@ __global__ void k3_scatter(K3Args a) {
   }
 }
 
-struct Key {
-  uint64_t a, b;
-};
-__device__ __forceinline__ bool key_less(const Key& x, const Key& y) { return x.a < y.a || (x.a == y.a && x.b < y.b); }
-
-__device__ __forceinline__ Key make_key(const K3Args& a, kmcpg_pair p, double nh) {
-  const uint32_t inv = ~p.count;
-  Key k;
-  if (a.sort_mode == 0) {
-    const uint64_t s = a.col_size[p.col];
-    k.a = ((uint64_t)inv << 32) | (s >> 32);
-    k.b = (s << 32) | p.col;
-  } else {
-    const double c = (double)p.count;
-    if (a.sort_mode == 3) k.a = p.col;
-    else {
-      const double nt = (double)a.col_size[p.col];
-      const double score = a.sort_mode == 1 ? c / nt : c / (nh + nt - c);  // :7487-7489, left to right as Go evaluates it
-      k.a = ~(uint64_t)__double_as_longlong(score);
-    }
-    k.b = ((uint64_t)inv << 32) | p.col;
-  }
-  return k;
-}
-
-__device__ __forceinline__ kmcpg_pair pair_of(const K3Args& a, const Key& k) {
-  kmcpg_pair p;
-  p.col = (uint32_t)k.b;
-  p.count = ~(uint32_t)((a.sort_mode == 0 ? k.a : k.b) >> 32);
-  return p;
-}
-
 // one compare-exchange step of the bitonic network over P keys in `t`, done by `nthreads` threads (tid = this thread's index)
 __device__ __forceinline__ void bitonic_step(Key* t, uint32_t P, uint32_t k, uint32_t j, uint32_t tid, uint32_t nthreads) {
   for (uint32_t q = tid; q < P / 2; q += nthreads) {
@@ -234,14 +202,14 @@ __global__ void __launch_bounds__(256) k3_sort_wave(K3Args a) {
     uint32_t P = 2;
     while (P < m) P <<= 1;
     const double nh = (double)a.nk[r0 + q];
-    for (uint32_t i = lane; i < P; i += 64) t[i] = i < m ? make_key(a, a.pairs[s0 + i], nh) : Key{~0ull, ~0ull};
+    for (uint32_t i = lane; i < P; i += 64) t[i] = i < m ? make_key(a.sort_mode, a.col_size, a.pairs[s0 + i], nh) : Key{~0ull, ~0ull};
     wave_lds_fence();
     for (uint32_t k = 2; k <= P; k <<= 1)
       for (uint32_t j = k >> 1; j > 0; j >>= 1) {
         bitonic_step(t, P, k, j, lane, 64);
         wave_lds_fence();
       }
-    for (uint32_t i = lane; i < m; i += 64) a.pairs[s0 + i] = pair_of(a, t[i]);
+    for (uint32_t i = lane; i < m; i += 64) a.pairs[s0 + i] = pair_of(a.sort_mode, t[i]);
     wave_lds_fence();  // the tile is reused by the next read
   }
 }
@@ -269,14 +237,14 @@ __global__ void __launch_bounds__(256) k3_sort_wg(K3Args a) {
       uint32_t P = 2;
       while (P < m) P <<= 1;
       const double nh = (double)a.nk[r];
-      for (uint32_t i = threadIdx.x; i < P; i += 256) big[i] = i < m ? make_key(a, a.pairs[s0 + i], nh) : Key{~0ull, ~0ull};
+      for (uint32_t i = threadIdx.x; i < P; i += 256) big[i] = i < m ? make_key(a.sort_mode, a.col_size, a.pairs[s0 + i], nh) : Key{~0ull, ~0ull};
       __syncthreads();
       for (uint32_t k = 2; k <= P; k <<= 1)
         for (uint32_t j = k >> 1; j > 0; j >>= 1) {
           bitonic_step(big, P, k, j, threadIdx.x, 256);
           __syncthreads();
         }
-      for (uint32_t i = threadIdx.x; i < m; i += 256) a.pairs[s0 + i] = pair_of(a, big[i]);
+      for (uint32_t i = threadIdx.x; i < m; i += 256) a.pairs[s0 + i] = pair_of(a.sort_mode, big[i]);
       __syncthreads();
     }
     __syncthreads();
