@@ -21,14 +21,6 @@ namespace kmcpg {
 // i.e. one XOR scan over the bases gives the hashes of every k (and of the s-mers of a syncmer) for two look-ups each,
 // instead of k table look-ups per k-mer.  The scans run on DPP within a wave (row_shr 1/2/4/8, row_bcast 15/31).
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint64_t rolv(uint64_t x, int n) {
-  n &= 63;
-  return (x << n) | (x >> ((64 - n) & 63));
-}
-__device__ __forceinline__ uint64_t rorv(uint64_t x, int n) {
-  n &= 63;
-  return (x >> n) | (x << ((64 - n) & 63));
-}
 
 // inclusive XOR scan over the 64 lanes of a wave (all lanes must be active)
 __device__ __forceinline__ uint32_t wave_xor_scan32(uint32_t v) {
@@ -1132,8 +1124,8 @@ __global__ void __launch_bounds__(64 * ROLL_WAVES) k1_seg_roll(const K1Args a) {
   if (tid < 256) {
     const uint64_t sd = seed_of(tid);
     tab[tid] = sd;
-    tab_out[tid] = rolv(sd, a.k - 1);
-    if (tid < 8) tab_in[tid] = rolv(sd, a.k);
+    tab_out[tid] = nt_tab_out(sd, a.k);
+    if (tid < 8) tab_in[tid] = nt_tab_in(sd, a.k);
   }
   const uint32_t r = blockIdx.x / a.segs_max, seg = blockIdx.x % a.segs_max;
   const uint64_t o1 = a.offs[r];
@@ -1170,9 +1162,7 @@ __global__ void __launch_bounds__(64 * ROLL_WAVES) k1_seg_roll(const K1Args a) {
     if (mine <= 0) return;
     uint64_t fh = 0, rh = 0;
     for (int j = 0; j < k; j++) {  // start-up (hash_at): fh = XOR_j rol(F[j], k-1-j), rh = XOR_j rol(R[j], j)
-      const uint8_t b = B[at(q0 + j)];
-      fh = rol1(fh) ^ tab[b];
-      rh ^= rolv(tab[b & 7], j);
+      nt_start_step(fh, rh, B[at(q0 + j)], j, tab);
     }
     const uint8_t* __restrict__ run = B + lane * ROLL_PITCH;  // the lane's own 128 bases; what follows them starts 4 bytes later
     for (int t = 0;; t++) {
@@ -1181,9 +1171,7 @@ __global__ void __launch_bounds__(64 * ROLL_WAVES) k1_seg_roll(const K1Args a) {
       if (t + 1 >= mine) break;
       const int ti = t + k;  // < 256: k <= 128
       const uint8_t bo = run[t], bi = run[ti + ((ti >> 7) << 2)];
-      fh = rol1(fh ^ tab_out[bo]) ^ tab[bi];
-      const uint64_t x = rh ^ tab[bo & 7] ^ tab_in[bi & 7];
-      rh = (x >> 1) | (x << 63);
+      nt_roll_step(fh, rh, bo, bi, tab, tab_out, tab_in);
     }
   };
   // (a FracMinHash database keeps one hash in hundreds: the first two a lane keeps stay in registers, and the second walk is only

@@ -1,0 +1,65 @@
+// nthash.hpp — ntHash v1 as kmcp uses it (will-rowe/nthash v0.4.0 behind bio/sketches; canonical hash = min(forward, reverse),
+// util-db-search.go:1037-1107 generateKmers), the parts that are plain arithmetic: the seed table, the rotations, and the ROLLING form
+// of the recurrence that k1_seg_roll walks along a lane's run of positions.  Compiles for the host as well: tests/nthash_check.cpp
+// runs the start-up + roll against the CPU restatement of the reference's k-mer hashes (tests/test_nthash_cpu.py).
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define KMCPG_NT_HD __host__ __device__ __forceinline__
+#else
+#define KMCPG_NT_HD inline
+#endif
+
+namespace kmcpg {
+
+KMCPG_NT_HD uint64_t rol1(uint64_t v) { return (v << 1) | (v >> 63); }
+KMCPG_NT_HD uint64_t rolv(uint64_t x, int n) {
+  n &= 63;
+  return (x << n) | (x >> ((64 - n) & 63));
+}
+KMCPG_NT_HD uint64_t rorv(uint64_t x, int n) {
+  n &= 63;
+  return (x >> n) | (x << ((64 - n) & 63));
+}
+
+// ntHash v1 seed table entry for byte b (rows 0..7 are N,T,N,G,A,A,N,C so that the complement of
+// base x is tab[x & 7]); will-rowe/nthash v0.4.0 seedTab.
+KMCPG_NT_HD uint64_t seed_of(int b) {
+  const uint64_t A = 0x3c8bfbb395c60474ULL, C = 0x3193c18562a02b4cULL, G = 0x20323ed082572324ULL,
+                 T = 0x295549f54be24456ULL;
+  switch (b) {
+    case 1: return T;
+    case 3: return G;
+    case 4: case 5: return A;
+    case 7: return C;
+    case 'A': case 'a': return A;
+    case 'C': case 'c': return C;
+    case 'G': case 'g': return G;
+    case 'T': case 't': case 'U': case 'u': return T;
+    default: return 0;
+  }
+}
+
+// Rolling form, position i -> i + 1 of a k-mer window (F = seed of a base, R = seed of its complement = tab[b & 7]):
+//     fh(i+1) = rol1(fh(i) ^ rol(F[i], k-1)) ^ F[i+k]        rh(i+1) = ror1(rh(i) ^ R[i] ^ rol(R[i+k], k))
+// with two rotated copies of the seed table instead of two variable 64-bit rotates per k-mer:
+//     tab_out[b] = rol(F[b], k-1)  (the base that drops out of fh),   tab_in[j] = rol(tab[j], k), j < 8  (the base that enters rh)
+KMCPG_NT_HD uint64_t nt_tab_out(uint64_t seed, int k) { return rolv(seed, k - 1); }  // seed = seed_of(b)
+KMCPG_NT_HD uint64_t nt_tab_in(uint64_t seed, int k) { return rolv(seed, k); }       // seed = seed_of(j), j < 8
+
+// one base of the start-up at offset j of the first window: fh = XOR_j rol(F[j], k-1-j), rh = XOR_j rol(R[j], j)
+KMCPG_NT_HD void nt_start_step(uint64_t& fh, uint64_t& rh, uint8_t b, int j, const uint64_t* tab) {
+  fh = rol1(fh) ^ tab[b];
+  rh ^= rolv(tab[b & 7], j);
+}
+
+// bo leaves the window, bi enters it
+KMCPG_NT_HD void nt_roll_step(uint64_t& fh, uint64_t& rh, uint8_t bo, uint8_t bi, const uint64_t* tab, const uint64_t* tab_out, const uint64_t* tab_in) {
+  fh = rol1(fh ^ tab_out[bo]) ^ tab[bi];
+  const uint64_t x = rh ^ tab[bo & 7] ^ tab_in[bi & 7];
+  rh = (x >> 1) | (x << 63);
+}
+
+}  // namespace kmcpg
