@@ -120,4 +120,18 @@ KMCPG_CSA_HD void csa4(uint32_t (&pl)[NPL], uint32_t x0, uint32_t x1, uint32_t x
   }
 }
 
+// The integer threshold a column's count has to reach: the reference keeps a column when count >= minMatched and
+// float64(count) > float64(NumKmers) * queryCov (util-db-search.go:7468-7470) — the smallest such integer, from one float64 product
+// (no fused multiply-add: the product is rounded exactly as Go rounds it).  n * t >= 0.
+KMCPG_CSA_HD uint32_t count_threshold(int n, double min_qcov, int min_matched) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const double thr = __dmul_rn((double)n, min_qcov);
+#else
+  const double thr = (double)n * min_qcov;
+#endif
+  uint32_t cmin = (uint32_t)thr + 1u;  // smallest integer c with (double)c > thr
+  if (cmin < (uint32_t)min_matched) cmin = (uint32_t)min_matched;
+  return cmin;
+}
+
 }  // namespace kmcpg

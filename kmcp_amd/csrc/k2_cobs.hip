@@ -139,9 +139,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((NPL =
   const uint32_t boff = (slot.tile * LPR + li) * 16u;
   const bool active = n > 0 && boff < stride;
   // integer threshold (:7468-7470): count >= minMatched && float64(count) > nHashes*queryCov
-  const double thr = __dmul_rn((double)n, a.min_qcov);
-  uint32_t cmin = (uint32_t)thr + 1u;  // smallest integer c with (double)c > thr  (thr >= 0)
-  if (cmin < (uint32_t)a.min_matched) cmin = (uint32_t)a.min_matched;
+  uint32_t cmin = count_threshold(n, a.min_qcov, a.min_matched);
   // counts below this fail the host's FPR(n, count) <= max_fpr test (:7474-7478), see fpr_bound in query.cpp
   if (!SPLIT && a.cmin_fpr && n <= a.cmin_fpr_n) cmin = max(cmin, (uint32_t)a.cmin_fpr[n]);
   // Branch and bound: once count + (k-mers still to come) < cmin for every column of a 128-byte sector of the row, nothing
@@ -591,10 +589,7 @@ __global__ void k_threshold_long(const K2Args a) {
       const uint32_t li = (uint32_t)(i / a.ncols_total);
       col = (uint32_t)(i % a.ncols_total);
       r = a.long_list[li];
-      const double thr = __dmul_rn((double)a.nk[r], a.min_qcov);
-      uint32_t cmin = (uint32_t)thr + 1u;
-      if (cmin < (uint32_t)a.min_matched) cmin = (uint32_t)a.min_matched;
-      pass = c >= cmin;
+      pass = c >= count_threshold(a.nk[r], a.min_qcov, a.min_matched);
     }
     const uint64_t m = __ballot(pass);
     if (m == 0) continue;

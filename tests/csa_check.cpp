@@ -1,7 +1,8 @@
 // csa_check.cpp — host instantiation of kmcp_amd/csrc/csa.hpp (the bit-sliced counters of k2_cobs) against scalar counts:
 // the 8-row and 4-row groups of the short-query kernels, and the deferred carries of the 16 / 24-plane kernels driven the way
 // the kernel drives them (blocks of up to four 8-row groups, groups past the end of a chunk handing in zero carries), up to the
-// largest count the planes hold.  Built and run by tests/test_csa_cpu.py.
+// largest count the planes hold; and the integer threshold of a query against the reference's float64 test, count by count.
+// Built and run by tests/test_csa_cpu.py.
 #include <stdio.h>
 #include <string.h>
 
@@ -94,6 +95,22 @@ int main() {
   long_query<16>(g, 65535, 8, false);  // the largest count 16 planes hold, in every column
   long_query<16>(g, 65535, 8, true);
   long_query<24>(g, 300000, 8, true);
+  // the integer threshold against the reference's own test, count by count: count >= minMatched && float64(count) > float64(n) * t
+  {
+    const double ts[] = {0.0, 1e-12, 0.1, 0.3, 0.31, 0.4, 0.5, 0.55, 0.7, 0.8, 0.9, 0.99, 0.9995, 1.0};
+    for (int rep = 0; rep < 400000; rep++) {
+      const int n = rep < 70000 ? rep : (int)(g() % 16777215) + 1;
+      const double t = rep % 3 == 0 ? ts[g() % (sizeof ts / sizeof ts[0])] : (double)(g() >> 11) / 9007199254740992.0;
+      const int m = (rep % 5 == 0) ? (int)(g() % 200) + 1 : 10;
+      const uint32_t c = count_threshold(n, t, m);
+      auto passes = [&](uint64_t x) { return x >= (uint64_t)m && (double)x > (double)n * t; };
+      checked++;
+      if (!passes(c) || (c > 0 && passes((uint64_t)c - 1))) {
+        if (bad < 5) printf("threshold n=%d t=%.17g -c %d: %u\n", n, t, m, c);
+        bad++;
+      }
+    }
+  }
   printf("%llu counts checked, %llu wrong\n", checked, bad);
   return bad ? 1 : 0;
 }

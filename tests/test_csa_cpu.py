@@ -1,5 +1,6 @@
 """The bit-sliced counters of k2_cobs (kmcp_amd/csrc/csa.hpp: carry-save groups of 8 / 4 rows; the deferred carries of the
-16 / 24-plane kernels) compiled for the host, against scalar per-column counts (tests/csa_check.cpp).  The reference counts
+16 / 24-plane kernels; the integer count threshold of a query) compiled for the host, against scalar per-column counts and the
+reference's float64 test count by count (tests/csa_check.cpp).  The reference counts
 the same rows into per-column bytes / uint16 (util-db-search.go:6811-6972)."""
 import os
 import subprocess
