@@ -16,7 +16,7 @@ namespace kmcpg {
 
 // carry-save adder: h = majority, l = parity of three words.  CSA3 spells them as one v_bitop3_b32 each (gfx950) for the long-query
 // kernels, which run near their issue limits; the short-query kernels (8 / 10 planes) wait for HBM and keep the form and the
-// instruction schedule they were tuned with (same-box A/B, scratch/call14.sh: the GTDB-scale launch is 1.7 % slower with CSA3 and
+// instruction schedule they were tuned with (same-box A/B, tools/ab/r04_call14.sh: the GTDB-scale launch is 1.7 % slower with CSA3 and
 // the regrouped loads).
 #define CSA(h, l, a_, b_, c_)              \
   {                                        \

@@ -274,7 +274,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((NPL =
       // 32 rows, which is where the pruning test runs (a sector dies <= 24 rows later than with a test per group: < 2 % of a HiFi
       // sketch); groups past the end of the chunk contribute zero carries.
       static_assert(GR == 8, "deferred carries are written for 8-row groups");
-      constexpr int GI_UNROLL = 4;  // (multi-hash: 174 VGPRs = 2 waves per SIMD unrolled, 166 = 3 waves rolled — and the unrolled form is 2 % faster, scratch/call17.sh)
+      constexpr int GI_UNROLL = 4;  // (multi-hash: 174 VGPRs = 2 waves per SIMD unrolled, 166 = 3 waves rolled — and the unrolled form is 2 % faster, tools/ab/r04_call17.sh)
       for (int j = 0; j < cnt; j += 32) {
         uint32_t e8[4] = {0, 0, 0, 0}, s16[4] = {0, 0, 0, 0};
         // (single hash function: the loads of group gi + 1 are issued before the adders of group gi run — 16 rows in flight per lane)

@@ -343,7 +343,7 @@ extern "C" int kmcpg_query_device(kmcpg_db* db, const uint8_t* d_seqs, const uin
   if (const char* e = getenv("KMCPG_GROUP_ROWS")) a.group_rows = atoi(e) == 4 ? 4 : 8;
   // How often the test runs in the 8/10-plane kernels: after every group (they wait for HBM; KMCPG_PRUNE_EVERY = 2/4/8 for experiments).
   // The 16/24-plane kernels resolve their carries every 32 rows and test there (k2_cobs.hip): the test was a quarter of their VALU
-  // work at one test per group, and they run near their issue limits — same-box A/B scratch/call13.sh: equal-width HiFi index
+  // work at one test per group, and they run near their issue limits — same-box A/B tools/ab/r04_call13.sh: equal-width HiFi index
   // 3.88 -> 3.55 ms per 16 384 reads, genome search 5.73 -> 5.48 ms per 256 genomes with a test every 4th group alone.
   a.prune_every = 1;
   if (const char* e = getenv("KMCPG_PRUNE_EVERY")) {
