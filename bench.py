@@ -7,8 +7,8 @@ expansion to finalized matches in host memory (kmcpg_finalize_grouped); the host
 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--workload gtdb|config1|gtdb_unchunked_k31|config2_genome_search|config4_hifi|...]
 
-N>1 is launched by the driver as `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`:
-one rank per GPU; the index's independent blocks are partitioned over the ranks (libkmcpgpu shards by
+N>1 is launched by the driver as `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`; a plain
+`python bench.py --gpus N` re-executes itself under that launcher on a free local port.  One rank per GPU; the index's independent blocks are partitioned over the ranks (libkmcpgpu shards by
 bytes), every rank searches the whole batch against its blocks, the per-read hit lists are gathered on
 rank 0 over RCCL and K3 runs there over the concatenation.  Total work is fixed as N grows => "scaling": "strong".
 Every line carries `sanity_batch.hits_checksum` (the same at every N by construction), `ranks` (who ran, per-rank kernel times) and,
@@ -469,7 +469,7 @@ def run_workload(name, ctx, steps, warmup, batch_reads=0, cpu_baseline=True, cpu
     # ---- roofline of the dominant kernel (k2_cobs) on this rank.
     #  algorithmic bytes per launch: sum over reads of kept k-mers x sum over local blocks of numHashes x NumRowBytes,
     #  + qLen, + 12 B per hit.  The kernel does NOT move all of them: exact sector pruning stops loading rows whose columns cannot
-    #  reach the threshold any more, so algorithmic bytes / time can exceed the chip's peak and is reported as `effective_gbps`.
+    #  reach the threshold any more, so algorithmic bytes / time can exceed the chip's peak and is reported as `algorithmic_gbps`.
     #  `achieved` / `frac` are what the kernel actually moved, measured in this run (below: the kernel counts its own row loads
     #  on the very batches of the timed steps; the committed --pmc FETCH_SIZE pass of the same command is carried beside it).
     last = (warmup + steps - 1) % n_batches
@@ -528,10 +528,10 @@ def run_workload(name, ctx, steps, warmup, batch_reads=0, cpu_baseline=True, cpu
                                      "Cache (MALL, 256 MiB) or by HBM.  `peak` is the HBM3E spec peak; `frac` therefore compares fabric-side bytes with "
                                      "the DRAM peak and part of those bytes never left the die - see mall_split for how many",
                      "definition": "achieved = bytes the kernel moved per launch (traffic) / its mean HIP-event duration over the timed steps; "
-                                   "frac = achieved / peak.  effective_gbps = ALGORITHMIC bytes (SURVEY 8d) / the same duration: larger than "
+                                   "frac = achieved / peak.  algorithmic_gbps = ALGORITHMIC bytes (SURVEY 8d) / the same duration: larger than "
                                    "achieved, and possibly than peak, by what exact sector pruning never fetches",
                      "mall_split": mall,
-                     "algorithmic_bytes_per_launch": alg_bytes, "effective_gbps": effective, "frac_algorithmic": effective / HBM_PEAK_GBS,
+                     "algorithmic_bytes_per_launch": alg_bytes, "algorithmic_gbps": effective, "algorithmic_over_peak": effective / HBM_PEAK_GBS,
                      "traffic_pmc": pmc, "traffic_pmc_source": pmc_src,
                      "measured_ceiling": {"gbps": FABRIC_CEILING_GBS, "what": "random 128-B gathers that miss L2 (L2->fabric path), tools/ubench_cache.cpp",
                                           "source": "profiles/r02_ubench_cache.txt"},
@@ -611,13 +611,12 @@ def run_workload(name, ctx, steps, warmup, batch_reads=0, cpu_baseline=True, cpu
     rf["achieved"] = gathered / (k2_avg_ms * 1e-3) / 1e9
     rf["frac"] = rf["achieved"] / HBM_PEAK_GBS
     rf["traffic_over_algorithmic"] = gathered / alg_bytes
-    rf["measured_ceiling"]["frac"] = rf["achieved"] / FABRIC_CEILING_GBS
+    rf["measured_ceiling"]["achieved_over_it"] = rf["achieved"] / FABRIC_CEILING_GBS
     # the device-to-device copy rate of THIS box beside the vendor peak (a streaming figure: half of the bytes are
     # writes, all of them sequential; the kernel's gathers are reads of 1 KB at random rows)
     d2d = d2d_copy_gbps(dev)
     if d2d:
-        rf["d2d_copy"] = {"gbps": d2d, "what": "torch copy of 2 GiB device to device on this box, read + written bytes / time (best of 5)",
-                          "frac": rf["achieved"] / d2d}
+        rf["d2d_copy"] = {"gbps": d2d, "what": "torch copy of 2 GiB device to device on this box, read + written bytes / time (best of 5)"}
     if pmc:
         rf["pmc_gbps"] = pmc / (k2_avg_ms * 1e-3) / 1e9
         rf["frac_pmc"] = rf["pmc_gbps"] / HBM_PEAK_GBS
@@ -655,16 +654,16 @@ def run_workload(name, ctx, steps, warmup, batch_reads=0, cpu_baseline=True, cpu
             # narrow rows (one 64-byte request per (k-mer, block)): the bound is the rate at which the L2->fabric path serves
             # requests that miss L2, not bytes — 56e9/s whatever their size up to 128 B (profiles/r02_ubench_cache.txt)
             req = rf["row_bytes_per_launch"] / stride0 + rf["hash_bytes_per_launch"] / 128.0  # one request per row; hashes arrive in 128-byte lines
-            out["roofline"]["request_bound"] = {"bound": "L2->fabric request rate", "requests_per_launch": req, "achieved": req / (k2_avg_ms * 1e-3),
-                                                "peak": 60e9, "unit": "requests/s", "frac": req / (k2_avg_ms * 1e-3) / 60e9,
-                                                "peak_source": "profiles/r02_ubench_cache.txt (64-B gathers over >= 64 MiB: 55-60 G/s; the upper end is "
-                                                               "taken as the peak)"}
+            out["roofline"]["requests"] = {"what": "L2->fabric requests (one per narrow row + one per 128-byte line of hashes)",
+                                           "per_launch": req, "per_s": req / (k2_avg_ms * 1e-3),
+                                           "ubench_per_s": "55-60e9 for 64-B gathers over >= 64 MiB, 158e9 L2-resident (profiles/r02_ubench_cache.txt): a "
+                                                           "measured rate of another kernel, not a ceiling"}
         # sector pruning switched off: every row byte of every k-mer is fetched whatever the index holds (traffic = algorithmic
         # bytes + row padding), the data-independent figure of the same kernel
         _, k2_np = kernel_only(max(2, min(steps, 4)), {"KMCPG_PRUNE": "0"})
         g_np = float(np.mean([r_ + h_ for r_, h_ in measure_gathered({"KMCPG_PRUNE": "0"})]))
         rf["prune_off"] = {"kernel_ms": k2_np, "traffic": g_np, "achieved": g_np / (k2_np * 1e-3) / 1e9, "frac": g_np / (k2_np * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                           "effective_gbps": alg_bytes / (k2_np * 1e-3) / 1e9, "frac_algorithmic": alg_bytes / (k2_np * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                           "algorithmic_gbps": alg_bytes / (k2_np * 1e-3) / 1e9, "algorithmic_over_peak": alg_bytes / (k2_np * 1e-3) / 1e9 / HBM_PEAK_GBS,
                            "traffic_over_algorithmic": g_np / alg_bytes}
 
     # ---- the drop-in boundary with host buffers (PCIe-inclusive; reported beside `value`, never as `value`): batches through
@@ -793,6 +792,7 @@ def run_workload(name, ctx, steps, warmup, batch_reads=0, cpu_baseline=True, cpu
         if world == 1:
             out["cpu_baseline"] = {
                 "value": R / tcpu * frac_blocks, "unit": unit, "cores": threads, "kind": "port", "sample": sample_txt,
+                "sample_short": f"{R} queries x {S}/{wl['n_blocks']} blocks, {tcpu:.1f} s on {threads} threads (oracle port, OpenMP)",
                 "parity_on_sample": parity, "sample_hits": int(len(ohits)),
                 "reference_binary": {"kmcp": shutil.which("kmcp"), "go": shutil.which("go"),
                                      "note": "BASELINE.md 3.1 probe: the Go reference is timed instead when a kmcp binary is on PATH (none in this image)"},
@@ -820,6 +820,123 @@ def run_workload(name, ctx, steps, warmup, batch_reads=0, cpu_baseline=True, cpu
     return out
 
 
+# ---------------------------------------------------------------------------------------------------------------------------------
+# The ONE JSON line.  Numbers only, < 6 KB (the driver keeps an 8 KB tail of stdout and parses the line out of it): every sentence
+# (definitions, sources, sample descriptions) and every sub-measurement lives in the sidecar `bench_detail.json`.
+# ---------------------------------------------------------------------------------------------------------------------------------
+LINE_LIMIT = 6000
+_HEAD_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data")
+_ROOF_KEYS = ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "traffic_pmc", "algorithmic_bytes_per_launch", "algorithmic_over_peak",
+              "traffic_over_algorithmic", "kernel_ms", "kmers_kernel_ms", "finalize_kernels_ms")
+
+
+def _num(v, digits=6):
+    """floats to `digits` significant digits (the line is for parsers and tables, the sidecar keeps full precision)"""
+    if isinstance(v, float):
+        return float(f"{v:.{digits}g}")
+    return v
+
+
+def _roofline_numbers(rf):
+    r = {k: _num(rf.get(k)) for k in _ROOF_KEYS if k in rf}
+    if isinstance(r.get("kernel"), str):
+        r["kernel"] = r["kernel"].split(" ")[0]  # the template instance; what runs beside it is in the sidecar
+    if rf.get("prune_off"):
+        r["prune_off_frac"] = _num(rf["prune_off"].get("frac"))
+    return r
+
+
+def _cpu_numbers(cb, short_sample=True):
+    if not cb:
+        return None
+    c = {"value": _num(cb.get("value")), "unit": cb.get("unit"), "cores": cb.get("cores"), "kind": cb.get("kind"),
+         "parity_on_sample": cb.get("parity_on_sample")}
+    if short_sample and cb.get("sample_short"):
+        c["sample"] = cb["sample_short"]
+    if cb.get("reference_shaped"):
+        c["reference_shaped"] = {"value": _num(cb["reference_shaped"].get("value"))}
+    return c
+
+
+def _secondary_numbers(o):
+    rf = o.get("roofline") or {}
+    cb = o.get("cpu_baseline") or {}
+    d = {"value": o.get("value"), "unit": o.get("unit"), "ms_per_step": o.get("ms_per_step"), "value_host_to_host": o.get("value_host_to_host"),
+         "kernel_ms": rf.get("kernel_ms"), "frac": rf.get("frac"), "algorithmic_over_peak": rf.get("algorithmic_over_peak"),
+         "traffic_over_algorithmic": rf.get("traffic_over_algorithmic"), "cpu": cb.get("value"), "cpu_cores": cb.get("cores"),
+         "cpu_reference_shaped": (cb.get("reference_shaped") or {}).get("value"), "parity_on_sample": cb.get("parity_on_sample"),
+         "planted_recall": o.get("planted_recall")}
+    return {k: _num(v, 5) for k, v in d.items() if v is not None}
+
+
+def compact_line(out, detail_path="bench_detail.json"):
+    """The contract line from a full result dict: headline keys + config + roofline + cpu_baseline + numeric secondaries."""
+    line = {k: _num(out.get(k)) for k in _HEAD_KEYS}
+    cfg = out.get("config") or {}
+    line["config"] = {k: _num(cfg[k]) for k in ("workload", "batch_reads", "read_len", "mean_kmers_per_query", "k", "num_hashes", "index_bytes", "index_bytes_this_rank",
+                                                "blocks", "columns", "parallelism", "search_flags") if k in cfg}
+    line["roofline"] = _roofline_numbers(out.get("roofline") or {})
+    cb = _cpu_numbers(out.get("cpu_baseline"))
+    if cb:
+        line["cpu_baseline"] = cb
+    for k in ("value_host_to_host", "planted_recall", "hits_per_step", "matches_per_step"):
+        if out.get(k) is not None:
+            line[k] = _num(out[k])
+    sb = out.get("sanity_batch")
+    if sb:
+        line["sanity_batch"] = {"hits": sb.get("hits"), "hits_checksum": sb.get("hits_checksum"), "batch_seed": sb.get("batch_seed")}
+    rk = out.get("ranks")
+    if rk:
+        line["ranks"] = {"world_size": rk.get("world_size"), "backend": rk.get("backend"), "ranks_reporting": sorted(p_["rank"] for p_ in rk.get("per_rank", [])),
+                         "k2_ms_min_max": [_num(x) for x in rk.get("k2_ms_min_max", [])]}
+    if out.get("parity_at_n"):
+        line["parity_at_n"] = {"parity_on_sample": out["parity_at_n"].get("parity_on_sample"), "sample_hits": out["parity_at_n"].get("sample_hits")}
+    if out.get("secondary"):
+        line["secondary"] = {nm: _secondary_numbers(o) for nm, o in out["secondary"].items()}
+    line["detail"] = detail_path
+    txt = json.dumps(line, allow_nan=False, separators=(", ", ": "))
+    if len(txt) > LINE_LIMIT:  # never let the line outgrow the driver again: shed the secondaries' minor keys, then the secondaries
+        for nm in list(line.get("secondary", {})):
+            line["secondary"][nm] = {k: v for k, v in line["secondary"][nm].items() if k in ("value", "unit", "ms_per_step", "frac", "kernel_ms", "cpu", "parity_on_sample")}
+        txt = json.dumps(line, allow_nan=False, separators=(", ", ": "))
+    if len(txt) > LINE_LIMIT:
+        line.pop("secondary", None)
+        txt = json.dumps(line, allow_nan=False, separators=(", ", ": "))
+    assert len(txt) <= LINE_LIMIT, len(txt)
+    return txt
+
+
+def _finite(o):
+    """NaN / inf -> None, recursively (strict JSON for the sidecar)"""
+    if isinstance(o, float):
+        return o if o == o and abs(o) != float("inf") else None
+    if isinstance(o, dict):
+        return {k: _finite(v) for k, v in o.items()}
+    if isinstance(o, (list, tuple)):
+        return [_finite(v) for v in o]
+    if isinstance(o, (np.integer,)):
+        return int(o)
+    if isinstance(o, (np.floating,)):
+        return _finite(float(o))
+    return o
+
+
+def write_detail(out):
+    """The full record (every sub-measurement and every sentence) beside bench.py and, on a gpurun box, under gpurun_out/."""
+    txt = json.dumps(_finite(out), indent=1)
+    written = []
+    for d in (ROOT, os.path.join(ROOT, "gpurun_out")):
+        try:
+            if d != ROOT and not os.path.isdir(d):
+                continue
+            with open(os.path.join(d, "bench_detail.json"), "w") as f:
+                f.write(txt + "\n")
+            written.append(os.path.join(d, "bench_detail.json"))
+        except OSError:
+            pass
+    return written
+
+
 def main():
     # The contract is ONE JSON line on stdout.  Libraries write there too (RCCL prints its version banner to stdout when a
     # communicator is created): for the duration of the run file descriptor 1 points at stderr, and only the JSON line goes
@@ -843,9 +960,18 @@ def main():
     ctx.rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != ctx.world:
-        if ctx.world == 1 and args.gpus > 1:
-            raise SystemExit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 "
-                             "--master-port P bench.py --gpus N ...")
+        if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+            # started the way `--gpus 1` is started (plain `python bench.py --gpus N`): become the launcher the driver would
+            # have used - one rank per GPU under torch.distributed.run on a free local port; rank 0 prints the line
+            import socket
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                port = sk.getsockname()[1]
+            os.dup2(real_stdout, 1)
+            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            os.environ.setdefault("OMP_NUM_THREADS", str(max(1, effective_cpus() // args.gpus)))
+            os.execv(sys.executable, [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+                                      "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:])
         args.gpus = ctx.world
     # KMCP_BENCH_SAME_GPU=1 (debugging on a 1-GPU box): every rank uses GPU 0 and the exchange runs over gloo, because
     # RCCL refuses two ranks on one device.  Never set by the driver; the measured path is nccl = RCCL over xGMI.
@@ -904,7 +1030,8 @@ def main():
         pass
     os.dup2(real_stdout, 1)
     if ctx.rank == 0:
-        os.write(1, (json.dumps(out) + "\n").encode())
+        write_detail(out)
+        os.write(1, (compact_line(_finite(out)) + "\n").encode())
 
 
 if __name__ == "__main__":
