@@ -107,6 +107,13 @@ WORKLOADS = {
                                       cpu_sample_start=64, kernel="k2_cobs<64,16,false,false,8> + k2_cobs<16,16,false,false,8> (k1_windows_wave<2> beside them)",
                                       metric="reads/sec searched (HiFi ~10 kb, Closed Syncmer s=11, k=21) vs a 10k-chunk index with one NumSigs",
                                       name="HiFi synthetic, blocks with equal NumSigs (grouped rows): 32 x 312 cols x 300 k sigs, closed syncmer s=11 k=21"),
+    # EXPERIMENT (VERDICT r4 #3 gate, profiles/r05_rowsort_gate.txt): ONE narrow block of the HiFi index and enough reads to fill the
+    # chip with (read, block) units; KMCPG_DEBUG_ROWSORT=1|2 re-orders every read's k-mers by the row they address
+    "config4_oneblock": dict(k=21, num_hashes=1, fpr=0.3, n_blocks=1, cols_per_block=312, num_sigs=300000, sigs_step=0, kmers_per_col=100000, syncmer_s=11,
+                             batch_reads=131072, read_len=("normal", 10000, 2000, 2000, 20000), sub_rate=0.001, unit="reads/s", cpu_sample_start=64,
+                             distinct_batches=1, kernel="k2_cobs<4,16,false,false,8>",
+                             metric="reads/sec searched (HiFi ~10 kb, Closed Syncmer s=11, k=21) vs ONE 312-column block (experiment)",
+                             name="HiFi synthetic, one block: 1 x 312 cols x 300 k sigs (19 MB), closed syncmer s=11 k=21"),
 }
 READ_LEN = 150
 

@@ -918,7 +918,7 @@ static int search_batch_pieces(kmcpg_db* db, const uint8_t* seqs, const uint64_t
   if (const char* e = getenv("KMCPG_PIECE_MIN")) kMinPiece = (uint32_t)std::max(1, atoi(e));  // tests and tools/stress_async.py: pieces of small batches
   int want = 4;
   if (const char* e = getenv("KMCPG_PIECES")) want = atoi(e);
-  if (want < 2 || n < 2 * kMinPiece) return 0;
+  if (want < 2 || (uint64_t)n < 2 * (uint64_t)kMinPiece) return 0;
   if (!db->shards.empty() || db->paged_passes > 0 || db->opts.device < 0 || db->opts.shard_count != 1) return 0;
   if ((p.try_se && seqs2) || (p.k <= 0 && db->ks_desc.size() > 1)) return 0;
   AsyncState* A = nullptr;

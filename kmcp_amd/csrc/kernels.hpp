@@ -32,6 +32,9 @@ void launch_plant_reads(const BlockDev* blocks, uint32_t nblocks, int num_hashes
 void launch_build_scatter(uint8_t* sigs, uint64_t num_sigs, uint64_t mh, uint32_t row_bytes, int num_hashes, const uint64_t* hashes,
                           const uint64_t* col_off, uint32_t col0, uint32_t n_cols, uint64_t n, hipStream_t st);
 
+// experiment only (KMCPG_DEBUG_ROWSORT): every query's hashes re-ordered by h % num_sigs of one block; mode 2 = rotated
+void launch_debug_rowsort(uint64_t* hashes, const uint64_t* offs, const int32_t* nk, uint32_t n_reads, uint64_t num_sigs, uint64_t mh, int mode, hipStream_t st);
+
 // queries of up to this many emissions above -u are sorted by one wave (k_dedup_wave), which reads them from hashes[]; the
 // long-read sketch kernels keep the raw emissions of such queries for it (k1_kmers.hip)
 constexpr int DEDUP_WAVE_CAP = 512;

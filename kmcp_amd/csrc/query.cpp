@@ -264,8 +264,11 @@ extern "C" int kmcpg_query_device(kmcpg_db* db, const uint8_t* d_seqs, const uin
   hipStream_t st = (hipStream_t)stream;
   // test hook: behave as if the k-mer workspace of a batch above this many bases could not be allocated (the batch-halving path
   // of kmcpg_search_batch, tests/test_gpu_paged.py)
-  if (const char* e = getenv("KMCPG_TEST_MAX_BASES"))
-    if (total_bases > (uint64_t)atoll(e)) return kmcpg_fail(KMCPG_ENOMEM, "hipMalloc failed (KMCPG_TEST_MAX_BASES)");
+  // (honoured only together with KMCPG_TEST_HOOKS=1: a stray variable in a production environment must not fake an ENOMEM)
+  static const bool test_hooks = getenv("KMCPG_TEST_HOOKS") && atoi(getenv("KMCPG_TEST_HOOKS")) == 1;
+  if (test_hooks)
+    if (const char* e = getenv("KMCPG_TEST_MAX_BASES"))
+      if (total_bases > (uint64_t)atoll(e)) return kmcpg_fail(KMCPG_ENOMEM, "hipMalloc failed (KMCPG_TEST_MAX_BASES)");
   if (int rc0 = ws_begin(db, st)) return rc0;
   WsGuard wsg{db, st};
   if (db->w_hashes.ensure(total_bases + 1) || db->w_nk_raw.ensure(n_reads + 1) || db->w_nk1.ensure(n_reads + 1)) return kmcpg_fail(KMCPG_ENOMEM, "hipMalloc failed");
@@ -285,6 +288,9 @@ extern "C" int kmcpg_query_device(kmcpg_db* db, const uint8_t* d_seqs, const uin
   if (rc) return rc;
   HIPCHK(hipMemsetAsync(d_counters, 0, 2 * sizeof(uint64_t), st));
   launch_max_nk(d_qkmers, n_reads, (unsigned long long*)d_counters + 1, st);
+  static const int debug_rowsort = getenv("KMCPG_DEBUG_ROWSORT") ? atoi(getenv("KMCPG_DEBUG_ROWSORT")) : 0;
+  if (debug_rowsort && !d_offs2 && !db->h_groupdev.empty())  // experiment only: profiles/r05_rowsort_gate.txt
+    launch_debug_rowsort(db->w_hashes.p, d_offs, d_qkmers, n_reads, db->h_groupdev[0].num_sigs, db->h_groupdev[0].magic_hi, debug_rowsort, st);
   if (db->profiling) HIPCHK(hipEventRecord(pev[1], st));
   // long queries (whole genomes, -g) are split into chunks of k-mers so that they spread over the chip; short ones keep
   // the one-wave-per-(query, slot) kernel.  Which queries are long is only known on the device: one small D2H read.

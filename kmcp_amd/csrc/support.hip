@@ -221,3 +221,54 @@ void launch_build_scatter(uint8_t* sigs, uint64_t num_sigs, uint64_t mh, uint32_
 }
 
 }  // namespace kmcpg
+
+namespace kmcpg {
+
+// ------------------------------------------------------------------------------------------------
+// EXPERIMENT ONLY (KMCPG_DEBUG_ROWSORT, profiles/r05_rowsort_gate.txt): the hashes of every query re-ordered by the row they
+// address in ONE block (h % num_sigs), so that all units in flight sweep that block's rows in the same direction.  mode 2
+// rotates each query's sorted list by a pseudo-random offset: the same per-unit locality without the phase coherence.
+// One workgroup per query of at most 4096 k-mers (longer ones are left as they are); bitonic sort of (row, index) keys in LDS.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_debug_rowsort(uint64_t* __restrict__ hashes, const uint64_t* __restrict__ offs, const int32_t* __restrict__ nk,
+                                                       uint64_t num_sigs, uint64_t mh, int mode) {
+  __shared__ uint64_t key[4096];
+  __shared__ uint64_t val[4096];
+  const uint32_t r = blockIdx.x;
+  const int n = nk[r];
+  if (n <= 1 || n > 4096) return;
+  uint64_t* h = hashes + offs[r];
+  int m = 1;
+  while (m < n) m <<= 1;
+  for (int i = threadIdx.x; i < m; i += 256) {
+    if (i < n) {
+      val[i] = h[i];
+      key[i] = (fastmod_u64(val[i], num_sigs, mh) << 12) | (uint64_t)i;
+    } else {
+      key[i] = ~0ULL;
+    }
+  }
+  __syncthreads();
+  for (int size = 2; size <= m; size <<= 1)
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      for (int i = threadIdx.x; i < m / 2; i += 256) {
+        const int lo = 2 * i - (i & (stride - 1)), hi = lo + stride;
+        const bool up = (lo & size) == 0;
+        const uint64_t a = key[lo], b = key[hi];
+        if ((a > b) == up) {
+          key[lo] = b;
+          key[hi] = a;
+        }
+      }
+      __syncthreads();
+    }
+  const int rot = mode == 2 ? (int)(splitmix64(r) % (uint64_t)n) : 0;
+  for (int i = threadIdx.x; i < n; i += 256) h[(i + rot) % n] = val[key[i] & 4095u];
+}
+
+void launch_debug_rowsort(uint64_t* hashes, const uint64_t* offs, const int32_t* nk, uint32_t n_reads, uint64_t num_sigs, uint64_t mh, int mode, hipStream_t st) {
+  if (n_reads == 0) return;
+  hipLaunchKernelGGL(k_debug_rowsort, dim3(n_reads), dim3(256), 0, st, hashes, offs, nk, num_sigs, mh, mode);
+}
+
+}  // namespace kmcpg
