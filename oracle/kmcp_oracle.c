@@ -239,7 +239,13 @@ uint64_t ko_calc_signature_size(uint64_t n_elements, int num_hashes, double fpr)
 }
 
 /* ================================================================================================
- * Query FPR — util-fpr.go:32-71 (QueryFPR, BinomialCoeff) and :140-191 (cached variant; same values)
+ * Query FPR — util-fpr.go:32-71 (QueryFPR, BinomialCoeff).
+ * The search path calls the CACHED variant (util-fpr.go:140-191, built at util-db-search.go:683 with bufSize 249 / 499):
+ * for n <= bufSize it stores FPR(n, k) in slot n*h + min(k, n-k), so (n, k) and (n, n-k) share a slot and the Go binary
+ * returns whichever of the two was computed first.  For k > n-k for every passing count - i.e. `-t >= 0.5`, the default 0.55
+ * included - the slot is unique per k and cached == uncached.  With `-t < 0.5` and n <= 249 (499 paired) the reference's FPR
+ * column depends on arrival order; this restatement (and the product) always return the uncached FPR(n, k).  The cache is
+ * restated slot for slot in tests/test_fpr_golden.py (GoFprCache), which shows both outputs for one (n, k).
  * ============================================================================================== */
 /* Go math.Pow (src/math/pow.go, pure Go on amd64), restated. */
 double ko_go_pow(double x, double y) {
