@@ -220,7 +220,8 @@ int kmcpg_finalize(const kmcpg_db* db, const kmcpg_hit* hits, uint64_t n_hits, c
  *    (kmcpg_finalize_grouped sorts those).  d_pairs needs room for hit_cap pairs, d_read_offs for n_reads + 2 words: the last
  *    one receives the number of hits that named a read or column that does not exist (must be 0).  Only enqueues on `stream`.
  *    kmcpg_finalize_grouped: the float64 Match values (qCov, tCov, jacc :7487-7489), the FPR column and its -f test (:7474-7478),
- *    --keep-top-scores (:285-311) and the name-independent metadata; same result as kmcpg_finalize on the same hits. */
+ *    --keep-top-scores (:285-311) and the name-independent metadata; same result as kmcpg_finalize on the same hits.  Segments
+ *    that are not in that order (longer than 4096 matches, or a list that did not come from kmcpg_group_device) are sorted here. */
 typedef struct {
   uint32_t col;   /* global column */
   uint32_t count; /* matched k-mers */

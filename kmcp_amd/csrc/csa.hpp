@@ -86,17 +86,19 @@ KMCPG_CSA_HD void carry_step(uint32_t (&pl)[NPL], int gi, uint32_t en, uint32_t&
   }
 }
 
-// 8 rows, carry rippled at once (8 / 10 planes)
-template <int NPL>
+// 8 rows, carry rippled at once (8 / 10 planes).  B3: the adders as v_bitop3 pairs (experiment knob of the narrow-row forms)
+#define CSA_SEL(h, l, a_, b_, c_) \
+  if constexpr (B3) CSA3(h, l, a_, b_, c_) else CSA(h, l, a_, b_, c_)
+template <int NPL, bool B3 = false>
 KMCPG_CSA_HD void csa8(uint32_t (&pl)[NPL], uint32_t x0, uint32_t x1, uint32_t x2, uint32_t x3, uint32_t x4, uint32_t x5, uint32_t x6, uint32_t x7) {
   uint32_t ta, tb, fa, fb, e;
-  CSA(ta, pl[0], pl[0], x0, x1);
-  CSA(tb, pl[0], pl[0], x2, x3);
-  CSA(fa, pl[1], pl[1], ta, tb);
-  CSA(ta, pl[0], pl[0], x4, x5);
-  CSA(tb, pl[0], pl[0], x6, x7);
-  CSA(fb, pl[1], pl[1], ta, tb);
-  CSA(e, pl[2], pl[2], fa, fb);
+  CSA_SEL(ta, pl[0], pl[0], x0, x1);
+  CSA_SEL(tb, pl[0], pl[0], x2, x3);
+  CSA_SEL(fa, pl[1], pl[1], ta, tb);
+  CSA_SEL(ta, pl[0], pl[0], x4, x5);
+  CSA_SEL(tb, pl[0], pl[0], x6, x7);
+  CSA_SEL(fb, pl[1], pl[1], ta, tb);
+  CSA_SEL(e, pl[2], pl[2], fa, fb);
 #pragma unroll
   for (int p = 3; p < NPL; p++) {
     uint32_t t = pl[p] & e;
@@ -106,12 +108,12 @@ KMCPG_CSA_HD void csa8(uint32_t (&pl)[NPL], uint32_t x0, uint32_t x1, uint32_t x
 }
 
 // the same for 4 rows (the short groups of the zone where sectors die, see k2_cobs)
-template <int NPL>
+template <int NPL, bool B3 = false>
 KMCPG_CSA_HD void csa4(uint32_t (&pl)[NPL], uint32_t x0, uint32_t x1, uint32_t x2, uint32_t x3) {
   uint32_t ta, tb, e;
-  CSA(ta, pl[0], pl[0], x0, x1);
-  CSA(tb, pl[0], pl[0], x2, x3);
-  CSA(e, pl[1], pl[1], ta, tb);
+  CSA_SEL(ta, pl[0], pl[0], x0, x1);
+  CSA_SEL(tb, pl[0], pl[0], x2, x3);
+  CSA_SEL(e, pl[1], pl[1], ta, tb);
 #pragma unroll
   for (int p = 2; p < NPL; p++) {
     uint32_t t = pl[p] & e;

@@ -13,6 +13,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <condition_variable>
 #include <mutex>
 #include <set>
 #include <string>
@@ -71,13 +72,22 @@ bool load_api(Api* a, std::string* why) {
 }
 }  // namespace
 
+// one gather in flight: its concatenation buffer on devices[0] and the events that say when its transfers are done
+struct GatherSlot {
+  DevBuf<uint8_t> buf;               // on devices[0]
+  hipEvent_t done = nullptr;         // devices[0]: the receives (and what on_device queued behind them) have completed
+  std::vector<hipEvent_t> sent;      // per device: its send has left the source buffer
+  bool busy = false;
+};
+
 struct Exchange {
   Api api;
   std::vector<int> devices;
   std::vector<ncclComm_t> comms;
   std::vector<hipStream_t> streams;  // one per device: the exchange never queues behind the next batches' kernels
-  std::mutex mu;                     // group calls on one set of communicators are serialised
-  DevBuf<uint8_t> d_gather;          // on devices[0]
+  std::mutex mu;                     // group calls on one set of communicators are serialised: held from ncclGroupStart to ncclGroupEnd only
+  std::condition_variable cv;        // a slot came back
+  GatherSlot slots[4];               // as many gathers in flight as a handle has lanes
   std::string note;
 };
 
@@ -85,48 +95,102 @@ const char* exchange_note(const Exchange* x) { return x ? x->note.c_str() : "hos
 
 // Brings parts[r] (count[r] bytes at device pointer src[r] on devices[r]) together on devices[0] and copies the concatenation to
 // `dst` (pinned host memory, sum of the counts) — rank order.  Every src[r] must be complete (its kernels waited for).
+// Several host threads may be in here at once (one per batch in flight): each takes a gather slot of its own; only the group call
+// itself — ncclGroupStart ... ncclGroupEnd on the shared communicators — runs under the mutex.  What follows (on_device's kernels
+// and copies, the waits) is ordered by the streams and by the slot's events, so one batch's K3 and D2H overlap the next batch's
+// transfers instead of holding them up.
 int exchange_gather(Exchange* x, const std::vector<const void*>& src, const std::vector<uint64_t>& bytes, uint8_t* dst, const ExchangeOnDevice& on_device) {
   const int n = (int)x->devices.size();
   if ((int)src.size() != n || (int)bytes.size() != n) return kmcpg_fail(KMCPG_EINVAL, "exchange: %zu parts for %d devices", src.size(), n);
   uint64_t total = 0;
   for (uint64_t b : bytes) total += b;
   if (total == 0) return 0;
-  std::lock_guard<std::mutex> g(x->mu);
-  HIPCHK(hipSetDevice(x->devices[0]));
-  if (x->d_gather.ensure(total + 32)) return kmcpg_fail(KMCPG_ENOMEM, "hipMalloc failed");
-  uint8_t* const d_cat = x->d_gather.p + 16;  // 16 bytes in front of the concatenation belong to on_device (a count word)
-  auto chk = [&](ncclResult_t r, const char* what) { return r == 0 ? 0 : kmcpg_fail(KMCPG_EDEVICE, "RCCL %s: %s", what, x->api.GetErrorString(r)); };
-  if (int rc = chk(x->api.GroupStart(), "ncclGroupStart")) return rc;
-  int rc = 0;
-  uint64_t off = 0;
-  for (int r = 0; r < n && rc == 0; r++) {
-    if (bytes[r] == 0) continue;
-    // both halves of every transfer inside one group: rank r sends its list, rank 0 receives it at its place in the concatenation
-    // (r == 0 is a send to itself, which RCCL turns into a device-local copy)
-    (void)hipSetDevice(x->devices[r]);
-    rc = chk(x->api.Send(src[r], bytes[r], kNcclUint8, 0, x->comms[(size_t)r], x->streams[(size_t)r]), "ncclSend");
-    if (rc) break;
-    (void)hipSetDevice(x->devices[0]);
-    rc = chk(x->api.Recv(d_cat + off, bytes[r], kNcclUint8, r, x->comms[0], x->streams[0]), "ncclRecv");
-    off += bytes[r];
+  GatherSlot* sl = nullptr;
+  {
+    std::unique_lock<std::mutex> g(x->mu);
+    x->cv.wait(g, [&] {
+      for (auto& s : x->slots)
+        if (!s.busy) {
+          sl = &s;
+          return true;
+        }
+      return false;
+    });
+    sl->busy = true;
   }
-  const int rc_end = chk(x->api.GroupEnd(), "ncclGroupEnd");
-  if (rc == 0) rc = rc_end;
-  if (rc) return rc;
+  struct Release {  // every way out hands the slot back
+    Exchange* x;
+    GatherSlot* sl;
+    ~Release() {
+      {
+        std::lock_guard<std::mutex> g(x->mu);
+        sl->busy = false;
+      }
+      x->cv.notify_one();
+    }
+  } release{x, sl};
+  HIPCHK(hipSetDevice(x->devices[0]));
+  if (sl->buf.ensure(total + 32)) return kmcpg_fail(KMCPG_ENOMEM, "hipMalloc failed");
+  if (!sl->done) HIPCHK(hipEventCreateWithFlags(&sl->done, hipEventDisableTiming));
+  if (sl->sent.empty()) {
+    sl->sent.assign((size_t)n, nullptr);
+    for (int r = 1; r < n; r++) {
+      HIPCHK(hipSetDevice(x->devices[r]));
+      HIPCHK(hipEventCreateWithFlags(&sl->sent[(size_t)r], hipEventDisableTiming));
+    }
+    HIPCHK(hipSetDevice(x->devices[0]));
+  }
+  uint8_t* const d_cat = sl->buf.p + 16;  // 16 bytes in front of the concatenation belong to on_device (a count word)
+  auto chk = [&](ncclResult_t r, const char* what) { return r == 0 ? 0 : kmcpg_fail(KMCPG_EDEVICE, "RCCL %s: %s", what, x->api.GetErrorString(r)); };
+  int rc = 0;
+  {
+    std::lock_guard<std::mutex> g(x->mu);
+    if (int rc0 = chk(x->api.GroupStart(), "ncclGroupStart")) return rc0;
+    uint64_t off = 0;
+    for (int r = 0; r < n && rc == 0; r++) {
+      if (bytes[r] == 0) continue;
+      // both halves of every transfer inside one group: rank r sends its list, rank 0 receives it at its place in the concatenation
+      // (r == 0 is a send to itself, which RCCL turns into a device-local copy)
+      (void)hipSetDevice(x->devices[r]);
+      rc = chk(x->api.Send(src[r], bytes[r], kNcclUint8, 0, x->comms[(size_t)r], x->streams[(size_t)r]), "ncclSend");
+      if (rc) break;
+      (void)hipSetDevice(x->devices[0]);
+      rc = chk(x->api.Recv(d_cat + off, bytes[r], kNcclUint8, r, x->comms[0], x->streams[0]), "ncclRecv");
+      off += bytes[r];
+    }
+    const int rc_end = chk(x->api.GroupEnd(), "ncclGroupEnd");
+    if (rc == 0) rc = rc_end;
+    // this gather's sends, marked on the senders' streams before anybody else's group can follow them
+    for (int r = 1; r < n && rc == 0; r++) {
+      if (hipSetDevice(x->devices[r]) != hipSuccess || hipEventRecord(sl->sent[(size_t)r], x->streams[(size_t)r]) != hipSuccess)
+        rc = kmcpg_fail(KMCPG_EDEVICE, "exchange: hipEventRecord failed on device %d", x->devices[r]);
+    }
+  }
+  if (rc) {  // something may be queued: nothing of this slot is handed back while it could still be written
+    for (int r = 0; r < n; r++)
+      if (hipSetDevice(x->devices[r]) == hipSuccess) (void)hipStreamSynchronize(x->streams[(size_t)r]);
+    (void)hipSetDevice(x->devices[0]);
+    return rc;
+  }
   HIPCHK(hipSetDevice(x->devices[0]));
   if (on_device) {
     rc = on_device(d_cat, total, (void*)x->streams[0]);
-    const hipError_t e = hipStreamSynchronize(x->streams[0]);
-    if (rc) return rc;
-    HIPCHK(e);
   } else {
-    HIPCHK(hipMemcpyAsync(dst, d_cat, total, hipMemcpyDeviceToHost, x->streams[0]));
-    HIPCHK(hipStreamSynchronize(x->streams[0]));
+    const hipError_t e = hipMemcpyAsync(dst, d_cat, total, hipMemcpyDeviceToHost, x->streams[0]);
+    if (e != hipSuccess) rc = kmcpg_fail(KMCPG_EDEVICE, "exchange: hipMemcpyAsync: %s", hipGetErrorString(e));
   }
-  for (int r = 1; r < n; r++) {  // the senders' buffers are free again once their streams have drained
-    HIPCHK(hipSetDevice(x->devices[r]));
-    HIPCHK(hipStreamSynchronize(x->streams[(size_t)r]));
+  // (stream order: everything this call queued on streams[0] precedes the event, whatever other gathers queued in between)
+  hipError_t e = hipEventRecord(sl->done, x->streams[0]);
+  if (e == hipSuccess) e = hipEventSynchronize(sl->done);
+  else (void)hipStreamSynchronize(x->streams[0]);
+  for (int r = 1; r < n; r++) {  // the senders' buffers are free again once their sends have completed
+    if (hipSetDevice(x->devices[r]) != hipSuccess || hipEventSynchronize(sl->sent[(size_t)r]) != hipSuccess) {
+      if (e == hipSuccess) e = hipErrorUnknown;
+    }
   }
+  (void)hipSetDevice(x->devices[0]);
+  if (rc) return rc;
+  HIPCHK(e);
   return 0;
 }
 
@@ -142,8 +206,16 @@ void exchange_destroy(Exchange* x) {
       (void)hipSetDevice(x->devices[r]);
       (void)hipStreamDestroy(x->streams[r]);
     }
-  if (!x->devices.empty()) (void)hipSetDevice(x->devices[0]);
-  x->d_gather.release();
+  for (auto& sl : x->slots) {
+    for (size_t r = 1; r < sl.sent.size(); r++)
+      if (sl.sent[r]) {
+        (void)hipSetDevice(x->devices[r]);
+        (void)hipEventDestroy(sl.sent[r]);
+      }
+    if (!x->devices.empty()) (void)hipSetDevice(x->devices[0]);
+    if (sl.done) (void)hipEventDestroy(sl.done);
+    sl.buf.release();
+  }
   delete x;
 }
 

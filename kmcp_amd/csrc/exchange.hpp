@@ -12,7 +12,7 @@ void exchange_destroy(Exchange* x);
 const char* exchange_note(const Exchange* x);
 // `on_device` (optional): called instead of the copy to `dst`, with the concatenation still on devices[0] — 16-byte aligned, an
 // 8-byte word in front of it (d_cat - 16) free for the caller — and the exchange stream of that device: what it enqueues there runs
-// behind the receives; exchange_gather waits for the stream before it returns (the gather buffer is shared by all batches).
+// behind the receives; exchange_gather waits for what it queued before it returns (each gather in flight has a buffer of its own).
 #include <functional>
 typedef std::function<int(uint8_t* d_cat, uint64_t total_bytes, void* stream)> ExchangeOnDevice;
 int exchange_gather(Exchange* x, const std::vector<const void*>& src, const std::vector<uint64_t>& bytes, uint8_t* dst, const ExchangeOnDevice& on_device = nullptr);

@@ -326,10 +326,20 @@ extern "C" int kmcpg_finalize(const kmcpg_db* db, const kmcpg_hit* hits, uint64_
   // handle), fetched once so that the workers below never lock.  (Looked up per read here, not per hit in phase A: a random
   // access into qkmers for every hit was a third of that phase.)
   QueryFpr* F = db->fpr.get();
-  std::unordered_map<int, const std::vector<double>*> fpr_rows;
+  // (the shared_ptrs keep the rows alive for this call whatever other callers make the cache do; queries of up to 4 096 k-mers —
+  // every short read — are found through a flat table, longer ones through the map)
+  constexpr int kFlat = 4096;
+  std::vector<const std::vector<double>*> flat_rows((size_t)kFlat + 1, nullptr);
+  std::unordered_map<int, FprRow> fpr_rows;
   if (n_hits) {
-    for (uint32_t r = 0; r < n_reads; r++)
-      if (qkmers[r] > 0 && !fpr_rows.count(qkmers[r])) fpr_rows.emplace(qkmers[r], F->ensure_row(qkmers[r]));
+    for (uint32_t r = 0; r < n_reads; r++) {
+      const int n = qkmers[r];
+      if (n <= 0) continue;
+      if (n <= kFlat && flat_rows[(size_t)n]) continue;
+      if (n > kFlat && fpr_rows.count(n)) continue;
+      const auto it = fpr_rows.emplace(n, F->ensure_row(n)).first;
+      if (n <= kFlat) flat_rows[(size_t)n] = it->second.get();
+    }
   }
   t_2 = now();
   kmcpg_match* const mbase = o->matches.data();
@@ -370,7 +380,7 @@ extern "C" int kmcpg_finalize(const kmcpg_db* db, const kmcpg_hit* hits, uint64_
       if (n > 0) {
         if (n != row_n) {
           row_n = n;
-          row_of_n = fpr_rows.find(n)->second;
+          row_of_n = n <= kFlat ? flat_rows[(size_t)n] : fpr_rows.find(n)->second.get();
         }
         row = row_of_n;
       }
@@ -513,8 +523,9 @@ extern "C" int kmcpg_finalize(const kmcpg_db* db, const kmcpg_hit* hits, uint64_
 // match; what is left is the float64 arithmetic of a Match (util-db-search.go:7487-7489), the FPR column with its -f test
 // (:7474-7478; for queries of up to 1 024 k-mers K2 has applied it already through the bound table — the running value of
 // util-fpr.go:32-50 only ever falls, so "count >= smallest passing count" IS the test), --keep-top-scores (:285-311) and the
-// columns' metadata.  Every threshold is applied again (a no-op on lists K2 + K3 produced): a list from elsewhere is finalized
-// correctly too, and segments longer than K3 orders (K3_WG_CAP) are sorted here.
+// columns' metadata.  Every threshold is applied again (a no-op on lists K2 + K3 produced) and the order of every segment is checked
+// while it streams: a list from elsewhere is finalized correctly too — segments longer than K3 orders (K3_WG_CAP) and segments
+// found out of order are sorted here.
 namespace kmcpg {
 ResultOwner* result_owner_take() { return take_owner(); }
 void result_owner_give(ResultOwner* o) { give_owner(o); }
@@ -564,7 +575,7 @@ int finalize_grouped_into(const kmcpg_db* db, const kmcpg_pair* pairs, const uin
     uint64_t pos = lo < n_reads ? read_offs[lo] : n_pairs;
     const uint64_t pos0 = pos;
     int row_n = -1;
-    const std::vector<double>* row = nullptr;
+    FprRow row;  // held while in use: the cache may drop its own reference at any time
     static thread_local std::vector<kmcpg_match> tmp;
     for (uint32_t r = lo; r < hi; r++) {
       const uint64_t s0 = read_offs[r], s1 = read_offs[r + 1];
@@ -581,7 +592,11 @@ int finalize_grouped_into(const kmcpg_db* db, const kmcpg_pair* pairs, const uin
         row = F->ensure_row(n);
       }
       const uint64_t m = s1 - s0;
-      const bool host_sort = m > (uint64_t)K3_WG_CAP;  // K3 left this segment unordered
+      // K3 leaves segments above K3_WG_CAP unordered; a list from elsewhere (the public kmcpg_finalize_grouped) may hold shorter
+      // ones out of order too: the records are checked against their predecessor while they stream and the segment is done again
+      // through the host sort if one is out of place (never, on K3's output)
+      bool host_sort = m > (uint64_t)K3_WG_CAP;
+     again:
       // A handful of matches (the usual read): plain stores, straight into the result.  Many: the records are built in a scratch
       // array and then written in one tight loop of streaming stores — streaming stores interleaved with the loads and divisions
       // of the loop below leave half-filled write-combining buffers behind, which the memory system pays for with partial
@@ -594,8 +609,11 @@ int finalize_grouped_into(const kmcpg_db* db, const kmcpg_pair* pairs, const uin
       int nn = 0;
       double pscore = 1024;
       const bool top = p.top_n_scores > 0 && !p.do_not_sort;
-      bool cut = false;
-      for (uint64_t i = s0; i < s1 && !cut; i++) {
+      bool cut = false, out_of_order = false;
+      kmcpg_match prev{};
+      bool have_prev = false;
+      // (after the --keep-top-scores cut the rest of an ordered segment is only looked at — the cut is right only if ALL of it is in order)
+      for (uint64_t i = s0; i < s1; i++) {
         const kmcpg_pair h = pairs[i];
         if (h.col >= n_cols) {
           bad.store(1);
@@ -624,6 +642,13 @@ int finalize_grouped_into(const kmcpg_db* db, const kmcpg_pair* pairs, const uin
           tmp[kept++] = mm;
           continue;
         }
+        if (have_prev && (p.do_not_sort ? mm.col < prev.col : match_less(mm, prev, p.sort_by))) {
+          out_of_order = true;
+          break;
+        }
+        prev = mm;
+        have_prev = true;
+        if (cut) continue;
         if (via_tmp) tmp[kept] = mm;
         else mbase[first + kept] = mm;
         kept++;
@@ -635,6 +660,10 @@ int finalize_grouped_into(const kmcpg_db* db, const kmcpg_pair* pairs, const uin
             pscore = score;
           }
         }
+      }
+      if (out_of_order) {
+        host_sort = true;
+        goto again;
       }
       if (via_tmp && !host_sort)
         for (uint64_t i = 0; i < kept; i++) store_record(mbase + first + i, tmp[i]);

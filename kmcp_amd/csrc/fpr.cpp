@@ -109,20 +109,17 @@ static std::vector<double> fpr_row(double p_, int n, int upto) {
   return out;
 }
 
-const std::vector<double>& QueryFpr::row(int n) {
+const QueryFpr::Row& QueryFpr::row(int n) {
   auto it = rows_.find(n);
-  if (it != rows_.end()) return *it->second;
-  if (rows_.size() >= kMaxRows) {  // a host that feeds queries of ever new lengths: start over; the rows handed out so far stay
-    retired_.clear();              // readable until the NEXT reset (callers hold a row for the duration of one call)
-    for (auto& kv : rows_) retired_.push_back(std::move(kv.second));
-    rows_.clear();
-  }
-  return *rows_.emplace(n, std::make_unique<std::vector<double>>(fpr_row(p_, n, n))).first->second;
+  if (it != rows_.end()) return it->second;
+  // a host that feeds queries of ever new lengths: start over (rows handed out stay alive through their holders' references)
+  if (rows_.size() >= kMaxRows) rows_.clear();
+  return rows_.emplace(n, std::make_shared<const std::vector<double>>(fpr_row(p_, n, n))).first->second;
 }
 
-const std::vector<double>* QueryFpr::ensure_row(int n) {
+QueryFpr::Row QueryFpr::ensure_row(int n) {
   std::lock_guard<std::mutex> g(mu_);
-  return &row(n);  // the vector lives on the heap, owned by the map (or, after a reset, by retired_)
+  return row(n);
 }
 
 double QueryFpr::get(int n, int k) {
@@ -130,7 +127,7 @@ double QueryFpr::get(int n, int k) {
   if (k > n) k = n;
   if (k < 0) return 1;
   std::lock_guard<std::mutex> g(mu_);
-  const std::vector<double>& r = row(n);
+  const std::vector<double>& r = *row(n);
   return (size_t)k < r.size() ? r[(size_t)k] : 0.0;
 }
 

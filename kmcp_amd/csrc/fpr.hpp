@@ -20,10 +20,11 @@ class QueryFpr {
   // queryFPR(n, k): 1 - sum_{i<=k} C(n,i) p^i (1-p)^(n-i), clamped at 0
   double get(int n, int k);
   // Rows are cached for every n (a row ends at its first dead entry, see fpr.cpp: at most ~1 030 + 1 values whatever n is; at
-  // most kMaxRows rows are kept).  ensure_row builds row n if needed and returns it: value(row, k) reads FPR(n, k) without a lock.
-  // The pointer stays valid until kMaxRows further distinct n have been asked for (never, for a read-length distribution).
+  // most kMaxRows rows are kept, then the cache starts over).  ensure_row builds row n if needed and returns a reference-counted
+  // handle: value(*row, n, k) reads FPR(n, k) without a lock, and the row lives as long as anybody holds it, whatever the cache does.
   static constexpr size_t kMaxRows = 65536;
-  const std::vector<double>* ensure_row(int n);
+  typedef std::shared_ptr<const std::vector<double>> Row;
+  Row ensure_row(int n);
   static double value(const std::vector<double>& row, int n, int k) {
     if (k > n) k = n;
     if (k < 0) return 1;
@@ -31,11 +32,11 @@ class QueryFpr {
   }
 
  private:
-  const std::vector<double>& row(int n);
+  const Row& row(int n);
   double p_;
   std::mutex mu_;
-  std::unordered_map<int, std::unique_ptr<std::vector<double>>> rows_;
-  std::vector<std::unique_ptr<std::vector<double>>> retired_;  // rows of the generation before the last reset: still readable
+  std::unordered_map<int, Row> rows_;
 };
+typedef QueryFpr::Row FprRow;
 
 }  // namespace kmcpg

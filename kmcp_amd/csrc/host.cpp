@@ -316,7 +316,11 @@ int enqueue(kmcpg_db* db, AsyncState* A, Lane* L, const kmcpg_params& p, bool ge
   // batch): HBM pinned for the life of the handle is HBM the workspace of a later, larger batch may need
   // (16x, not 4x: a lane that serves whole batches and quarter-batch pieces in turn must not free and reallocate its buffer every time —
   // hipFree waits for the device)
-  if (L->d_hits.cap > 16 * want && L->d_hits.cap > (1u << 20)) L->d_hits.release();
+  // (d_pairs is sized by d_hits.cap and re-ensured by enqueue_query: it goes wherever d_hits goes)
+  if (L->d_hits.cap > 16 * want && L->d_hits.cap > (1u << 20)) {
+    L->d_hits.release();
+    L->d_pairs.release();
+  }
   uint64_t cap = std::max<uint64_t>(L->d_hits.cap, want);
   if (L->d_seqs.ensure(L->tb1 + 16) || L->d_offs.ensure((size_t)n + 1) || L->d_cnt.ensure(2) || L->d_qk.ensure(n) || L->d_ql.ensure(n) ||
       (L->paired && (L->d_seqs2.ensure(L->tb2 + 16) || L->d_offs2.ensure((size_t)n + 1))))
@@ -350,11 +354,15 @@ int enqueue(kmcpg_db* db, AsyncState* A, Lane* L, const kmcpg_params& p, bool ge
     {
       std::lock_guard<std::mutex> g(A->mu);
       for (auto& l : A->lanes)
-        if (!l->busy && l.get() != L && l->d_hits.cap > 0) l->d_hits.release();
+        if (!l->busy && l.get() != L && l->d_hits.cap > 0) {
+          l->d_hits.release();
+          l->d_pairs.release();
+        }
     }
     if (L->d_hits.cap > base_cap + base_cap / 8 + 64) {
       HIPCHK(hipStreamSynchronize(st));  // kernels of the failed attempt may have been enqueued with the old buffer
       L->d_hits.release();
+      L->d_pairs.release();
       if (L->d_hits.ensure(base_cap)) return kmcpg_fail(KMCPG_ENOMEM, "hipMalloc failed");
     }
     rc = enqueue_query(db, A, L, p);
@@ -619,7 +627,7 @@ int finish_raw(kmcpg_ticket* t, kmcpg_result* out) {
     if (sh0->async->device_finalize && t->n && n_hits) {
       // K3 on the gathering GPU, over the concatenation of all shards' lists (every shard knows every column's k-mer count):
       // grouped by read, filtered by -T, in final order; 8 bytes per match and the reads' offsets come to the host
-      if (L0->d_pairs.ensure(n_hits) || L0->d_roffs.ensure((size_t)t->n + 2) || L0->h_pairs.ensure(n_hits) || L0->h_roffs.ensure((size_t)t->n + 2))
+      if (L0->d_pairs.ensure(n_hits) || L0->d_roffs.ensure((size_t)t->n + 2) || L0->h_roffs.ensure((size_t)t->n + 2))
         return kmcpg_fail(KMCPG_ENOMEM, "hipMalloc failed");
       uint64_t* h_word = L0->h_cnt.p;  // pinned; the lane's counters have been read by collect()
       h_word[0] = n_hits;
@@ -631,8 +639,12 @@ int finish_raw(kmcpg_ticket* t, kmcpg_result* out) {
         int rc2 = kmcpg_group_device(sh0, (const kmcpg_hit*)d_cat, d_word, n_hits, L0->d_qk.p, n, &p, L0->d_pairs.p, L0->d_roffs.p, st);
         if (rc2) return rc2;
         HIPCHK(hipMemcpyAsync(L0->h_roffs.p, L0->d_roffs.p, ((size_t)n + 2) * sizeof(uint64_t), hipMemcpyDeviceToHost, (hipStream_t)st));
-        // (at most n_hits pairs survive -T; h_roffs says how many)
-        HIPCHK(hipMemcpyAsync(L0->h_pairs.p, L0->d_pairs.p, n_hits * sizeof(kmcpg_pair), hipMemcpyDeviceToHost, (hipStream_t)st));
+        // only what survived -T comes down: the offsets first (nobody else's gather is held up by this wait: the exchange mutex is
+        // not held here), then h_roffs[n] pairs, as collect() does on the single-GPU path
+        HIPCHK(hipStreamSynchronize((hipStream_t)st));
+        const uint64_t kept = std::min<uint64_t>(L0->h_roffs.p[n], n_hits);
+        if (L0->h_pairs.ensure(kept + 1)) return kmcpg_fail(KMCPG_ENOMEM, "hipHostMalloc failed");
+        if (kept) HIPCHK(hipMemcpyAsync(L0->h_pairs.p, L0->d_pairs.p, kept * sizeof(kmcpg_pair), hipMemcpyDeviceToHost, (hipStream_t)st));
         return 0;
       });
       if (rc) return rc;

@@ -334,16 +334,20 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((NPL =
           }
         }
         if (a.gathered) g_acc += (uint32_t)__popcll(__ballot(live)) * NR * (MULTI ? nh : 1);  // measurement runs only
+#ifndef KMCPG_CSA3_LPR8
+#define KMCPG_CSA3_LPR8 0
+#endif
+        constexpr bool B3 = KMCPG_CSA3_LPR8 && LPR == 8;  // A/B knob: v_bitop3 adders on the 128-byte-row form only (profiles/r04_rows128.txt)
         if constexpr (NR == 8) {
-          csa8<NPL>(pl[0], x[0].x, x[1].x, x[2].x, x[3].x, x[4].x, x[5].x, x[6].x, x[7].x);
-          csa8<NPL>(pl[1], x[0].y, x[1].y, x[2].y, x[3].y, x[4].y, x[5].y, x[6].y, x[7].y);
-          csa8<NPL>(pl[2], x[0].z, x[1].z, x[2].z, x[3].z, x[4].z, x[5].z, x[6].z, x[7].z);
-          csa8<NPL>(pl[3], x[0].w, x[1].w, x[2].w, x[3].w, x[4].w, x[5].w, x[6].w, x[7].w);
+          csa8<NPL, B3>(pl[0], x[0].x, x[1].x, x[2].x, x[3].x, x[4].x, x[5].x, x[6].x, x[7].x);
+          csa8<NPL, B3>(pl[1], x[0].y, x[1].y, x[2].y, x[3].y, x[4].y, x[5].y, x[6].y, x[7].y);
+          csa8<NPL, B3>(pl[2], x[0].z, x[1].z, x[2].z, x[3].z, x[4].z, x[5].z, x[6].z, x[7].z);
+          csa8<NPL, B3>(pl[3], x[0].w, x[1].w, x[2].w, x[3].w, x[4].w, x[5].w, x[6].w, x[7].w);
         } else {
-          csa4<NPL>(pl[0], x[0].x, x[1].x, x[2].x, x[3].x);
-          csa4<NPL>(pl[1], x[0].y, x[1].y, x[2].y, x[3].y);
-          csa4<NPL>(pl[2], x[0].z, x[1].z, x[2].z, x[3].z);
-          csa4<NPL>(pl[3], x[0].w, x[1].w, x[2].w, x[3].w);
+          csa4<NPL, B3>(pl[0], x[0].x, x[1].x, x[2].x, x[3].x);
+          csa4<NPL, B3>(pl[1], x[0].y, x[1].y, x[2].y, x[3].y);
+          csa4<NPL, B3>(pl[2], x[0].z, x[1].z, x[2].z, x[3].z);
+          csa4<NPL, B3>(pl[3], x[0].w, x[1].w, x[2].w, x[3].w);
         }
         if (!SPLIT && a.prune && ((((j / NR) + 1) & (a.prune_every - 1)) == 0 || j + NR >= cnt)) {
           const int done = min(n, c0 + j + NR);

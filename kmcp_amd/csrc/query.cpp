@@ -210,7 +210,8 @@ int fpr_bound(kmcpg_db* db, double max_fpr, uint64_t max_kmers, hipStream_t st, 
   QueryFpr* F = db->fpr.get();
   t.h[0] = 0;
   for (int n = 1; n <= want_n; n++) {
-    const std::vector<double>& row = *F->ensure_row(n);
+    const FprRow held = F->ensure_row(n);
+    const std::vector<double>& row = *held;
     int c = 0;
     while (c <= n && !(QueryFpr::value(row, n, c) <= max_fpr)) c++;
     t.h[n] = (uint16_t)c;  // n + 1: no count passes

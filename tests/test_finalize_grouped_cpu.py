@@ -79,3 +79,33 @@ def test_long_segments_are_sorted_here_and_bad_input_is_refused():
             db.finalize_grouped(good, np.array([0, 1, 0, 0], np.uint64), qk, ql)  # offsets run backwards / past the end
         with pytest.raises(lib.KmcpGpuError):
             db.finalize_grouped(good, np.array([1, 1, 1, 0], np.uint64), qk, ql)  # must start at 0
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(sort_by=1), dict(sort_by=2, top_n_scores=2), dict(do_not_sort=1), dict(top_n_scores=1)])
+def test_short_segments_out_of_order_are_sorted_here_too(kw):
+    """a caller of the public kmcpg_finalize_grouped whose short segments are NOT in K3's order (a list that did not come
+    from kmcpg_group_device) used to get them streamed as given - wrong order, and --keep-top-scores cutting in the wrong place.
+    Every record is now compared with its predecessor; a segment with one out of place goes through the host sort."""
+    from kmcp_amd import Database, default_params, lib
+    rng = np.random.default_rng(13)
+    n_reads, per = 500, 40  # > 8 per read: the scratch-array path; the first 50 reads get 5 each: the in-place path
+    with Database.open(DB, device=-1) as db:
+        ncols = int(db.info.n_cols)
+        per = min(per, ncols)
+        assert per > 8
+        per_read = np.where(np.arange(n_reads) < 50, 5, per)
+        reads = np.repeat(np.arange(n_reads, dtype=np.uint32), per_read)
+        hits = np.empty(len(reads), dtype=lib.HIT_DTYPE)
+        hits["read"] = reads
+        hits["col"] = np.concatenate([rng.permutation(ncols)[:c] for c in per_read]).astype(np.uint32)
+        hits["count"] = rng.integers(75, 131, size=len(reads)).astype(np.uint32)
+        qk = np.full(n_reads, 130, np.int32)
+        ql = np.full(n_reads, 150, np.int32)
+        p = default_params(**kw)
+        want = db.finalize(hits, qk, ql, params=p)
+        # grouped by read (hits are), but in the random order they were drawn in
+        pairs = np.ascontiguousarray(np.stack([hits["col"], hits["count"]], axis=1).astype(np.uint32))
+        roffs = np.concatenate([[0], np.cumsum(per_read), [0]]).astype(np.uint64)
+        got = db.finalize_grouped(pairs, roffs, qk, ql, params=p)
+        assert np.array_equal(got.offs, want.offs) and got.matches.tobytes() == want.matches.tobytes()
+        assert len(want.matches) > 400
