@@ -32,6 +32,14 @@ struct Seg {
   uint32_t ncols;
 };
 
+// 2-bit packed upload of a batch's bases (host.cpp stage / support.hip k_unpack2): a run of bytes that are not A/C/G/T/U in either
+// case, restored after unpacking (positions in bases from the start of the batch)
+struct ExcRun {
+  uint64_t pos;
+  uint32_t len;
+  uint32_t byte;
+};
+
 // One unit of COBS work per read: (local block, tile of LPR*16 bytes of the row).
 struct Slot {
   uint32_t block;  // index into the group array

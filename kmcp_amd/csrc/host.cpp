@@ -27,6 +27,7 @@
 #include "exchange.hpp"
 #include "fpr.hpp"
 #include "kernels.hpp"
+#include "pack2.hpp"
 
 using namespace kmcpg;
 
@@ -78,6 +79,13 @@ struct Lane {
   DevBuf<uint64_t> d_roffs;
   PinBuf<kmcpg_pair> h_pairs;
   PinBuf<uint64_t> h_roffs;
+  // 2-bit packed upload (stage): the batch's bases as codes + the runs of foreign bytes instead of h_seqs; unpacked on the device
+  PinBuf<uint8_t> h_pack;
+  PinBuf<ExcRun> h_exc;
+  DevBuf<uint8_t> d_pack;
+  DevBuf<ExcRun> d_exc;
+  bool packed = false;
+  uint32_t n_exc = 0;
   bool grouped = false;  // this batch went through K3: h_pairs / h_roffs hold its result, h_hits is not filled
   hipEvent_t k3_ev = nullptr, eager_ev = nullptr;  // K3 done on the kernel stream -> the eager copy of the pairs on the copy stream
   bool eager_aside = false;                        // ... when it was put there (pieces of a large kmcpg_search_batch call)
@@ -92,6 +100,7 @@ struct Lane {
     h_seqs.release(); h_seqs2.release(); h_offs.release(); h_offs2.release(); h_cnt.release(); h_qk.release(); h_ql.release(); h_hits.release();
     d_seqs.release(); d_seqs2.release(); d_offs.release(); d_offs2.release(); d_cnt.release(); d_qk.release(); d_ql.release(); d_hits.release();
     d_pairs.release(); d_roffs.release(); h_pairs.release(); h_roffs.release();
+    h_pack.release(); h_exc.release(); d_pack.release(); d_exc.release();
     if (done) (void)hipEventDestroy(done);
     if (uploaded) (void)hipEventDestroy(uploaded);
     if (k3_ev) (void)hipEventDestroy(k3_ev);
@@ -249,8 +258,23 @@ void par_memcpy(void* dst, const void* src, size_t n) {
 }
 
 // caller's batch -> the lane's pinned buffers (the caller may reuse its buffers as soon as kmcpg_submit returns)
-int stage(Lane* L, const uint8_t* seqs, const uint64_t* offs, const uint8_t* seqs2, const uint64_t* offs2, uint32_t n) {
+// Long-query batches go up as 2-bit codes (pack2.hpp): a batch of 256 genomes is 1 GB of ASCII, and at ~35 k genomes/s of kernel
+// rate the 40-50 GB/s of PCIe were what bounded the host-to-host rate (9.9 k genomes/s, round 4).  The pack IS the staging copy —
+// it reads the caller's buffer once and writes a quarter of it to pinned memory — and the device expands it again in ~0.3 ms per
+// GB (k_unpack2); the k-mer kernels read ASCII as before.  Only where nothing re-reads the staged ASCII (retries of --try-se and
+// of multi-k databases do: `allow_pack` is false there) and only for batches whose bases dominate the upload (mean query >= 1 kb:
+// a batch of 150-bp reads is 150 MB and its staging copy is not what limits it).  KMCPG_PACK=0 switches it off.
+bool pack_wanted(uint64_t total_bases, uint32_t n) {
+  static const int env = getenv("KMCPG_PACK") ? atoi(getenv("KMCPG_PACK")) : -1;  // 0 never, 1 always (tests), default by shape
+  if (env == 0) return false;
+  if (env == 1) return total_bases >= 64;
+  return total_bases >= (8ull << 20) && total_bases / std::max<uint32_t>(1, n) >= 1000;
+}
+
+int stage(Lane* L, const uint8_t* seqs, const uint64_t* offs, const uint8_t* seqs2, const uint64_t* offs2, uint32_t n, bool allow_pack = false) {
   L->n = n;
+  L->packed = false;
+  L->n_exc = 0;
   L->paired = seqs2 != nullptr;
   L->tb1 = L->tb2 = 0;
   L->maxlen = 0;
@@ -267,9 +291,25 @@ int stage(Lane* L, const uint8_t* seqs, const uint64_t* offs, const uint8_t* seq
   L->maxlen = (uint32_t)maxlen;
   L->tb1 = offs[n];
   L->tb2 = seqs2 ? offs2[n] : 0;
-  if (L->h_seqs.ensure(L->tb1 + 16) || L->h_offs.ensure((size_t)n + 1) || (seqs2 && (L->h_seqs2.ensure(L->tb2 + 16) || L->h_offs2.ensure((size_t)n + 1))))
+  if (L->h_offs.ensure((size_t)n + 1) || (seqs2 && (L->h_seqs2.ensure(L->tb2 + 16) || L->h_offs2.ensure((size_t)n + 1))))
     return kmcpg_fail(KMCPG_ENOMEM, "hipHostMalloc failed");
-  par_memcpy(L->h_seqs.p, seqs, L->tb1);
+  if (allow_pack && !seqs2 && pack_wanted(L->tb1, n)) {
+    static thread_local std::vector<PackRun> exc;
+    static_assert(sizeof(PackRun) == sizeof(ExcRun), "one layout");
+    if (L->h_pack.ensure(L->tb1 / 4 + 16)) return kmcpg_fail(KMCPG_ENOMEM, "hipHostMalloc failed");
+    static const unsigned pack_threads = std::max(1u, std::min(8u, std::thread::hardware_concurrency()));
+    // more than one foreign run per 256 bases: not nucleotide text, sent as it is
+    if (pack2_parallel(seqs, L->tb1, L->h_pack.p, exc, std::max<size_t>(1024, L->tb1 / 256), pack_threads)) {
+      if (L->h_exc.ensure(exc.size() + 1)) return kmcpg_fail(KMCPG_ENOMEM, "hipHostMalloc failed");
+      if (!exc.empty()) memcpy(L->h_exc.p, exc.data(), exc.size() * sizeof(ExcRun));
+      L->n_exc = (uint32_t)exc.size();
+      L->packed = true;
+    }
+  }
+  if (!L->packed) {
+    if (L->h_seqs.ensure(L->tb1 + 16)) return kmcpg_fail(KMCPG_ENOMEM, "hipHostMalloc failed");
+    par_memcpy(L->h_seqs.p, seqs, L->tb1);
+  }
   par_memcpy(L->h_offs.p, offs, ((size_t)n + 1) * sizeof(uint64_t));
   if (seqs2) {
     par_memcpy(L->h_seqs2.p, seqs2, L->tb2);
@@ -338,7 +378,13 @@ int enqueue(kmcpg_db* db, AsyncState* A, Lane* L, const kmcpg_params& p, bool ge
   // the reads go up on a stream of their own (150 MB per million reads: 4 ms of PCIe that would otherwise sit between the
   // kernels of consecutive batches); the lane's device buffers are idle, its previous batch was waited for
   hipStream_t up = A->up_stream;
-  if (L->tb1) HIPCHK(hipMemcpyAsync(L->d_seqs.p, L->h_seqs.p, L->tb1, hipMemcpyHostToDevice, up));
+  if (L->packed) {
+    if (L->d_pack.ensure(L->tb1 / 4 + 16) || (L->n_exc && L->d_exc.ensure(L->n_exc))) return kmcpg_fail(KMCPG_ENOMEM, "hipMalloc failed");
+    HIPCHK(hipMemcpyAsync(L->d_pack.p, L->h_pack.p, (L->tb1 + 3) / 4, hipMemcpyHostToDevice, up));
+    if (L->n_exc) HIPCHK(hipMemcpyAsync(L->d_exc.p, L->h_exc.p, (size_t)L->n_exc * sizeof(ExcRun), hipMemcpyHostToDevice, up));
+  } else if (L->tb1) {
+    HIPCHK(hipMemcpyAsync(L->d_seqs.p, L->h_seqs.p, L->tb1, hipMemcpyHostToDevice, up));
+  }
   HIPCHK(hipMemcpyAsync(L->d_offs.p, L->h_offs.p, ((size_t)n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, up));
   if (L->paired) {
     if (L->tb2) HIPCHK(hipMemcpyAsync(L->d_seqs2.p, L->h_seqs2.p, L->tb2, hipMemcpyHostToDevice, up));
@@ -346,6 +392,7 @@ int enqueue(kmcpg_db* db, AsyncState* A, Lane* L, const kmcpg_params& p, bool ge
   }
   HIPCHK(hipEventRecord(L->uploaded, up));
   HIPCHK(hipStreamWaitEvent(st, L->uploaded, 0));
+  if (L->packed) launch_unpack2(L->d_pack.p, L->d_seqs.p, L->tb1, L->n_exc ? L->d_exc.p : nullptr, L->n_exc, st);  // codes -> the ASCII K1 reads
   int rc = enqueue_query(db, A, L, p);
   if (rc == KMCPG_ENOMEM) {
     // the shared workspace (hashes, dedup scratch, long-query counters) did not fit: hit buffers above the plain size are the
@@ -565,9 +612,11 @@ int submit_impl(kmcpg_db* db, const uint8_t* seqs, const uint64_t* offs, const u
   // every GPU gets the whole batch (150 B per read; cheaper than moving k-mer hashes between GPUs)
   std::vector<int> rcs(t->parts.size(), 0);
   std::vector<std::string> errs(t->parts.size());
+  // the staged ASCII is read again only by the retries of retry_unmatched (--try-se on pairs, the smaller k of a multi-k database)
+  const bool can_pack = !seqs2 && !retry && (p.k > 0 || db->ks_desc.size() < 2);
   auto one = [&](size_t i) {
     auto& pt = t->parts[i];
-    rcs[i] = stage(pt.lane, seqs, offs, seqs2, offs2, n);
+    rcs[i] = stage(pt.lane, seqs, offs, seqs2, offs2, n, can_pack);
     if (rcs[i] == 0) rcs[i] = enqueue(pt.shard, pt.shard->async, pt.lane, p);
     if (rcs[i]) errs[i] = kmcpg_err_ref();
   };
@@ -999,7 +1048,7 @@ static int search_batch_pieces(kmcpg_db* db, const uint8_t* seqs, const uint64_t
       o2.resize((size_t)q.cnt + 1);
       for (uint32_t r = 0; r <= q.cnt; r++) o2[r] = offs2[q.lo + r] - offs2[q.lo];
     }
-    rc = stage(L, seqs + offs[q.lo], o1.data(), seqs2 ? seqs2 + offs2[q.lo] : nullptr, offs2 ? o2.data() : nullptr, q.cnt);
+    rc = stage(L, seqs + offs[q.lo], o1.data(), seqs2 ? seqs2 + offs2[q.lo] : nullptr, offs2 ? o2.data() : nullptr, q.cnt, !seqs2);
     if (rc == 0) rc = enqueue(db, A, L, p, true);
     if (timing) fprintf(stderr, "piece %u: enqueued at %.2f ms\n", next_submit, now() - t_begin);
     next_submit++;

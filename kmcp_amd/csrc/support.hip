@@ -225,6 +225,46 @@ void launch_build_scatter(uint8_t* sigs, uint64_t num_sigs, uint64_t mh, uint32_
 namespace kmcpg {
 
 // ------------------------------------------------------------------------------------------------
+// 2-bit packed upload (host.cpp stage): a batch of long queries is 4x smaller over PCIe as 2-bit codes; K1 reads ASCII as before.
+// One thread expands 4 packed bytes to 16 bases (one 16-byte store); the few bytes that are not A/C/G/T/U come as runs and are
+// written over the result (the hash of such a byte depends on its exact value: seed 0, complement by its low 3 bits — nthash.hpp).
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_unpack2(const uint8_t* __restrict__ packed, uint8_t* __restrict__ out, uint64_t n_bases) {
+  const uint64_t n16 = n_bases / 16;
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  constexpr uint32_t LUT = ('A') | ('C' << 8) | ('T' << 16) | ('G' << 24);  // code -> base
+  if (i < n16) {
+    const uint32_t w = reinterpret_cast<const uint32_t*>(packed)[i];
+    uint32_t o[4];
+#pragma unroll
+    for (int b = 0; b < 4; b++) {
+      const uint32_t byte = (w >> (8 * b)) & 0xffu;
+      uint32_t v = 0;
+#pragma unroll
+      for (int j = 0; j < 4; j++) v |= ((LUT >> (8 * ((byte >> (2 * j)) & 3u))) & 0xffu) << (8 * j);
+      o[b] = v;
+    }
+    reinterpret_cast<uint4*>(out)[i] = make_uint4(o[0], o[1], o[2], o[3]);
+  } else if (i == n16) {  // the last < 16 bases
+    for (uint64_t j = n16 * 16; j < n_bases; j++) out[j] = (uint8_t)((LUT >> (8 * ((packed[j >> 2] >> (2 * (j & 3))) & 3u))) & 0xffu);
+  }
+}
+
+__global__ void __launch_bounds__(256) k_apply_exc(const ExcRun* __restrict__ runs, uint32_t n_runs, uint8_t* __restrict__ out) {
+  for (uint32_t r = blockIdx.x; r < n_runs; r += gridDim.x) {
+    const ExcRun e = runs[r];
+    for (uint32_t j = threadIdx.x; j < e.len; j += blockDim.x) out[e.pos + j] = (uint8_t)e.byte;
+  }
+}
+
+void launch_unpack2(const uint8_t* packed, uint8_t* out, uint64_t n_bases, const ExcRun* runs, uint32_t n_runs, hipStream_t st) {
+  if (n_bases == 0) return;
+  const uint64_t threads = n_bases / 16 + 1;
+  hipLaunchKernelGGL(k_unpack2, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, packed, out, n_bases);
+  if (n_runs) hipLaunchKernelGGL(k_apply_exc, dim3(std::min<unsigned>(n_runs, 65536u)), dim3(256), 0, st, runs, n_runs, out);
+}
+
+// ------------------------------------------------------------------------------------------------
 // EXPERIMENT ONLY (KMCPG_DEBUG_ROWSORT, profiles/r05_rowsort_gate.txt): the hashes of every query re-ordered by the row they
 // address in ONE block (h % num_sigs), so that all units in flight sweep that block's rows in the same direction.  mode 2
 // rotates each query's sorted list by a pseudo-random offset: the same per-unit locality without the phase coherence.
