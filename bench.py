@@ -318,7 +318,11 @@ def run_workload(name, ctx, steps, warmup, batch_reads=0, cpu_baseline=True, cpu
     # D2H (and, N > 1, the exchange) of a finished step while the next step's kernels run on `main`: a high-priority stream, so
     # that its small copies / collectives are not queued behind a 60-500 ms kernel that fills the chip
     side = torch.cuda.Stream(dev, priority=-1)
-    stream = main.cuda_stream
+    # two kernel streams taken in turn by consecutive steps: the library keeps two k-mer workspaces (engine.hpp Workspace), so K1 of
+    # step i + 1 (VALU-bound) runs beside K2 of step i (memory-bound); the K2s themselves follow each other (query.cpp cobs_ev).
+    # KMCP_BENCH_STREAMS=1: everything on one stream, as in rounds 1-4 (A/B)
+    kstreams = [main, torch.cuda.Stream(dev)] if os.environ.get("KMCP_BENCH_STREAMS", "2") != "1" else [main, main]
+    poll = os.environ.get("KMCP_BENCH_POLL") == "1"  # experiment: busy-poll hipEventQuery instead of hipEventSynchronize
 
     class Buf:  # device outputs of one step in flight + their pinned host copies
         def __init__(self):
@@ -345,6 +349,8 @@ def run_workload(name, ctx, steps, warmup, batch_reads=0, cpu_baseline=True, cpu
             self.grouped = False
 
     bufs = [Buf(), Buf()]  # two steps in flight, with and without a collective
+    for b_, st_ in zip(bufs, kstreams):
+        b_.stream = st_
 
     use_k3 = os.environ.get("KMCP_BENCH_K3", "1") != "0"  # 0: the round-3 host half (kmcpg_finalize on the raw hit list)
     k3_ms = []
@@ -353,26 +359,32 @@ def run_workload(name, ctx, steps, warmup, batch_reads=0, cpu_baseline=True, cpu
         """Enqueues K1 + K2 of batch i on this rank's blocks and, at N = 1, K3 behind them (nothing waits here).
         raw: leave the hit list as K2 emitted it (the sanity step: checksum and oracle diff work on the raw tuples)."""
         bt = batches[i % n_batches]
+        ks = bf.stream
         if bf.used:
-            main.wait_event(bf.copied)  # the previous step that used these buffers has left them
-        db.query_device(bt.reads.data_ptr(), bt.offs.data_ptr(), B, bt.total, bt.maxlen, bf.d_hits.data_ptr(), cap, bf.d_cnt.data_ptr(),
-                        bf.d_qk.data_ptr(), bf.d_ql.data_ptr(), params=params, stream=stream)
-        bf.h_cnt.copy_(bf.d_cnt, non_blocking=True)
-        bf.grouped = use_k3 and not raw
-        if bf.grouped and not coll:
-            bf.k3_start.record(main)
-            db.group_device(bf.d_hits.data_ptr(), bf.d_cnt.data_ptr(), cap, bf.d_qk.data_ptr(), B, bf.d_pairs.data_ptr(), bf.d_roffs.data_ptr(),
-                            params=params, stream=stream)
-            bf.k3_end.record(main)
-            bf.h_roffs.copy_(bf.d_roffs, non_blocking=True)
-        bf.kernels_done.record(main)
+            ks.wait_event(bf.copied)  # the previous step that used these buffers has left them
+        with torch.cuda.stream(ks):
+            db.query_device(bt.reads.data_ptr(), bt.offs.data_ptr(), B, bt.total, bt.maxlen, bf.d_hits.data_ptr(), cap, bf.d_cnt.data_ptr(),
+                            bf.d_qk.data_ptr(), bf.d_ql.data_ptr(), params=params, stream=ks.cuda_stream)
+            bf.h_cnt.copy_(bf.d_cnt, non_blocking=True)
+            bf.grouped = use_k3 and not raw
+            if bf.grouped and not coll:
+                bf.k3_start.record(ks)
+                db.group_device(bf.d_hits.data_ptr(), bf.d_cnt.data_ptr(), cap, bf.d_qk.data_ptr(), B, bf.d_pairs.data_ptr(), bf.d_roffs.data_ptr(),
+                                params=params, stream=ks.cuda_stream)
+                bf.k3_end.record(ks)
+                bf.h_roffs.copy_(bf.d_roffs, non_blocking=True)
+            bf.kernels_done.record(ks)
         bf.used = True
 
     def exchange(bf):
         """Waits for the step's kernels; hit lists to rank 0 (RCCL when N > 1) and on their way to pinned host memory
         (`copied` fires when the host may read).  Returns #hits on rank 0.  Holds collectives when N > 1."""
         if not coll:
-            bf.kernels_done.synchronize()
+            if poll:
+                while not bf.kernels_done.query():
+                    pass
+            else:
+                bf.kernels_done.synchronize()
             n = int(bf.h_cnt[0])
             assert n <= cap, "hit buffer overflow"
             side.wait_event(bf.kernels_done)
@@ -592,7 +604,7 @@ def run_workload(name, ctx, steps, warmup, batch_reads=0, cpu_baseline=True, cpu
             for i in range(n_batches):
                 gpu_half(i, bufs[0])
                 torch.cuda.synchronize()
-                bufs[0].copied.record(main)
+                bufs[0].copied.record(bufs[0].stream)
                 per_batch.append((db.last_gathered_bytes(), db.last_hash_bytes()))
         finally:
             db.set_profiling(True)

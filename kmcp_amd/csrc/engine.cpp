@@ -618,23 +618,14 @@ extern "C" int kmcpg_close(kmcpg_db* db) {
   if (db->d_segs) (void)hipFree(db->d_segs);
   for (auto& c : db->classes)
     if (c.d_slots) (void)hipFree(c.d_slots);
-  db->w_hashes.release();
-  db->w_scratch.release();
-  db->w_nk_raw.release();
-  db->w_nk1.release();
-  db->w_seg_cnt.release();
-  db->w_long_list.release();
-  db->w_long_meta.release();
-  db->w_long_counts.release();
-  db->w_huge_info.release();
-  db->w_huge_temp.release();
-  db->w_gathered.release();
+  for (auto& w : db->ws) w.release();
   db->w_fin_cnt.release();
   db->w_fin_sums.release();
   if (db->d_col_size) (void)hipFree(db->d_col_size);
   kmcpg::release_fpr_bounds(db);
   kmcpg::async_release(db);
-  if (db->ws_ev) (void)hipEventDestroy(db->ws_ev);
+  if (db->cobs_ev) (void)hipEventDestroy(db->cobs_ev);
+  if (db->fin_ev) (void)hipEventDestroy(db->fin_ev);
   for (auto& ev : db->ev)
     if (ev) (void)hipEventDestroy(ev);
   delete db;

@@ -123,18 +123,39 @@ struct kmcpg_db {
   };
   std::vector<ColMeta> col_meta;
   std::unique_ptr<kmcpg::QueryFpr> fpr;
-  std::mutex mu;      // serialises the enqueueing of GPU-half calls (their kernels share the workspace below, in stream order;
-                      // calls on different streams are ordered by ws_ev)
-  hipEvent_t ws_ev = nullptr;  // recorded at the end of every kmcpg_query_device: the next call's stream waits for it
-  bool ws_ev_valid = false;
+  std::mutex mu;      // serialises the enqueueing of GPU-half calls (kernels of one workspace slot follow each other in stream order;
+                      // calls on different streams are ordered by the slot's event)
   std::vector<int> ks_desc;    // k-mer sizes of the database, descending (`ks` of __db.yml; one entry for most databases)
   kmcpg::AsyncState* async = nullptr;  // lanes + stream of kmcpg_submit/kmcpg_wait (host.cpp), created on first use
-  // workspace of kmcpg_query_device
-  kmcpg::DevBuf<uint64_t> w_hashes, w_scratch;
-  kmcpg::DevBuf<int32_t> w_nk_raw, w_nk1, w_seg_cnt;
-  kmcpg::DevBuf<uint32_t> w_long_list, w_long_meta, w_long_counts;  // long-query (split) path
-  kmcpg::DevBuf<uint64_t> w_huge_info;                             // whole-genome queries: (read, n, offset)
-  kmcpg::DevBuf<uint8_t> w_huge_temp;                              // histogram table of the device-wide radix sort
+  // The k-mer workspace of kmcpg_query_device, twice: consecutive calls take the slots in turn, so that the k-mer kernels of batch
+  // i + 1 (VALU-bound) may run on another stream BESIDE the COBS kernels of batch i (memory-bound) instead of behind them.  A call
+  // waits for the previous user of ITS slot only (Workspace::ev); the COBS kernels themselves stay one batch at a time (cobs_ev:
+  // two of them side by side would only share the memory system, and their HIP-event durations would stop meaning anything).
+  // The second slot is used only while a second workspace of the batch's size fits beside the index (query.cpp pick_slot).
+  struct Workspace {
+    kmcpg::DevBuf<uint64_t> w_hashes, w_scratch;
+    kmcpg::DevBuf<int32_t> w_nk_raw, w_nk1, w_seg_cnt;
+    kmcpg::DevBuf<uint32_t> w_long_list, w_long_meta, w_long_counts;  // long-query (split) path
+    kmcpg::DevBuf<uint64_t> w_huge_info;                             // whole-genome queries: (read, n, offset)
+    kmcpg::DevBuf<uint8_t> w_huge_temp;                              // histogram table of the device-wide radix sort
+    kmcpg::DevBuf<uint64_t> w_gathered;                              // profiling level 2: the row loads k2_cobs issued
+    hipEvent_t ev = nullptr;  // recorded at the end of every call that used the slot: the slot's next user waits for it
+    bool ev_valid = false;
+    void release() {
+      w_hashes.release(); w_scratch.release(); w_nk_raw.release(); w_nk1.release(); w_seg_cnt.release(); w_long_list.release();
+      w_long_meta.release(); w_long_counts.release(); w_huge_info.release(); w_huge_temp.release(); w_gathered.release();
+      if (ev) (void)hipEventDestroy(ev);
+      ev = nullptr;
+      ev_valid = false;
+    }
+  };
+  Workspace ws[2];
+  uint64_t ws_calls = 0;       // kmcpg_query_device calls so far: slot = ws_calls & 1 (when the second slot may be used)
+  int ws_last = 0;             // slot of the last kmcpg_query_device call (kmcpg_last_gathered_bytes reads its counters)
+  hipEvent_t cobs_ev = nullptr;  // end of the last call's COBS kernels: the next call's COBS kernels wait for it
+  bool cobs_ev_valid = false;
+  hipEvent_t fin_ev = nullptr;   // K3's scratch (w_fin_cnt, w_fin_sums) has one user at a time, whatever the k-mer slots do
+  bool fin_ev_valid = false;
   bool synthetic = false;
   // in-process multi-GPU front handle (kmcpg_open_devices): metadata only itself, one resident shard handle per device
   std::vector<kmcpg_db*> shards;
@@ -151,13 +172,12 @@ struct kmcpg_db {
   uint64_t paged_reserve = 0;  // HBM plan_passes() kept free beside the largest shard: what a batch's workspace may take
   // optional HIP-event timing of the last kmcpg_query_device call
   int profiling = 0;  // 1: HIP-event timing of the kernels; 2: + count the row loads k2_cobs issues
-  kmcpg::DevBuf<uint64_t> w_gathered;
   // K3 (device half of finalize): Header.Sizes of every global column on the device, per-read counters and scan scratch
   uint64_t* d_col_size = nullptr;
   kmcpg::DevBuf<uint32_t> w_fin_cnt;
   kmcpg::DevBuf<uint64_t> w_fin_sums;
   std::vector<kmcpg::FprBoundTable> fpr_bounds;  // -f bound tables (query.cpp fpr_bound): one per (max_fpr, size), never rewritten
-  hipEvent_t ev[12] = {};   // ring of 4 calls x (start, k-mers done, COBS done)
+  hipEvent_t ev[16] = {};   // ring of 4 calls x (start, COBS start, COBS done, k-mers done)
   uint64_t ev_calls = 0;    // profiled calls so far
 };
 

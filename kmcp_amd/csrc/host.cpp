@@ -90,6 +90,7 @@ struct Lane {
   hipEvent_t k3_ev = nullptr, eager_ev = nullptr;  // K3 done on the kernel stream -> the eager copy of the pairs on the copy stream
   bool eager_aside = false;                        // ... when it was put there (pieces of a large kmcpg_search_batch call)
   hipEvent_t done = nullptr, uploaded = nullptr;
+  hipStream_t st = nullptr;  // the kernel stream this batch was enqueued on (AsyncState::stream or stream2, taken in turn)
   uint32_t n = 0;
   bool paired = false;
   uint64_t tb1 = 0, tb2 = 0;
@@ -115,6 +116,10 @@ struct AsyncState {
   // (Exactly three streams per handle beside the null stream: the runtime multiplexes HIP streams onto 4 hardware queues, and a
   // fifth stream — tried for the pieces' eager copies — made uploads and kernels share one: -8 % on the pipelined path, same-box A/B.)
   hipStream_t up_stream = nullptr;    // H2D of a batch's reads, beside the kernels of the batches before it
+  // a second kernel stream: consecutive batches alternate between the two, so that the k-mer kernels of one run beside the COBS
+  // kernels of the one before it (the handle keeps two k-mer workspaces, engine.hpp; KMCPG_KSTREAMS=1: one stream as before)
+  hipStream_t stream2 = nullptr;
+  uint64_t enqueued = 0;
   std::atomic<uint64_t> hits_hint{0};  // hits per 1024 reads seen lately: sizes the hit buffers and the eager D2H of the next batches
   uint64_t lane_hit_budget = 0;        // entries a lane's device hit buffer may grow to beyond the plain size (from free HBM at first use)
   bool hits_stay_on_device = false;    // shard of a handle that gathers the hit lists over RCCL: no per-shard D2H of hits
@@ -142,9 +147,11 @@ void async_release(kmcpg_db* db) {
   if (db->opts.device >= 0) (void)hipSetDevice(db->opts.device);
   if (db->async->up_stream) (void)hipStreamSynchronize(db->async->up_stream);
   if (db->async->stream) (void)hipStreamSynchronize(db->async->stream);
+  if (db->async->stream2) (void)hipStreamSynchronize(db->async->stream2);
   for (auto& l : db->async->lanes) l->release();
   db->async->retry.release();
   if (db->async->stream) (void)hipStreamDestroy(db->async->stream);
+  if (db->async->stream2) (void)hipStreamDestroy(db->async->stream2);
   if (db->async->copy_stream) (void)hipStreamDestroy(db->async->copy_stream);
   if (db->async->up_stream) (void)hipStreamDestroy(db->async->up_stream);
   delete db->async;
@@ -191,6 +198,7 @@ int async_state(kmcpg_db* db, AsyncState** out) {
     if (hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi) != hipSuccess) prio_lo = prio_hi = 0;
     HIPCHK(hipStreamCreateWithPriority(&a->copy_stream, hipStreamNonBlocking, prio_hi));
     HIPCHK(hipStreamCreateWithFlags(&a->up_stream, hipStreamNonBlocking));
+    if (!(getenv("KMCPG_KSTREAMS") && atoi(getenv("KMCPG_KSTREAMS")) < 2)) HIPCHK(hipStreamCreateWithFlags(&a->stream2, hipStreamNonBlocking));
     if (const char* e = getenv("KMCPG_INFLIGHT")) a->max_lanes = (size_t)std::max(1, std::min(atoi(e), 16));
     if (const char* e = getenv("KMCPG_DEVICE_FINALIZE")) a->device_finalize = atoi(e) != 0;
     // Hit buffers follow the data (a database full of close relatives returns hundreds of hits per read) but must never crowd
@@ -319,7 +327,7 @@ int stage(Lane* L, const uint8_t* seqs, const uint64_t* offs, const uint8_t* seq
 }
 
 int enqueue_query(kmcpg_db* db, AsyncState* A, Lane* L, const kmcpg_params& p) {
-  hipStream_t st = A->stream;
+  hipStream_t st = L->st;
   int rc = kmcpg_query_device(db, L->d_seqs.p, L->d_offs.p, L->paired ? L->d_seqs2.p : nullptr, L->paired ? L->d_offs2.p : nullptr, L->n, L->tb1 + L->tb2,
                               L->maxlen, &p, L->d_hits.p, L->d_hits.cap, L->d_cnt.p, L->d_qk.p, L->d_ql.p, st);
   if (rc) return rc;
@@ -342,7 +350,11 @@ int enqueue(kmcpg_db* db, AsyncState* A, Lane* L, const kmcpg_params& p, bool ge
   if (!L->uploaded) HIPCHK(hipEventCreateWithFlags(&L->uploaded, hipEventDisableTiming));
   const uint32_t n = L->n;
   if (n == 0) return 0;
-  hipStream_t st = A->stream;
+  {
+    std::lock_guard<std::mutex> g(A->mu);
+    L->st = (A->stream2 && (A->enqueued++ & 1)) ? A->stream2 : A->stream;
+  }
+  hipStream_t st = L->st;
   // ~1 hit per read is typical for distinct references, dozens to hundreds for a database full of close relatives: the
   // buffers follow what the last large batches produced (hits_hint = hits per 1024 reads).  Too small a device buffer costs
   // a rerun of the batch (collect), too short an eager copy a late one on the copy stream, so the device buffer is generous
@@ -448,12 +460,12 @@ int collect(kmcpg_db* db, AsyncState* A, Lane* L, const kmcpg_params& p, uint64_
   uint64_t cnt = L->h_cnt.p[0];
   for (int attempt = 0; cnt > L->d_hits.cap; attempt++) {  // the hit buffer was too small: rerun with room for every hit
     if (attempt == 2) return kmcpg_fail(KMCPG_ENOMEM, "hit buffer overflow");
-    HIPCHK(hipStreamSynchronize(A->stream));
+    HIPCHK(hipStreamSynchronize(L->st));
     HIPCHK(hipStreamSynchronize(A->copy_stream));  // (the eager copy of the attempt that overflowed)
     if (L->d_hits.ensure(cnt + cnt / 4)) return kmcpg_fail(KMCPG_ENOMEM, "hipMalloc failed");
     int rc = enqueue_query(db, A, L, p);
     if (rc) return rc;
-    HIPCHK(hipStreamSynchronize(A->stream));
+    HIPCHK(hipStreamSynchronize(L->st));
     cnt = L->h_cnt.p[0];
     L->copied = 0;
   }
@@ -499,6 +511,7 @@ void drop_ticket(kmcpg_ticket* t, bool failed = false) {
     if (failed && pt.shard->async && pt.shard->async->stream) {
       if (pt.shard->async->up_stream) (void)hipStreamSynchronize(pt.shard->async->up_stream);
       (void)hipStreamSynchronize(pt.shard->async->stream);
+      if (pt.shard->async->stream2) (void)hipStreamSynchronize(pt.shard->async->stream2);
       if (pt.shard->async->copy_stream) (void)hipStreamSynchronize(pt.shard->async->copy_stream);
     }
     else if (pt.lane->done && pt.lane->n) {
@@ -574,6 +587,7 @@ int search_paged(kmcpg_db* front, const uint8_t* seqs, const uint64_t* offs, con
       }
     } else {
       (void)hipStreamSynchronize(A->stream);
+      if (A->stream2) (void)hipStreamSynchronize(A->stream2);
     }
     release_lane(A, L, false);
     if (rc) return kmcpg_fail(rc, "pass %d of %d: %s", r + 1, S, std::string(kmcpg_err_ref()).c_str());
@@ -1026,6 +1040,7 @@ static int search_batch_pieces(kmcpg_db* db, const uint8_t* seqs, const uint64_t
     if (r) {
       (void)hipStreamSynchronize(A->up_stream);
       (void)hipStreamSynchronize(A->stream);
+      if (A->stream2) (void)hipStreamSynchronize(A->stream2);
       (void)hipStreamSynchronize(A->copy_stream);
     }
     release_lane(A, q.lane, false);
@@ -1056,6 +1071,7 @@ static int search_batch_pieces(kmcpg_db* db, const uint8_t* seqs, const uint64_t
       const std::string keep = kmcpg_err_ref();
       (void)hipStreamSynchronize(A->up_stream);
       (void)hipStreamSynchronize(A->stream);
+      if (A->stream2) (void)hipStreamSynchronize(A->stream2);
       (void)hipStreamSynchronize(A->copy_stream);
       release_lane(A, L, false);
       q.lane = nullptr;
@@ -1068,6 +1084,7 @@ static int search_batch_pieces(kmcpg_db* db, const uint8_t* seqs, const uint64_t
     const std::string keep = kmcpg_err_ref();
     (void)hipStreamSynchronize(A->up_stream);
     (void)hipStreamSynchronize(A->stream);
+    if (A->stream2) (void)hipStreamSynchronize(A->stream2);
     (void)hipStreamSynchronize(A->copy_stream);
     for (uint32_t j = next_finish; j < next_submit; j++)
       if (pc[j].lane) release_lane(A, pc[j].lane, false);

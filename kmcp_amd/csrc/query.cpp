@@ -50,7 +50,7 @@ uint64_t max_hash_for(uint32_t scale) {
 }
 
 // K1 (+K1d): hashes of read i end up at d_hashes[offs[i] + offs2[i] ...], NumKmers in d_nk_search
-int run_kmers(kmcpg_db* db, const uint8_t* d_seqs, const uint64_t* d_offs, const uint8_t* d_seqs2, const uint64_t* d_offs2, uint32_t n_reads,
+int run_kmers(kmcpg_db* db, kmcpg_db::Workspace& W, const uint8_t* d_seqs, const uint64_t* d_offs, const uint8_t* d_seqs2, const uint64_t* d_offs2, uint32_t n_reads,
               uint32_t max_read_len, const kmcpg_params& p, uint64_t* d_hashes, uint64_t* d_scratch, uint64_t scratch_half, int32_t* d_nk_raw, int32_t* d_nk1,
               int32_t* d_nk_search, int32_t* d_qlen, hipStream_t st, uint64_t* max_n_out) {
   const kmcpg_info& I = db->info;
@@ -76,8 +76,8 @@ int run_kmers(kmcpg_db* db, const uint8_t* d_seqs, const uint64_t* d_offs, const
   // whole genomes (single-end, plain or FracMinHash k-mers): segments of a read on their own workgroups
   const uint32_t segs = (max_read_len + (uint32_t)k1_segment_len() - 1) / (uint32_t)k1_segment_len();
   if (a.mode == 0 && !d_seqs2 && segs > 1 && d_scratch && (uint64_t)n_reads * segs <= (1ull << 21)) {  // one workgroup of 1024 threads per segment, < 2^32 threads per launch
-    if (db->w_seg_cnt.ensure((size_t)n_reads * segs)) return kmcpg_fail(KMCPG_ENOMEM, "hipMalloc failed");
-    a.seg_cnt = db->w_seg_cnt.p;
+    if (W.w_seg_cnt.ensure((size_t)n_reads * segs)) return kmcpg_fail(KMCPG_ENOMEM, "hipMalloc failed");
+    a.seg_cnt = W.w_seg_cnt.p;
     a.segs_max = segs;
   }
   a.nk_adj = d_nk_search;
@@ -107,23 +107,23 @@ int run_kmers(kmcpg_db* db, const uint8_t* d_seqs, const uint64_t* d_offs, const
       // sort + unique per such query
       const int32_t thr = std::max<int32_t>((int32_t)HUGE_MIN, p.dedup_threshold);
       uint32_t meta[2] = {0, 0};
-      if (db->w_long_list.ensure(n_reads + 1) || db->w_long_meta.ensure(2)) return kmcpg_fail(KMCPG_ENOMEM, "hipMalloc failed");
-      HIPCHK(hipMemsetAsync(db->w_long_meta.p, 0, 2 * sizeof(uint32_t), st));
-      launch_list_long(d_nk_raw, n_reads, thr, db->w_long_list.p, db->w_long_meta.p, st);
-      HIPCHK(hipMemcpyAsync(meta, db->w_long_meta.p, sizeof meta, hipMemcpyDeviceToHost, st));
+      if (W.w_long_list.ensure(n_reads + 1) || W.w_long_meta.ensure(2)) return kmcpg_fail(KMCPG_ENOMEM, "hipMalloc failed");
+      HIPCHK(hipMemsetAsync(W.w_long_meta.p, 0, 2 * sizeof(uint32_t), st));
+      launch_list_long(d_nk_raw, n_reads, thr, W.w_long_list.p, W.w_long_meta.p, st);
+      HIPCHK(hipMemcpyAsync(meta, W.w_long_meta.p, sizeof meta, hipMemcpyDeviceToHost, st));
       HIPCHK(hipStreamSynchronize(st));
       if (meta[0]) {
         const size_t tb = huge_dedup_temp_bytes(meta[1]);
-        if (db->w_huge_info.ensure(3 * (size_t)meta[0] + 1) || db->w_huge_temp.ensure(tb + 64)) return kmcpg_fail(KMCPG_ENOMEM, "hipMalloc failed");
-        launch_gather_huge(db->w_long_list.p, meta[0], d_nk_raw, d_offs, d_offs2, db->w_huge_info.p, st);
+        if (W.w_huge_info.ensure(3 * (size_t)meta[0] + 1) || W.w_huge_temp.ensure(tb + 64)) return kmcpg_fail(KMCPG_ENOMEM, "hipMalloc failed");
+        launch_gather_huge(W.w_long_list.p, meta[0], d_nk_raw, d_offs, d_offs2, W.w_huge_info.p, st);
         std::vector<uint64_t> hinfo(3 * (size_t)meta[0]);
-        HIPCHK(hipMemcpyAsync(hinfo.data(), db->w_huge_info.p, hinfo.size() * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+        HIPCHK(hipMemcpyAsync(hinfo.data(), W.w_huge_info.p, hinfo.size() * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
-        int* d_num = (int*)db->w_huge_temp.p;  // first 64 bytes: the unique count
+        int* d_num = (int*)W.w_huge_temp.p;  // first 64 bytes: the unique count
         for (uint32_t i = 0; i < meta[0]; i++) {
           const uint32_t r = (uint32_t)hinfo[3 * i], n = (uint32_t)hinfo[3 * i + 1];
           const uint64_t koff = hinfo[3 * i + 2];
-          if (huge_dedup(d_hashes + koff, d_scratch + koff, n, d_num, db->w_huge_temp.p + 64, tb, d_nk_search, r, p.min_matched, st) != 0)
+          if (huge_dedup(d_hashes + koff, d_scratch + koff, n, d_num, W.w_huge_temp.p + 64, tb, d_nk_search, r, p.min_matched, st) != 0)
             return kmcpg_fail(KMCPG_EDEVICE, "device-wide sort of a %u-k-mer query failed", n);
         }
       }
@@ -134,35 +134,58 @@ int run_kmers(kmcpg_db* db, const uint8_t* d_seqs, const uint64_t* d_offs, const
   return 0;
 }
 
-// The k-mer workspace (w_hashes, w_scratch, ...) is shared by every GPU-half call on a handle; calls are enqueued under
-// db->mu, and a call on another stream than its predecessor's waits for the predecessor's last kernel.
-int ws_begin(kmcpg_db* db, hipStream_t st) {
-  if (!db->ws_ev) HIPCHK(hipEventCreateWithFlags(&db->ws_ev, hipEventDisableTiming));
-  if (db->ws_ev_valid) HIPCHK(hipStreamWaitEvent(st, db->ws_ev, 0));
+// The k-mer workspace exists twice (engine.hpp Workspace): calls are enqueued under db->mu and take the slots in turn; a call waits
+// for the last kernel of the previous user of ITS slot, so the k-mer kernels of a batch may run beside the COBS kernels of the
+// batch before it when the two calls are on different streams.  The second slot costs a second workspace (24 bytes per base of a
+// batch): it is used only while that fits into a quarter of the free HBM (or is there already).
+int pick_slot(kmcpg_db* db, uint64_t total_bases) {
+  static const int env = getenv("KMCPG_WS_SLOTS") ? atoi(getenv("KMCPG_WS_SLOTS")) : 2;
+  if (env < 2) return 0;
+  const int slot = (int)(db->ws_calls & 1);
+  if (slot == 0) return 0;
+  kmcpg_db::Workspace& W = db->ws[1];
+  if (W.w_hashes.cap >= total_bases + 1 && W.w_scratch.cap >= 2 * total_bases + 2) return 1;
+  size_t free_b = 0, total_b = 0;
+  if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return 0;
+  uint64_t limit = free_b;
+  if (const char* e = getenv("KMCPG_HBM_LIMIT_MB")) limit = std::min<uint64_t>(limit, (uint64_t)std::max(0ll, atoll(e)) << 20);
+  return 24 * (total_bases + 2) <= limit / 4 ? 1 : 0;
+}
+
+int ws_begin(kmcpg_db::Workspace& W, hipStream_t st) {
+  if (!W.ev) HIPCHK(hipEventCreateWithFlags(&W.ev, hipEventDisableTiming));
+  if (W.ev_valid) HIPCHK(hipStreamWaitEvent(st, W.ev, 0));
   return 0;
 }
 
-int ws_end(kmcpg_db* db, hipStream_t st) {
-  HIPCHK(hipEventRecord(db->ws_ev, st));
-  db->ws_ev_valid = true;
+int ws_end(kmcpg_db::Workspace& W, hipStream_t st) {
+  HIPCHK(hipEventRecord(W.ev, st));
+  W.ev_valid = true;
   return 0;
 }
 
 // Every way out of a GPU-half call that has passed ws_begin leaves the event behind, error paths included: kernels that use
 // the workspace may already be on the stream when a later step fails (an allocation, the FPR table, a launch), and the next
-// call — possibly on another stream — must still be ordered behind them.
+// user of the slot — possibly on another stream — must still be ordered behind them.
 struct WsGuard {
-  kmcpg_db* db;
+  kmcpg_db::Workspace& W;
   hipStream_t st;
   bool armed = true;
   ~WsGuard() {
-    if (armed && db->ws_ev && hipEventRecord(db->ws_ev, st) == hipSuccess) db->ws_ev_valid = true;
+    if (armed && W.ev && hipEventRecord(W.ev, st) == hipSuccess) W.ev_valid = true;
   }
   int finish() {  // the success path: errors of the record are reported
     armed = false;
-    return ws_end(db, st);
+    return ws_end(W, st);
   }
 };
+
+// a per-handle event of its own kind (COBS kernels one batch at a time; K3's scratch one user at a time)
+int chain_begin(hipEvent_t* ev, bool valid, hipStream_t st) {
+  if (!*ev) HIPCHK(hipEventCreateWithFlags(ev, hipEventDisableTiming));
+  if (valid) HIPCHK(hipStreamWaitEvent(st, *ev, 0));
+  return 0;
+}
 
 // The reference drops a column whose FPR(n, count) exceeds -f right where it counts it (util-db-search.go:7474-7478); here
 // that test runs on the host in float64, but the GPU can already leave out every count that cannot pass it: for each
@@ -234,13 +257,14 @@ extern "C" int kmcpg_kmers_device(kmcpg_db* db, const uint8_t* d_seqs, const uin
   KMCPG_USE_DEVICE(db);
   const kmcpg_params p = params ? *params : default_params();
   hipStream_t st = (hipStream_t)stream;
-  if (int rc0 = ws_begin(db, st)) return rc0;
-  WsGuard wsg{db, st};
-  if (db->w_scratch.ensure(2 * total_bases + 2) || db->w_nk_raw.ensure(n_reads + 1) || db->w_nk1.ensure(n_reads + 1)) return kmcpg_fail(KMCPG_ENOMEM, "hipMalloc failed");
+  kmcpg_db::Workspace& W = db->ws[0];
+  if (int rc0 = ws_begin(W, st)) return rc0;
+  WsGuard wsg{W, st};
+  if (W.w_scratch.ensure(2 * total_bases + 2) || W.w_nk_raw.ensure(n_reads + 1) || W.w_nk1.ensure(n_reads + 1)) return kmcpg_fail(KMCPG_ENOMEM, "hipMalloc failed");
   DevBuf<int32_t> ql;
   if (ql.ensure(n_reads + 1)) return kmcpg_fail(KMCPG_ENOMEM, "hipMalloc failed");
   uint64_t maxn = 0;
-  int rc = run_kmers(db, d_seqs, d_offs, nullptr, nullptr, n_reads, max_read_len, p, d_hashes, db->w_scratch.p, total_bases + 1, db->w_nk_raw.p, db->w_nk1.p,
+  int rc = run_kmers(db, W, d_seqs, d_offs, nullptr, nullptr, n_reads, max_read_len, p, d_hashes, W.w_scratch.p, total_bases + 1, W.w_nk_raw.p, W.w_nk1.p,
                      d_nk, ql.p, st, &maxn);
   if (rc == 0 && d_koff) HIPCHK(hipMemcpyAsync(d_koff, d_offs, (size_t)n_reads * sizeof(uint64_t), hipMemcpyDeviceToDevice, st));
   hipError_t e = hipStreamSynchronize(st);
@@ -270,29 +294,32 @@ extern "C" int kmcpg_query_device(kmcpg_db* db, const uint8_t* d_seqs, const uin
   if (test_hooks)
     if (const char* e = getenv("KMCPG_TEST_MAX_BASES"))
       if (total_bases > (uint64_t)atoll(e)) return kmcpg_fail(KMCPG_ENOMEM, "hipMalloc failed (KMCPG_TEST_MAX_BASES)");
-  if (int rc0 = ws_begin(db, st)) return rc0;
-  WsGuard wsg{db, st};
-  if (db->w_hashes.ensure(total_bases + 1) || db->w_nk_raw.ensure(n_reads + 1) || db->w_nk1.ensure(n_reads + 1)) return kmcpg_fail(KMCPG_ENOMEM, "hipMalloc failed");
+  const int slot = pick_slot(db, total_bases);
+  db->ws_calls++;
+  db->ws_last = slot;
+  kmcpg_db::Workspace& W = db->ws[slot];
+  if (int rc0 = ws_begin(W, st)) return rc0;
+  WsGuard wsg{W, st};
+  if (W.w_hashes.ensure(total_bases + 1) || W.w_nk_raw.ensure(n_reads + 1) || W.w_nk1.ensure(n_reads + 1)) return kmcpg_fail(KMCPG_ENOMEM, "hipMalloc failed");
   uint64_t ub = max_read_len >= (uint32_t)k_used ? (uint64_t)(max_read_len - k_used + 1) : 0;
   if (d_seqs2) ub *= 2;
   const bool window_sketch = db->info.syncmer || db->info.minimizer;
-  if ((ub > (uint64_t)p.dedup_threshold || window_sketch) && db->w_scratch.ensure(2 * total_bases + 2)) return kmcpg_fail(KMCPG_ENOMEM, "hipMalloc failed");
+  if ((ub > (uint64_t)p.dedup_threshold || window_sketch) && W.w_scratch.ensure(2 * total_bases + 2)) return kmcpg_fail(KMCPG_ENOMEM, "hipMalloc failed");
   uint64_t maxn = 0;
-  hipEvent_t* pev = db->ev + 3 * (db->ev_calls % 4);
+  hipEvent_t* pev = db->ev + 4 * (db->ev_calls % 4);
   if (db->profiling) {
     for (auto& ev : db->ev)
       if (!ev) HIPCHK(hipEventCreate(&ev));
     HIPCHK(hipEventRecord(pev[0], st));
   }
-  int rc = run_kmers(db, d_seqs, d_offs, d_seqs2, d_offs2, n_reads, max_read_len, p, db->w_hashes.p, db->w_scratch.p, total_bases + 1, db->w_nk_raw.p,
-                     db->w_nk1.p, d_qkmers, d_qlen, st, &maxn);
+  int rc = run_kmers(db, W, d_seqs, d_offs, d_seqs2, d_offs2, n_reads, max_read_len, p, W.w_hashes.p, W.w_scratch.p, total_bases + 1, W.w_nk_raw.p,
+                     W.w_nk1.p, d_qkmers, d_qlen, st, &maxn);
   if (rc) return rc;
   HIPCHK(hipMemsetAsync(d_counters, 0, 2 * sizeof(uint64_t), st));
   launch_max_nk(d_qkmers, n_reads, (unsigned long long*)d_counters + 1, st);
   static const int debug_rowsort = getenv("KMCPG_DEBUG_ROWSORT") ? atoi(getenv("KMCPG_DEBUG_ROWSORT")) : 0;
   if (debug_rowsort && !d_offs2 && !db->h_groupdev.empty())  // experiment only: profiles/r05_rowsort_gate.txt
-    launch_debug_rowsort(db->w_hashes.p, d_offs, d_qkmers, n_reads, db->h_groupdev[0].num_sigs, db->h_groupdev[0].magic_hi, debug_rowsort, st);
-  if (db->profiling) HIPCHK(hipEventRecord(pev[1], st));
+    launch_debug_rowsort(W.w_hashes.p, d_offs, d_qkmers, n_reads, db->h_groupdev[0].num_sigs, db->h_groupdev[0].magic_hi, debug_rowsort, st);
   // long queries (whole genomes, -g) are split into chunks of k-mers so that they spread over the chip; short ones keep
   // the one-wave-per-(query, slot) kernel.  Which queries are long is only known on the device: one small D2H read.
   const char* sm_env = getenv("KMCPG_SPLIT_MIN");
@@ -305,10 +332,10 @@ extern "C" int kmcpg_query_device(kmcpg_db* db, const uint8_t* d_seqs, const uin
   // and whose queries are bounded by 32 768 k-mers (HiFi reads, contigs) runs the plain kernel on 16 planes without asking.
   const bool ask = split_min > 0 && maxn > (uint64_t)split_min && (sm_env || maxn > 32768 || (uint64_t)n_reads * total_slots <= 16384);
   if (ask) {
-    if (db->w_long_list.ensure(n_reads + 1) || db->w_long_meta.ensure(2)) return kmcpg_fail(KMCPG_ENOMEM, "hipMalloc failed");
-    HIPCHK(hipMemsetAsync(db->w_long_meta.p, 0, 2 * sizeof(uint32_t), st));
-    launch_list_long(d_qkmers, n_reads, split_min, db->w_long_list.p, db->w_long_meta.p, st);
-    HIPCHK(hipMemcpyAsync(long_meta, db->w_long_meta.p, sizeof long_meta, hipMemcpyDeviceToHost, st));
+    if (W.w_long_list.ensure(n_reads + 1) || W.w_long_meta.ensure(2)) return kmcpg_fail(KMCPG_ENOMEM, "hipMalloc failed");
+    HIPCHK(hipMemsetAsync(W.w_long_meta.p, 0, 2 * sizeof(uint32_t), st));
+    launch_list_long(d_qkmers, n_reads, split_min, W.w_long_list.p, W.w_long_meta.p, st);
+    HIPCHK(hipMemcpyAsync(long_meta, W.w_long_meta.p, sizeof long_meta, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
   }
   uint32_t n_long = long_meta[0];
@@ -333,7 +360,7 @@ extern "C" int kmcpg_query_device(kmcpg_db* db, const uint8_t* d_seqs, const uin
   a.blocks = db->d_groupdev;
   a.segs = db->d_segs;
   a.n_reads = n_reads;
-  a.hashes = db->w_hashes.p;
+  a.hashes = W.w_hashes.p;
   a.offs = d_offs;
   a.offs2 = d_offs2;
   a.nk = d_qkmers;
@@ -362,14 +389,18 @@ extern "C" int kmcpg_query_device(kmcpg_db* db, const uint8_t* d_seqs, const uin
   // from is ~1/64 of the index (GTDB scale: 575 -> 510 ms per 524 k reads; profiles/r02_order_exp.txt)
   a.slot_major = getenv("KMCPG_SLOT_MAJOR") ? atoi(getenv("KMCPG_SLOT_MAJOR")) : 1;
   if (db->profiling >= 2) {
-    if (db->w_gathered.ensure((size_t)K2_GATHER_SLOTS * 16)) return kmcpg_fail(KMCPG_ENOMEM, "hipMalloc failed");
-    HIPCHK(hipMemsetAsync(db->w_gathered.p, 0, (size_t)K2_GATHER_SLOTS * 16 * sizeof(uint64_t), st));
-    a.gathered = (unsigned long long*)db->w_gathered.p;
+    if (W.w_gathered.ensure((size_t)K2_GATHER_SLOTS * 16)) return kmcpg_fail(KMCPG_ENOMEM, "hipMalloc failed");
+    HIPCHK(hipMemsetAsync(W.w_gathered.p, 0, (size_t)K2_GATHER_SLOTS * 16 * sizeof(uint64_t), st));
+    a.gathered = (unsigned long long*)W.w_gathered.p;
   }
   if (int rcb = fpr_bound(db, p.max_fpr, max_short, st, &a.cmin_fpr, &a.cmin_fpr_n)) return rcb;
   a.hits = d_hits;
   a.hit_cap = hit_cap;
   a.counter = (unsigned long long*)d_counters;
+  // COBS kernels one batch at a time (the k-mer kernels above may have run beside the previous batch's)
+  if (db->profiling) HIPCHK(hipEventRecord(pev[3], st));  // k-mers done: what follows may be a wait for the previous batch
+  if (int rcc = chain_begin(&db->cobs_ev, db->cobs_ev_valid, st)) return rcc;
+  if (db->profiling) HIPCHK(hipEventRecord(pev[1], st));
   for (const auto& c : db->classes) {
     a.slots = c.d_slots;
     a.nslots = (uint32_t)c.slots.size();
@@ -385,10 +416,10 @@ extern "C" int kmcpg_query_device(kmcpg_db* db, const uint8_t* d_seqs, const uin
     a.split_chunks = (long_meta[1] + chk - 1) / chk;
     // count arrays of at most ~2 GB at a time
     const uint32_t group = (uint32_t)std::max<uint64_t>(1, (2ull << 30) / ((uint64_t)a.ncols_total * 4));
-    if (db->w_long_counts.ensure((size_t)std::min<uint32_t>(group, n_long) * a.ncols_total)) return kmcpg_fail(KMCPG_ENOMEM, "hipMalloc failed");
-    a.long_counts = db->w_long_counts.p;
+    if (W.w_long_counts.ensure((size_t)std::min<uint32_t>(group, n_long) * a.ncols_total)) return kmcpg_fail(KMCPG_ENOMEM, "hipMalloc failed");
+    a.long_counts = W.w_long_counts.p;
     for (uint32_t g0 = 0; g0 < n_long; g0 += group) {
-      a.long_list = db->w_long_list.p + g0;
+      a.long_list = W.w_long_list.p + g0;
       a.n_long = std::min<uint32_t>(group, n_long - g0);
       HIPCHK(hipMemsetAsync(a.long_counts, 0, (size_t)a.n_long * a.ncols_total * sizeof(uint32_t), st));
       for (const auto& c : db->classes) {
@@ -399,6 +430,8 @@ extern "C" int kmcpg_query_device(kmcpg_db* db, const uint8_t* d_seqs, const uin
       launch_threshold_long(a, st);
     }
   }
+  HIPCHK(hipEventRecord(db->cobs_ev, st));
+  db->cobs_ev_valid = true;
   if (db->profiling) {
     HIPCHK(hipEventRecord(pev[2], st));
     db->ev_calls++;
@@ -417,8 +450,14 @@ extern "C" int kmcpg_group_device(kmcpg_db* db, const kmcpg_hit* d_hits, const u
   KMCPG_USE_DEVICE(db);
   const kmcpg_params p = params ? *params : default_params();
   hipStream_t st = (hipStream_t)stream;
-  if (int rc0 = ws_begin(db, st)) return rc0;
-  WsGuard wsg{db, st};
+  if (int rc0 = chain_begin(&db->fin_ev, db->fin_ev_valid, st)) return rc0;
+  struct FinGuard {  // as WsGuard: every way out leaves the event behind
+    kmcpg_db* db;
+    hipStream_t st;
+    ~FinGuard() {
+      if (db->fin_ev && hipEventRecord(db->fin_ev, st) == hipSuccess) db->fin_ev_valid = true;
+    }
+  } fing{db, st};
   if (db->w_fin_cnt.ensure((size_t)n_reads + 2) || db->w_fin_sums.ensure((size_t)k3_scan_tiles_for(n_reads + 1) + 1)) return kmcpg_fail(KMCPG_ENOMEM, "hipMalloc failed");
   // counters of the reads + the word that counts hits naming a read / column that does not exist
   HIPCHK(hipMemsetAsync(db->w_fin_cnt.p, 0, ((size_t)n_reads + 2) * sizeof(uint32_t), st));
@@ -444,7 +483,6 @@ extern "C" int kmcpg_group_device(kmcpg_db* db, const kmcpg_hit* d_hits, const u
     HIPCHK(hipMemsetAsync(d_read_offs + n_reads + 1, 0, sizeof(uint64_t), st));
     HIPCHK(hipMemcpyAsync(d_read_offs + n_reads + 1, a.bad, sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
   }
-  if (int rc1 = wsg.finish()) return rc1;
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -461,12 +499,13 @@ extern "C" int kmcpg_set_profiling(kmcpg_db* db, int enable) {
 static int read_gather_slots(kmcpg_db* db, int word, uint64_t unit, uint64_t* bytes) {
   if (!db || !bytes) return kmcpg_fail(KMCPG_EINVAL, "null argument");
   std::lock_guard<std::mutex> g(db->mu);
-  if (db->profiling < 2 || !db->w_gathered.p || db->ev_calls == 0) return kmcpg_fail(KMCPG_EINVAL, "no kmcpg_query_device call at profiling level 2 yet");
+  kmcpg_db::Workspace& W = db->ws[db->ws_last];
+  if (db->profiling < 2 || !W.w_gathered.p || db->ev_calls == 0) return kmcpg_fail(KMCPG_EINVAL, "no kmcpg_query_device call at profiling level 2 yet");
   KMCPG_USE_DEVICE(db);
-  hipEvent_t* pev = db->ev + 3 * ((db->ev_calls - 1) % 4);
+  hipEvent_t* pev = db->ev + 4 * ((db->ev_calls - 1) % 4);
   HIPCHK(hipEventSynchronize(pev[2]));
   std::vector<uint64_t> slots((size_t)K2_GATHER_SLOTS * 16);
-  HIPCHK(hipMemcpy(slots.data(), db->w_gathered.p, slots.size() * sizeof(uint64_t), hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(slots.data(), W.w_gathered.p, slots.size() * sizeof(uint64_t), hipMemcpyDeviceToHost));
   uint64_t n = 0;
   for (int i = 0; i < K2_GATHER_SLOTS; i++) n += slots[(size_t)i * 16 + (size_t)word];
   *bytes = n * unit;
@@ -481,10 +520,10 @@ extern "C" int kmcpg_timing_at(kmcpg_db* db, uint32_t age, float* kmers_ms, floa
   std::lock_guard<std::mutex> g(db->mu);
   if (!db->profiling || age >= 4 || db->ev_calls <= age) return kmcpg_fail(KMCPG_EINVAL, "no profiled kmcpg_query_device call of that age (the last 4 are kept)");
   KMCPG_USE_DEVICE(db);
-  hipEvent_t* pev = db->ev + 3 * ((db->ev_calls - 1 - age) % 4);
+  hipEvent_t* pev = db->ev + 4 * ((db->ev_calls - 1 - age) % 4);
   HIPCHK(hipEventSynchronize(pev[2]));
   float a = 0, b = 0;
-  HIPCHK(hipEventElapsedTime(&a, pev[0], pev[1]));
+  HIPCHK(hipEventElapsedTime(&a, pev[0], pev[3]));
   HIPCHK(hipEventElapsedTime(&b, pev[1], pev[2]));
   if (kmers_ms) *kmers_ms = a;
   if (cobs_ms) *cobs_ms = b;
@@ -499,9 +538,10 @@ extern "C" int kmcpg_plant_reads_device(kmcpg_db* db, const uint8_t* d_seqs, con
   std::lock_guard<std::mutex> g(db->mu);
   KMCPG_USE_DEVICE(db);
   hipStream_t st = (hipStream_t)stream;
-  if (int rc0 = ws_begin(db, st)) return rc0;
-  WsGuard wsg{db, st};
-  if (db->w_hashes.ensure(total_bases + 1) || db->w_nk_raw.ensure(n_reads + 1) || db->w_nk1.ensure(n_reads + 1)) return kmcpg_fail(KMCPG_ENOMEM, "hipMalloc failed");
+  kmcpg_db::Workspace& W = db->ws[0];
+  if (int rc0 = ws_begin(W, st)) return rc0;
+  WsGuard wsg{W, st};
+  if (W.w_hashes.ensure(total_bases + 1) || W.w_nk_raw.ensure(n_reads + 1) || W.w_nk1.ensure(n_reads + 1)) return kmcpg_fail(KMCPG_ENOMEM, "hipMalloc failed");
   DevBuf<int32_t> tmp;
   if (tmp.ensure(2 * (size_t)n_reads + 2)) return kmcpg_fail(KMCPG_ENOMEM, "hipMalloc failed");
   kmcpg_params p = default_params();
@@ -509,11 +549,11 @@ extern "C" int kmcpg_plant_reads_device(kmcpg_db* db, const uint8_t* d_seqs, con
   p.min_matched = 1;
   p.dedup_threshold = 0x7fffffff;  // plant every k-mer occurrence (idempotent)
   uint64_t maxn = 0;
-  if ((db->info.syncmer || db->info.minimizer) && db->w_scratch.ensure(2 * total_bases + 2)) return kmcpg_fail(KMCPG_ENOMEM, "hipMalloc failed");
-  int rc = run_kmers(db, d_seqs, d_offs, nullptr, nullptr, n_reads, max_read_len, p, db->w_hashes.p, db->w_scratch.p, total_bases + 1, db->w_nk_raw.p,
-                     db->w_nk1.p, tmp.p, tmp.p + n_reads + 1, st, &maxn);
+  if ((db->info.syncmer || db->info.minimizer) && W.w_scratch.ensure(2 * total_bases + 2)) return kmcpg_fail(KMCPG_ENOMEM, "hipMalloc failed");
+  int rc = run_kmers(db, W, d_seqs, d_offs, nullptr, nullptr, n_reads, max_read_len, p, W.w_hashes.p, W.w_scratch.p, total_bases + 1, W.w_nk_raw.p,
+                     W.w_nk1.p, tmp.p, tmp.p + n_reads + 1, st, &maxn);
   if (rc == 0)
-    launch_plant_reads(db->d_blockdev, (uint32_t)db->h_blockdev.size(), db->info.num_hashes, db->w_hashes.p, d_offs, db->w_nk_raw.p, d_cols, n_reads, st);
+    launch_plant_reads(db->d_blockdev, (uint32_t)db->h_blockdev.size(), db->info.num_hashes, W.w_hashes.p, d_offs, W.w_nk_raw.p, d_cols, n_reads, st);
   hipError_t e = hipStreamSynchronize(st);
   tmp.release();
   if (rc) return rc;
