@@ -318,10 +318,10 @@ def run_workload(name, ctx, steps, warmup, batch_reads=0, cpu_baseline=True, cpu
     # D2H (and, N > 1, the exchange) of a finished step while the next step's kernels run on `main`: a high-priority stream, so
     # that its small copies / collectives are not queued behind a 60-500 ms kernel that fills the chip
     side = torch.cuda.Stream(dev, priority=-1)
-    # two kernel streams taken in turn by consecutive steps: the library keeps two k-mer workspaces (engine.hpp Workspace), so K1 of
-    # step i + 1 (VALU-bound) runs beside K2 of step i (memory-bound); the K2s themselves follow each other (query.cpp cobs_ev).
-    # KMCP_BENCH_STREAMS=1: everything on one stream, as in rounds 1-4 (A/B)
-    kstreams = [main, torch.cuda.Stream(dev)] if os.environ.get("KMCP_BENCH_STREAMS", "2") != "1" else [main, main]
+    # KMCP_BENCH_STREAMS=2 (experiment, with KMCPG_WS_SLOTS=2): two kernel streams taken in turn by consecutive steps, so that K1 of
+    # step i + 1 (VALU-bound) may run beside K2 of step i (memory-bound); the K2s themselves follow each other (query.cpp cobs_ev).
+    # Default: everything on one stream - the two-stream form lost on four of five workloads (profiles/r05_k1_beside_k2.txt)
+    kstreams = [main, torch.cuda.Stream(dev)] if os.environ.get("KMCP_BENCH_STREAMS", "1") == "2" else [main, main]
     poll = os.environ.get("KMCP_BENCH_POLL") == "1"  # experiment: busy-poll hipEventQuery instead of hipEventSynchronize
 
     class Buf:  # device outputs of one step in flight + their pinned host copies

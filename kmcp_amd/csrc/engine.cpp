@@ -624,6 +624,7 @@ extern "C" int kmcpg_close(kmcpg_db* db) {
   if (db->d_col_size) (void)hipFree(db->d_col_size);
   kmcpg::release_fpr_bounds(db);
   kmcpg::async_release(db);
+  if (db->k1_stream) (void)hipStreamDestroy(db->k1_stream);
   if (db->cobs_ev) (void)hipEventDestroy(db->cobs_ev);
   if (db->fin_ev) (void)hipEventDestroy(db->fin_ev);
   for (auto& ev : db->ev)

@@ -141,17 +141,21 @@ struct kmcpg_db {
     kmcpg::DevBuf<uint64_t> w_gathered;                              // profiling level 2: the row loads k2_cobs issued
     hipEvent_t ev = nullptr;  // recorded at the end of every call that used the slot: the slot's next user waits for it
     bool ev_valid = false;
+    hipEvent_t in_ev = nullptr, k1_ev = nullptr;  // KMCPG_K1_STREAM: inputs ready on the caller's stream / k-mers ready on k1_stream
     void release() {
       w_hashes.release(); w_scratch.release(); w_nk_raw.release(); w_nk1.release(); w_seg_cnt.release(); w_long_list.release();
       w_long_meta.release(); w_long_counts.release(); w_huge_info.release(); w_huge_temp.release(); w_gathered.release();
       if (ev) (void)hipEventDestroy(ev);
-      ev = nullptr;
+      if (in_ev) (void)hipEventDestroy(in_ev);
+      if (k1_ev) (void)hipEventDestroy(k1_ev);
+      ev = in_ev = k1_ev = nullptr;
       ev_valid = false;
     }
   };
   Workspace ws[2];
   uint64_t ws_calls = 0;       // kmcpg_query_device calls so far: slot = ws_calls & 1 (when the second slot may be used)
   int ws_last = 0;             // slot of the last kmcpg_query_device call (kmcpg_last_gathered_bytes reads its counters)
+  hipStream_t k1_stream = nullptr;  // experiment (KMCPG_K1_STREAM=1): the k-mer kernels on a high-priority stream of the handle's own
   hipEvent_t cobs_ev = nullptr;  // end of the last call's COBS kernels: the next call's COBS kernels wait for it
   bool cobs_ev_valid = false;
   hipEvent_t fin_ev = nullptr;   // K3's scratch (w_fin_cnt, w_fin_sums) has one user at a time, whatever the k-mer slots do

@@ -117,7 +117,8 @@ struct AsyncState {
   // fifth stream — tried for the pieces' eager copies — made uploads and kernels share one: -8 % on the pipelined path, same-box A/B.)
   hipStream_t up_stream = nullptr;    // H2D of a batch's reads, beside the kernels of the batches before it
   // a second kernel stream: consecutive batches alternate between the two, so that the k-mer kernels of one run beside the COBS
-  // kernels of the one before it (the handle keeps two k-mer workspaces, engine.hpp; KMCPG_KSTREAMS=1: one stream as before)
+  // kernels of the one before it (with KMCPG_WS_SLOTS=2 the handle keeps two k-mer workspaces, engine.hpp).  Off unless KMCPG_KSTREAMS=2: measured a loss on
+  // four of five workloads (profiles/r05_k1_beside_k2.txt)
   hipStream_t stream2 = nullptr;
   uint64_t enqueued = 0;
   std::atomic<uint64_t> hits_hint{0};  // hits per 1024 reads seen lately: sizes the hit buffers and the eager D2H of the next batches
@@ -198,7 +199,7 @@ int async_state(kmcpg_db* db, AsyncState** out) {
     if (hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi) != hipSuccess) prio_lo = prio_hi = 0;
     HIPCHK(hipStreamCreateWithPriority(&a->copy_stream, hipStreamNonBlocking, prio_hi));
     HIPCHK(hipStreamCreateWithFlags(&a->up_stream, hipStreamNonBlocking));
-    if (!(getenv("KMCPG_KSTREAMS") && atoi(getenv("KMCPG_KSTREAMS")) < 2)) HIPCHK(hipStreamCreateWithFlags(&a->stream2, hipStreamNonBlocking));
+    if (getenv("KMCPG_KSTREAMS") && atoi(getenv("KMCPG_KSTREAMS")) >= 2) HIPCHK(hipStreamCreateWithFlags(&a->stream2, hipStreamNonBlocking));
     if (const char* e = getenv("KMCPG_INFLIGHT")) a->max_lanes = (size_t)std::max(1, std::min(atoi(e), 16));
     if (const char* e = getenv("KMCPG_DEVICE_FINALIZE")) a->device_finalize = atoi(e) != 0;
     // Hit buffers follow the data (a database full of close relatives returns hundreds of hits per read) but must never crowd

@@ -139,7 +139,7 @@ int run_kmers(kmcpg_db* db, kmcpg_db::Workspace& W, const uint8_t* d_seqs, const
 // batch before it when the two calls are on different streams.  The second slot costs a second workspace (24 bytes per base of a
 // batch): it is used only while that fits into a quarter of the free HBM (or is there already).
 int pick_slot(kmcpg_db* db, uint64_t total_bases) {
-  static const int env = getenv("KMCPG_WS_SLOTS") ? atoi(getenv("KMCPG_WS_SLOTS")) : 2;
+  static const int env = getenv("KMCPG_WS_SLOTS") ? atoi(getenv("KMCPG_WS_SLOTS")) : 1;  // (default 1: see profiles/r05_k1_beside_k2.txt)
   if (env < 2) return 0;
   const int slot = (int)(db->ws_calls & 1);
   if (slot == 0) return 0;
@@ -298,7 +298,24 @@ extern "C" int kmcpg_query_device(kmcpg_db* db, const uint8_t* d_seqs, const uin
   db->ws_calls++;
   db->ws_last = slot;
   kmcpg_db::Workspace& W = db->ws[slot];
-  if (int rc0 = ws_begin(W, st)) return rc0;
+  // experiment (KMCPG_K1_STREAM=1): the k-mer kernels on a high-priority stream of the handle's own, so that their workgroups are
+  // dispatched AHEAD of the previous batch's COBS workgroups whenever a slot frees up (on equal terms the dispatcher keeps feeding the
+  // kernel that came first and the k-mer kernels only get the COBS kernel's tail: tools/ab/r05_call3.sh)
+  static const bool k1_own = getenv("KMCPG_K1_STREAM") && atoi(getenv("KMCPG_K1_STREAM")) == 1;
+  hipStream_t kst = st;
+  if (k1_own) {
+    if (!db->k1_stream) {
+      int lo = 0, hi = 0;
+      if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) lo = hi = 0;
+      HIPCHK(hipStreamCreateWithPriority(&db->k1_stream, hipStreamNonBlocking, hi));
+    }
+    if (!W.in_ev) HIPCHK(hipEventCreateWithFlags(&W.in_ev, hipEventDisableTiming));
+    if (!W.k1_ev) HIPCHK(hipEventCreateWithFlags(&W.k1_ev, hipEventDisableTiming));
+    kst = db->k1_stream;
+    HIPCHK(hipEventRecord(W.in_ev, st));  // the batch's inputs are ordered on the caller's stream
+    HIPCHK(hipStreamWaitEvent(kst, W.in_ev, 0));
+  }
+  if (int rc0 = ws_begin(W, kst)) return rc0;
   WsGuard wsg{W, st};
   if (W.w_hashes.ensure(total_bases + 1) || W.w_nk_raw.ensure(n_reads + 1) || W.w_nk1.ensure(n_reads + 1)) return kmcpg_fail(KMCPG_ENOMEM, "hipMalloc failed");
   uint64_t ub = max_read_len >= (uint32_t)k_used ? (uint64_t)(max_read_len - k_used + 1) : 0;
@@ -310,13 +327,18 @@ extern "C" int kmcpg_query_device(kmcpg_db* db, const uint8_t* d_seqs, const uin
   if (db->profiling) {
     for (auto& ev : db->ev)
       if (!ev) HIPCHK(hipEventCreate(&ev));
-    HIPCHK(hipEventRecord(pev[0], st));
+    HIPCHK(hipEventRecord(pev[0], kst));
   }
   int rc = run_kmers(db, W, d_seqs, d_offs, d_seqs2, d_offs2, n_reads, max_read_len, p, W.w_hashes.p, W.w_scratch.p, total_bases + 1, W.w_nk_raw.p,
-                     W.w_nk1.p, d_qkmers, d_qlen, st, &maxn);
+                     W.w_nk1.p, d_qkmers, d_qlen, kst, &maxn);
   if (rc) return rc;
-  HIPCHK(hipMemsetAsync(d_counters, 0, 2 * sizeof(uint64_t), st));
-  launch_max_nk(d_qkmers, n_reads, (unsigned long long*)d_counters + 1, st);
+  HIPCHK(hipMemsetAsync(d_counters, 0, 2 * sizeof(uint64_t), kst));
+  launch_max_nk(d_qkmers, n_reads, (unsigned long long*)d_counters + 1, kst);
+  if (db->profiling) HIPCHK(hipEventRecord(pev[3], kst));  // k-mers done
+  if (k1_own) {
+    HIPCHK(hipEventRecord(W.k1_ev, kst));
+    HIPCHK(hipStreamWaitEvent(st, W.k1_ev, 0));
+  }
   static const int debug_rowsort = getenv("KMCPG_DEBUG_ROWSORT") ? atoi(getenv("KMCPG_DEBUG_ROWSORT")) : 0;
   if (debug_rowsort && !d_offs2 && !db->h_groupdev.empty())  // experiment only: profiles/r05_rowsort_gate.txt
     launch_debug_rowsort(W.w_hashes.p, d_offs, d_qkmers, n_reads, db->h_groupdev[0].num_sigs, db->h_groupdev[0].magic_hi, debug_rowsort, st);
@@ -398,7 +420,6 @@ extern "C" int kmcpg_query_device(kmcpg_db* db, const uint8_t* d_seqs, const uin
   a.hit_cap = hit_cap;
   a.counter = (unsigned long long*)d_counters;
   // COBS kernels one batch at a time (the k-mer kernels above may have run beside the previous batch's)
-  if (db->profiling) HIPCHK(hipEventRecord(pev[3], st));  // k-mers done: what follows may be a wait for the previous batch
   if (int rcc = chain_begin(&db->cobs_ev, db->cobs_ev_valid, st)) return rcc;
   if (db->profiling) HIPCHK(hipEventRecord(pev[1], st));
   for (const auto& c : db->classes) {
