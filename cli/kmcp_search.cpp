@@ -250,7 +250,7 @@ struct Batch {
   std::vector<uint64_t> id_offs{0};
   std::vector<uint8_t> seqs, seqs2;
   std::vector<uint64_t> offs{0}, offs2{0};
-  kmcpg_result res{};
+  kmcpg_result_pairs res{};  // compact result: (column, mKmers) pairs; the formatter threads expand a query's pairs right before its rows
   bool paired = false;
   size_t size() const { return id_offs.size() - 1; }
   std::string_view id(size_t i) const { return std::string_view(id_buf.data() + id_offs[i], (size_t)(id_offs[i + 1] - id_offs[i])); }
@@ -454,6 +454,7 @@ class Out {
 // what printf gives); the fast paths below produce the same digits and fall back to snprintf whenever a rounding tie is near.
 struct RowFormatter {
   char tmp[64];
+  std::vector<kmcpg_match> scratch;  // the records of the query being formatted (kmcpg_expand_pairs)
   std::unordered_map<uint64_t, std::string> fpr_cache;  // the FPR of a match depends on (qKmers, mKmers) only
 
   // A row is assembled in a fixed scratch line through a moving pointer (no capacity checks per character) and appended to the
@@ -1060,16 +1061,16 @@ int main(int argc, char** argv) {
         if (!q_in.pop(&b)) break;
         const auto t0 = std::chrono::steady_clock::now();
         my_wait += std::chrono::duration<double>(t0 - tw).count();
-        int rc = kmcpg_search_batch(db, b->seqs.data(), b->offs.data(), b->paired ? b->seqs2.data() : nullptr, b->paired ? b->offs2.data() : nullptr,
-                                    (uint32_t)b->size(), &params, &b->res);
+        int rc = kmcpg_search_batch_pairs(db, b->seqs.data(), b->offs.data(), b->paired ? b->seqs2.data() : nullptr, b->paired ? b->offs2.data() : nullptr,
+                                          (uint32_t)b->size(), &params, &b->res);
         if (rc != 0) die("%s", kmcpg_last_error());
         my_gpu += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         if (verbose) {  // order-independent checksum of the (query, column, mKmers) tuples: the same on 1, 2, 4, 8 GPUs
-          const kmcpg_result& r = b->res;
+          const kmcpg_result_pairs& r = b->res;
           for (uint32_t i = 0; i < r.n_reads; i++)
             for (uint64_t j = r.match_offs[i]; j < r.match_offs[i + 1]; j++)
-              my_sum += tuple_mix(b->first_idx + i, r.matches[j].col, (uint32_t)r.matches[j].mkmers);
-          my_matches += r.match_offs[r.n_reads];
+              my_sum += tuple_mix(b->first_idx + i, r.pairs[j].col, r.pairs[j].count);
+          if (r.n_reads) my_matches += r.match_offs[r.n_reads];
         }
         q_out.push(std::move(b));
       }
@@ -1125,7 +1126,7 @@ int main(int argc, char** argv) {
       }
       next_seq++;
       const auto tf0 = std::chrono::steady_clock::now();
-      const kmcpg_result& r = b->res;
+      const kmcpg_result_pairs& r = b->res;
       const uint32_t n = r.n_reads;
       // parts of about equal work: a query costs one unit, a row one more (reads of a family database carry hundreds of rows)
       const uint64_t rows = n ? r.match_offs[n] : 0;
@@ -1163,7 +1164,11 @@ int main(int argc, char** argv) {
             continue;
           }
           part_matched[(size_t)pi]++;
-          F.rows(buf, b->id(i), r.qlen[i], r.qkmers[i], r.matches + m0, m1 - m0, target, r.ksize[i], qidx);
+          // the query's Match records (float64 qCov / tCov / jacc, the FPR column, tLen ...) from its pairs, into a scratch array that
+          // stays in this thread's cache: the batch's records never exist as a whole (1.5 GB per 131 072 reads of a family database)
+          if (F.scratch.size() < m1 - m0) F.scratch.resize((size_t)(m1 - m0));
+          if (kmcpg_expand_pairs(db, r.qkmers[i], r.pairs + m0, m1 - m0, F.scratch.data()) != 0) die("%s", kmcpg_last_error());
+          F.rows(buf, b->id(i), r.qlen[i], r.qkmers[i], F.scratch.data(), m1 - m0, target, r.ksize[i], qidx);
         }
         if (out.gz()) buf = gzip_member(buf);
       };
@@ -1171,7 +1176,7 @@ int main(int argc, char** argv) {
       for (int pi = 0; pi < parts; pi++) matched += part_matched[(size_t)pi];
       q_flush.push(std::move(chunk_p));
       total += n;
-      kmcpg_result_free(&b->res);
+      kmcpg_result_pairs_free(&b->res);
       t_fmt += std::chrono::duration<double>(std::chrono::steady_clock::now() - tf0).count();
       if (verbose && !o.quiet) {
         double min = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_search).count() / 60.0;

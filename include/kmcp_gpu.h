@@ -226,6 +226,30 @@ typedef struct {
   uint32_t col;   /* global column */
   uint32_t count; /* matched k-mers */
 } kmcpg_pair;
+/* -- compact results (round 5): on a database full of close relatives a read has hundreds of matches, and writing a 56-byte Match
+ *    record for each (1.5 GB per 131 072 reads) was what bounded kmcpg_search_batch (6.8 M reads/s against 12.7 M for the kernels).
+ *    The *_pairs forms return the FINAL matches of every query — every threshold, -f and --keep-top-scores applied, in the order
+ *    kmcp search prints them — as 8-byte (column, mKmers) pairs; match_offs[i+1] - match_offs[i] is the query's `hits` column.
+ *    kmcpg_expand_pairs derives the Match records of one query's pairs (qCov, tCov, jacc :7487-7489, the FPR column, column
+ *    metadata) on the caller's thread, typically into a small scratch array right before the rows are formatted: the same bits as
+ *    kmcpg_search_batch / kmcpg_wait would have written.  Everything else (arguments, errors, ownership: kmcpg_result_pairs_free)
+ *    is as for the record forms; a ticket is consumed by EITHER kmcpg_wait or kmcpg_wait_pairs. */
+typedef struct {
+  uint32_t n_reads;
+  int32_t k;
+  int32_t* qlen;
+  int32_t* qkmers;
+  int32_t* ksize;
+  uint64_t* match_offs;  /* [n_reads+1] */
+  kmcpg_pair* pairs;     /* [match_offs[n_reads]] */
+  void* owner;           /* internal */
+} kmcpg_result_pairs;
+int kmcpg_search_batch_pairs(kmcpg_db* db, const uint8_t* seqs, const uint64_t* offs, const uint8_t* seqs2, const uint64_t* offs2,
+                             uint32_t n_reads, const kmcpg_params* params, kmcpg_result_pairs* out);
+int kmcpg_wait_pairs(kmcpg_ticket* ticket, kmcpg_result_pairs* out);
+void kmcpg_result_pairs_free(kmcpg_result_pairs* r);
+int kmcpg_expand_pairs(const kmcpg_db* db, int32_t qkmers, const kmcpg_pair* pairs, uint64_t n, kmcpg_match* out);
+
 int kmcpg_group_device(kmcpg_db* db, const kmcpg_hit* d_hits, const uint64_t* d_n_hits, uint64_t hit_cap, const int32_t* d_qkmers,
                        uint32_t n_reads, const kmcpg_params* params, kmcpg_pair* d_pairs, uint64_t* d_read_offs, void* stream);
 int kmcpg_finalize_grouped(const kmcpg_db* db, const kmcpg_pair* pairs, const uint64_t* read_offs, const int32_t* qkmers,

@@ -234,7 +234,13 @@ struct ResultOwner {
   std::vector<int32_t> qlen, qkmers, ksize;
   std::vector<uint64_t> offs;
   MatchVec matches;
+  // compact results (kmcpg_search_batch_pairs / kmcpg_wait_pairs): the final (column, count) pairs of every read, in the order its
+  // Match records would have, instead of the records themselves
+  std::vector<kmcpg_pair, NoInitAlloc<kmcpg_pair>> pairs;
+  bool pairs_mode = false;
 };
+// set for the duration of a kmcpg_*_pairs call on the calling thread: results shaped meanwhile (result_owner_shape) collect pairs
+extern thread_local bool tl_pairs_mode;
 // finalize.cpp: a result assembled piece by piece (kmcpg_search_batch cuts large batches into pieces, host.cpp)
 ResultOwner* result_owner_take();
 void result_owner_give(ResultOwner* o);
@@ -242,5 +248,6 @@ void result_owner_shape(ResultOwner* o, uint32_t n_reads);
 int finalize_grouped_into(const kmcpg_db* db, const kmcpg_pair* pairs, const uint64_t* read_offs, const int32_t* qkmers, const int32_t* qlen, uint32_t n_reads,
                           const kmcpg_params& p, ResultOwner* o, uint32_t read_base, uint64_t match_base, uint64_t* kept_out);
 void result_publish(ResultOwner* o, uint32_t n_reads, int k_used, kmcpg_result* out);
+void result_records_to_pairs(ResultOwner* o);  // finalize.cpp: a result that holds records -> the pairs of a compact result
 
 }  // namespace kmcpg

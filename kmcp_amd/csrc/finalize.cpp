@@ -50,6 +50,7 @@ ResultOwner* take_owner() {
     if (!g_owner_pool.empty()) {
       ResultOwner* o = g_owner_pool.back();
       g_owner_pool.pop_back();
+      o->pairs_mode = false;
       return o;
     }
   }
@@ -57,7 +58,7 @@ ResultOwner* take_owner() {
 }
 
 void give_owner(ResultOwner* o) {
-  const size_t bytes = o->matches.capacity() * sizeof(kmcpg_match) + (o->qlen.capacity() + o->qkmers.capacity() + o->ksize.capacity()) * 4 + o->offs.capacity() * 8;
+  const size_t bytes = o->matches.capacity() * sizeof(kmcpg_match) + o->pairs.capacity() * sizeof(kmcpg_pair) + (o->qlen.capacity() + o->qkmers.capacity() + o->ksize.capacity()) * 4 + o->offs.capacity() * 8;
   {
     std::lock_guard<std::mutex> g(g_owner_mu);
     // (a database full of close relatives returns hundreds of matches per read: 1.7 GB of records for a batch of 131 072 reads;
@@ -527,6 +528,7 @@ extern "C" int kmcpg_finalize(const kmcpg_db* db, const kmcpg_hit* hits, uint64_
 // while it streams: a list from elsewhere is finalized correctly too — segments longer than K3 orders (K3_WG_CAP) and segments
 // found out of order are sorted here.
 namespace kmcpg {
+thread_local bool tl_pairs_mode = false;
 ResultOwner* result_owner_take() { return take_owner(); }
 void result_owner_give(ResultOwner* o) { give_owner(o); }
 
@@ -551,7 +553,9 @@ int finalize_grouped_into(const kmcpg_db* db, const kmcpg_pair* pairs, const uin
     memcpy(o->qkmers.data() + read_base, qkmers, (size_t)n_reads * sizeof(int32_t));
     std::fill(o->ksize.begin() + read_base, o->ksize.begin() + read_base + n_reads, k_used);
   }
-  o->matches.resize(match_base + n_pairs);
+  const bool as_pairs = o->pairs_mode;  // compact result: the surviving pairs themselves, no records
+  if (as_pairs) o->pairs.resize(match_base + n_pairs);
+  else o->matches.resize(match_base + n_pairs);
   const double t_1 = now();
   WorkerPool& pool = WorkerPool::get();
   // contiguous ranges of reads holding ~64 k matches each (the offsets are at hand: a binary search per boundary)
@@ -566,7 +570,8 @@ int finalize_grouped_into(const kmcpg_db* db, const kmcpg_pair* pairs, const uin
   QueryFpr* F = db->fpr.get();
   const size_t n_cols = db->col_meta.size();
   const kmcpg_db::ColMeta* const col_meta = db->col_meta.data();
-  kmcpg_match* const mbase = o->matches.data() + match_base;
+  kmcpg_match* const mbase = as_pairs ? nullptr : o->matches.data() + match_base;
+  kmcpg_pair* const pbase = as_pairs ? o->pairs.data() + match_base : nullptr;
   uint64_t* const per_read = o->offs.data() + 1 + read_base;  // counts; the caller makes offsets of them
   std::vector<uint64_t> wcount((size_t)R, 0);
   std::atomic<int> bad{0};
@@ -601,7 +606,7 @@ int finalize_grouped_into(const kmcpg_db* db, const kmcpg_pair* pairs, const uin
       // array and then written in one tight loop of streaming stores — streaming stores interleaved with the loads and divisions
       // of the loop below leave half-filled write-combining buffers behind, which the memory system pays for with partial
       // writes (measured: 0.5 us per record instead of 0.03).
-      const bool via_tmp = host_sort || m > 8;
+      const bool via_tmp = host_sort || (m > 8 && !as_pairs);  // (8-byte pairs go straight to their place)
       if (via_tmp && tmp.size() < m) tmp.resize(m);
       const uint64_t first = pos;
       uint64_t kept = 0;
@@ -650,6 +655,7 @@ int finalize_grouped_into(const kmcpg_db* db, const kmcpg_pair* pairs, const uin
         have_prev = true;
         if (cut) continue;
         if (via_tmp) tmp[kept] = mm;
+        else if (as_pairs) pbase[first + kept] = h;
         else mbase[first + kept] = mm;
         kept++;
         if (top) {
@@ -686,7 +692,10 @@ int finalize_grouped_into(const kmcpg_db* db, const kmcpg_pair* pairs, const uin
           if (i >= kept) i = kept - 1;
           keep = i + 1;
         }
-        for (uint64_t i = 0; i < keep; i++) store_record(mbase + first + i, tmp[i]);
+        if (as_pairs)
+          for (uint64_t i = 0; i < keep; i++) pbase[first + i] = kmcpg_pair{tmp[i].col, (uint32_t)tmp[i].mkmers};
+        else
+          for (uint64_t i = 0; i < keep; i++) store_record(mbase + first + i, tmp[i]);
         kept = keep;
       }
       per_read[r] = kept;
@@ -701,10 +710,14 @@ int finalize_grouped_into(const kmcpg_db* db, const kmcpg_pair* pairs, const uin
   uint64_t total = 0;
   for (int w = 0; w < R; w++) {  // close the gaps the filters / --keep-top-scores left between the ranges
     const uint64_t start = lo_of[(size_t)w] < n_reads ? read_offs[lo_of[(size_t)w]] : n_pairs;
-    if (start != total && wcount[(size_t)w]) memmove(mbase + total, mbase + start, wcount[(size_t)w] * sizeof(kmcpg_match));
+    if (start != total && wcount[(size_t)w]) {
+      if (as_pairs) memmove(pbase + total, pbase + start, wcount[(size_t)w] * sizeof(kmcpg_pair));
+      else memmove(mbase + total, mbase + start, wcount[(size_t)w] * sizeof(kmcpg_match));
+    }
     total += wcount[(size_t)w];
   }
-  o->matches.resize(match_base + total);
+  if (as_pairs) o->pairs.resize(match_base + total);
+  else o->matches.resize(match_base + total);
   *kept_out = total;
   return 0;
 }
@@ -724,6 +737,8 @@ void result_publish(ResultOwner* o, uint32_t n_reads, int k_used, kmcpg_result* 
 }
 
 void result_owner_shape(ResultOwner* o, uint32_t n_reads) {
+  o->pairs_mode = tl_pairs_mode;
+  o->pairs.clear();
   o->qlen.resize(n_reads);
   o->qkmers.resize(n_reads);
   o->ksize.resize(n_reads);
@@ -742,6 +757,60 @@ extern "C" int kmcpg_finalize_grouped(const kmcpg_db* db, const kmcpg_pair* pair
   if (int rc = finalize_grouped_into(db, pairs, read_offs, qkmers, qlen, n_reads, p, o.get(), 0, 0, &kept)) return rc;
   result_publish(o.release(), n_reads, p.k > 0 ? p.k : db->info.k, out);
   return 0;
+}
+
+// a result that holds records (a path that does not collect pairs natively: retries, host-merged lists, paged handles) -> pairs
+namespace kmcpg {
+void result_records_to_pairs(ResultOwner* o) {
+  if (o->pairs_mode) return;
+  const size_t n = o->matches.size();
+  o->pairs.resize(n);
+  for (size_t i = 0; i < n; i++) o->pairs[i] = kmcpg_pair{o->matches[i].col, (uint32_t)o->matches[i].mkmers};
+  o->pairs_mode = true;
+}
+}  // namespace kmcpg
+
+// The Match records of one query's pairs: the float64 values exactly as kmcpg_finalize_grouped writes them (util-db-search.go:7487-7489,
+// util-fpr.go:32-50).  No threshold is applied: the pairs of a kmcpg_result_pairs have passed all of them.
+extern "C" int kmcpg_expand_pairs(const kmcpg_db* db, int32_t qkmers, const kmcpg_pair* pairs, uint64_t n, kmcpg_match* out) {
+  if (!db || (n && (!pairs || !out))) return kmcpg_fail(KMCPG_EINVAL, "null argument");
+  if (n == 0) return 0;
+  const size_t n_cols = db->col_meta.size();
+  const kmcpg_db::ColMeta* const col_meta = db->col_meta.data();
+  const double nh = (double)qkmers;
+  // the row of this NumKmers stays with the thread: consecutive queries of a batch mostly share it (and a formatter thread asks for
+  // a few hundred thousand queries per second)
+  static thread_local const kmcpg_db* row_db = nullptr;
+  static thread_local int row_n = -1;
+  static thread_local FprRow row;
+  if (qkmers > 0 && (row_db != db || row_n != qkmers)) {
+    row = db->fpr->ensure_row(qkmers);
+    row_db = db;
+    row_n = qkmers;
+  }
+  for (uint64_t i = 0; i < n; i++) {
+    const kmcpg_pair h = pairs[i];
+    if (h.col >= n_cols) return kmcpg_fail(KMCPG_EINVAL, "pair %llu names column %u of %zu", (unsigned long long)i, h.col, n_cols);
+    const kmcpg_db::ColMeta cm = col_meta[h.col];
+    const double c = (double)h.count, nt = (double)cm.size;
+    kmcpg_match mm{};
+    mm.col = h.col;
+    mm.target_idx = cm.tidx;
+    mm.gsize = cm.gsize;
+    mm.mkmers = (int32_t)h.count;
+    mm.fpr = qkmers > 0 ? QueryFpr::value(*row, qkmers, (int)h.count) : 1.0;
+    mm.qcov = c / nh;
+    mm.tcov = c / nt;
+    mm.jacc = c / (nh + nt - c);
+    out[i] = mm;
+  }
+  return 0;
+}
+
+extern "C" void kmcpg_result_pairs_free(kmcpg_result_pairs* r) {
+  if (!r || !r->owner) return;
+  give_owner((ResultOwner*)r->owner);
+  memset(r, 0, sizeof *r);
 }
 
 extern "C" void kmcpg_result_free(kmcpg_result* r) {

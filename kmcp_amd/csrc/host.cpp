@@ -1143,7 +1143,12 @@ extern "C" int kmcpg_search_batch(kmcpg_db* db, const uint8_t* seqs, const uint6
   a->qkmers.insert(a->qkmers.end(), b->qkmers.begin(), b->qkmers.end());
   a->ksize.insert(a->ksize.end(), b->ksize.begin(), b->ksize.end());
   for (size_t r = 1; r < b->offs.size(); r++) a->offs.push_back(base + b->offs[r]);
+  if (a->pairs_mode != b->pairs_mode) {  // (one half took a path that collects records: retries, a paged pass)
+    result_records_to_pairs(a);
+    result_records_to_pairs(const_cast<ResultOwner*>(b));
+  }
   a->matches.insert(a->matches.end(), b->matches.begin(), b->matches.end());
+  a->pairs.insert(a->pairs.end(), b->pairs.begin(), b->pairs.end());
   *out = part[0];
   out->n_reads = n_reads;
   out->qlen = a->qlen.data();
@@ -1154,6 +1159,71 @@ extern "C" int kmcpg_search_batch(kmcpg_db* db, const uint8_t* seqs, const uint6
   kmcpg_result_free(&part[1]);
   if (getenv("KMCPG_VERBOSE")) fprintf(stderr, "kmcpg_search_batch: %u queries searched as two halves (%s)\n", n_reads, why.c_str());
   return 0;
+}
+
+// ---- compact results: the record forms under tl_pairs_mode (results shaped meanwhile collect pairs, finalize.cpp), then whatever a
+//      path without native pairs produced (retries, host-merged lists, paged passes) is converted
+namespace {
+struct PairsScope {
+  bool on;
+  explicit PairsScope(bool want) : on(want) {
+    if (on) tl_pairs_mode = true;
+  }
+  ~PairsScope() {
+    if (on) tl_pairs_mode = false;
+  }
+};
+
+int publish_pairs(kmcpg_result* r, kmcpg_result_pairs* out) {
+  ResultOwner* o = (ResultOwner*)r->owner;
+  memset(out, 0, sizeof *out);
+  if (!o) return 0;  // an empty result
+  result_records_to_pairs(o);
+  out->n_reads = r->n_reads;
+  out->k = r->k;
+  out->qlen = o->qlen.data();
+  out->qkmers = o->qkmers.data();
+  out->ksize = o->ksize.data();
+  out->match_offs = o->offs.data();
+  out->pairs = o->pairs.data();
+  out->owner = o;
+  memset(r, 0, sizeof *r);
+  return 0;
+}
+}  // namespace
+
+extern "C" int kmcpg_search_batch_pairs(kmcpg_db* db, const uint8_t* seqs, const uint64_t* offs, const uint8_t* seqs2, const uint64_t* offs2, uint32_t n_reads,
+                                        const kmcpg_params* params, kmcpg_result_pairs* out) {
+  if (!out) return kmcpg_fail(KMCPG_EINVAL, "null argument");
+  memset(out, 0, sizeof *out);
+  // queries that may be searched again (--try-se on pairs, the smaller k of a multi-k database) have their sub-results spliced
+  // record by record (retry_unmatched): those batches collect records and are converted at the end
+  const bool native = db && !((params && params->try_se && seqs2) || ((!params || params->k <= 0) && db->ks_desc.size() > 1));
+  kmcpg_result r{};
+  int rc;
+  {
+    PairsScope scope(native);
+    rc = kmcpg_search_batch(db, seqs, offs, seqs2, offs2, n_reads, params, &r);
+  }
+  if (rc) return rc;
+  return publish_pairs(&r, out);
+}
+
+extern "C" int kmcpg_wait_pairs(kmcpg_ticket* t, kmcpg_result_pairs* out) {
+  if (!t || !out) {
+    if (t) drop_ticket(t);
+    return kmcpg_fail(KMCPG_EINVAL, "null argument");
+  }
+  memset(out, 0, sizeof *out);
+  const bool native = !((t->p.try_se && t->paired) || (t->p.k <= 0 && t->db->ks_desc.size() > 1));
+  kmcpg_result r{};
+  int rc;
+  {
+    PairsScope scope(native);
+    rc = kmcpg_wait(t, &r);
+  }
+  if (rc) return rc;
+  return publish_pairs(&r, out);
 }
 
 // How many bases a batch may hold on this handle so that its workspace fits beside the resident index: K1/K1d take up to 24 B

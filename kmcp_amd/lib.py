@@ -17,6 +17,7 @@ EXPORTS = [
     "kmcpg_read_rows", "kmcpg_block_info", "kmcpg_kmers_device", "kmcpg_plant_reads_device", "kmcpg_set_profiling",
     "kmcpg_last_timing", "kmcpg_open_devices", "kmcpg_build_db", "kmcpg_submit", "kmcpg_wait", "kmcpg_read_row_range", "kmcpg_timing_at", "kmcpg_last_gathered_bytes", "kmcpg_last_hash_bytes",
     "kmcpg_db_ks", "kmcpg_open_paged", "kmcpg_paged_info", "kmcpg_exchange_info", "kmcpg_batch_hint", "kmcpg_group_device", "kmcpg_finalize_grouped",
+    "kmcpg_search_batch_pairs", "kmcpg_wait_pairs", "kmcpg_result_pairs_free", "kmcpg_expand_pairs",
 ]
 
 
@@ -142,6 +143,11 @@ def load():
     L.kmcpg_finalize.argtypes = [vp, vp, C.c_uint64, vp, vp, C.c_uint32, C.POINTER(Params), C.POINTER(Result)]
     L.kmcpg_group_device.argtypes = [vp, vp, vp, C.c_uint64, vp, C.c_uint32, C.POINTER(Params), vp, vp, vp]
     L.kmcpg_finalize_grouped.argtypes = [vp, vp, vp, vp, vp, C.c_uint32, C.POINTER(Params), C.POINTER(Result)]
+    L.kmcpg_search_batch_pairs.argtypes = [vp, vp, vp, vp, vp, C.c_uint32, C.POINTER(Params), C.POINTER(ResultPairs)]
+    L.kmcpg_wait_pairs.argtypes = [vp, C.POINTER(ResultPairs)]
+    L.kmcpg_result_pairs_free.argtypes = [C.POINTER(ResultPairs)]
+    L.kmcpg_result_pairs_free.restype = None
+    L.kmcpg_expand_pairs.argtypes = [vp, C.c_int32, vp, C.c_uint64, vp]
     L.kmcpg_plant.argtypes = [vp, C.c_uint32, vp, C.c_uint64]
     L.kmcpg_read_rows.argtypes = [vp, C.c_uint32, vp, C.c_uint64, vp]
     L.kmcpg_read_row_range.argtypes = [vp, C.c_uint32, C.c_uint64, C.c_uint64, vp]
@@ -161,6 +167,15 @@ def load():
 def _check(rc):
     if rc != 0:
         raise KmcpGpuError(rc, load().kmcpg_last_error().decode(errors="replace"))
+
+
+class Pair(C.Structure):
+    _fields_ = [("col", C.c_uint32), ("count", C.c_uint32)]
+
+
+class ResultPairs(C.Structure):
+    _fields_ = [("n_reads", C.c_uint32), ("k", C.c_int32), ("qlen", C.POINTER(C.c_int32)), ("qkmers", C.POINTER(C.c_int32)),
+                ("ksize", C.POINTER(C.c_int32)), ("match_offs", C.POINTER(C.c_uint64)), ("pairs", C.POINTER(Pair)), ("owner", C.c_void_p)]
 
 
 def pack_reads(reads):
@@ -216,6 +231,32 @@ def _copy_result(r):
     ks = np.ctypeslib.as_array(r.ksize, shape=(n,)).copy() if n else np.zeros(0, np.int32)
     out = BatchResult(qlen, qk, offs, matches, r.k, ks)
     load().kmcpg_result_free(C.byref(r))
+    return out
+
+
+class PairsResult:
+    """kmcpg_result_pairs for a batch (numpy copies): the final matches of every query as (column, mKmers) pairs."""
+
+    def __init__(self, qlen, qkmers, offs, pairs, k, ksize):
+        self.qlen, self.qkmers, self.offs, self.pairs, self.k, self.ksize = qlen, qkmers, offs, pairs, k, ksize
+
+    def __len__(self):
+        return len(self.qlen)
+
+    def read(self, i):
+        return self.pairs[int(self.offs[i]):int(self.offs[i + 1])]
+
+
+def _copy_pairs(r):
+    n = r.n_reads
+    qlen = np.ctypeslib.as_array(r.qlen, shape=(n,)).copy() if n else np.zeros(0, np.int32)
+    qk = np.ctypeslib.as_array(r.qkmers, shape=(n,)).copy() if n else np.zeros(0, np.int32)
+    offs = np.ctypeslib.as_array(r.match_offs, shape=(n + 1,)).copy() if n else np.zeros(1, np.uint64)
+    ks = np.ctypeslib.as_array(r.ksize, shape=(n,)).copy() if n else np.zeros(0, np.int32)
+    m = int(offs[-1])
+    pairs = np.frombuffer(C.string_at(r.pairs, m * 8), dtype=np.uint32).reshape(m, 2).copy() if m else np.zeros((0, 2), np.uint32)
+    out = PairsResult(qlen, qk, offs, pairs, r.k, ks)
+    load().kmcpg_result_pairs_free(C.byref(r))
     return out
 
 
@@ -336,6 +377,42 @@ class Database:
             load().kmcpg_result_free(C.byref(r))
             return m
         return _copy_result(r)
+
+    # ---- compact results: (column, mKmers) pairs instead of Match records ------------------------
+    def search_pairs(self, reads, reads2=None, params=None):
+        seqs, offs = pack_reads(reads)
+        s2 = o2 = None
+        if reads2 is not None:
+            s2, o2 = pack_reads(reads2)
+        return self.search_packed_pairs(seqs, offs, s2, o2, params)
+
+    def search_packed_pairs(self, seqs, offs, seqs2=None, offs2=None, params=None, count_only=False):
+        p = params or default_params()
+        r = ResultPairs()
+        n = len(offs) - 1
+        _check(load().kmcpg_search_batch_pairs(self._h, seqs.ctypes.data, offs.ctypes.data, seqs2.ctypes.data if seqs2 is not None else None,
+                                               offs2.ctypes.data if offs2 is not None else None, n, C.byref(p), C.byref(r)))
+        if count_only:
+            m = int(r.match_offs[n]) if n else 0
+            load().kmcpg_result_pairs_free(C.byref(r))
+            return m
+        return _copy_pairs(r)
+
+    def wait_pairs(self, ticket, count_only=False):
+        r = ResultPairs()
+        _check(load().kmcpg_wait_pairs(ticket, C.byref(r)))
+        if count_only:
+            m = int(r.match_offs[r.n_reads]) if r.n_reads else 0
+            load().kmcpg_result_pairs_free(C.byref(r))
+            return m
+        return _copy_pairs(r)
+
+    def expand_pairs(self, qkmers, pairs):
+        """kmcpg_expand_pairs: the Match records (MATCH_DTYPE) of one query's pairs"""
+        pairs = np.ascontiguousarray(pairs, dtype=np.uint32).reshape(-1, 2)
+        out = np.zeros(len(pairs), dtype=MATCH_DTYPE)
+        _check(load().kmcpg_expand_pairs(self._h, int(qkmers), pairs.ctypes.data, len(pairs), out.ctypes.data))
+        return out
 
     def search_packed_count(self, seqs, offs, params=None):
         """kmcpg_search_batch without copying the result into numpy: returns the number of matches (timing of the C boundary)."""

@@ -109,3 +109,29 @@ def test_short_segments_out_of_order_are_sorted_here_too(kw):
         got = db.finalize_grouped(pairs, roffs, qk, ql, params=p)
         assert np.array_equal(got.offs, want.offs) and got.matches.tobytes() == want.matches.tobytes()
         assert len(want.matches) > 400
+
+
+def test_expand_pairs_rebuilds_the_records_bit_for_bit():
+    """kmcpg_expand_pairs (the caller-side half of the compact results, round 5): the Match records derived from a query's final
+    (column, mKmers) pairs are the very bytes kmcpg_finalize wrote for them - qCov, tCov, jacc, the FPR column, column metadata."""
+    from kmcp_amd import Database, default_params, lib
+    rng = np.random.default_rng(17)
+    n_reads, per = 400, 9
+    with Database.open(DB, device=-1) as db:
+        ncols = int(db.info.n_cols)
+        per = min(per, ncols)
+        hits = np.empty(n_reads * per, dtype=lib.HIT_DTYPE)
+        hits["read"] = np.repeat(np.arange(n_reads, dtype=np.uint32), per)
+        hits["col"] = np.concatenate([rng.permutation(ncols)[:per] for _ in range(n_reads)]).astype(np.uint32)
+        qk = rng.integers(100, 3000, size=n_reads).astype(np.int32)  # short reads and long ones (FPR rows beyond the cached triangle)
+        hits["count"] = (qk[hits["read"]] * rng.uniform(0.56, 1.0, size=len(hits))).astype(np.uint32) + 1
+        hits["count"] = np.minimum(hits["count"], qk[hits["read"]].astype(np.uint32))
+        want = db.finalize(hits, qk, (qk + 20).astype(np.int32), params=default_params())
+        assert len(want.matches) > 1000
+        for i in range(n_reads):
+            ms = want.read(i)
+            pairs = np.stack([ms["col"].astype(np.uint32), ms["mkmers"].astype(np.uint32)], axis=1) if len(ms) else np.zeros((0, 2), np.uint32)
+            got = db.expand_pairs(int(qk[i]), pairs)
+            assert got.tobytes() == ms.tobytes(), i
+        with pytest.raises(lib.KmcpGpuError):
+            db.expand_pairs(130, np.array([[ncols + 3, 100]], np.uint32))

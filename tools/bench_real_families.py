@@ -128,6 +128,15 @@ def main():
                 ts.append(time.time() - t0)
             dt = min(ts)
             r.update(search_batch_s=dt, search_batch_reads_per_s=B / dt, search_batch_s_all=ts, matches=nm, matches_per_read=nm / B)
+            # compact results (round 5): the final matches as 8-byte pairs, no 56-byte records written
+            db.search_packed_pairs(h_reads, h_offs, params=params, count_only=True)
+            ts = []
+            for _ in range(3):
+                t0 = time.time()
+                nmp = db.search_packed_pairs(h_reads, h_offs, params=params, count_only=True)
+                ts.append(time.time() - t0)
+            assert nmp == nm, (nmp, nm)
+            r.update(search_batch_pairs_s=min(ts), search_batch_pairs_reads_per_s=B / min(ts), search_batch_pairs_s_all=ts)
             # ... and pipelined: batches through kmcpg_submit / kmcpg_wait from two host threads (what kmcp-search does)
             import threading
             NB = 8
@@ -146,6 +155,21 @@ def main():
             [x.join() for x in th]
             dtp = (time.time() - t0) / NB
             r.update(pipelined_s_per_batch=dtp, pipelined_reads_per_s=B / dtp)
+
+            def pump_pairs(t_):
+                tk = []
+                for i in range(t_, NB, 2):
+                    if len(tk) == 2:
+                        db.wait_pairs(tk.pop(0), count_only=True)
+                    tk.append(db.submit(h_reads, h_offs, params=params))
+                while tk:
+                    db.wait_pairs(tk.pop(0), count_only=True)
+            th = [threading.Thread(target=pump_pairs, args=(t_,)) for t_ in range(2)]
+            t0 = time.time()
+            [x.start() for x in th]
+            [x.join() for x in th]
+            dtp = (time.time() - t0) / NB
+            r.update(pipelined_pairs_s_per_batch=dtp, pipelined_pairs_reads_per_s=B / dtp)
         # the round-3 host half on the same batch (KMCPG_DEVICE_FINALIZE=0 is read when a handle makes its first search)
         os.environ["KMCPG_DEVICE_FINALIZE"] = "0"
         try:
