@@ -245,8 +245,18 @@ extern thread_local bool tl_pairs_mode;
 ResultOwner* result_owner_take();
 void result_owner_give(ResultOwner* o);
 void result_owner_shape(ResultOwner* o, uint32_t n_reads);
+// trusted: the list is what K2 + K3 made of this very batch with these very params (the library's own pipelines) — thresholds, -T, the
+// -f bound of short queries and the order of segments up to K3_WG_CAP hold by construction
 int finalize_grouped_into(const kmcpg_db* db, const kmcpg_pair* pairs, const uint64_t* read_offs, const int32_t* qkmers, const int32_t* qlen, uint32_t n_reads,
-                          const kmcpg_params& p, ResultOwner* o, uint32_t read_base, uint64_t match_base, uint64_t* kept_out);
+                          const kmcpg_params& p, ResultOwner* o, uint32_t read_base, uint64_t match_base, uint64_t* kept_out, bool trusted = false);
+int finalize_grouped_trusted(const kmcpg_db* db, const kmcpg_pair* pairs, const uint64_t* read_offs, const int32_t* qkmers, const int32_t* qlen, uint32_t n_reads,
+                             const kmcpg_params& p, kmcpg_result* out);
+// KMCPG_FPR_BOUND (default on): K2 leaves out counts that cannot pass -f for queries of up to 512 (1024) k-mers (query.cpp fpr_bound)
+inline bool fpr_bound_enabled() {
+  const char* e = getenv("KMCPG_FPR_BOUND");
+  return !(e && atoi(e) == 0);
+}
+constexpr int kFprBoundAlways = 512;  // queries of up to this many k-mers are covered by the bound table whatever the batch holds
 void result_publish(ResultOwner* o, uint32_t n_reads, int k_used, kmcpg_result* out);
 void result_records_to_pairs(ResultOwner* o);  // finalize.cpp: a result that holds records -> the pairs of a compact result
 

@@ -538,8 +538,9 @@ void result_owner_give(ResultOwner* o) { give_owner(o); }
 // kmcpg_search_batch cuts a large batch into pieces that follow each other through the GPU and lands them here one after the other,
 // so that the copy and the expansion of a piece overlap the kernels of the next (host.cpp).
 int finalize_grouped_into(const kmcpg_db* db, const kmcpg_pair* pairs, const uint64_t* read_offs, const int32_t* qkmers, const int32_t* qlen, uint32_t n_reads,
-                          const kmcpg_params& p, ResultOwner* o, uint32_t read_base, uint64_t match_base, uint64_t* kept_out) {
+                          const kmcpg_params& p, ResultOwner* o, uint32_t read_base, uint64_t match_base, uint64_t* kept_out, bool trusted) {
   const uint64_t n_pairs = read_offs[n_reads];
+  const bool bound_on = trusted && fpr_bound_enabled();
   if (n_pairs && !pairs) return kmcpg_fail(KMCPG_EINVAL, "null argument");
   if (read_offs[0] != 0) return kmcpg_fail(KMCPG_EINVAL, "read_offs[0] must be 0");
   if (read_offs[(size_t)n_reads + 1] != 0)
@@ -601,6 +602,14 @@ int finalize_grouped_into(const kmcpg_db* db, const kmcpg_pair* pairs, const uin
       // ones out of order too: the records are checked against their predecessor while they stream and the segment is done again
       // through the host sort if one is out of place (never, on K3's output)
       bool host_sort = m > (uint64_t)K3_WG_CAP;
+      // The library's own list of a short query, collected as pairs: every test below is a no-op on it (K2 applied -c, -t and the -f bound
+      // with these params, K3 applied -T and the order) — the segment is final as it stands
+      if (as_pairs && bound_on && !host_sort && n > 0 && n <= kFprBoundAlways && !(p.top_n_scores > 0 && !p.do_not_sort)) {
+        memcpy(pbase + pos, pairs + s0, (size_t)m * sizeof(kmcpg_pair));
+        per_read[r] = m;
+        pos += m;
+        continue;
+      }
      again:
       // A handful of matches (the usual read): plain stores, straight into the result.  Many: the records are built in a scratch
       // array and then written in one tight loop of streaming stores — streaming stores interleaved with the loads and divisions
@@ -744,6 +753,18 @@ void result_owner_shape(ResultOwner* o, uint32_t n_reads) {
   o->ksize.resize(n_reads);
   o->offs.assign((size_t)n_reads + 1, 0);
   o->matches.clear();
+}
+}  // namespace kmcpg
+
+namespace kmcpg {
+int finalize_grouped_trusted(const kmcpg_db* db, const kmcpg_pair* pairs, const uint64_t* read_offs, const int32_t* qkmers, const int32_t* qlen, uint32_t n_reads,
+                             const kmcpg_params& p, kmcpg_result* out) {
+  std::unique_ptr<ResultOwner, OwnerReturn> o(take_owner());
+  result_owner_shape(o.get(), n_reads);
+  uint64_t kept = 0;
+  if (int rc = finalize_grouped_into(db, pairs, read_offs, qkmers, qlen, n_reads, p, o.get(), 0, 0, &kept, true)) return rc;
+  result_publish(o.release(), n_reads, p.k > 0 ? p.k : db->info.k, out);
+  return 0;
 }
 }  // namespace kmcpg
 

@@ -670,7 +670,7 @@ int finish_raw(kmcpg_ticket* t, kmcpg_result* out) {
     int rc = collect(pt.shard, pt.shard->async, pt.lane, t->p, &n_hits);
     if (rc) return rc;
     if (pt.lane->grouped && t->n)
-      return kmcpg_finalize_grouped(t->db, pt.lane->h_pairs.p, pt.lane->h_roffs.p, pt.lane->h_qk.p, pt.lane->h_ql.p, t->n, &t->p, out);
+      return finalize_grouped_trusted(t->db, pt.lane->h_pairs.p, pt.lane->h_roffs.p, pt.lane->h_qk.p, pt.lane->h_ql.p, t->n, t->p, out);
     hits = pt.lane->h_hits.p;
   } else if (Exchange* x = t->db->exchange) {
     // the shards' lists meet on the first GPU (RCCL send/recv over xGMI, exactly the bytes each shard produced) and come to
@@ -712,7 +712,7 @@ int finish_raw(kmcpg_ticket* t, kmcpg_result* out) {
         return 0;
       });
       if (rc) return rc;
-      return kmcpg_finalize_grouped(t->db, L0->h_pairs.p, L0->h_roffs.p, L0->h_qk.p, L0->h_ql.p, t->n, &t->p, out);
+      return finalize_grouped_trusted(t->db, L0->h_pairs.p, L0->h_roffs.p, L0->h_qk.p, L0->h_ql.p, t->n, t->p, out);
     }
     if (L0->h_hits.ensure(n_hits + 1)) return kmcpg_fail(KMCPG_ENOMEM, "hipHostMalloc failed");
     int rc = exchange_gather(x, src, bytes, (uint8_t*)L0->h_hits.p);
@@ -1034,7 +1034,7 @@ static int search_batch_pieces(kmcpg_db* db, const uint8_t* seqs, const uint64_t
     const double tb = now();
     uint64_t kept = 0;
     if (r == 0)
-      r = finalize_grouped_into(db, q.lane->h_pairs.p, q.lane->h_roffs.p, q.lane->h_qk.p, q.lane->h_ql.p, q.cnt, p, o, q.lo, match_base, &kept);
+      r = finalize_grouped_into(db, q.lane->h_pairs.p, q.lane->h_roffs.p, q.lane->h_qk.p, q.lane->h_ql.p, q.cnt, p, o, q.lo, match_base, &kept, true);
     if (timing)
       fprintf(stderr, "piece %u: collect from %.2f to %.2f ms, expanded by %.2f ms (%llu hits, %llu kept)\n", next_finish, ta - t_begin, tb - t_begin, now() - t_begin,
               (unsigned long long)n_hits, (unsigned long long)kept);

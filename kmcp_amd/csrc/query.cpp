@@ -197,13 +197,12 @@ int chain_begin(hipEvent_t* ev, bool valid, hipStream_t st) {
 // 1024 when a batch may hold longer queries (+60 ms once).  Beyond ~1 100 k-mers the reference's FPR is numerically dead
 // anyway: BinomialCoeff leaves the float64 range, the running value drops below zero and is clamped (util-fpr.go:32-50), so
 // FPR(n, c) = 0 long before the crossing and the bound could never be the stricter threshold.
-constexpr int kFprBoundMinN = 512, kFprBoundMaxN = 1024;
+constexpr int kFprBoundMinN = kFprBoundAlways, kFprBoundMaxN = 1024;
 
 int fpr_bound(kmcpg_db* db, double max_fpr, uint64_t max_kmers, hipStream_t st, const uint16_t** out, int32_t* out_n) {
   *out = nullptr;
   *out_n = 0;
-  if (const char* e = getenv("KMCPG_FPR_BOUND"))
-    if (atoi(e) == 0) return 0;
+  if (!fpr_bound_enabled()) return 0;
   int want_n = kFprBoundMinN;
   while (want_n < kFprBoundMaxN && (uint64_t)want_n < max_kmers) want_n *= 2;
   uint64_t key;
