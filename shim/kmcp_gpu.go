@@ -234,6 +234,9 @@ func (db *GPUDB) Wait(b *gpuBatch, dbID int) ([]*QueryResult, error) {
 		r.DBId, r.K, r.NumKmers, r.Matches = dbID, int(ks[i]), int(qk[i]), nil
 		if offs[i+1] > offs[i] {
 			matches := poolMatches.Get().(*[]*Match)
+			// a pooled slice keeps whatever length its last user left it with unless every consumer resets it before Put (the
+			// reference does, search.go:582-583): reset here as well, so that the shim does not depend on it
+			*matches = (*matches)[:0]
 			for _, m := range ms[offs[i]:offs[i+1]] {
 				*matches = append(*matches, &Match{
 					Target: []string{db.names[int(m.col)]}, TargetIdx: []uint32{uint32(m.target_idx)},
