@@ -656,12 +656,16 @@ int finalize_grouped_into(const kmcpg_db* db, const kmcpg_pair* pairs, const uin
           tmp[kept++] = mm;
           continue;
         }
-        if (have_prev && (p.do_not_sort ? mm.col < prev.col : match_less(mm, prev, p.sort_by))) {
-          out_of_order = true;
+        if (!trusted) {  // (K3's own segments are in order by construction: the library's pipelines skip the comparison)
+          if (have_prev && (p.do_not_sort ? mm.col < prev.col : match_less(mm, prev, p.sort_by))) {
+            out_of_order = true;
+            break;
+          }
+          prev = mm;
+          have_prev = true;
+        } else if (cut) {
           break;
         }
-        prev = mm;
-        have_prev = true;
         if (cut) continue;
         if (via_tmp) tmp[kept] = mm;
         else if (as_pairs) pbase[first + kept] = h;
