@@ -17,7 +17,7 @@ namespace kmcpg {
 // K2: the COBS query.
 //
 // Work unit = (read, slot) with slot = (group of resident blocks that share NumSigs, tile of LPR*16 bytes of its rows).  LPR
-// lanes serve one unit, so a wave carries G = 64/LPR units: LPR = 64 for every whole KiB of a row (GTDB-scale: 1872 B), 16, 8 or 4
+// lanes serve one unit, so a wave carries G = 64/LPR units: LPR = 64 for every whole KiB of a row (GTDB-scale: 1872 B), 32, 16, 8 or 4
 // for what is left of it or for narrow rows (a lone 312-column block has 39-byte rows, `kmcp index -b 1024` gives 128-byte ones).  Units are numbered slot-major: all
 // waves in flight gather from one (group, tile) slice of the index.  Each lane owns 16 bytes = 128 columns of its unit's rows
 // and keeps their match counts as NPL bit-sliced planes (vertical counters): the rows of a group of GR = 8 (or 4) are reduced
@@ -518,6 +518,7 @@ int launch_k2(const K2Args& a, int lpr, int npl, hipStream_t st) {
     case 4: return launch_k2_l<4>(a, npl, multi, st);
     case 8: return launch_k2_l<8>(a, npl, multi, st);
     case 16: return launch_k2_l<16>(a, npl, multi, st);
+    case 32: return launch_k2_l<32>(a, npl, multi, st);
     case 64: return launch_k2_l<64>(a, npl, multi, st);
     default: return -1;
   }
@@ -545,6 +546,7 @@ int launch_k2_split(const K2Args& a, int lpr, hipStream_t st) {
     case 4: launch_k2_split_t<4>(a, multi, st); return 0;
     case 8: launch_k2_split_t<8>(a, multi, st); return 0;
     case 16: launch_k2_split_t<16>(a, multi, st); return 0;
+    case 32: launch_k2_split_t<32>(a, multi, st); return 0;
     case 64: launch_k2_split_t<64>(a, multi, st); return 0;
     default: return -1;
   }

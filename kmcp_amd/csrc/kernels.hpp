@@ -10,7 +10,7 @@ bool launch_k1(const K1Args& a, uint32_t max_read_len, hipStream_t st);  // true
 int k1_segment_len();  // positions per workgroup on the whole-genome path
 void launch_nk_simple(const int32_t* nk_raw, int32_t* nk_search, uint32_t n, int32_t min_matched, hipStream_t st);
 void launch_dedup(DedupArgs a, uint64_t max_n, hipStream_t st);  // queries above HUGE_MIN are left to huge_dedup
-// lpr in {4,8,16,64}: lanes per row tile; npl in {8,10,16,24}: counter planes.  <0 on bad arguments.
+// lpr in {4,8,16,32,64}: lanes per row tile; npl in {8,10,16,24}: counter planes.  <0 on bad arguments.
 int launch_k2(const K2Args& a, int lpr, int npl, hipStream_t st);
 // long queries: chunked counting into a.long_counts, then one thresholding pass
 int launch_k2_split(const K2Args& a, int lpr, hipStream_t st);

@@ -694,3 +694,22 @@ def test_threshold_at_the_top_of_a_plane_class(G, oracle_lib, tmp_path):
                         qk.data_ptr(), ql.data_ptr(), params=G["default_params"](min_qcov=1.0))
         torch.cuda.synchronize()
         assert int(cnt[0].item()) == 0
+
+
+@pytest.mark.parametrize("ncols,nh,split", [(6500, 3, "1"), (2500, 2, "1"), (4000, 3, "1"), (11000, 2, "1"), (6500, 1, "2"), (6500, 3, "0")])
+def test_row_remainders_cut_into_power_of_two_tiles(G, oracle_lib, tmp_path, monkeypatch, ncols, nh, split):
+    """Round 5: what is left of a row beyond its whole KiB tiles, 257..896 bytes, is cut into 512 / 256 / 128 / 64-byte tiles (32, 16, 8,
+    4 lanes per unit) on multi-hash databases instead of one 64-lane tile with idle lanes: 6 500 columns = 813-byte rows -> 512 + 256 + 64,
+    2 500 -> 256 + 64, 4 000 -> one 512-byte tile on the 32-lane form, 11 000 -> 1024 + 256 + 128.  KMCPG_SPLIT_TILES=2 does the same
+    to single-hash databases, 0 switches it off: same results everywhere.  Short reads (8 planes) and long queries (16 planes)."""
+    O = oracle_lib
+    monkeypatch.setenv("KMCPG_SPLIT_TILES", split)
+    genomes = synth.random_genomes(ncols + 21, 420, seed=900 + ncols + nh)
+    db_dir = synth.make_db(tmp_path, genomes, k=21, num_hashes=nh, fpr=0.05 if nh > 1 else 0.3, block_size=ncols, threads=4)
+    reads = synth.sample_reads(genomes, 500, 150, sub_rate=0.01, seed=7, frac_random=0.1)
+    # long queries: several genomes back to back (~1 600 distinct k-mers: the sort + unique path and 16 counter planes)
+    rng = np.random.default_rng(11)
+    longq = [b"".join(genomes[int(j)] for j in rng.integers(0, len(genomes), size=4)) for _ in range(40)]
+    kw = dict(min_qcov=0.2, min_matched=5)
+    n, res = _run(G, O, db_dir, reads + longq, oracle_kw=kw, gpu_kw=kw)
+    assert n > 400 and int(res.qkmers.max()) > 1024
