@@ -235,13 +235,12 @@ int finish_open(kmcpg_db* db) {
     // whole 1-KB tiles go to full waves (64 lanes x 16 B); what is left of the row to the narrowest lane group that covers it
     const uint32_t full = G.stride / 1024u, rem = G.stride % 1024u;
     for (uint32_t t = 0; t < full; t++) add_slot(64, (uint32_t)g, t * 1024u);
-    // A remainder of 257..896 bytes on the 64-lane form leaves 8..47 lanes of every wave without a row to load.  Where the kernel
-    // runs near its issue limits (several hash functions: h row loads ANDed per k-mer, 16 counter planes for long queries) those
-    // lanes are lost VALU cycles, and the remainder is cut into power-of-two tiles that fill their waves instead: 832 = 512 (32
-    // lanes, two units per wave) + 256 (16 lanes) + 64 (4 lanes) — each part aligned to its own tile size, as the slots want it.
-    // Single-hash databases keep the one tile: their kernels wait for HBM, and more launches only cost (KMCPG_SPLIT_TILES=0/1/2:
-    // never / multi-hash databases / always).
-    const int split_tiles = getenv("KMCPG_SPLIT_TILES") ? atoi(getenv("KMCPG_SPLIT_TILES")) : 1;  // (read at every open: tests flip it)
+    // EXPERIMENT, off (KMCPG_SPLIT_TILES=1: multi-hash databases, 2: all): a remainder of 257..896 bytes on the 64-lane form leaves
+    // 8..47 lanes of every wave without a row to load; cut into power-of-two tiles that fill their waves — 832 = 512 (32 lanes, two
+    // units per wave) + 256 (16 lanes) + 64 (4 lanes), each aligned to its own tile size — the genome search's K2 took 9.35 ms instead
+    // of 4.9 ms (same bytes moved): three launches read the hashes and compute the row indices three times, and the narrow parts run
+    // on the fabric's request rate.  The idle lanes were never the cost (profiles/r05_split_tiles.txt).
+    const int split_tiles = getenv("KMCPG_SPLIT_TILES") ? atoi(getenv("KMCPG_SPLIT_TILES")) : 0;  // (read at every open: tests flip it)
     const bool split = rem > 256 && rem <= 896 && __builtin_popcount(rem / 64u) <= 3 && (split_tiles == 2 || (split_tiles == 1 && db->info.num_hashes > 1));
     if (rem && split) {
       uint32_t at = full * 1024u, left = rem;
