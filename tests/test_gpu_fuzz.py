@@ -31,6 +31,18 @@ def _draw(rng):
     return k, kw, nh, fpr, n_genomes, glen, n_chunks, threads
 
 
+def _check_pairs(db, res, reads, reads2, params):
+    """KMCP_FUZZ_PAIRS=1: the compact result of the same search, expanded query by query, must be the records bit for bit"""
+    if not os.environ.get("KMCP_FUZZ_PAIRS"):
+        return
+    pr = db.search_pairs(reads, reads2, params=params)
+    for f in ("qlen", "qkmers", "ksize", "offs"):
+        assert np.array_equal(getattr(res, f), getattr(pr, f)), f
+    parts = [db.expand_pairs(int(pr.qkmers[i]), pr.read(i)) for i in range(len(pr)) if pr.offs[i + 1] > pr.offs[i]]
+    got = np.concatenate(parts).tobytes() if parts else b""
+    assert got == res.matches.tobytes()
+
+
 # KMCP_FUZZ_SEEDS=N / KMCP_FUZZ_LONG_SEEDS=N widen the sweeps (32 / 8 by default; the final round-1 build passed a soak run of
 # 20 000 + 6 000 seeds on MI355X: `pytest tests/test_gpu_fuzz.py -m gpu -n 14`, 3 minutes)
 @pytest.mark.parametrize("seed", list(range(int(os.environ.get("KMCP_FUZZ_SEEDS", "32")))))
@@ -62,6 +74,7 @@ def test_random_configuration(oracle_lib, tmp_path, seed):
     try:
         with Database.open(db_dir, device=0) as db:
             res = db.search(reads, reads2, params=default_params(**flags))
+            _check_pairs(db, res, reads, reads2, default_params(**flags))
         synth.assert_parity(odb, res, reads, reads2, O.default_params(**flags))
     finally:
         odb.close()
@@ -116,6 +129,7 @@ def test_random_long_queries(oracle_lib, tmp_path, seed):
     try:
         with Database.open(db_dir, device=0) as db:
             res = db.search(reads, reads2, params=default_params(**flags))
+            _check_pairs(db, res, reads, reads2, default_params(**flags))
         # (a few draws — large scale, high -t — legitimately have no matching read on either side)
         synth.assert_parity(odb, res, reads, reads2, O.default_params(**oflags))
     finally:
