@@ -805,12 +805,13 @@ extern "C" int kmcpg_expand_pairs(const kmcpg_db* db, int32_t qkmers, const kmcp
   const double nh = (double)qkmers;
   // the row of this NumKmers stays with the thread: consecutive queries of a batch mostly share it (and a formatter thread asks for
   // a few hundred thousand queries per second)
-  static thread_local const kmcpg_db* row_db = nullptr;
+  // (keyed on the FPR table's process-unique id, not on the handle's address: a database opened later may live where a closed one did)
+  static thread_local uint64_t row_of = 0;
   static thread_local int row_n = -1;
   static thread_local FprRow row;
-  if (qkmers > 0 && (row_db != db || row_n != qkmers)) {
+  if (qkmers > 0 && (row_of != db->fpr->id() || row_n != qkmers)) {
     row = db->fpr->ensure_row(qkmers);
-    row_db = db;
+    row_of = db->fpr->id();
     row_n = qkmers;
   }
   for (uint64_t i = 0; i < n; i++) {

@@ -4,6 +4,7 @@
 #include <math.h>
 
 #include <algorithm>
+#include <atomic>
 
 #include <limits>
 
@@ -107,6 +108,11 @@ static std::vector<double> fpr_row(double p_, int n, int upto) {
     out.push_back(r);
   }
   return out;
+}
+
+uint64_t QueryFpr::next_id() {
+  static std::atomic<uint64_t> counter{0};
+  return ++counter;
 }
 
 const QueryFpr::Row& QueryFpr::row(int n) {

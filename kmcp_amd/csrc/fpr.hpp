@@ -16,7 +16,10 @@ double go_pow(double x, double y);
 
 class QueryFpr {
  public:
-  explicit QueryFpr(double p) : p_(p) {}
+  explicit QueryFpr(double p) : p_(p), id_(next_id()) {}
+  // unique per object for the life of the process (callers that cache a row per thread key it on this, never on an address: a
+  // later database may be allocated where an earlier one lived)
+  uint64_t id() const { return id_; }
   // queryFPR(n, k): 1 - sum_{i<=k} C(n,i) p^i (1-p)^(n-i), clamped at 0
   double get(int n, int k);
   // Rows are cached for every n (a row ends at its first dead entry, see fpr.cpp: at most ~1 030 + 1 values whatever n is; at
@@ -33,7 +36,9 @@ class QueryFpr {
 
  private:
   const Row& row(int n);
+  static uint64_t next_id();
   double p_;
+  uint64_t id_;
   std::mutex mu_;
   std::unordered_map<int, Row> rows_;
 };

@@ -125,3 +125,20 @@ def test_reference_fpr_cache_aliases_k_and_n_minus_k_below_half_coverage(oracle_
     # beyond the buffer (n > 249 single-end, > 499 paired) the reference calls the uncached formula: nothing to alias
     d = GoFprCache(L, 249, p)
     assert d(260, 100) == L.ko_query_fpr(260, 100, p) and d(260, 160) == L.ko_query_fpr(260, 160, p)
+
+
+def test_expand_pairs_uses_the_fpr_of_the_database_it_is_given(oracle_lib, dbs):
+    """Found by the round-5 fuzz soak (7 of 6 200 draws): kmcpg_expand_pairs kept the FPR row of the last (handle address, NumKmers) per
+    thread - and a database opened later may be allocated where a closed one lived, so a query of the same NumKmers got the previous
+    database's FPR column.  The cache is keyed on a process-unique id of the FPR table now.  Here: three databases with three FPRs
+    opened and closed in turn, the same (n, k) asked of each, several rounds."""
+    from kmcp_amd.lib import Database
+    L = oracle_lib.lib()
+    for _ in range(4):
+        for p, d in dbs.items():
+            with Database.open(d, device=-1) as db:
+                for n, c in ((130, 100), (130, 72), (260, 150)):
+                    m = db.expand_pairs(n, np.array([[0, c]], np.uint32))
+                    w = L.ko_query_fpr(n, c, p)
+                    assert float(m["fpr"][0]) == w, (p, n, c, float(m["fpr"][0]), w)
+                    assert float(m["qcov"][0]) == c / n
