@@ -104,8 +104,8 @@ def test_strain_columns_equal_the_oracles_compute(oracle_lib):
 def test_full_size_sample(oracle_lib, tmp_path_factory):
     """Parity against the oracle on a sample of reads at FULL size: 21 000 real-genome columns (600 E. coli strains + 15 species x
     100 strains, 10 chunks each; 1.3 GB of index, 28 distinct NumSigs, ~200 matches per read).  The test builds the database itself
-    (tools/family_db.py: ~7 s of strain generation + ~6 s of kmcpg_build_db on the GPU box), for the reference's block layout and
-    for uniform_sigs = 1; KMCP_FAMILY_DB may point at one tools/bench_real_families.py left behind instead.  Skips only when the
+    (tools/family_db.py: ~7 s of strain generation + ~6 s of kmcpg_build_db on the GPU box), for the reference's block layout (and
+    for uniform_sigs = 1 under KMCP_FAMILY_BOTH=1); KMCP_FAMILY_DB may point at one tools/bench_real_families.py left behind instead.  Skips only when the
     box lacks the room (HBM, scratch disk)."""
     import shutil
 
@@ -135,7 +135,9 @@ def test_full_size_sample(oracle_lib, tmp_path_factory):
         cols, reads_a, info = family_db.generate(600, 100, 20000)
         assert info["columns"] == 21000
         from kmcp_amd import lib
-        db_dirs = {str(m): lib.build_db(str(tmp / f"u{m}"), cols, k=family_db.K, threads=32, uniform_sigs=m, alias="family-db") for m in (0, 1)}
+        # the reference's block layout always; uniform_sigs = 1 as well under KMCP_FAMILY_BOTH=1 (the reduced test above covers both)
+        modes = (0, 1) if os.environ.get("KMCP_FAMILY_BOTH") else (0,)
+        db_dirs = {str(m): lib.build_db(str(tmp / f"u{m}"), cols, k=family_db.K, threads=32, uniform_sigs=m, alias="family-db") for m in modes}
         del cols
         reads = _reads_list(reads_a[:400])
     for mode, db_dir in db_dirs.items():
