@@ -1127,6 +1127,7 @@ __global__ void __launch_bounds__(64 * ROLL_WAVES) k1_seg_roll(const K1Args a) {
     tab_out[tid] = nt_tab_out(sd, a.k);
     if (tid < 8) tab_in[tid] = nt_tab_in(sd, a.k);
   }
+  if (a.seg_only_flagged && a.seg_cnt[blockIdx.x] != -1) return;  // fallback pass behind k1_seg_roll2: uniform over the workgroup
   const uint32_t r = blockIdx.x / a.segs_max, seg = blockIdx.x % a.segs_max;
   const uint64_t o1 = a.offs[r];
   const int len = (int)(a.offs[r + 1] - o1);
@@ -1212,6 +1213,159 @@ __global__ void __launch_bounds__(64 * ROLL_WAVES) k1_seg_roll(const K1Args a) {
   if (tid == 0) a.seg_cnt[blockIdx.x] = total;
 }
 
+// The same segments once more (round 5), on 2-BIT CODES.  k1_seg_roll above spends ~60 lane-operations per base, most of them on getting
+// at its operands: two byte look-ups in LDS with their address arithmetic, four 64-bit table look-ups with theirs.  A genome is A, C, G, T
+// almost everywhere, and for those four letters (either case) everything the recurrence needs is a function of two 2-bit codes:
+//     fh' = rol1(fh) ^ F2[out][in],   F2[o][i] = rol1(rol(F[o], k-1)) ^ F[i]          rh' = ror1(rh ^ R2[out][in]),   R2[o][i] = R[o] ^ rol(R[i], k)
+// Here a wave converts its stretch of bases to codes while it stages them (16 bases per lane and step: (w >> 1) & 3 per byte, one multiply
+// folds four codes into a byte, one v_perm rebuilds the canonical letters to check that nothing else was there) into 2 KB of LDS instead
+// of 8.4 KB of bytes; a lane then takes its codes 16 at a time from one dword, the incoming ones from a funnel shift of two (the
+// offset k is the same for every group), and a roll costs two bit-field extracts, one table address, two look-ups and the 64-bit
+// arithmetic: ~22 operations per base.  A segment that holds ANY other byte (N, IUPAC codes, U: their hashes depend on the exact byte)
+// is left to k1_seg_roll: this kernel marks it (seg_cnt = -1) and the launcher runs the byte kernel behind it for the marked segments only.
+// Same outputs as k1_seg_roll / k1_seg_hash (out[], seg_cnt): tests/test_gpu_parity.py::test_k1_all_forms_across_k and the fuzz sweeps.
+constexpr int R2_PITCH = 9;                    // dwords per lane run (8 of codes + 1: runs 9 apart put the lanes' j-th words on 64 different banks)
+constexpr int R2_WORDS = 66 * R2_PITCH;        // 64 runs + what k - 1 <= 127 further bases and the funnel's upper word reach into
+
+__global__ void __launch_bounds__(64 * ROLL_WAVES) k1_seg_roll2(const K1Args a) {
+  __shared__ uint64_t S[4], RC[4], F2[16], R2[16];  // seeds by code (A 0, C 1, T 2, G 3 = (ascii >> 1) & 3), complements, the two pair tables
+  __shared__ uint32_t codes[ROLL_WAVES][R2_WORDS];
+  __shared__ int s_cnt[ROLL_WAVES];
+  __shared__ int s_bad;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int k = a.k;
+  if (tid < 16) {
+    F2[tid] = nt2_f2(tid >> 2, tid & 3, k);
+    R2[tid] = nt2_r2(tid >> 2, tid & 3, k);
+    if (tid < 4) {
+      S[tid] = seed_of(nt2_letter(tid));
+      RC[tid] = seed_of(nt2_letter(tid) & 7);  // complement of base b = tab[b & 7] (nthash.hpp)
+    }
+  }
+  if (tid == 0) s_bad = 0;
+  const uint32_t r = blockIdx.x / a.segs_max, seg = blockIdx.x % a.segs_max;
+  const uint64_t o1 = a.offs[r];
+  const int len = (int)(a.offs[r + 1] - o1);
+  const int npos = len - k + 1;
+  const int p_lo = (int)seg * K1SEG;
+  const bool on = len >= a.min_qlen && p_lo < npos;  // (:778-786 gate; ErrShortSeq => no k-mers) — uniform over the workgroup
+  const int P0 = p_lo + w * 64 * ROLL_L;             // first position of this wave
+  const int wpos = on ? max(0, min(npos - P0, 64 * ROLL_L)) : 0;  // positions of this wave
+  uint32_t* __restrict__ Wd = codes[w];
+  auto slot = [&](int word) -> int { return (word >> 3) * R2_PITCH + (word & 7); };  // word = base / 16 within the wave's stretch
+  __syncthreads();  // s_bad = 0 before anybody raises it
+  {
+    const uint8_t* __restrict__ s = a.seqs + o1 + P0;
+    const int nb = wpos > 0 ? wpos + k - 1 : 0;  // bases this wave needs
+    typedef uint32_t u32x4_any __attribute__((ext_vector_type(4), aligned(1)));
+    bool bad = false;
+    for (int gi = lane; gi < 8 * 66; gi += 64) {  // every word the walks may touch gets a value (zero past the stretch)
+      const int b0 = gi * 16;
+      uint32_t word = 0;
+      if (b0 + 16 <= nb) {
+        const u32x4_any v = *reinterpret_cast<const u32x4_any*>(s + b0);
+        const uint32_t in[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int d = 0; d < 4; d++) {
+          const uint32_t c = nt2_codes4(in[d]);   // the code of each byte, in its byte
+          bad |= !nt2_valid4(in[d], c);            // ... and back: anything but A/C/G/T in either case differs
+          word |= nt2_fold4(c) << (8 * d);         // four codes into one byte
+        }
+      } else if (b0 < nb) {
+        for (int j = 0; b0 + j < nb; j++) {
+          const uint32_t ch = s[b0 + j], c = (ch >> 1) & 3u;
+          bad |= (ch & 0xDFu) != (uint32_t)nt2_letter((int)c);
+          word |= c << (2 * j);
+        }
+      }
+      Wd[slot(gi)] = word;
+    }
+    if (__ballot(bad) != 0 && lane == 0) s_bad = 1;
+  }
+  __syncthreads();  // tables, codes, s_bad
+  if (s_bad) {  // a byte that is not A/C/G/T: the byte kernel takes this segment
+    if (tid == 0) a.seg_cnt[blockIdx.x] = -1;
+    return;
+  }
+  const bool scaled = a.scaled != 0;
+  const uint64_t max_hash = a.max_hash;
+  const int q0 = lane * ROLL_L;
+  const int mine = max(0, min(wpos - q0, ROLL_L));  // k-mer positions of this lane
+  const int kw = k >> 4, ksh = 2 * (k & 15);
+  auto walk = [&](auto&& emit) __attribute__((always_inline)) {
+    if (mine <= 0) return;
+    uint64_t fh = 0, rh = 0;
+    for (int j = 0; j < k; j++) {  // start-up: fh = XOR_j rol(F[j], k-1-j), rh = XOR_j rol(R[j], j)
+      const int q = q0 + j;
+      const uint32_t c = (Wd[slot(q >> 4)] >> (2 * (q & 15))) & 3u;
+      fh = nt2_rol1(fh) ^ S[c];
+      rh ^= rolv(RC[c], j);
+    }
+    const int w_out = 8 * lane;
+    int t = 0;
+    for (int g = 0; g < 8; g++) {
+      const uint32_t outw = Wd[slot(w_out + g)];
+      const uint32_t inw = nt2_funnel(Wd[slot(w_out + g + kw + 1)], Wd[slot(w_out + g + kw)], (uint32_t)ksh);
+      // the table index of every roll of the group, a nibble each: (code going out << 2) | code coming in
+      const uint32_t m[2] = {(nt2_spread(outw & 0xFFFFu) << 2) | nt2_spread(inw & 0xFFFFu), (nt2_spread(outw >> 16) << 2) | nt2_spread(inw >> 16)};
+      if (mine - t >= 16) {
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+          const uint64_t h = fh < rh ? fh : rh;
+          if (h != 0 && (!scaled || h <= max_hash)) emit(h);
+          const uint32_t idx = (m[j >> 3] >> (4 * (j & 7))) & 15u;
+          fh = nt2_rol1(fh) ^ F2[idx];
+          rh = nt2_ror1(rh ^ R2[idx]);
+        }
+        t += 16;
+        if (t >= mine) return;
+      } else {
+        for (int j = 0; t < mine; j++, t++) {
+          const uint64_t h = fh < rh ? fh : rh;
+          if (h != 0 && (!scaled || h <= max_hash)) emit(h);
+          const uint32_t idx = (m[j >> 3] >> (4 * (j & 7))) & 15u;
+          fh = nt2_rol1(fh) ^ F2[idx];
+          rh = nt2_ror1(rh ^ R2[idx]);
+        }
+        return;
+      }
+    }
+  };
+  int c = 0;
+  uint64_t h0 = 0, h1 = 0;
+  walk([&](uint64_t h) __attribute__((always_inline)) {
+    h0 = c == 0 ? h : h0;  // (selects, not branches into a two-element array on the stack)
+    h1 = c == 1 ? h : h1;
+    c++;
+  });
+  int incl = c;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const int t_ = __shfl_up(incl, off);
+    if (lane >= off) incl += t_;
+  }
+  if (lane == 63) s_cnt[w] = incl;
+  __syncthreads();
+  int before = 0, total = 0;
+#pragma unroll
+  for (int i = 0; i < ROLL_WAVES; i++) {
+    const int ci = s_cnt[i];
+    if (i < w) before += ci;
+    total += ci;
+  }
+  if (c > 0) {
+    uint64_t* __restrict__ out = a.scratch + o1 + p_lo + before + (incl - c);
+    if (c <= 2) {
+      out[0] = h0;
+      if (c == 2) out[1] = h1;
+    } else {
+      int i = 0;
+      walk([&](uint64_t h) __attribute__((always_inline)) { out[i++] = h; });
+    }
+  }
+  if (tid == 0) a.seg_cnt[blockIdx.x] = total;
+}
+
 __global__ void __launch_bounds__(256) k1_seg_pack(const K1Args a) {
   const uint32_t r = blockIdx.x / a.segs_max, seg = blockIdx.x % a.segs_max;
   const uint64_t o1 = a.offs[r];
@@ -1252,7 +1406,13 @@ bool launch_k1(const K1Args& a, uint32_t max_read_len, hipStream_t st) {
   if (a.seg_cnt && a.segs_max > 1) {  // whole genomes: one workgroup per 65536-position segment, then an ordered pack
     const unsigned blocks = a.n_reads * a.segs_max;
     // rolling hashes for every k the staging halo holds (flags bit 3 = 8: the prefix-XOR form, for A/B runs)
-    if (a.k <= 128 && !(a.flags & 8)) hipLaunchKernelGGL(k1_seg_roll, dim3(blocks), dim3(64 * ROLL_WAVES), 0, st, a);
+    // (flags bit 4 = 16: the byte kernel alone, for A/B runs)
+    if (a.k <= 128 && !(a.flags & 8) && !(a.flags & 16)) {
+      hipLaunchKernelGGL(k1_seg_roll2, dim3(blocks), dim3(64 * ROLL_WAVES), 0, st, a);  // 2-bit codes; marks the segments it cannot take
+      K1Args b = a;
+      b.seg_only_flagged = 1;
+      hipLaunchKernelGGL(k1_seg_roll, dim3(blocks), dim3(64 * ROLL_WAVES), 0, st, b);  // ... and the byte kernel does those
+    } else if (a.k <= 128 && !(a.flags & 8)) hipLaunchKernelGGL(k1_seg_roll, dim3(blocks), dim3(64 * ROLL_WAVES), 0, st, a);
     else hipLaunchKernelGGL(k1_seg_hash, dim3(blocks), dim3(K1WG), 0, st, a);
     hipLaunchKernelGGL(k1_seg_pack, dim3(blocks), dim3(256), 0, st, a);
     return false;

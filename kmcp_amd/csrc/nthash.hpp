@@ -62,4 +62,48 @@ KMCPG_NT_HD void nt_roll_step(uint64_t& fh, uint64_t& rh, uint8_t bo, uint8_t bi
   rh = (x >> 1) | (x << 63);
 }
 
+// ---- the 2-bit form (k1_seg_roll2): for A, C, G, T in either case everything the recurrence needs is a function of two codes
+//      code = (ascii >> 1) & 3:  A 0, C 1, T 2, G 3      fh' = rol1(fh) ^ F2[out][in]      rh' = ror1(rh ^ R2[out][in])
+constexpr uint32_t NT2_LETTERS = (uint32_t)'A' | ((uint32_t)'C' << 8) | ((uint32_t)'T' << 16) | ((uint32_t)'G' << 24);  // code -> letter
+KMCPG_NT_HD uint8_t nt2_letter(int c) { return (uint8_t)((NT2_LETTERS >> (8 * (c & 3))) & 0xFFu); }
+KMCPG_NT_HD uint64_t nt2_f2(int o, int i, int k) { return rol1(nt_tab_out(seed_of(nt2_letter(o)), k)) ^ seed_of(nt2_letter(i)); }
+KMCPG_NT_HD uint64_t nt2_r2(int o, int i, int k) { return seed_of(nt2_letter(o) & 7) ^ nt_tab_in(seed_of(nt2_letter(i) & 7), k); }
+// four bytes -> their codes, each in its byte; -> one byte c0 + 4 c1 + 16 c2 + 64 c3 (the products' other terms stay below bit 24
+// or leave the word); -> the four letters those codes stand for (what the bytes must equal, case aside, to be taken by this form)
+KMCPG_NT_HD uint32_t nt2_codes4(uint32_t w) { return (w >> 1) & 0x03030303u; }
+KMCPG_NT_HD uint32_t nt2_fold4(uint32_t c) { return (c * 0x01041040u) >> 24; }
+KMCPG_NT_HD uint32_t nt2_canon4(uint32_t c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_amdgcn_perm(0u, NT2_LETTERS, c);  // v_perm_b32: selector bytes 0..3 pick the bytes of the second operand
+#else
+  uint32_t r = 0;
+  for (int b = 0; b < 4; b++) r |= (uint32_t)nt2_letter((int)((c >> (8 * b)) & 3u)) << (8 * b);
+  return r;
+#endif
+}
+KMCPG_NT_HD bool nt2_valid4(uint32_t w, uint32_t c) { return (w & 0xDFDFDFDFu) == nt2_canon4(c); }
+// 8 two-bit fields (16 bits) -> the low halves of 8 nibbles; (spread(out) << 2) | spread(in) = the table index of 8 rolls, a nibble each
+KMCPG_NT_HD uint32_t nt2_spread(uint32_t x) {
+  x = (x | (x << 8)) & 0x00FF00FFu;
+  x = (x | (x << 4)) & 0x0F0F0F0Fu;
+  x = (x | (x << 2)) & 0x33333333u;
+  return x;
+}
+// ({hi, lo} >> s)[31:0], s < 32 (v_alignbit_b32)
+KMCPG_NT_HD uint32_t nt2_funnel(uint32_t hi, uint32_t lo, uint32_t s) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_amdgcn_alignbit(hi, lo, s);
+#else
+  return (uint32_t)((((uint64_t)hi << 32) | lo) >> (s & 31u));
+#endif
+}
+KMCPG_NT_HD uint64_t nt2_rol1(uint64_t v) {
+  const uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
+  return ((uint64_t)nt2_funnel(hi, lo, 31u) << 32) | nt2_funnel(lo, hi, 31u);
+}
+KMCPG_NT_HD uint64_t nt2_ror1(uint64_t v) {
+  const uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
+  return ((uint64_t)nt2_funnel(lo, hi, 1u) << 32) | nt2_funnel(hi, lo, 1u);
+}
+
 }  // namespace kmcpg

@@ -387,6 +387,69 @@ def test_k1_all_forms_across_k(G, oracle_lib, k):
                     assert np.array_equal(got, want), (kw, i, len(r))
 
 
+@pytest.mark.parametrize("k,flags", [(21, "3"), (31, "3"), (64, "3"), (100, "3"), (128, "3"), (21, "19")])
+def test_genome_path_two_bit_kernel_and_its_fallback(G, oracle_lib, monkeypatch, k, flags):
+    """Round 5: whole genomes go through k1_seg_roll2 (2-bit codes; A / C / G / T in either case) and every 65 536-position segment that
+    holds any other byte through the byte kernel k1_seg_roll behind it.  Queries: clean, soft-masked, an N in ONE segment of several
+    (its neighbours stay on the fast kernel), N runs across a segment boundary, U, IUPAC codes, a byte >= 128, lengths that end inside a
+    16-base group or right at a segment boundary; plain and FracMinHash k-mers.  KMCPG_K1_FLAGS=19 (the byte kernel alone): same hashes."""
+    import torch
+    O = oracle_lib
+    lib = G["lib"]
+    monkeypatch.setenv("KMCPG_K1_FLAGS", flags)
+    dev = torch.device("cuda:0")
+    g = synth.random_genomes(3, 300000, seed=700 + k)
+    rng = np.random.default_rng(k)
+
+    def edit(seq, fn):
+        b = bytearray(seq)
+        fn(b)
+        return bytes(b)
+
+    def soft_mask(b):
+        for _ in range(30):
+            p = int(rng.integers(0, len(b) - 5000))
+            n = int(rng.integers(1, 5000))
+            b[p:p + n] = bytes(b[p:p + n]).lower()
+
+    def one_n(b):
+        b[65536 + 1000] = ord("N")  # inside the second segment only
+
+    def n_runs(b):
+        b[65536 - 300:65536 + 700] = b"N" * 1000  # across the boundary of segments 0 and 1
+        b[200000:200003] = b"nNn"
+
+    def rna(b):
+        b[:] = bytes(b).replace(b"T", b"U")
+
+    def iupac(b):
+        for p in rng.integers(0, len(b), size=60):
+            b[int(p)] = int(rng.choice(list(b"RYKMSWBDHV-*.") + [200]))
+
+    huge = [g[0][:280000], edit(g[1][:250001], soft_mask), edit(g[2][:262144 + k - 1], one_n), edit(g[0][:299990], n_runs), edit(g[1][:70000], rna),
+            edit(g[2][:200017], iupac), g[0][:65536 + k], g[1][:65536 * 2 + k - 1], g[2][:131072 + 5], edit(g[0][100:66000], soft_mask)]
+    for kw in (dict(), dict(scale=7)):
+        spec = lib.SynthSpec(k=k, num_hashes=1, fpr=0.3, n_blocks=1, cols_per_block=8, num_sigs=1000, kmers_per_col=10, seed=1, scale=kw.get("scale", 1))
+        cfg = O.sketch_cfg(k=k, **kw)
+        with G["Database"].open_synthetic(spec) as db:
+            seqs, offs = lib.pack_reads(huge)
+            t_seqs = torch.from_numpy(seqs).to(dev)
+            t_offs = torch.from_numpy(offs.view(np.int64)).to(dev)
+            t_h = torch.zeros(len(seqs) + 8, dtype=torch.int64, device=dev)
+            t_nk = torch.zeros(len(huge), dtype=torch.int32, device=dev)
+            p = G["default_params"](min_qlen=0, min_matched=1, dedup_threshold=1 << 30)
+            db.kmers_device(t_seqs.data_ptr(), t_offs.data_ptr(), len(huge), len(seqs), max(len(r) for r in huge), t_h.data_ptr(), t_h.numel(), None,
+                            t_nk.data_ptr(), params=p)
+            torch.cuda.synchronize()
+            h = t_h.cpu().numpy().view(np.uint64)
+            nk = t_nk.cpu().numpy()
+            for i, r in enumerate(huge):
+                want = O.generate_kmers(r, cfg)
+                got = h[int(offs[i]):int(offs[i]) + int(nk[i])]
+                assert len(want) == nk[i], (kw, i, len(r), len(want), nk[i])
+                assert np.array_equal(got, want), (kw, i, len(r))
+
+
 @pytest.mark.parametrize("flags", ["3", "7", "4"])
 def test_window_sketch_kernel_forms_on_long_reads(G, oracle_lib, tmp_path, monkeypatch, flags):
     """The three forms the window sketches of long reads can take — the barrier-free wave form (default; KMCPG_K1_FLAGS=3), the

@@ -41,3 +41,37 @@ def test_rolling_hashes_equal_the_oracle(nt, oracle_lib):
         # shorter than k: nothing
         assert nt.nt_roll_all(b"ACGT" * 40, k - 1, k, 0, 0, np.zeros(4, np.uint64).ctypes.data) == 0
     assert n_kmers > 50000
+
+
+def test_two_bit_rolling_form_equals_the_oracle(nt, oracle_lib):
+    """k1_seg_roll2's arithmetic on the host (round 5): bytes folded to 2-bit codes four at a time, pair tables F2 / R2, table indices
+    from nibble words (spread + funnel shift by k), funnel-shift rotations - against the oracle's k-mer hashes for every k the kernel
+    takes, upper and lower case; any other byte (N, IUPAC, U) must be reported (-1: the kernel hands the segment to the byte kernel)."""
+    O = oracle_lib
+    nt.nt_roll2_all.restype = __import__("ctypes").c_long
+    nt.nt_roll2_all.argtypes = nt.nt_roll_all.argtypes
+    rng = np.random.default_rng(8)
+    acgt = np.frombuffer(b"ACGTacgt", dtype=np.uint8)
+    n_kmers = 0
+    for k in (1, 2, 7, 15, 16, 17, 21, 31, 32, 33, 47, 48, 63, 64, 65, 96, 127, 128):
+        for scale in (1, 3, 200):
+            for length in (k, k + 1, k + 15, k + 16, int(rng.integers(k, 5000)), 4096 + k):
+                seq = acgt[rng.integers(0, 8 if length % 2 else 4, size=length)].tobytes()
+                cfg = O.sketch_cfg(k=k, scale=scale)
+                want = O.generate_kmers(seq, cfg)
+                out = np.zeros(length + 1, dtype=np.uint64)
+                max_hash = (2**64 - 1) // scale if scale > 1 else 0
+                n = nt.nt_roll2_all(seq, length, k, int(scale > 1), max_hash, out.ctypes.data)
+                assert n == len(want), (k, scale, length, n, len(want))
+                assert np.array_equal(out[:n], want), (k, scale, length)
+                n_kmers += n
+    assert n_kmers > 100000
+    # every byte that is not A / C / G / T in either case is refused, wherever it sits (full groups and the tail)
+    base = acgt[rng.integers(0, 4, size=200)].copy()
+    out = np.zeros(256, dtype=np.uint64)
+    assert nt.nt_roll2_all(base.tobytes(), 200, 21, 0, 0, out.ctypes.data) == 180
+    for pos in (0, 3, 15, 16, 100, 191, 192, 199):
+        for ch in b"NnUuRYKM-*.\x00\xff@[`{BDEFHIJLOPQSVWXZ1":
+            s = base.copy()
+            s[pos] = ch
+            assert nt.nt_roll2_all(s.tobytes(), 200, 21, 0, 0, out.ctypes.data) == -1, (pos, ch)
