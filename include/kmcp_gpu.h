@@ -230,8 +230,10 @@ typedef struct {
  *    record for each (1.5 GB per 131 072 reads) was what bounded kmcpg_search_batch (6.8 M reads/s against 12.7 M for the kernels).
  *    The *_pairs forms return the FINAL matches of every query — every threshold, -f and --keep-top-scores applied, in the order
  *    kmcp search prints them — as 8-byte (column, mKmers) pairs; match_offs[i+1] - match_offs[i] is the query's `hits` column.
- *    kmcpg_expand_pairs derives the Match records of one query's pairs (qCov, tCov, jacc :7487-7489, the FPR column, column
- *    metadata) on the caller's thread, typically into a small scratch array right before the rows are formatted: the same bits as
+ *    Reference counterpart: the Match structs a worker appends (util-db-search.go:7479-7489) and the row loop that prints them
+ *    (search.go:517-575) — here the second is what needs the first, one query at a time.
+ *    kmcpg_expand_pairs derives the Match records of one query's pairs (qCov, tCov, jacc util-db-search.go:7487-7489, the FPR column
+ *    util-fpr.go:32-50, column metadata) on the caller's thread, typically into a small scratch array right before the rows are formatted: the same bits as
  *    kmcpg_search_batch / kmcpg_wait would have written.  Everything else (arguments, errors, ownership: kmcpg_result_pairs_free)
  *    is as for the record forms; a ticket is consumed by EITHER kmcpg_wait or kmcpg_wait_pairs. */
 typedef struct {
