@@ -107,6 +107,11 @@ WORKLOADS = {
                                       cpu_sample_start=64, kernel="k2_cobs<64,16,false,false,8> + k2_cobs<16,16,false,false,8> (k1_windows_wave<2> beside them)",
                                       metric="reads/sec searched (HiFi ~10 kb, Closed Syncmer s=11, k=21) vs a 10k-chunk index with one NumSigs",
                                       name="HiFi synthetic, blocks with equal NumSigs (grouped rows): 32 x 312 cols x 300 k sigs, closed syncmer s=11 k=21"),
+    # a mid-sized database as `kmcp index -j 32` cuts it: 100 000 chunks -> 32 blocks x 3 125 columns = 391-byte rows (round 5: the 32-lane form)
+    "mid_rows": dict(k=21, num_hashes=1, fpr=0.3, n_blocks=32, cols_per_block=3125, num_sigs=1121470, sigs_step=64, kmers_per_col=400000,
+                     batch_reads=1048576, kernel="k2_cobs<32,8,false,false,4>",
+                     metric="reads/sec searched (150bp, k=21) vs a 100k-chunk index of 391-byte rows",
+                     name="100k-chunk synthetic: 32 blocks x 3125 cols x ~1.12 M sigs (14 GB), 150bp k=21"),
     # EXPERIMENT (VERDICT r4 #3 gate, profiles/r05_rowsort_gate.txt): ONE narrow block of the HiFi index and enough reads to fill the
     # chip with (read, block) units; KMCPG_DEBUG_ROWSORT=1|2 re-orders every read's k-mers by the row they address
     "config4_oneblock": dict(k=21, num_hashes=1, fpr=0.3, n_blocks=1, cols_per_block=312, num_sigs=300000, sigs_step=0, kmers_per_col=100000, syncmer_s=11,

@@ -67,7 +67,9 @@ uint32_t device_stride(uint32_t row_bytes) {
 int lpr_for_stride(uint32_t stride) {
   if (const char* e = getenv("KMCPG_LPR8"))
     if (atoi(e) == 0) return stride <= 64 ? 4 : (stride <= 256 ? 16 : 64);
-  return stride <= 64 ? 4 : (stride <= 128 ? 8 : (stride <= 256 ? 16 : 64));
+  // 257..512 bytes: the 32-lane form, two units per wave (KMCPG_LPR32=0: the 64-lane form with half of its lanes idle, as before round 5)
+  const bool lpr32 = !(getenv("KMCPG_LPR32") && atoi(getenv("KMCPG_LPR32")) == 0);
+  return stride <= 64 ? 4 : (stride <= 128 ? 8 : (stride <= 256 ? 16 : (stride <= 512 && lpr32 ? 32 : 64)));
 }
 
 
