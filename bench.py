@@ -112,6 +112,11 @@ WORKLOADS = {
                      batch_reads=1048576, kernel="k2_cobs<32,8,false,false,4>",
                      metric="reads/sec searched (150bp, k=21) vs a 100k-chunk index of 391-byte rows",
                      name="100k-chunk synthetic: 32 blocks x 3125 cols x ~1.12 M sigs (14 GB), 150bp k=21"),
+    # ... and a 200 000-chunk one: 32 blocks x 6 250 columns = 782-byte rows (832-byte pitch), single hash, short reads
+    "mid_rows_782": dict(k=21, num_hashes=1, fpr=0.3, n_blocks=32, cols_per_block=6250, num_sigs=1121470, sigs_step=64, kmers_per_col=400000,
+                         batch_reads=1048576, kernel="k2_cobs<64,8,false,false,4>",
+                         metric="reads/sec searched (150bp, k=21) vs a 200k-chunk index of 782-byte rows",
+                         name="200k-chunk synthetic: 32 blocks x 6250 cols x ~1.12 M sigs (28 GB), 150bp k=21"),
     # EXPERIMENT (VERDICT r4 #3 gate, profiles/r05_rowsort_gate.txt): ONE narrow block of the HiFi index and enough reads to fill the
     # chip with (read, block) units; KMCPG_DEBUG_ROWSORT=1|2 re-orders every read's k-mers by the row they address
     "config4_oneblock": dict(k=21, num_hashes=1, fpr=0.3, n_blocks=1, cols_per_block=312, num_sigs=300000, sigs_step=0, kmers_per_col=100000, syncmer_s=11,
