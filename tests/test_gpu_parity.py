@@ -759,11 +759,11 @@ def test_threshold_at_the_top_of_a_plane_class(G, oracle_lib, tmp_path):
         assert int(cnt[0].item()) == 0
 
 
-@pytest.mark.parametrize("ncols,nh,split", [(6500, 3, "1"), (4000, 3, "1"), (11000, 2, "1"), (6500, 1, "2"), (3000, 1, "0"), (3900, 2, "0")])
+@pytest.mark.parametrize("ncols,nh,split", [(6500, 3, "1"), (6500, 1, "2"), (3000, 1, "0"), (3900, 2, "0")])
 def test_row_remainders_cut_into_power_of_two_tiles(G, oracle_lib, tmp_path, monkeypatch, ncols, nh, split):
     """Round 5: what is left of a row beyond its whole KiB tiles, 257..896 bytes, is cut into 512 / 256 / 128 / 64-byte tiles (32, 16, 8,
-    4 lanes per unit) on multi-hash databases instead of one 64-lane tile with idle lanes: 6 500 columns = 813-byte rows -> 512 + 256 + 64,
-    2 500 -> 256 + 64, 4 000 -> one 512-byte tile on the 32-lane form, 11 000 -> 1024 + 256 + 128.  KMCPG_SPLIT_TILES=2 does the same
+    4 lanes per unit) under KMCPG_SPLIT_TILES=1 (multi-hash databases) instead of one 64-lane tile with idle lanes: 6 500 columns = 813-byte
+    rows -> 512 + 256 + 64 (an experiment that lost, profiles/r05_split_tiles.txt: the knob is off by default).  KMCPG_SPLIT_TILES=2 does the same
     to single-hash databases, 0 (the default) switches it off - and then 3 000 / 3 900 columns (375- / 488-byte rows) sit on ONE 32-lane
     tile, the default for 257..512-byte remainders since round 5: same results everywhere.  Short reads (8 planes) and long queries (16 planes)."""
     O = oracle_lib
