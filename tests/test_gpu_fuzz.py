@@ -134,3 +134,34 @@ def test_random_long_queries(oracle_lib, tmp_path, seed):
         synth.assert_parity(odb, res, reads, reads2, O.default_params(**oflags))
     finally:
         odb.close()
+
+
+@pytest.mark.parametrize("seed", list(range(int(os.environ.get("KMCP_FUZZ_WIDE_SEEDS", "2")))))
+def test_random_mid_width_rows(oracle_lib, tmp_path, seed):
+    """Rows of 257..512 bytes (2 049 .. 4 096 columns per block: the 32-lane form of k2_cobs, round 5) with random widths, hash counts,
+    k and thresholds, a second ragged block beside the wide one; short reads and long queries against the oracle."""
+    from kmcp_amd import Database, default_params
+    O = oracle_lib
+    rng = np.random.default_rng(9000 + seed)
+    ncols = int(rng.integers(2049, 4097))
+    extra = int(rng.choice([0, 5, 300, 2600]))
+    nh = int(rng.choice([1, 1, 2, 3]))
+    k = int(rng.choice([21, 31, 64]))
+    fpr = 0.3 if nh == 1 else float(rng.choice([0.05, 0.01]))
+    genomes = synth.random_genomes(ncols + extra, 380, seed=9500 + seed)
+    db_dir = synth.make_db(tmp_path, genomes, k=k, num_hashes=nh, fpr=fpr, block_size=ncols, threads=4)
+    reads = synth.sample_reads(genomes, 300, 150, sub_rate=float(rng.choice([0, 0.01, 0.03])), seed=int(rng.integers(1 << 30)), frac_random=0.15)
+    longq = [b"".join(genomes[int(j)] for j in rng.integers(0, len(genomes), size=int(rng.integers(2, 9)))) for _ in range(25)]
+    t = max(float(rng.choice([0.55, 0.3, 0.15])), fpr + 0.05) if nh > 1 else float(rng.choice([0.55, 0.4]))
+    flags = dict(min_qcov=t if nh == 1 else min(t, 0.55), min_matched=int(rng.choice([1, 5, 10])), sort_by=int(rng.integers(0, 3)), top_n_scores=int(rng.choice([0, 0, 2])))
+    if nh > 1:
+        flags["min_qcov"] = float(rng.choice([0.12, 0.3, 0.55]))
+    odb = O.OracleDB(db_dir)
+    try:
+        with Database.open(db_dir, device=0) as db:
+            assert any(256 < db.block_info(b)["stride"] <= 512 for b in range(db.info.n_blocks))
+            res = db.search(reads + longq, params=default_params(**flags))
+            _check_pairs(db, res, reads + longq, None, default_params(**flags))
+        synth.assert_parity(odb, res, reads + longq, None, O.default_params(**flags))
+    finally:
+        odb.close()
