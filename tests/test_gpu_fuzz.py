@@ -148,7 +148,8 @@ def test_random_mid_width_rows(oracle_lib, tmp_path, seed):
     nh = int(rng.choice([1, 1, 2, 3]))
     k = int(rng.choice([21, 31, 64]))
     fpr = 0.3 if nh == 1 else float(rng.choice([0.05, 0.01]))
-    genomes = synth.random_genomes(ncols + extra, 380, seed=9500 + seed)
+    # (the ragged second block holds longer genomes: another NumSigs, so the two are not laid side by side into one wider row)
+    genomes = synth.random_genomes(ncols, 380, seed=9500 + seed) + synth.random_genomes(extra, 520, seed=9700 + seed)
     db_dir = synth.make_db(tmp_path, genomes, k=k, num_hashes=nh, fpr=fpr, block_size=ncols, threads=4)
     reads = synth.sample_reads(genomes, 300, 150, sub_rate=float(rng.choice([0, 0.01, 0.03])), seed=int(rng.integers(1 << 30)), frac_random=0.15)
     longq = [b"".join(genomes[int(j)] for j in rng.integers(0, len(genomes), size=int(rng.integers(2, 9)))) for _ in range(25)]
