@@ -333,6 +333,10 @@ def run_workload(name, ctx, steps, warmup, batch_reads=0, cpu_baseline=True, cpu
     # Default: everything on one stream - the two-stream form lost on four of five workloads (profiles/r05_k1_beside_k2.txt)
     kstreams = [main, torch.cuda.Stream(dev)] if os.environ.get("KMCP_BENCH_STREAMS", "1") == "2" else [main, main]
     poll = os.environ.get("KMCP_BENCH_POLL") == "1"  # experiment: busy-poll hipEventQuery instead of hipEventSynchronize
+    # experiment (profiles/r05_restart_stall.txt): wait for a step by polling a word of PINNED memory that the step's last copy writes (its
+    # sequence number), i.e. without asking the runtime whether an event has completed
+    flag_wait = os.environ.get("KMCP_BENCH_FLAG") == "1"
+    seq_no = [0]
 
     class Buf:  # device outputs of one step in flight + their pinned host copies
         def __init__(self):
@@ -341,6 +345,9 @@ def run_workload(name, ctx, steps, warmup, batch_reads=0, cpu_baseline=True, cpu
             self.d_qk = torch.zeros(B, dtype=torch.int32, device=dev)
             self.d_ql = torch.zeros(B, dtype=torch.int32, device=dev)
             self.h_cnt = torch.zeros(2, dtype=torch.int64).pin_memory()
+            self.d_seq = torch.zeros(1, dtype=torch.int64, device=dev)
+            self.h_seq = torch.zeros(1, dtype=torch.int64).pin_memory()
+            self.want_seq = 0
             self.h_hits = torch.empty((cap * world, 3), dtype=torch.int32).pin_memory()
             self.h_qk = torch.empty(B, dtype=torch.int32).pin_memory()
             self.h_ql = torch.empty(B, dtype=torch.int32).pin_memory()
@@ -383,6 +390,11 @@ def run_workload(name, ctx, steps, warmup, batch_reads=0, cpu_baseline=True, cpu
                                 params=params, stream=ks.cuda_stream)
                 bf.k3_end.record(ks)
                 bf.h_roffs.copy_(bf.d_roffs, non_blocking=True)
+            if flag_wait:
+                seq_no[0] += 1
+                bf.want_seq = seq_no[0]
+                bf.d_seq.fill_(bf.want_seq)
+                bf.h_seq.copy_(bf.d_seq, non_blocking=True)  # the step's last command: the word arrives when everything before it is done
             bf.kernels_done.record(ks)
         bf.used = True
 
@@ -390,7 +402,10 @@ def run_workload(name, ctx, steps, warmup, batch_reads=0, cpu_baseline=True, cpu
         """Waits for the step's kernels; hit lists to rank 0 (RCCL when N > 1) and on their way to pinned host memory
         (`copied` fires when the host may read).  Returns #hits on rank 0.  Holds collectives when N > 1."""
         if not coll:
-            if poll:
+            if flag_wait:
+                while int(bf.h_seq[0]) != bf.want_seq:
+                    pass
+            elif poll:
                 while not bf.kernels_done.query():
                     pass
             else:
