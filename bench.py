@@ -360,7 +360,8 @@ def run_workload(name, ctx, steps, warmup, batch_reads=0, cpu_baseline=True, cpu
             self.h_roffs = torch.zeros(B + 2, dtype=torch.int64).pin_memory()
             self.k3_start = torch.cuda.Event(enable_timing=True)
             self.k3_end = torch.cuda.Event(enable_timing=True)
-            self.kernels_done = torch.cuda.Event()
+            # (experiment KMCP_BENCH_EVT_TIMING=1: a timing-enabled event, profiles/r05_restart_stall.txt)
+            self.kernels_done = torch.cuda.Event(enable_timing=os.environ.get("KMCP_BENCH_EVT_TIMING") == "1")
             self.copied = torch.cuda.Event()
             self.used = False
             self.grouped = False
