@@ -306,7 +306,8 @@ int stage(Lane* L, const uint8_t* seqs, const uint64_t* offs, const uint8_t* seq
     static thread_local std::vector<PackRun> exc;
     static_assert(sizeof(PackRun) == sizeof(ExcRun), "one layout");
     if (L->h_pack.ensure(L->tb1 / 4 + 16)) return kmcpg_fail(KMCPG_ENOMEM, "hipHostMalloc failed");
-    static const unsigned pack_threads = std::max(1u, std::min(8u, std::thread::hardware_concurrency()));
+    static const unsigned pack_threads = getenv("KMCPG_PACK_THREADS") ? (unsigned)std::max(1, std::min(atoi(getenv("KMCPG_PACK_THREADS")), 64))
+                                                                      : std::max(1u, std::min(8u, std::thread::hardware_concurrency()));
     // more than one foreign run per 256 bases: not nucleotide text, sent as it is
     if (pack2_parallel(seqs, L->tb1, L->h_pack.p, exc, std::max<size_t>(1024, L->tb1 / 256), pack_threads)) {
       if (L->h_exc.ensure(exc.size() + 1)) return kmcpg_fail(KMCPG_ENOMEM, "hipHostMalloc failed");
