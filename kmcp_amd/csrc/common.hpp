@@ -71,6 +71,8 @@ struct K1Args {
   int32_t* nk_adj;
   int32_t dedup_threshold;
   int32_t flags;         // experiments (KMCPG_K1_FLAGS): bit 0 = two-level window arg-min, bit 1 = fused adjacent-repeat filter
+  uint32_t* seg_list;    // ... the segments k1_seg_roll2 left to the byte kernel, and how many (launch_k1 places both behind seg_cnt[])
+  uint32_t* seg_nflag;
   int32_t seg_only_flagged;  // k1_seg_roll as the fallback of k1_seg_roll2: only the segments that kernel marked (seg_cnt == -1)
 };
 

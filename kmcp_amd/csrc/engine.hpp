@@ -248,9 +248,15 @@ void result_owner_shape(ResultOwner* o, uint32_t n_reads);
 // trusted: the list is what K2 + K3 made of this very batch with these very params (the library's own pipelines) — thresholds, -T, the
 // -f bound of short queries and the order of segments up to K3_WG_CAP hold by construction
 int finalize_grouped_into(const kmcpg_db* db, const kmcpg_pair* pairs, const uint64_t* read_offs, const int32_t* qkmers, const int32_t* qlen, uint32_t n_reads,
-                          const kmcpg_params& p, ResultOwner* o, uint32_t read_base, uint64_t match_base, uint64_t* kept_out, bool trusted = false);
+                          const kmcpg_params& p, ResultOwner* o, uint32_t read_base, uint64_t match_base, uint64_t* kept_out, bool trusted = false,
+                          int32_t bound_n = 0);
 int finalize_grouped_trusted(const kmcpg_db* db, const kmcpg_pair* pairs, const uint64_t* read_offs, const int32_t* qkmers, const int32_t* qlen, uint32_t n_reads,
-                             const kmcpg_params& p, kmcpg_result* out);
+                             const kmcpg_params& p, kmcpg_result* out, int32_t bound_n);
+// bound_n: what the kmcpg_query_device call(s) that produced the list actually did — every query of up to bound_n k-mers had the -f bound
+// applied on the device, whichever kernel form served it (0: no bound table in that call).  kmcpg_query_device leaves the value of its
+// call in tl_query_bound_n on the calling thread; host.cpp keeps it with the batch (Lane::bound_n) and hands it to the finalizer, which
+// takes a compact segment as final only for n <= bound_n — it does not look at the environment again.
+extern thread_local int32_t tl_query_bound_n;
 // KMCPG_FPR_BOUND (default on): K2 leaves out counts that cannot pass -f for queries of up to 512 (1024) k-mers (query.cpp fpr_bound)
 inline bool fpr_bound_enabled() {
   const char* e = getenv("KMCPG_FPR_BOUND");

@@ -529,6 +529,7 @@ extern "C" int kmcpg_finalize(const kmcpg_db* db, const kmcpg_hit* hits, uint64_
 // found out of order are sorted here.
 namespace kmcpg {
 thread_local bool tl_pairs_mode = false;
+thread_local int32_t tl_query_bound_n = 0;
 ResultOwner* result_owner_take() { return take_owner(); }
 void result_owner_give(ResultOwner* o) { give_owner(o); }
 
@@ -538,9 +539,9 @@ void result_owner_give(ResultOwner* o) { give_owner(o); }
 // kmcpg_search_batch cuts a large batch into pieces that follow each other through the GPU and lands them here one after the other,
 // so that the copy and the expansion of a piece overlap the kernels of the next (host.cpp).
 int finalize_grouped_into(const kmcpg_db* db, const kmcpg_pair* pairs, const uint64_t* read_offs, const int32_t* qkmers, const int32_t* qlen, uint32_t n_reads,
-                          const kmcpg_params& p, ResultOwner* o, uint32_t read_base, uint64_t match_base, uint64_t* kept_out, bool trusted) {
+                          const kmcpg_params& p, ResultOwner* o, uint32_t read_base, uint64_t match_base, uint64_t* kept_out, bool trusted, int32_t bound_n) {
   const uint64_t n_pairs = read_offs[n_reads];
-  const bool bound_on = trusted && fpr_bound_enabled();
+  const int final_n = trusted ? std::min<int>(bound_n, kFprBoundAlways) : 0;  // segments of queries up to this size are final as they stand
   if (n_pairs && !pairs) return kmcpg_fail(KMCPG_EINVAL, "null argument");
   if (read_offs[0] != 0) return kmcpg_fail(KMCPG_EINVAL, "read_offs[0] must be 0");
   if (read_offs[(size_t)n_reads + 1] != 0)
@@ -604,7 +605,9 @@ int finalize_grouped_into(const kmcpg_db* db, const kmcpg_pair* pairs, const uin
       bool host_sort = m > (uint64_t)K3_WG_CAP;
       // The library's own list of a short query, collected as pairs: every test below is a no-op on it (K2 applied -c, -t and the -f bound
       // with these params, K3 applied -T and the order) — the segment is final as it stands
-      if (as_pairs && bound_on && !host_sort && n > 0 && n <= kFprBoundAlways && !(p.top_n_scores > 0 && !p.do_not_sort)) {
+      // (final_n is what the query call reported for THIS batch: the device applied the bound table to every query of up to that many
+      // k-mers, plain or chunked form — not what the environment says now)
+      if (as_pairs && !host_sort && n > 0 && n <= final_n && !(p.top_n_scores > 0 && !p.do_not_sort)) {
         memcpy(pbase + pos, pairs + s0, (size_t)m * sizeof(kmcpg_pair));
         per_read[r] = m;
         pos += m;
@@ -762,11 +765,11 @@ void result_owner_shape(ResultOwner* o, uint32_t n_reads) {
 
 namespace kmcpg {
 int finalize_grouped_trusted(const kmcpg_db* db, const kmcpg_pair* pairs, const uint64_t* read_offs, const int32_t* qkmers, const int32_t* qlen, uint32_t n_reads,
-                             const kmcpg_params& p, kmcpg_result* out) {
+                             const kmcpg_params& p, kmcpg_result* out, int32_t bound_n) {
   std::unique_ptr<ResultOwner, OwnerReturn> o(take_owner());
   result_owner_shape(o.get(), n_reads);
   uint64_t kept = 0;
-  if (int rc = finalize_grouped_into(db, pairs, read_offs, qkmers, qlen, n_reads, p, o.get(), 0, 0, &kept, true)) return rc;
+  if (int rc = finalize_grouped_into(db, pairs, read_offs, qkmers, qlen, n_reads, p, o.get(), 0, 0, &kept, true, bound_n)) return rc;
   result_publish(o.release(), n_reads, p.k > 0 ? p.k : db->info.k, out);
   return 0;
 }
@@ -792,6 +795,9 @@ void result_records_to_pairs(ResultOwner* o) {
   o->pairs.resize(n);
   for (size_t i = 0; i < n; i++) o->pairs[i] = kmcpg_pair{o->matches[i].col, (uint32_t)o->matches[i].mkmers};
   o->pairs_mode = true;
+  // the records are dead from here on: a compact result must not carry a 56-byte copy of every match along (nor hand a consumer
+  // records whose offsets mean pairs)
+  MatchVec().swap(o->matches);
 }
 }  // namespace kmcpg
 

@@ -86,6 +86,7 @@ struct Lane {
   DevBuf<ExcRun> d_exc;
   bool packed = false;
   uint32_t n_exc = 0;
+  int32_t bound_n = 0;   // the -f bound of the LAST kmcpg_query_device call for this batch covered queries of up to this many k-mers
   bool grouped = false;  // this batch went through K3: h_pairs / h_roffs hold its result, h_hits is not filled
   hipEvent_t k3_ev = nullptr, eager_ev = nullptr;  // K3 done on the kernel stream -> the eager copy of the pairs on the copy stream
   bool eager_aside = false;                        // ... when it was put there (pieces of a large kmcpg_search_batch call)
@@ -333,6 +334,7 @@ int enqueue_query(kmcpg_db* db, AsyncState* A, Lane* L, const kmcpg_params& p) {
   int rc = kmcpg_query_device(db, L->d_seqs.p, L->d_offs.p, L->paired ? L->d_seqs2.p : nullptr, L->paired ? L->d_offs2.p : nullptr, L->n, L->tb1 + L->tb2,
                               L->maxlen, &p, L->d_hits.p, L->d_hits.cap, L->d_cnt.p, L->d_qk.p, L->d_ql.p, st);
   if (rc) return rc;
+  L->bound_n = tl_query_bound_n;
   HIPCHK(hipMemcpyAsync(L->h_cnt.p, L->d_cnt.p, 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
   if (L->grouped) {  // K3 right behind K2 (an overflowing hit buffer makes both run again, collect())
     if (L->d_pairs.ensure(L->d_hits.cap) || L->d_roffs.ensure((size_t)L->n + 2) || L->h_roffs.ensure((size_t)L->n + 2)) return kmcpg_fail(KMCPG_ENOMEM, "hipMalloc failed");
@@ -671,7 +673,7 @@ int finish_raw(kmcpg_ticket* t, kmcpg_result* out) {
     int rc = collect(pt.shard, pt.shard->async, pt.lane, t->p, &n_hits);
     if (rc) return rc;
     if (pt.lane->grouped && t->n)
-      return finalize_grouped_trusted(t->db, pt.lane->h_pairs.p, pt.lane->h_roffs.p, pt.lane->h_qk.p, pt.lane->h_ql.p, t->n, t->p, out);
+      return finalize_grouped_trusted(t->db, pt.lane->h_pairs.p, pt.lane->h_roffs.p, pt.lane->h_qk.p, pt.lane->h_ql.p, t->n, t->p, out, pt.lane->bound_n);
     hits = pt.lane->h_hits.p;
   } else if (Exchange* x = t->db->exchange) {
     // the shards' lists meet on the first GPU (RCCL send/recv over xGMI, exactly the bytes each shard produced) and come to
@@ -713,7 +715,9 @@ int finish_raw(kmcpg_ticket* t, kmcpg_result* out) {
         return 0;
       });
       if (rc) return rc;
-      return finalize_grouped_trusted(t->db, L0->h_pairs.p, L0->h_roffs.p, L0->h_qk.p, L0->h_ql.p, t->n, t->p, out);
+      int32_t bound_n = INT32_MAX;  // every shard ran the same params on the same batch; the smallest cover is what holds for the merged list
+      for (auto& pt : t->parts) bound_n = std::min(bound_n, pt.lane->bound_n);
+      return finalize_grouped_trusted(t->db, L0->h_pairs.p, L0->h_roffs.p, L0->h_qk.p, L0->h_ql.p, t->n, t->p, out, bound_n);
     }
     if (L0->h_hits.ensure(n_hits + 1)) return kmcpg_fail(KMCPG_ENOMEM, "hipHostMalloc failed");
     int rc = exchange_gather(x, src, bytes, (uint8_t*)L0->h_hits.p);
@@ -1035,7 +1039,7 @@ static int search_batch_pieces(kmcpg_db* db, const uint8_t* seqs, const uint64_t
     const double tb = now();
     uint64_t kept = 0;
     if (r == 0)
-      r = finalize_grouped_into(db, q.lane->h_pairs.p, q.lane->h_roffs.p, q.lane->h_qk.p, q.lane->h_ql.p, q.cnt, p, o, q.lo, match_base, &kept, true);
+      r = finalize_grouped_into(db, q.lane->h_pairs.p, q.lane->h_roffs.p, q.lane->h_qk.p, q.lane->h_ql.p, q.cnt, p, o, q.lo, match_base, &kept, true, q.lane->bound_n);
     if (timing)
       fprintf(stderr, "piece %u: collect from %.2f to %.2f ms, expanded by %.2f ms (%llu hits, %llu kept)\n", next_finish, ta - t_begin, tb - t_begin, now() - t_begin,
               (unsigned long long)n_hits, (unsigned long long)kept);
@@ -1148,8 +1152,8 @@ extern "C" int kmcpg_search_batch(kmcpg_db* db, const uint8_t* seqs, const uint6
     result_records_to_pairs(a);
     result_records_to_pairs(const_cast<ResultOwner*>(b));
   }
-  a->matches.insert(a->matches.end(), b->matches.begin(), b->matches.end());
-  a->pairs.insert(a->pairs.end(), b->pairs.begin(), b->pairs.end());
+  if (a->pairs_mode) a->pairs.insert(a->pairs.end(), b->pairs.begin(), b->pairs.end());
+  else a->matches.insert(a->matches.end(), b->matches.begin(), b->matches.end());
   *out = part[0];
   out->n_reads = n_reads;
   out->qlen = a->qlen.data();

@@ -1127,8 +1127,12 @@ __global__ void __launch_bounds__(64 * ROLL_WAVES) k1_seg_roll(const K1Args a) {
     tab_out[tid] = nt_tab_out(sd, a.k);
     if (tid < 8) tab_in[tid] = nt_tab_in(sd, a.k);
   }
-  if (a.seg_only_flagged && a.seg_cnt[blockIdx.x] != -1) return;  // fallback pass behind k1_seg_roll2: uniform over the workgroup
-  const uint32_t r = blockIdx.x / a.segs_max, seg = blockIdx.x % a.segs_max;
+  // As the fallback pass behind k1_seg_roll2 (seg_only_flagged) the launch is a small fixed grid that walks the LIST of segments that
+  // kernel marked (a.seg_nflag entries of a.seg_list; none at all for a clean batch); alone, workgroup b takes segment b, once.
+  const uint32_t n_todo = a.seg_only_flagged ? *a.seg_nflag : gridDim.x;
+  for (uint32_t it = blockIdx.x; it < n_todo; it += gridDim.x) {
+  const uint32_t bid = a.seg_only_flagged ? a.seg_list[it] : it;
+  const uint32_t r = bid / a.segs_max, seg = bid % a.segs_max;
   const uint64_t o1 = a.offs[r];
   const int len = (int)(a.offs[r + 1] - o1);
   const int k = a.k;
@@ -1210,7 +1214,9 @@ __global__ void __launch_bounds__(64 * ROLL_WAVES) k1_seg_roll(const K1Args a) {
       walk([&](uint64_t h) { out[i++] = h; });
     }
   }
-  if (tid == 0) a.seg_cnt[blockIdx.x] = total;
+  if (tid == 0) a.seg_cnt[bid] = total;
+  __syncthreads();  // bases[] and s_cnt[] are free for the next segment of the list
+  }
 }
 
 // The same segments once more (round 5), on 2-BIT CODES.  k1_seg_roll above spends ~60 lane-operations per base, most of them on getting
@@ -1284,7 +1290,10 @@ __global__ void __launch_bounds__(64 * ROLL_WAVES) k1_seg_roll2(const K1Args a) 
   }
   __syncthreads();  // tables, codes, s_bad
   if (s_bad) {  // a byte that is not A/C/G/T: the byte kernel takes this segment
-    if (tid == 0) a.seg_cnt[blockIdx.x] = -1;
+    if (tid == 0) {  // (-1 never reaches k1_seg_pack: the byte kernel, launched right behind over this list, overwrites it)
+      a.seg_cnt[blockIdx.x] = -1;
+      a.seg_list[atomicAdd(a.seg_nflag, 1u)] = blockIdx.x;
+    }
     return;
   }
   const bool scaled = a.scaled != 0;
@@ -1376,7 +1385,7 @@ __global__ void __launch_bounds__(256) k1_seg_pack(const K1Args a) {
   const int* __restrict__ sc = a.seg_cnt + (size_t)r * a.segs_max;
   int dest = 0;
   for (uint32_t t = 0; t < seg; t++) dest += sc[t];
-  const int cnt = sc[seg];
+  const int cnt = sc[seg];  // >= 0: a segment k1_seg_roll2 marked -1 has been redone by the byte kernel before this launch
   const uint64_t* __restrict__ src = a.scratch + o1 + (uint64_t)seg * K1SEG;
   uint64_t* __restrict__ dst = a.hashes + o1 + dest;
   for (int i = threadIdx.x; i < cnt; i += blockDim.x) dst[i] = src[i];
@@ -1408,10 +1417,16 @@ bool launch_k1(const K1Args& a, uint32_t max_read_len, hipStream_t st) {
     // rolling hashes for every k the staging halo holds (flags bit 3 = 8: the prefix-XOR form, for A/B runs)
     // (flags bit 4 = 16: the byte kernel alone, for A/B runs)
     if (a.k <= 128 && !(a.flags & 8) && !(a.flags & 16)) {
-      hipLaunchKernelGGL(k1_seg_roll2, dim3(blocks), dim3(64 * ROLL_WAVES), 0, st, a);  // 2-bit codes; marks the segments it cannot take
+      // the list of segments the 2-bit kernel leaves to the byte kernel lives behind seg_cnt[] (run_kmers sizes it: 2 * blocks + 1 words)
       K1Args b = a;
+      b.seg_nflag = (uint32_t*)(a.seg_cnt + blocks);
+      b.seg_list = b.seg_nflag + 1;
+      (void)hipMemsetAsync(b.seg_nflag, 0, sizeof(uint32_t), st);
+      hipLaunchKernelGGL(k1_seg_roll2, dim3(blocks), dim3(64 * ROLL_WAVES), 0, st, b);  // 2-bit codes; lists the segments it cannot take
       b.seg_only_flagged = 1;
-      hipLaunchKernelGGL(k1_seg_roll, dim3(blocks), dim3(64 * ROLL_WAVES), 0, st, b);  // ... and the byte kernel does those
+      // ... and the byte kernel does those: a grid that fills the chip once (2 workgroups of 8 waves per CU) walks the list — nothing
+      // but the read of one counter for a clean batch, where a launch over all segments was up to 2^21 workgroups exiting at once
+      hipLaunchKernelGGL(k1_seg_roll, dim3(std::min(blocks, 512u)), dim3(64 * ROLL_WAVES), 0, st, b);
     } else if (a.k <= 128 && !(a.flags & 8)) hipLaunchKernelGGL(k1_seg_roll, dim3(blocks), dim3(64 * ROLL_WAVES), 0, st, a);
     else hipLaunchKernelGGL(k1_seg_hash, dim3(blocks), dim3(K1WG), 0, st, a);
     hipLaunchKernelGGL(k1_seg_pack, dim3(blocks), dim3(256), 0, st, a);

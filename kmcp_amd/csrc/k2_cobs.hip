@@ -595,7 +595,12 @@ __global__ void k_threshold_long(const K2Args a) {
       const uint32_t li = (uint32_t)(i / a.ncols_total);
       col = (uint32_t)(i % a.ncols_total);
       r = a.long_list[li];
-      pass = c >= count_threshold(a.nk[r], a.min_qcov, a.min_matched);
+      const int n = a.nk[r];
+      uint32_t cmin = count_threshold(n, a.min_qcov, a.min_matched);
+      // the -f bound as in the plain kernel's epilogue: a query that took the chunked form because KMCPG_SPLIT_MIN is small is still
+      // covered by the table (the host's trusted path for compact results relies on "n <= cmin_fpr_n => bound applied", whichever form ran)
+      if (a.cmin_fpr && n <= a.cmin_fpr_n) cmin = max(cmin, (uint32_t)a.cmin_fpr[n]);
+      pass = c >= cmin;
     }
     const uint64_t m = __ballot(pass);
     if (m == 0) continue;

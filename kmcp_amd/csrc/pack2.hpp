@@ -10,6 +10,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <atomic>
 #include <thread>
 #include <vector>
 
@@ -107,25 +108,37 @@ inline void pack2_range(const uint8_t* s, size_t i0, size_t i1, uint8_t* d, uint
 
 // n bases of s -> d[(n + 3) / 4] on up to `threads` threads; false (and nothing usable in d / exc) when more than max_runs
 // exception runs turn up — input that is not nucleotide text is better sent as it is
-inline bool pack2_parallel(const uint8_t* s, size_t n, uint8_t* d, std::vector<PackRun>& exc, size_t max_runs, unsigned threads) {
+// (*scanned, if given, receives the number of input bytes actually looked at: the host test of the give-up rule)
+inline bool pack2_parallel(const uint8_t* s, size_t n, uint8_t* d, std::vector<PackRun>& exc, size_t max_runs, unsigned threads, size_t* scanned = nullptr) {
   exc.clear();
   const size_t kMin = 4u << 20;
+  const size_t kSlice = 1u << 20;  // a multiple of 32 bases: the budget is looked at between slices
   const size_t T = std::max<size_t>(1, std::min<size_t>(threads, n / kMin));
+  // Input that is not nucleotide text (protein, binary) makes a run of almost every byte: nobody goes on once ONE share has used the
+  // whole budget — at most max_runs + one slice of runs per thread are ever held, and the rest of the batch is neither read nor written.
+  std::atomic<bool> abort{false};
+  std::atomic<size_t> seen{0};
+  auto range = [&](size_t a, size_t b, std::vector<PackRun>& out) {
+    for (size_t lo = a; lo < b && !abort.load(std::memory_order_relaxed); lo += kSlice) {
+      pack2_range(s, lo, std::min(b, lo + kSlice), d, 0, out);
+      seen.fetch_add(std::min(b, lo + kSlice) - lo, std::memory_order_relaxed);
+      if (out.size() > max_runs) abort.store(true, std::memory_order_relaxed);
+    }
+  };
   if (T == 1) {
-    pack2_range(s, 0, n, d, 0, exc);
-    return exc.size() <= max_runs;
+    range(0, n, exc);
+    if (scanned) *scanned = seen.load();
+    return !abort.load() && exc.size() <= max_runs;
   }
   std::vector<std::vector<PackRun>> part(T);
   auto lo_of = [&](size_t t) { return t >= T ? n : (n / T * t) & ~(size_t)31; };  // multiples of 32 bases = whole packed bytes
-  auto work = [&](size_t t) {
-    const size_t a = lo_of(t), b = lo_of(t + 1);
-    // give up early on one's own share: every thread may use max_runs before the total is looked at
-    pack2_range(s, a, b, d, 0, part[t]);
-  };
+  auto work = [&](size_t t) { range(lo_of(t), lo_of(t + 1), part[t]); };
   std::vector<std::thread> th;
   for (size_t t = 1; t < T; t++) th.emplace_back(work, t);
   work(0);
   for (auto& x : th) x.join();
+  if (scanned) *scanned = seen.load();
+  if (abort.load()) return false;
   size_t total = 0;
   for (auto& v : part) total += v.size();
   if (total > max_runs) return false;

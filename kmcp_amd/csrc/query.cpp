@@ -76,7 +76,7 @@ int run_kmers(kmcpg_db* db, kmcpg_db::Workspace& W, const uint8_t* d_seqs, const
   // whole genomes (single-end, plain or FracMinHash k-mers): segments of a read on their own workgroups
   const uint32_t segs = (max_read_len + (uint32_t)k1_segment_len() - 1) / (uint32_t)k1_segment_len();
   if (a.mode == 0 && !d_seqs2 && segs > 1 && d_scratch && (uint64_t)n_reads * segs <= (1ull << 21)) {  // one workgroup of 1024 threads per segment, < 2^32 threads per launch
-    if (W.w_seg_cnt.ensure((size_t)n_reads * segs)) return kmcpg_fail(KMCPG_ENOMEM, "hipMalloc failed");
+    if (W.w_seg_cnt.ensure(2 * (size_t)n_reads * segs + 1)) return kmcpg_fail(KMCPG_ENOMEM, "hipMalloc failed");  // counts + launch_k1's fallback list
     a.seg_cnt = W.w_seg_cnt.p;
     a.segs_max = segs;
   }
@@ -170,9 +170,13 @@ int ws_end(kmcpg_db::Workspace& W, hipStream_t st) {
 struct WsGuard {
   kmcpg_db::Workspace& W;
   hipStream_t st;
+  hipStream_t kst = nullptr;  // the k-mer kernels' own stream when they have one (KMCPG_K1_STREAM=1), else == st
   bool armed = true;
   ~WsGuard() {
-    if (armed && W.ev && hipEventRecord(W.ev, st) == hipSuccess) W.ev_valid = true;
+    if (!armed || !W.ev) return;
+    // work queued on kst must be covered too: st waits for it first, then the slot's event on st stands for both streams
+    if (kst != st && W.k1_ev && hipEventRecord(W.k1_ev, kst) == hipSuccess) (void)hipStreamWaitEvent(st, W.k1_ev, 0);
+    if (hipEventRecord(W.ev, st) == hipSuccess) W.ev_valid = true;
   }
   int finish() {  // the success path: errors of the record are reported
     armed = false;
@@ -258,7 +262,7 @@ extern "C" int kmcpg_kmers_device(kmcpg_db* db, const uint8_t* d_seqs, const uin
   hipStream_t st = (hipStream_t)stream;
   kmcpg_db::Workspace& W = db->ws[0];
   if (int rc0 = ws_begin(W, st)) return rc0;
-  WsGuard wsg{W, st};
+  WsGuard wsg{W, st, st};
   if (W.w_scratch.ensure(2 * total_bases + 2) || W.w_nk_raw.ensure(n_reads + 1) || W.w_nk1.ensure(n_reads + 1)) return kmcpg_fail(KMCPG_ENOMEM, "hipMalloc failed");
   DevBuf<int32_t> ql;
   if (ql.ensure(n_reads + 1)) return kmcpg_fail(KMCPG_ENOMEM, "hipMalloc failed");
@@ -315,7 +319,7 @@ extern "C" int kmcpg_query_device(kmcpg_db* db, const uint8_t* d_seqs, const uin
     HIPCHK(hipStreamWaitEvent(kst, W.in_ev, 0));
   }
   if (int rc0 = ws_begin(W, kst)) return rc0;
-  WsGuard wsg{W, st};
+  WsGuard wsg{W, st, kst};
   if (W.w_hashes.ensure(total_bases + 1) || W.w_nk_raw.ensure(n_reads + 1) || W.w_nk1.ensure(n_reads + 1)) return kmcpg_fail(KMCPG_ENOMEM, "hipMalloc failed");
   uint64_t ub = max_read_len >= (uint32_t)k_used ? (uint64_t)(max_read_len - k_used + 1) : 0;
   if (d_seqs2) ub *= 2;
@@ -414,7 +418,9 @@ extern "C" int kmcpg_query_device(kmcpg_db* db, const uint8_t* d_seqs, const uin
     HIPCHK(hipMemsetAsync(W.w_gathered.p, 0, (size_t)K2_GATHER_SLOTS * 16 * sizeof(uint64_t), st));
     a.gathered = (unsigned long long*)W.w_gathered.p;
   }
+  tl_query_bound_n = 0;
   if (int rcb = fpr_bound(db, p.max_fpr, max_short, st, &a.cmin_fpr, &a.cmin_fpr_n)) return rcb;
+  tl_query_bound_n = a.cmin_fpr ? a.cmin_fpr_n : 0;  // both kernel forms apply the table to every query of up to this many k-mers
   a.hits = d_hits;
   a.hit_cap = hit_cap;
   a.counter = (unsigned long long*)d_counters;
@@ -560,7 +566,7 @@ extern "C" int kmcpg_plant_reads_device(kmcpg_db* db, const uint8_t* d_seqs, con
   hipStream_t st = (hipStream_t)stream;
   kmcpg_db::Workspace& W = db->ws[0];
   if (int rc0 = ws_begin(W, st)) return rc0;
-  WsGuard wsg{W, st};
+  WsGuard wsg{W, st, st};
   if (W.w_hashes.ensure(total_bases + 1) || W.w_nk_raw.ensure(n_reads + 1) || W.w_nk1.ensure(n_reads + 1)) return kmcpg_fail(KMCPG_ENOMEM, "hipMalloc failed");
   DevBuf<int32_t> tmp;
   if (tmp.ensure(2 * (size_t)n_reads + 2)) return kmcpg_fail(KMCPG_ENOMEM, "hipMalloc failed");

@@ -88,6 +88,22 @@ int main() {
       }
     }
   }
+  {  // ... and it gives up EARLY: 48 MB of protein-like text, every thread stops after the slice in which its budget ran out
+    const size_t n = 48u << 20;
+    std::vector<uint8_t> x(n);
+    for (size_t j = 0; j < n; j++) x[j] = (uint8_t)"ACDEFGHIKLMNPQRSTVWY"[rng() % 20];
+    std::vector<uint8_t> d((n + 3) / 4 + 8);
+    std::vector<PackRun> exc;
+    size_t scanned = 0;
+    if (pack2_parallel(x.data(), n, d.data(), exc, n / 256, 4, &scanned)) {
+      printf("FAIL protein text accepted\n");
+      return 1;
+    }
+    if (scanned > (8u << 20)) {  // 4 threads x (one 1-MiB slice to use up 196 608 runs, + the slice in flight when the flag went up)
+      printf("FAIL gave up only after %zu of %zu bytes\n", scanned, n);
+      return 1;
+    }
+  }
   printf("ok %zu cases %zu runs\n", cases, runs_total);
   return 0;
 }

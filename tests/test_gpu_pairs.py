@@ -116,3 +116,33 @@ def test_pairs_on_the_paths_that_collect_records(oracle_lib, tmp_path):
         # empty batch
         e = db.search_pairs([], params=p)
         assert len(e) == 0 and len(e.pairs) == 0
+
+
+def test_pairs_when_short_queries_take_the_chunked_kernel(family, oracle_lib, monkeypatch):
+    """KMCPG_SPLIT_MIN below the read length sends 130-k-mer queries through k2_cobs<SPLIT> + k_threshold_long.  The compact path takes a
+    short query's segment as final only when the query call reported that the -f bound covered it (Lane::bound_n) - and the chunked
+    form applies the bound too: with -t just above the database's FPR the bound is the stricter threshold, so a path that skipped it
+    would print matches that fail -f (finalize.cpp trusted path)."""
+    from kmcp_amd import Database, default_params
+    db_dir, reads = family
+    O = oracle_lib
+    odb = O.OracleDB(db_dir)
+    try:
+        with Database.open(db_dir) as db:
+            fpr = db.info.fpr
+            for kw in (dict(min_qcov=fpr + 0.02, min_matched=1), dict(min_qcov=fpr + 0.02, min_matched=1, max_fpr=1e-6), dict()):
+                p = default_params(**kw)
+                monkeypatch.delenv("KMCPG_SPLIT_MIN", raising=False)
+                want = db.search(reads[:400], params=p)
+                monkeypatch.setenv("KMCPG_SPLIT_MIN", "50")
+                rec = db.search(reads[:400], params=p)
+                pr = db.search_pairs(reads[:400], params=p)
+                assert rec.matches.tobytes() == want.matches.tobytes()
+                _same(db, rec, pr)
+                # ... and with the bound switched off for the call, the host half applies -f itself
+                monkeypatch.setenv("KMCPG_FPR_BOUND", "0")
+                _same(db, want, db.search_pairs(reads[:400], params=p))
+                monkeypatch.delenv("KMCPG_FPR_BOUND")
+            synth.assert_parity(odb, want, reads[:100])
+    finally:
+        odb.close()
