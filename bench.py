@@ -829,6 +829,8 @@ def run_workload(name, ctx, steps, warmup, batch_reads=0, cpu_baseline=True, cpu
         hi_col = blocks[-1][2] + blocks[-1][1]
         g = hh[(hh[:, 0] < R) & (hh[:, 1] < hi_col)]
         g = g[np.lexsort((g[:, 1], g[:, 0]))]
+        if os.environ.get("KMCP_BENCH_FAULT") == "parity" and len(g):  # test hook (tests/test_gpu_multirank.py): what a broken exchange would look like
+            g = g[:-1]
         parity = bool(np.array_equal(g, ohits.astype(np.int64))) and bool(np.array_equal(oqk[:R], qk[:R]))
         frac_blocks = S / wl["n_blocks"]
         sample_txt = (f"{R} queries ({int(offs_h[R])} bases) x {S} of {wl['n_blocks']} blocks ({sum(b_[3].nbytes for b_ in blocks)/1e9:.1f} GB of index rows "
@@ -855,7 +857,13 @@ def run_workload(name, ctx, steps, warmup, batch_reads=0, cpu_baseline=True, cpu
                                   "note": "rank 0 ran the CPU oracle on rows fetched from every rank's shard and compared the merged multi-GPU hit list of the sample with it"}
         odb.close()
         del blocks
-        assert parity, "GPU hits differ from the CPU oracle on the sample"
+        if not parity:
+            # The line must still come out: a first run on hardware this code has never seen (N > 1) has to show WHAT broke, not a
+            # traceback in one rank's stderr and seven ranks waiting at a barrier.  main() prints the line and exits nonzero.
+            dg, do = {tuple(x) for x in g.tolist()}, {tuple(x) for x in ohits.astype(np.int64).tolist()}
+            out["parity_failure"] = {"gpu_only": len(dg - do), "oracle_only": len(do - dg), "qkmers_differ": int(np.count_nonzero(oqk[:R] != qk[:R])),
+                                     "first_gpu_only": sorted(dg - do)[:4], "first_oracle_only": sorted(do - dg)[:4]}
+            print(f"bench.py: PARITY FAILURE on the sample: {out['parity_failure']}", file=sys.stderr)
     if coll:
         dist.barrier()
 
@@ -936,6 +944,9 @@ def compact_line(out, detail_path="bench_detail.json"):
                          "k2_ms_min_max": [_num(x) for x in rk.get("k2_ms_min_max", [])]}
     if out.get("parity_at_n"):
         line["parity_at_n"] = {"parity_on_sample": out["parity_at_n"].get("parity_on_sample"), "sample_hits": out["parity_at_n"].get("sample_hits")}
+    if out.get("parity_failure"):  # (the process exits with status 3 after printing this line)
+        line["parity_ok"] = False
+        line["parity_failure"] = {k: out["parity_failure"].get(k) for k in ("gpu_only", "oracle_only", "qkmers_differ")}
     if out.get("secondary"):
         line["secondary"] = {nm: _secondary_numbers(o) for nm, o in out["secondary"].items()}
     line["detail"] = detail_path
@@ -1042,7 +1053,7 @@ def main():
     if ctx.world == 1 and args.workload == "gtdb" and not args.no_secondary and not args.batch_reads:
         sec = run_workload("config1", ctx, min(max(args.steps, 5), 20), 2, cpu_baseline=not args.no_cpu_baseline, cpu_target_s=3.0)
         keys = ("value", "value_host_to_host", "unit", "ms_per_step", "config", "roofline", "planted_recall", "sanity_batch", "device_only", "host_boundary",
-                "cpu_baseline", "hits_per_step", "matches_per_step", "setup_s")
+                "cpu_baseline", "hits_per_step", "matches_per_step", "setup_s", "parity_failure")
         out["secondary"] = {"config1": {k: sec[k] for k in keys if k in sec}}
         # the same index with every block on its own (what a database with a different NumSigs per block gets): KMCPG_FUSE=0
         os.environ["KMCPG_FUSE"] = "0"
@@ -1077,6 +1088,9 @@ def main():
     if ctx.rank == 0:
         write_detail(out)
         os.write(1, (compact_line(_finite(out)) + "\n").encode())
+        failed = bool(out.get("parity_failure")) or any(bool(o.get("parity_failure")) for o in (out.get("secondary") or {}).values())
+        if failed:
+            sys.exit(3)
 
 
 if __name__ == "__main__":

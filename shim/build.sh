@@ -7,9 +7,11 @@
 # What it does:  1. builds libkmcpgpu.so (make in kmcp_amd/csrc; needs hipcc) unless it is there already;
 #                2. copies shim/kmcp_gpu.go + shim/kmcp_gpu_test.go into <kmcp>/kmcp/cmd/ and include/kmcp_gpu.h into <kmcp>/include/
 #                   (the layout the `#cgo CFLAGS: -I${SRCDIR}/../../include` line of kmcp_gpu.go assumes);
-#                3. runs `go vet` and `go test -tags kmcpgpu -run TestGPUSearchFixture ./kmcp/cmd/` against shim/testdata (the TSV the
-#                   reference prints for the fixture reads; the same fixture is checked against the CPU oracle and against
-#                   kmcp-search on the GPU by this repository's own tests);
+#                3. runs `go vet` and `go test -tags kmcpgpu -run TestGPUSearchFixture ./kmcp/cmd/` against shim/testdata (expected.tsv there was
+#                   printed by this repository's CPU oracle — oracle/kmcp_oracle.c, the restatement of the reference's algorithm pinned
+#                   by the reference's demo tables — NOT by the Go reference, which could not be built where the fixture was made:
+#                   tests/golden/make_shim_fixture.py; run `kmcp search` on shim/testdata yourself to close that loop.  The same
+#                   fixture is checked against kmcp-search on the GPU by this repository's own tests);
 #                4. builds the kmcp binary with the tag (the wiring of NewGPUSearchEngine into search.go:400 is shown in
 #                   kmcp_gpu.go and INTEGRATION.md; without it the binary simply carries the binding).
 # There is no Go toolchain in the image this repository was built in: this script and the two .go files have never been run there.

@@ -133,6 +133,39 @@ def test_cli_single_end_gz_and_flags(oracle_lib, tmp_path):
     odb.close()
 
 
+def test_cli_over_every_visible_gpu(oracle_lib, tmp_path):
+    """`kmcp-search --gpus N` when the box shows N >= 2 GPUs: the index blocks partitioned over the devices inside one process, the
+    hit lists gathered over RCCL (announced in the log), the TSV byte-identical to the oracle's and the log's checksum equal to the
+    one-GPU run's.  Skipped, with the reason, on a one-GPU box (there `--gpu-ids 0,0` and KMCPG_RCCL=force cover the code paths)."""
+    import re
+    import torch
+    n_dev = min(torch.cuda.device_count(), 8)
+    if n_dev < 2:
+        pytest.skip(f"{torch.cuda.device_count()} GPU visible: --gpus N needs N devices")
+    O = oracle_lib
+    genomes = synth.random_genomes(40, 12000, seed=45)
+    db_dir = synth.make_db(tmp_path / "db", genomes, k=21, n_chunks=2, overlap=150, threads=8)
+    db_root = os.path.dirname(db_dir)
+    reads = synth.sample_reads(genomes, 3000, 150, sub_rate=0.01, seed=46, frac_random=0.15)
+    ids = [f"read{i}" for i in range(len(reads))]
+    fq = str(tmp_path / "reads.fq")
+    write_fastq(fq, ids, reads)
+    odb = O.OracleDB(db_dir)
+    want, trailer = oracle_tsv(O, odb, ids, reads)
+    odb.close()
+    sums = set()
+    for extra in (["--gpus", str(n_dev)], ["--gpus", str(n_dev), "--gpu-batch", "500"], ["--gpus", "2"], []):
+        out = str(tmp_path / "o.tsv")
+        r = subprocess.run([CLI, "-d", db_root, fq, "-o", out] + extra, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr
+        if extra:
+            n = int(extra[1])
+            assert f"exchange of the hit lists: RCCL gather over {n} device(s)" in r.stderr, r.stderr
+        compare(open(out).read().split("\n"), want, trailer)
+        sums.add(re.search(r"matches: (\d+), checksum ([0-9a-f]{16})", r.stderr).groups())
+    assert len(sums) == 1 and int(next(iter(sums))[0]) == len(want), sums
+
+
 def test_cli_paired_end_and_whole_file(oracle_lib, tmp_path):
     O = oracle_lib
     genomes = synth.random_genomes(10, 20000, seed=42)

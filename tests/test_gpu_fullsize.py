@@ -5,6 +5,11 @@ through size-independent properties, plus an oracle check on rows read back from
   * shard invariance: the union of the hit lists of the two halves of the index == the hit list of the whole index
     (this is also the multi-GPU merge, exercised here with two handles on one GPU);
   * oracle on a sample: for a few reads the 130 x 32 rows they touch are copied back and counted by the oracle.
+
+Two layouts of the same 58 GB: every block with the same NumSigs (the 32 blocks are laid side by side and served as ONE 59 904-byte
+row: `setup`), and every block with a NumSigs of its own (`sigs_step=64`: 32 groups of one block, 1872-byte rows, what a real
+database has and what bench.py's `gtdb` workload measures: `setup_distinct`) - a different slot / tile decomposition of the same
+kernel, each with its own oracle check.
 """
 import os
 
@@ -17,17 +22,19 @@ N_BLOCKS, COLS, NUM_SIGS, KMERS = 32, 14976, 968700, 345510
 B, L = 8192, 150
 
 
-@pytest.fixture(scope="module")
-def setup():
+SIGS_STEP = 64  # bench.py WORKLOADS["gtdb"]["sigs_step"]
+
+
+def _build(sigs_step, with_halves, need_bytes):
     import torch
     from kmcp_amd import Database, default_params, lib
     free_b, _ = torch.cuda.mem_get_info(0)
-    if free_b < 130e9:
-        pytest.skip("needs 130 GB of free HBM")
+    if free_b < need_bytes:
+        pytest.skip(f"needs {need_bytes / 1e9:.0f} GB of free HBM")
     dev = torch.device("cuda:0")
-    spec = lib.SynthSpec(k=21, num_hashes=1, fpr=0.3, n_blocks=N_BLOCKS, cols_per_block=COLS, num_sigs=NUM_SIGS, kmers_per_col=KMERS, seed=7)
+    spec = lib.SynthSpec(k=21, num_hashes=1, fpr=0.3, n_blocks=N_BLOCKS, cols_per_block=COLS, num_sigs=NUM_SIGS, kmers_per_col=KMERS, seed=7, sigs_step=sigs_step)
     whole = Database.open_synthetic(spec, device=0)
-    halves = [Database.open_synthetic(spec, device=0, shard_rank=r, shard_count=2) for r in range(2)]
+    halves = [Database.open_synthetic(spec, device=0, shard_rank=r, shard_count=2) for r in range(2)] if with_halves else []
     g = torch.Generator(device=dev)
     g.manual_seed(99)
     acgt = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=dev)
@@ -37,9 +44,24 @@ def setup():
     offs = (torch.arange(B + 1, device=dev, dtype=torch.int64) * L).contiguous()
     for db in [whole] + halves:  # the same generator + the same plants => identical bit matrices
         db.plant_reads_device(reads.data_ptr(), offs.data_ptr(), B, B * L, L, cols.data_ptr())
-    yield dict(torch=torch, dev=dev, whole=whole, halves=halves, reads=reads, offs=offs, cols=cols.cpu().numpy(), params=default_params(), lib=lib)
-    for db in [whole] + halves:
+    return dict(torch=torch, dev=dev, whole=whole, halves=halves, reads=reads, offs=offs, cols=cols.cpu().numpy(), params=default_params(), lib=lib,
+                sigs_step=sigs_step)
+
+
+@pytest.fixture(scope="module")
+def setup():
+    s = _build(0, True, 130e9)
+    yield s
+    for db in [s["whole"]] + s["halves"]:
         db.close()
+
+
+@pytest.fixture(scope="module")
+def setup_distinct():
+    """the layout bench.py measures: block b has NUM_SIGS + 64 b rows, so no two blocks can share a gather"""
+    s = _build(SIGS_STEP, False, 70e9)
+    yield s
+    s["whole"].close()
 
 
 def _query(s, db):
@@ -65,7 +87,7 @@ def test_info_is_gtdb_scale(setup):
     assert setup["halves"][0].info.n_blocks_local == 16 and setup["halves"][1].info.n_blocks_local == 16
 
 
-def test_planted_fragments_have_no_false_negatives(setup):
+def _check_planted(setup):
     h, qk, ql = _query(setup, setup["whole"])
     assert (qk == 130).all() and (ql == 150).all()
     got = {(int(r), int(c)): int(n) for r, c, n in h}
@@ -75,6 +97,17 @@ def test_planted_fragments_have_no_false_negatives(setup):
     # chance hits: P(Bin(130, 0.3) >= 72) ~ 1e-9 per (read, column) x 3.9e9 pairs => a handful, all barely above 72
     chance = [n for (r, c), n in got.items() if r >= B // 2 or c != int(cols[r])]
     assert len(chance) < 60 and all(72 <= n < 85 for n in chance)
+
+
+def test_planted_fragments_have_no_false_negatives(setup):
+    _check_planted(setup)
+
+
+def test_planted_fragments_have_no_false_negatives_distinct_numsigs(setup_distinct):
+    i = setup_distinct["whole"].info
+    assert i.n_blocks == 32 and i.matrix_bytes == sum((NUM_SIGS + SIGS_STEP * b) * 1872 for b in range(N_BLOCKS))
+    assert [setup_distinct["whole"].block_info(b)["num_sigs"] for b in (0, 1, 31)] == [NUM_SIGS, NUM_SIGS + SIGS_STEP, NUM_SIGS + 31 * SIGS_STEP]
+    _check_planted(setup_distinct)
 
 
 def test_shard_union_equals_whole(setup):
@@ -96,6 +129,15 @@ def test_shard_union_equals_whole(setup):
 
 def test_oracle_on_rows_read_back(setup, oracle_lib):
     """Counts of 6 reads recomputed by the oracle from the very rows resident in HBM (130 x 32 rows each)."""
+    _check_rows_read_back(setup, oracle_lib)
+
+
+def test_oracle_on_rows_read_back_distinct_numsigs(setup_distinct, oracle_lib):
+    """... and on the benchmarked layout: 32 different NumSigs, each block's rows addressed with that block's own modulus."""
+    _check_rows_read_back(setup_distinct, oracle_lib)
+
+
+def _check_rows_read_back(setup, oracle_lib):
     O = oracle_lib
     db = setup["whole"]
     h, qk, _ = _query(setup, db)
@@ -106,7 +148,7 @@ def test_oracle_on_rows_read_back(setup, oracle_lib):
         assert len(km) == qk[r] == 130
         want = []
         for b in range(N_BLOCKS):
-            rows = db.read_rows(b, km % np.uint64(NUM_SIGS))          # [130, 1872] bytes
+            rows = db.read_rows(b, km % np.uint64(NUM_SIGS + setup["sigs_step"] * b))  # [130, 1872] bytes; loc = h % NumSigs of THIS block (:6811-6816)
             bits = np.unpackbits(rows, axis=1)[:, :COLS]               # bit 7 of byte c/8 = column c
             cnt = bits.sum(axis=0)
             for c in np.nonzero(cnt >= 72)[0]:                         # float64(c) > 130*0.55 = 71.5

@@ -113,6 +113,57 @@ def test_bench_two_ranks_hit_list_equals_the_cpu_oracle():
     assert j2["sanity_batch"] == j1["sanity_batch"]
 
 
+def test_bench_eight_ranks_dry_run():
+    """`python bench.py --gpus 8` end to end before the driver's scaling run does it for real: eight ranks (all on GPU 0 over gloo
+    when the box has fewer than eight GPUs, one per GPU over nccl otherwise), four blocks of the GTDB-scale index each, ragged gather
+    sizes, K3 on rank 0 over eight hit lists, the merged list checked against the CPU oracle over rows fetched from every rank
+    (`parity_at_n`), and the same order-independent checksum as the one-rank run of the same batches."""
+    import torch
+    free_b, _ = torch.cuda.mem_get_info(0)
+    n_dev = torch.cuda.device_count()
+    if n_dev < 8 and free_b < 80e9:
+        pytest.skip("needs 80 GB of free HBM for the 58 GB index + eight ranks' workspaces on one GPU")
+    env, _ = _env("KMCP_BENCH_SAME_GPU")
+    multi = n_dev >= 8
+    if not multi:
+        env["KMCP_BENCH_SAME_GPU"] = "1"
+    args = ["--batch-reads", "65536", "--steps", "2", "--warmup", "1"]
+    eight = subprocess.run([sys.executable, "bench.py", "--gpus", "8"] + args, capture_output=True, text=True, timeout=1500, env=env, cwd=ROOT)
+    if eight.returncode != 0:
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(ROOT, "gpurun_out", "eight_ranks_failure.txt"), "w") as fh:
+            fh.write(eight.stdout + "\n" + eight.stderr)
+    assert eight.returncode == 0, (eight.stdout[-2000:], eight.stderr[-4000:])
+    j8 = _bench_line(eight.stdout)
+    assert j8["n_gpus"] == 8 and j8["scaling"] == "strong" and j8["config"]["parallelism"] == "block-shard x8"
+    assert j8["ranks"]["world_size"] == 8 and j8["ranks"]["ranks_reporting"] == list(range(8))
+    assert j8["ranks"]["backend"] == ("nccl" if multi else "gloo")
+    assert j8["parity_at_n"]["parity_on_sample"] is True and j8["parity_at_n"]["sample_hits"] > 100 and "parity_ok" not in j8
+    assert abs(j8["config"]["index_bytes_this_rank"] * 8 - j8["config"]["index_bytes"]) < 0.02 * j8["config"]["index_bytes"]
+    assert j8["planted_recall"] > 0.99 and j8["value"] > 0
+    one = subprocess.run([sys.executable, "bench.py", "--gpus", "1", "--no-cpu-baseline", "--no-secondary", "--no-extras"] + args, capture_output=True, text=True,
+                         timeout=900, env={k: v for k, v in env.items() if k != "KMCP_BENCH_SAME_GPU"}, cwd=ROOT)
+    assert one.returncode == 0, one.stderr[-3000:]
+    j1 = _bench_line(one.stdout)
+    assert j8["sanity_batch"] == j1["sanity_batch"] and j1["sanity_batch"]["hits"] > 10000
+    assert j8["hits_per_step"] == j1["hits_per_step"] and j8["matches_per_step"] == j1["matches_per_step"]
+
+
+def test_bench_reports_a_parity_failure_on_the_line_and_in_the_exit_status():
+    """If the merged multi-GPU hit list ever differs from the oracle, the run must not die in a traceback with the other ranks at a
+    barrier: the line comes out with `parity_ok: false` + what differed, and the exit status is 3 (KMCP_BENCH_FAULT=parity drops
+    one GPU hit of the sample before the comparison)."""
+    env, _ = _env("KMCP_BENCH_SAME_GPU")
+    env["KMCP_BENCH_FAULT"] = "parity"
+    args = ["--steps", "2", "--warmup", "1", "--workload", "config1", "--batch-reads", "32768", "--no-secondary", "--no-extras"]
+    two = subprocess.run([sys.executable, "bench.py", "--gpus", "2"] + args, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert two.returncode != 0, two.stdout[-2000:]
+    j2 = _bench_line(two.stdout)
+    assert j2["parity_ok"] is False and j2["parity_at_n"]["parity_on_sample"] is False
+    assert j2["parity_failure"] == {"gpu_only": 0, "oracle_only": 1, "qkmers_differ": 0}
+    assert j2["value"] > 0 and j2["ranks"]["ranks_reporting"] == [0, 1]
+
+
 def test_sharded_searcher_overflow_loop(oracle_lib, tmp_path):
     """Hundreds of chance hits per read: the per-rank hit buffers (8 per read) overflow on every rank; the ranks agree on the
     largest count with an all-reduce and rerun (kmcp_amd/dist.py)."""

@@ -327,6 +327,60 @@ def test_rccl_exchange_of_the_in_process_handle(G, oracle_lib, tmp_path, monkeyp
         odb.close()
 
 
+def test_in_process_handle_over_every_visible_gpu(G, oracle_lib, tmp_path):
+    """The first time this suite meets a box with two or more GPUs, kmcpg_open_devices runs for real: one shard per device, one
+    RCCL communicator per device (ncclCommInitAll), the shards' hit lists gathered on the first GPU with grouped send/recv over
+    xGMI (exchange.cpp) — the reference's concatenation of its per-block workers' replies (util-db-search.go:939-964).  It must say
+    so, match the oracle (single-end; paired-end with --try-se, whose retries go through the exchange again) and keep four
+    batches in flight from two waiter threads.  On a one-GPU box this is skipped, with the reason."""
+    import threading
+    import torch
+    n_dev = torch.cuda.device_count()
+    if n_dev < 2:
+        pytest.skip(f"{n_dev} GPU visible: the RCCL exchange between devices needs two (its one-rank form is test_rccl_exchange_of_the_in_process_handle)")
+    n_dev = min(n_dev, 8)
+    O = oracle_lib
+    genomes = synth.random_genomes(40, 10000, seed=86)
+    db_dir = synth.make_db(tmp_path, genomes, k=21, n_chunks=2, overlap=150, threads=8)  # 80 columns -> 8+ blocks: every device gets one
+    r1 = synth.sample_reads(genomes, 2500, 150, seed=87, frac_random=0.05)
+    r2 = synth.sample_reads(genomes, 2500, 150, seed=88, frac_random=0.5)
+    odb = O.OracleDB(db_dir)
+    try:
+        with G["Database"].open_devices(db_dir, list(range(n_dev))) as db:
+            assert db.exchange_info() == f"RCCL gather over {n_dev} device(s)", db.exchange_info()
+            assert db.info.n_blocks_local == db.info.n_blocks >= n_dev
+            res = db.search(r1, params=G["default_params"]())
+            assert synth.assert_parity(odb, res, r1) > 1500
+            res = db.search(r1, r2, params=G["default_params"](try_se=1))
+            assert synth.assert_parity(odb, res, r1, r2, O.default_params(try_se=1)) > 500
+            seqs, offs = G["lib"].pack_reads(r1)
+            ref = db.search_packed(seqs, offs, params=G["default_params"]())
+            out, err = {}, []
+
+            def pump(t):
+                try:
+                    tk = [db.submit(seqs, offs, params=G["default_params"]()) for _ in range(2)]
+                    out[t] = [db.wait(x) for x in tk]
+                except Exception as e:  # noqa: BLE001 - reported by the main thread
+                    err.append(e)
+            th = [threading.Thread(target=pump, args=(t,)) for t in range(2)]
+            [x.start() for x in th]
+            [x.join() for x in th]
+            assert not err, err
+            for t in range(2):
+                for r in out[t]:
+                    assert np.array_equal(r.offs, ref.offs) and np.array_equal(r.matches, ref.matches)
+            # compact results over the exchange (K3 on the gathering GPU over the concatenated lists)
+            pr = db.search_pairs(r1, params=G["default_params"]())
+            assert np.array_equal(pr.offs, ref.offs) and np.array_equal(pr.pairs["col"], ref.matches["col"]) and np.array_equal(pr.pairs["count"], ref.matches["mkmers"])
+        # the same database on one device: identical records (the merged list is the one-GPU list)
+        with G["Database"].open(db_dir, device=0) as db1:
+            one = db1.search_packed(seqs, offs, params=G["default_params"]())
+            assert np.array_equal(one.offs, ref.offs) and np.array_equal(one.matches, ref.matches)
+    finally:
+        odb.close()
+
+
 @pytest.mark.parametrize("split_min", ["50", "3000"])
 def test_long_query_split_path(G, oracle_lib, tmp_path, monkeypatch, split_min):
     """The chunked long-query form of the COBS kernel (whole genomes): forced onto ordinary reads with KMCPG_SPLIT_MIN so
