@@ -873,6 +873,177 @@ def run_workload(name, ctx, steps, warmup, batch_reads=0, cpu_baseline=True, cpu
     return out
 
 
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# "report also end-to-end incl. FASTQ parse + TSV write" (reference: search.go:793-1000 reader, :448-588 writer).
+# BASELINE configs[1] as a database ON DISK and 10 M reads as a FASTQ FILE, searched by the kmcp-search binary (C++ host above the
+# C ABI: parallel FASTQ reader, kmcpg_search_batch_pairs, parallel row formatter) into a TSV file and into /dev/null; wall clock of
+# the whole process (exec to exit: HIP start-up and the upload of the index included).  A prefix of the TSV is byte-compared with the
+# rows the CPU oracle prints for the same reads.
+# ---------------------------------------------------------------------------------------------------------------------------------
+def _pick_workdir(need_bytes):
+    import shutil
+    import tempfile
+    for d in ("/dev/shm", tempfile.gettempdir(), ROOT):
+        try:
+            if shutil.disk_usage(d).free > 1.2 * need_bytes:
+                return tempfile.mkdtemp(prefix="kmcp_cli_e2e_", dir=d)
+        except OSError:
+            continue
+    return None
+
+
+def _write_fastq(path, reads, first_id):
+    """reads: uint8 [n, L] -> four-line FASTQ records `@r<9 digits>` / bases / `+` / quality 'I' x L, appended to `path`"""
+    n, L = reads.shape
+    rec = np.empty((n, 11 + L + 3 + L + 1), dtype=np.uint8)
+    rec[:, 0] = ord("@")
+    rec[:, 1] = ord("r")
+    ids = np.arange(first_id, first_id + n, dtype=np.int64)
+    for d in range(9):
+        rec[:, 2 + d] = (ids // 10 ** (8 - d)) % 10 + ord("0")
+    rec[:, 11] = ord("\n")
+    rec[:, 12:12 + L] = reads
+    rec[:, 12 + L:15 + L] = np.frombuffer(b"\n+\n", dtype=np.uint8)
+    rec[:, 15 + L:15 + 2 * L] = ord("I")
+    rec[:, 15 + 2 * L] = ord("\n")
+    with open(path, "ab") as fh:
+        fh.write(rec.tobytes())
+
+
+def run_cli_end_to_end(ctx, n_reads=10_000_000, check_reads=100_000, check_budget_s=25.0):
+    import re
+    import shutil
+    import subprocess
+    from concurrent.futures import ThreadPoolExecutor
+    from kmcp_amd import Database, lib
+    cli = os.path.join(ROOT, "kmcp_amd", "kmcp-search")
+    if not os.path.exists(cli):
+        return {"skipped": "kmcp_amd/kmcp-search is not built"}
+    wl = dict(WORKLOADS["config1"])
+    L = READ_LEN
+    need = n_reads * (15 + 2 * L + 11 + 140) + 2.0e9
+    work = _pick_workdir(need)
+    if work is None:
+        return {"skipped": f"no directory with {need/1e9:.1f} GB free"}
+    out = {"workdir": os.path.dirname(work), "reads": n_reads}
+    try:
+        t0 = time.time()
+        spec = lib.SynthSpec(k=wl["k"], num_hashes=wl["num_hashes"], fpr=wl["fpr"], n_blocks=wl["n_blocks"], cols_per_block=wl["cols_per_block"],
+                             num_sigs=wl["num_sigs"], kmers_per_col=wl["kmers_per_col"], seed=42, sigs_step=wl.get("sigs_step", 0))
+        db = Database.open_synthetic(spec, device=ctx.dev_index)
+        n_cols = int(db.info.n_cols)
+
+        def plant(frag, offs, n, total, maxlen, cols):
+            db.plant_reads_device(frag.data_ptr(), offs.data_ptr(), n, total, maxlen, cols.data_ptr())
+
+        fq = os.path.join(work, "reads.fq")
+        first_reads = None
+        done = 0
+        while done < n_reads:  # 90 % of the reads are mutated, randomly reverse-complemented fragments planted into a random column
+            nb = min(1 << 20, n_reads - done)
+            bt = make_batch(ctx.dev, wl, nb, n_cols, 7000 + done // (1 << 20), plant)
+            h = bt.reads.cpu().numpy().reshape(nb, L)
+            if first_reads is None:
+                first_reads = h[:check_reads].copy()
+            _write_fastq(fq, h, done)
+            done += nb
+            del bt, h
+        torch.cuda.synchronize()
+        db_root = os.path.join(work, "db")
+        db_dir = db.save(db_root)
+        db.close()
+        torch.cuda.empty_cache()
+        out["setup_s"] = time.time() - t0
+        out["fastq_bytes"] = os.path.getsize(fq)
+        out["db_bytes"] = sum(os.path.getsize(os.path.join(db_dir, f)) for f in os.listdir(db_dir))
+
+        tsv = os.path.join(work, "out.tsv")
+        env = dict(os.environ)
+        for k_ in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+            env.pop(k_, None)
+
+        def one(dest):
+            t1 = time.perf_counter()
+            r = subprocess.run([cli, "-d", db_root, fq, "-o", dest], capture_output=True, text=True, env=env, timeout=900)
+            wall = time.perf_counter() - t1
+            if r.returncode != 0:
+                raise RuntimeError("kmcp-search failed: " + r.stderr[-2000:])
+            m = re.search(r"pipeline: ([\d.]+) s in the GPU library, ([\d.]+) s formatting/writing, ([\d.]+) s waiting for the reader; reader: ([\d.]+) s parsing, "
+                          r"([\d.]+) s\s+blocked; ([\d.]+) s before the search started", r.stderr)
+            split = dict(zip(("gpu_library_s", "formatting_s", "waiting_for_reader_s", "reader_parsing_s", "reader_blocked_s", "before_search_s"),
+                             (float(x) for x in m.groups()))) if m else {}
+            mm = re.search(r"matches: (\d+), checksum ([0-9a-f]{16})", r.stderr)
+            return wall, split, (int(mm.group(1)), mm.group(2)) if mm else None
+
+        one(tsv)  # untimed: first touch of the binary, the database files and the driver
+        runs_file = [one(tsv) for _ in range(3)]
+        runs_null = [one("/dev/null") for _ in range(3)]
+        best_f = min(runs_file, key=lambda x: x[0])
+        best_n = min(runs_null, key=lambda x: x[0])
+        rows = best_f[2][0] if best_f[2] else None
+        out.update({
+            "value": n_reads / best_f[0], "unit": "reads/s", "wall_s": best_f[0], "wall_s_all": [r_[0] for r_ in runs_file],
+            "value_dev_null": n_reads / best_n[0], "wall_s_dev_null": best_n[0], "wall_s_dev_null_all": [r_[0] for r_ in runs_null],
+            "rows": rows, "rows_per_s": (rows / best_f[0]) if rows else None, "tsv_bytes": os.path.getsize(tsv),
+            "split": best_f[1], "split_dev_null": best_n[1],
+            "definition": "wall clock of the kmcp-search process (exec to exit), best of 3: FASTQ file -> parallel parse -> kmcpg_search_batch_pairs -> "
+                          "parallel row formatting -> TSV file (value) or /dev/null (value_dev_null); HIP start-up and the index upload included",
+            "checksums_agree": len({r_[2] for r_ in runs_file + runs_null}) == 1,
+        })
+        # ---- the TSV's prefix against the oracle's rows (test infrastructure as the checker: ko_search + ko_format_match per read)
+        from oracle import oracle as O
+        import ctypes as C
+        odb = O.OracleDB(db_dir)
+        OL = O.lib()
+        p = O.default_params()
+        threads = effective_cpus()
+        t2 = time.perf_counter()
+
+        def rows_of(lo, hi):
+            buf = C.create_string_buffer(4096)
+            lines = []
+            for i in range(lo, hi):
+                if time.perf_counter() - t2 > check_budget_s:
+                    return lo, i, lines
+                res = O.Result()
+                r = first_reads[i].tobytes()
+                OL.ko_search(odb.h, r, len(r), None, 0, C.byref(p), C.byref(res))
+                for j in range(max(0, res.nmatches)):
+                    OL.ko_format_match(buf, 4096, b"r%09d" % i, C.byref(res), C.byref(res.matches[j]), i)
+                    lines.append(buf.value)
+                OL.ko_result_free(C.byref(res))
+            return lo, hi, lines
+
+        step = 512
+        with ThreadPoolExecutor(threads) as ex:
+            parts = list(ex.map(lambda lo: rows_of(lo, min(lo + step, len(first_reads))), range(0, len(first_reads), step)))
+        odb.close()
+        covered = 0
+        want = []
+        for lo, hi, lines in parts:  # the longest prefix every chunk of which was finished inside the budget
+            if hi < min(lo + step, len(first_reads)):
+                break
+            covered = hi
+            want.extend(lines)
+        got = []
+        with open(tsv, "rb") as fh:
+            for ln in fh:
+                if ln.startswith(b"#"):
+                    continue
+                if int(ln.rsplit(b"\t", 1)[1]) >= covered:
+                    break
+                got.append(ln)
+        out["parity_on_sample"] = bool(covered > 0 and got == want)
+        out["sample"] = f"first {covered} reads: {len(want)} TSV rows byte-compared with the oracle's (ko_search + ko_format_match, {threads} threads, {time.perf_counter()-t2:.1f} s)"
+        out["sample_reads"] = covered
+        out["sample_rows"] = len(want)
+        if not out["parity_on_sample"]:
+            out["parity_failure"] = {"gpu_only": len(set(got) - set(want)), "oracle_only": len(set(want) - set(got)), "qkmers_differ": 0}
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
+    return out
+
 # ---------------------------------------------------------------------------------------------------------------------------------
 # The ONE JSON line.  Numbers only, < 6 KB (the driver keeps an 8 KB tail of stdout and parses the line out of it): every sentence
 # (definitions, sources, sample descriptions) and every sub-measurement lives in the sidecar `bench_detail.json`.
@@ -918,7 +1089,16 @@ def _secondary_numbers(o):
          "kernel_ms": rf.get("kernel_ms"), "frac": rf.get("frac"), "algorithmic_over_peak": rf.get("algorithmic_over_peak"),
          "traffic_over_algorithmic": rf.get("traffic_over_algorithmic"), "cpu": cb.get("value"), "cpu_cores": cb.get("cores"),
          "cpu_reference_shaped": (cb.get("reference_shaped") or {}).get("value"), "parity_on_sample": cb.get("parity_on_sample"),
-         "planted_recall": o.get("planted_recall")}
+         "planted_recall": o.get("planted_recall"),
+         # (the kmcp-search end-to-end leg)
+         "value_dev_null": o.get("value_dev_null"), "wall_s": o.get("wall_s"), "rows_per_s": o.get("rows_per_s"), "reads": o.get("reads"),
+         "sample_reads": o.get("sample_reads")}
+    if "parity_on_sample" in o:
+        d["parity_on_sample"] = o["parity_on_sample"]
+    for k, v in (o.get("split") or {}).items():
+        d[k] = v
+    if o.get("error") or o.get("skipped"):
+        return {"error": str(o.get("error") or o.get("skipped"))[:120]}
     return {k: _num(v, 5) for k, v in d.items() if v is not None}
 
 
@@ -1008,6 +1188,7 @@ def main():
     ap.add_argument("--cpu-sample-reads", type=int, default=0, help="0 = size the CPU sample to several seconds of CPU work")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the configs[1] numbers that ride along at N=1")
+    ap.add_argument("--cli-only", type=int, default=0, metavar="READS", help="run only the kmcp-search end-to-end leg on this many reads and print its record")
     ap.add_argument("--no-extras", action="store_true", help="timed steps only (profiling runs: no pruning-off / host-boundary launches in the trace)")
     args = ap.parse_args()
 
@@ -1048,6 +1229,11 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=ctx.dev)
 
+    if args.cli_only:
+        rec = run_cli_end_to_end(ctx, n_reads=args.cli_only, check_reads=min(100_000, args.cli_only))
+        os.dup2(real_stdout, 1)
+        os.write(1, (json.dumps(_finite(rec)) + "\n").encode())
+        sys.exit(3 if rec.get("parity_failure") or rec.get("error") else 0)
     out = run_workload(args.workload, ctx, args.steps, args.warmup, args.batch_reads, cpu_baseline=not args.no_cpu_baseline,
                        cpu_sample_reads=args.cpu_sample_reads, extras=not args.no_extras)
     if ctx.world == 1 and args.workload == "gtdb" and not args.no_secondary and not args.batch_reads:
@@ -1073,6 +1259,11 @@ def main():
             r_ = run_workload(nm, ctx, min(max(args.steps, 3), st_), 2, cpu_baseline=not args.no_cpu_baseline and nm != "config4_hifi_uniform_sigs",
                               cpu_target_s=3.0)
             out["secondary"][nm] = {k: r_[k] for k in keys + ("metric",) if k in r_}
+        if os.environ.get("KMCP_BENCH_CLI", "1") != "0":
+            try:
+                out["secondary"]["cli_end_to_end"] = run_cli_end_to_end(ctx)
+            except Exception as e:  # the leg must not take the headline line with it
+                out["secondary"]["cli_end_to_end"] = {"error": repr(e)[:300]}
         out["secondary"]["config2_genome_search"]["published"] = {
             "value": [1.6, 1.9], "unit": "queries/s", "threads": 8,
             "source": "reference benchmarks/searching/README.md:382-432 (genome search against GTDB, FracMinHash scale 1000: 0.53-0.62 s per query, 8 threads)"}

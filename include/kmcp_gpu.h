@@ -344,6 +344,10 @@ typedef struct {
   uint64_t n_hashes;
 } kmcpg_build_col;
 int kmcpg_build_db(const char* out_dir, const kmcpg_build_cfg* cfg, const kmcpg_build_col* cols, uint32_t n_cols, int32_t device);
+/* The resident database written back as <out_dir>/R001/{_blockNNN.uniki, __db.yml, __name_mapping.tsv} in the reference's format
+ * (index/serialization.go:159-300, util-db-info.go:46-79): bench.py puts its synthetic configs[1] index (planted reads included) on
+ * /dev/shm this way and searches it with kmcp-search, FASTQ in, TSV out.  Every block must be resident on the handle. */
+int kmcpg_save_db(kmcpg_db* db, const char* out_dir);
 
 #ifdef __cplusplus
 }

@@ -14,12 +14,13 @@
 #include <vector>
 
 #include "fpr.hpp"
+#include "engine.hpp"
 #include "fastmod.hpp"
 #include "kernels.hpp"
 
 using namespace kmcpg;
 
-int kmcpg_fail(int code, const char* fmt, ...);  // engine.cpp
+
 
 namespace {
 
@@ -250,6 +251,88 @@ extern "C" int kmcpg_build_db(const char* out_dir, const kmcpg_build_cfg* cfg, c
   f = fopen((dir + "/__name_mapping.tsv").c_str(), "w");
   if (f) {
     for (uint32_t i = 0; i < n_cols; i++) fprintf(f, "%s\t%s\n", cols[i].name, cols[i].name);
+    fclose(f);
+  }
+  return 0;
+}
+
+// The resident database back to disk in the reference's format (benchmarking support, no counterpart in the reference): a synthetic
+// index generated in HBM (kmcpg_open_synthetic + kmcpg_plant_reads_device) becomes <out_dir>/R001/{_blockNNN.uniki, __db.yml,
+// __name_mapping.tsv}, which kmcp-search — or `kmcp search` — opens like any database `kmcp index` wrote (index/serialization.go:159-300,
+// util-db-info.go:46-79).  bench.py's end-to-end leg uses it to put BASELINE configs[1] on /dev/shm.  Every block must be resident.
+extern "C" int kmcpg_save_db(kmcpg_db* db, const char* out_dir) {
+  if (!db || !out_dir) return kmcpg_fail(KMCPG_EINVAL, "null argument");
+  for (const auto& b : db->blocks)
+    if (!b.local) return kmcpg_fail(KMCPG_EINVAL, "kmcpg_save_db needs every block resident on this handle (one GPU, one shard)");
+  const std::string dir = std::string(out_dir) + "/R001";
+  if (mkdirs(dir) != 0) return kmcpg_fail(KMCPG_EIO, "cannot create %s: %s", dir.c_str(), strerror(errno));
+  std::vector<std::string> files;
+  std::vector<uint8_t> host;
+  uint64_t total_kmers = 0;
+  for (size_t bi = 0; bi < db->blocks.size(); bi++) {
+    const kmcpg::UnikiHeader& h = db->blocks[bi].h;
+    const uint32_t n = (uint32_t)h.names.size();
+    char name[64];
+    snprintf(name, sizeof name, "_block%03zu.uniki", bi + 1);
+    const std::string path = dir + "/" + name;
+    FILE* f = fopen(path.c_str(), "wb");
+    if (!f) return kmcpg_fail(KMCPG_EIO, "cannot write %s: %s", path.c_str(), strerror(errno));
+    fwrite(".kmcpidx", 1, 8, f);
+    const uint8_t meta[4] = {4, (uint8_t)h.k, (uint8_t)((h.canonical ? 1 : 0) | 2), (uint8_t)h.num_hashes};
+    fwrite(meta, 1, 4, f);
+    be64(f, h.num_sigs);
+    be32(f, n);
+    for (const auto& nm : h.names) {
+      be32(f, (uint32_t)nm.size() + 1);
+      fwrite(nm.data(), 1, nm.size(), f);
+      fputc('\n', f);
+    }
+    be32(f, n);
+    for (uint32_t c = 0; c < n; c++) {
+      be32(f, 1);
+      be64(f, h.gsizes[c]);
+    }
+    be32(f, n);
+    for (uint32_t c = 0; c < n; c++) {
+      be32(f, 1);
+      be32(f, h.indices[c]);
+    }
+    for (uint32_t c = 0; c < n; c++) {
+      be64(f, h.sizes[c]);
+      total_kmers += h.sizes[c];
+    }
+    const uint64_t chunk = std::max<uint64_t>(1, (256ull << 20) / h.row_bytes);
+    host.resize((size_t)(std::min(chunk, h.num_sigs) * h.row_bytes));
+    int rc = 0;
+    for (uint64_t r0 = 0; r0 < h.num_sigs && rc == 0; r0 += chunk) {
+      const uint64_t nr = std::min(chunk, h.num_sigs - r0);
+      rc = kmcpg_read_row_range(db, (uint32_t)bi, r0, nr, host.data());
+      if (rc == 0 && fwrite(host.data(), 1, (size_t)(nr * h.row_bytes), f) != (size_t)(nr * h.row_bytes)) rc = kmcpg_fail(KMCPG_EIO, "short write on %s", path.c_str());
+    }
+    fclose(f);
+    if (rc) return rc;
+    files.push_back(name);
+  }
+  const kmcpg_info& I = db->info;
+  FILE* f = fopen((dir + "/__db.yml").c_str(), "w");
+  if (!f) return kmcpg_fail(KMCPG_EIO, "cannot write %s/__db.yml", dir.c_str());
+  auto b = [](int v) { return v ? "true" : "false"; };
+  fprintf(f, "version: 4\nunikiVersion: 4\nalias: kmcp-gpu-saved\nk: %d\nks:\n", I.k);
+  std::vector<int> ks(db->ks_desc.rbegin(), db->ks_desc.rend());  // ascending, as `kmcp index` lists them
+  if (ks.empty()) ks.push_back(I.k);
+  for (int k : ks) fprintf(f, "- %d\n", k);
+  fprintf(f, "hashed: true\ncanonical: %s\n", b(I.canonical));
+  fprintf(f, "scaled: %s\nscale: %u\nminimizer: %s\nminimizer-w: %u\nsyncmer: %s\nsyncmer-s: %u\n", b(I.scaled), I.scaled ? I.scale : 1, b(I.minimizer),
+          I.minimizer_w, b(I.syncmer), I.syncmer_s);
+  fprintf(f, "split-seq: false\nsplit-size: 0\nsplit-num: 0\nsplit-overlap: 0\ncompact-size: true\n");
+  fprintf(f, "hashes: %d\nfpr: %.17g\nnumNameGroups: %llu\nblocksize: %u\ntotalKmers: %llu\nfiles:\n", I.num_hashes, I.fpr, (unsigned long long)I.n_cols,
+          db->blocks.empty() ? 0u : (uint32_t)db->blocks[0].h.names.size(), (unsigned long long)total_kmers);
+  for (const auto& fn : files) fprintf(f, "- %s\n", fn.c_str());
+  fclose(f);
+  f = fopen((dir + "/__name_mapping.tsv").c_str(), "w");
+  if (f) {
+    for (const auto& bl : db->blocks)
+      for (const auto& nm : bl.h.names) fprintf(f, "%s\t%s\n", nm.c_str(), nm.c_str());
     fclose(f);
   }
   return 0;

@@ -17,7 +17,7 @@ EXPORTS = [
     "kmcpg_read_rows", "kmcpg_block_info", "kmcpg_kmers_device", "kmcpg_plant_reads_device", "kmcpg_set_profiling",
     "kmcpg_last_timing", "kmcpg_open_devices", "kmcpg_build_db", "kmcpg_submit", "kmcpg_wait", "kmcpg_read_row_range", "kmcpg_timing_at", "kmcpg_last_gathered_bytes", "kmcpg_last_hash_bytes",
     "kmcpg_db_ks", "kmcpg_open_paged", "kmcpg_paged_info", "kmcpg_exchange_info", "kmcpg_batch_hint", "kmcpg_group_device", "kmcpg_finalize_grouped",
-    "kmcpg_search_batch_pairs", "kmcpg_wait_pairs", "kmcpg_result_pairs_free", "kmcpg_expand_pairs",
+    "kmcpg_search_batch_pairs", "kmcpg_wait_pairs", "kmcpg_result_pairs_free", "kmcpg_expand_pairs", "kmcpg_save_db",
 ]
 
 
@@ -160,6 +160,7 @@ def load():
     L.kmcpg_last_hash_bytes.argtypes = [vp, u64p]
     L.kmcpg_timing_at.argtypes = [vp, C.c_uint32, C.POINTER(C.c_float), C.POINTER(C.c_float)]
     L.kmcpg_build_db.argtypes = [C.c_char_p, C.POINTER(BuildCfg), C.POINTER(BuildCol), C.c_uint32, C.c_int32]
+    L.kmcpg_save_db.argtypes = [vp, C.c_char_p]
     _lib = L
     return L
 
@@ -296,6 +297,11 @@ class Database:
         h = C.c_void_p()
         _check(load().kmcpg_open_paged(os.fsencode(db_dir), device, passes, C.byref(h)))
         return cls(h)
+
+    def save(self, out_dir):
+        """kmcpg_save_db: the resident database as <out_dir>/R001 in the reference's on-disk format; returns that directory."""
+        _check(load().kmcpg_save_db(self._h, os.fsencode(out_dir)))
+        return os.path.join(out_dir, "R001")
 
     def exchange_info(self):
         return load().kmcpg_exchange_info(self._h).decode()
