@@ -896,7 +896,7 @@ def _pick_workdir(need_bytes):
 def _write_fastq(path, reads, first_id):
     """reads: uint8 [n, L] -> four-line FASTQ records `@r<9 digits>` / bases / `+` / quality 'I' x L, appended to `path`"""
     n, L = reads.shape
-    rec = np.empty((n, 11 + L + 3 + L + 1), dtype=np.uint8)
+    rec = np.empty((n, 12 + L + 3 + L + 1), dtype=np.uint8)
     rec[:, 0] = ord("@")
     rec[:, 1] = ord("r")
     ids = np.arange(first_id, first_id + n, dtype=np.int64)
@@ -922,7 +922,7 @@ def run_cli_end_to_end(ctx, n_reads=10_000_000, check_reads=100_000, check_budge
         return {"skipped": "kmcp_amd/kmcp-search is not built"}
     wl = dict(WORKLOADS["config1"])
     L = READ_LEN
-    need = n_reads * (15 + 2 * L + 11 + 140) + 2.0e9
+    need = n_reads * (16 + 2 * L + 140) + 2.0e9
     work = _pick_workdir(need)
     if work is None:
         return {"skipped": f"no directory with {need/1e9:.1f} GB free"}
@@ -964,6 +964,8 @@ def run_cli_end_to_end(ctx, n_reads=10_000_000, check_reads=100_000, check_budge
             env.pop(k_, None)
 
         def one(dest):
+            if dest != "/dev/null" and os.path.exists(dest):
+                os.unlink(dest)  # (truncating last run's 0.9 GB of tmpfs pages inside the timed process cost 0.1-0.3 s: not part of a search)
             t1 = time.perf_counter()
             r = subprocess.run([cli, "-d", db_root, fq, "-o", dest], capture_output=True, text=True, env=env, timeout=900)
             wall = time.perf_counter() - t1
@@ -973,6 +975,10 @@ def run_cli_end_to_end(ctx, n_reads=10_000_000, check_reads=100_000, check_budge
                           r"([\d.]+) s\s+blocked; ([\d.]+) s before the search started", r.stderr)
             split = dict(zip(("gpu_library_s", "formatting_s", "waiting_for_reader_s", "reader_parsing_s", "reader_blocked_s", "before_search_s"),
                              (float(x) for x in m.groups()))) if m else {}
+            me = re.search(r"elapsed time: ([\d.]+)s", r.stderr)
+            if me and split:
+                split["elapsed_in_main_s"] = float(me.group(1))
+                split["search_phase_s"] = float(me.group(1)) - split["before_search_s"]
             mm = re.search(r"matches: (\d+), checksum ([0-9a-f]{16})", r.stderr)
             return wall, split, (int(mm.group(1)), mm.group(2)) if mm else None
 
@@ -986,6 +992,9 @@ def run_cli_end_to_end(ctx, n_reads=10_000_000, check_reads=100_000, check_budge
             "value": n_reads / best_f[0], "unit": "reads/s", "wall_s": best_f[0], "wall_s_all": [r_[0] for r_ in runs_file],
             "value_dev_null": n_reads / best_n[0], "wall_s_dev_null": best_n[0], "wall_s_dev_null_all": [r_[0] for r_ in runs_null],
             "rows": rows, "rows_per_s": (rows / best_f[0]) if rows else None, "tsv_bytes": os.path.getsize(tsv),
+            # the same run without what a process pays once whatever it searches: exec + dynamic loading + exit (wall - elapsed_in_main), HIP
+            # runtime start-up (0.2 s, tools/ubench_init.cpp) and the upload of the index (before_search): first batch submitted -> last row written
+            "value_search_phase": (n_reads / best_f[1]["search_phase_s"]) if best_f[1].get("search_phase_s") else None,
             "split": best_f[1], "split_dev_null": best_n[1],
             "definition": "wall clock of the kmcp-search process (exec to exit), best of 3: FASTQ file -> parallel parse -> kmcpg_search_batch_pairs -> "
                           "parallel row formatting -> TSV file (value) or /dev/null (value_dev_null); HIP start-up and the index upload included",
@@ -1041,7 +1050,12 @@ def run_cli_end_to_end(ctx, n_reads=10_000_000, check_reads=100_000, check_budge
         if not out["parity_on_sample"]:
             out["parity_failure"] = {"gpu_only": len(set(got) - set(want)), "oracle_only": len(set(want) - set(got)), "qkmers_differ": 0}
     finally:
-        shutil.rmtree(work, ignore_errors=True)
+        keep = os.environ.get("KMCP_BENCH_KEEP")  # experiments (tools/ab/r06_cli_probe.sh): leave the database and the reads behind
+        if keep:
+            shutil.rmtree(keep, ignore_errors=True)
+            shutil.move(work, keep)
+        else:
+            shutil.rmtree(work, ignore_errors=True)
     return out
 
 # ---------------------------------------------------------------------------------------------------------------------------------
@@ -1091,7 +1105,7 @@ def _secondary_numbers(o):
          "cpu_reference_shaped": (cb.get("reference_shaped") or {}).get("value"), "parity_on_sample": cb.get("parity_on_sample"),
          "planted_recall": o.get("planted_recall"),
          # (the kmcp-search end-to-end leg)
-         "value_dev_null": o.get("value_dev_null"), "wall_s": o.get("wall_s"), "rows_per_s": o.get("rows_per_s"), "reads": o.get("reads"),
+         "value_dev_null": o.get("value_dev_null"), "value_search_phase": o.get("value_search_phase"), "wall_s": o.get("wall_s"), "rows_per_s": o.get("rows_per_s"), "reads": o.get("reads"),
          "sample_reads": o.get("sample_reads")}
     if "parity_on_sample" in o:
         d["parity_on_sample"] = o["parity_on_sample"]

@@ -532,6 +532,47 @@ struct FastqChunk {
   size_t size() const { return offs.size() - 1; }
 };
 
+// The vectors of chunks that have been searched and printed go round: a batch is ~20 MB of bases, IDs and offsets, and a fresh set per
+// batch is mapped, page-faulted in by the parser and unmapped by the writer (TLB shootdowns across every thread of the process) — at
+// 80 batches per second that was a fifth of the search phase (profiles/r06_cli_e2e.txt).  take() hands out a cleared set that keeps its
+// capacity, give() takes one back; a handful are kept.
+class ChunkPool {
+ public:
+  static ChunkPool& get() {
+    static ChunkPool* p = new ChunkPool();
+    return *p;
+  }
+  std::unique_ptr<FastqChunk> take() {
+    {
+      std::lock_guard<std::mutex> l(m_);
+      if (!free_.empty()) {
+        std::unique_ptr<FastqChunk> c = std::move(free_.back());
+        free_.pop_back();
+        return c;
+      }
+    }
+    return std::unique_ptr<FastqChunk>(new FastqChunk());
+  }
+  void give(std::vector<char>& id_buf, std::vector<uint64_t>& id_offs, std::vector<uint8_t>& seqs, std::vector<uint64_t>& offs) {
+    if (seqs.capacity() > ((size_t)256 << 20)) return;  // an unusually large batch (long reads): let it go
+    std::unique_ptr<FastqChunk> c(new FastqChunk());
+    c->id_buf.swap(id_buf);
+    c->id_offs.swap(id_offs);
+    c->seqs.swap(seqs);
+    c->offs.swap(offs);
+    c->id_buf.clear();
+    c->id_offs.assign(1, 0);
+    c->seqs.clear();
+    c->offs.assign(1, 0);
+    std::lock_guard<std::mutex> l(m_);
+    if (free_.size() < 48) free_.push_back(std::move(c));
+  }
+
+ private:
+  std::mutex m_;
+  std::vector<std::unique_ptr<FastqChunk>> free_;
+};
+
 class ParallelFastq {
  public:
   // a regular, uncompressed file that starts with '@' and whose first records are strict four-line FASTQ
@@ -698,8 +739,10 @@ class ParallelFastq {
     while (lo < size_) {
       size_t hi = lo + chunk_bytes_ >= size_ ? size_ : record_start(lo + chunk_bytes_);
       std::shared_ptr<Task> t(new Task());
-      t->c.reset(new FastqChunk());
+      t->c = ChunkPool::get().take();
       t->c->file_off = lo;
+      t->c->strict = true;
+      t->c->done = false;
       t->lo = lo;
       t->hi = hi;
       std::unique_lock<std::mutex> l(m_);

@@ -32,6 +32,7 @@
 
 #include <dirent.h>
 #include <fcntl.h>
+#include <sched.h>
 #include <unistd.h>
 #include <sys/stat.h>
 
@@ -243,8 +244,68 @@ static inline uint64_t tuple_mix(uint64_t query, uint32_t col, uint32_t count) {
   return x;
 }
 
+// Host cores this process may use: the affinity mask capped by the cgroup CPU quota (a GPU box shows 256 hardware threads and grants 16)
+static unsigned usable_cpus() {
+  unsigned n = std::max(1u, std::thread::hardware_concurrency());
+  cpu_set_t set;
+  if (sched_getaffinity(0, sizeof set, &set) == 0) n = (unsigned)std::max(1, CPU_COUNT(&set));
+  if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+    char q[64];
+    long long period = 0;
+    if (fscanf(f, "%63s %lld", q, &period) == 2 && strcmp(q, "max") != 0 && period > 0) n = std::min<unsigned>(n, (unsigned)std::max(1ll, atoll(q) / period));
+    fclose(f);
+  }
+  return n;
+}
+
+// On a two-socket host the threads of this process — parsers, searchers, formatters, the flusher — pass every batch from one to the next;
+// spread over both sockets each hand-over crosses the interconnect (formatting cost 1.5-2x the thread-seconds, profiles/r06_cli_e2e.txt).
+// When the affinity mask spans several NUMA nodes and one node has the cores the CPU quota grants anyway, the process keeps to the node it
+// was started on (KMCP_SEARCH_NUMA=<node> picks another, KMCP_SEARCH_NUMA=off leaves the mask alone).  Called before any thread exists.
+static void keep_to_one_numa_node() {
+  const char* env = getenv("KMCP_SEARCH_NUMA");
+  if (env && (!strcmp(env, "off") || !strcmp(env, "no"))) return;
+  cpu_set_t mask;
+  if (sched_getaffinity(0, sizeof mask, &mask) != 0) return;
+  std::vector<cpu_set_t> nodes;
+  for (int n = 0; n < 64; n++) {
+    char path[96];
+    snprintf(path, sizeof path, "/sys/devices/system/node/node%d/cpulist", n);
+    FILE* f = fopen(path, "r");
+    if (!f) break;
+    char buf[4096];
+    cpu_set_t cs;
+    CPU_ZERO(&cs);
+    if (fgets(buf, sizeof buf, f))
+      for (char* tok = strtok(buf, ",\n"); tok; tok = strtok(nullptr, ",\n")) {
+        int a = 0, b = 0;
+        const int got = sscanf(tok, "%d-%d", &a, &b);
+        if (got == 1) b = a;
+        if (got >= 1)
+          for (int c = a; c <= b && c < CPU_SETSIZE; c++) CPU_SET(c, &cs);
+      }
+    fclose(f);
+    cpu_set_t both;
+    CPU_AND(&both, &cs, &mask);
+    nodes.push_back(both);
+  }
+  int spanned = 0;
+  for (const auto& n : nodes) spanned += CPU_COUNT(&n) > 0;
+  if (spanned < 2) return;
+  int want = -1;
+  if (env && *env >= '0' && *env <= '9') want = atoi(env);
+  else {
+    const int cpu = sched_getcpu();
+    for (size_t n = 0; n < nodes.size(); n++)
+      if (cpu >= 0 && CPU_ISSET(cpu, &nodes[n])) want = (int)n;
+  }
+  if (want < 0 || want >= (int)nodes.size() || (unsigned)CPU_COUNT(&nodes[(size_t)want]) < std::min(usable_cpus(), 4u)) return;
+  (void)sched_setaffinity(0, sizeof(cpu_set_t), &nodes[(size_t)want]);
+}
+
 struct Batch {
   uint64_t seq = 0;  // position in the input: the writer emits batches in this order
+  uint64_t n_seq = 1;  // how many of the reader's batches this one holds (batches read before the database was open are joined for a paged index)
   uint64_t first_idx = 0;
   std::vector<char> id_buf;  // query IDs back to back
   std::vector<uint64_t> id_offs{0};
@@ -254,6 +315,19 @@ struct Batch {
   bool paired = false;
   size_t size() const { return id_offs.size() - 1; }
   std::string_view id(size_t i) const { return std::string_view(id_buf.data() + id_offs[i], (size_t)(id_offs[i + 1] - id_offs[i])); }
+  // the queries of `o` (the reader's next batch) behind this one's
+  void append(const Batch& o) {
+    const uint64_t ib = id_buf.size(), sb = seqs.size(), sb2 = seqs2.size();
+    id_buf.insert(id_buf.end(), o.id_buf.begin(), o.id_buf.end());
+    for (size_t i = 1; i < o.id_offs.size(); i++) id_offs.push_back(ib + o.id_offs[i]);
+    seqs.insert(seqs.end(), o.seqs.begin(), o.seqs.end());
+    for (size_t i = 1; i < o.offs.size(); i++) offs.push_back(sb + o.offs[i]);
+    if (paired) {
+      seqs2.insert(seqs2.end(), o.seqs2.begin(), o.seqs2.end());
+      for (size_t i = 1; i < o.offs2.size(); i++) offs2.push_back(sb2 + o.offs2[i]);
+    }
+    n_seq += o.n_seq;
+  }
 };
 
 template <typename T>
@@ -269,6 +343,14 @@ class Queue {
   bool pop(T* v) {
     std::unique_lock<std::mutex> l(m_);
     cv_.wait(l, [&] { return !q_.empty() || closed_; });
+    if (q_.empty()) return false;
+    *v = std::move(q_.front());
+    q_.pop_front();
+    cv_.notify_all();
+    return true;
+  }
+  bool try_pop(T* v) {  // what is there right now, without waiting
+    std::lock_guard<std::mutex> l(m_);
     if (q_.empty()) return false;
     *v = std::move(q_.front());
     q_.pop_front();
@@ -313,7 +395,7 @@ static uint64_t read_single_end(const std::string& file, size_t batch_reads, siz
   uint64_t resume = 0;
   bool serial = true;
   if (ParallelFastq::eligible(file)) {
-    int w = (int)std::min(8u, std::max(2u, std::thread::hardware_concurrency() / 2));
+    int w = (int)std::min(8u, std::max(2u, usable_cpus() / 2));
     if (const char* e = getenv("KMCP_READER_THREADS")) w = std::max(1, atoi(e));
     ParallelFastq pf(file, batch_reads, w, 2 * max_bases);  // a record is its bases twice (qualities) plus the header
     serial = false;
@@ -453,6 +535,21 @@ class Out {
 // ---- TSV rows.  Number formatting must equal Go's strconv (FormatFloat 'f',4 / 'e',4 = correctly rounded decimals, which is
 // what printf gives); the fast paths below produce the same digits and fall back to snprintf whenever a rounding tie is near.
 struct RowFormatter {
+  // text buffers this formatter has filled before (the flusher hands them back): the next part is written where this thread's last ones were
+  std::mutex free_mu;
+  std::vector<std::string> free_bufs;
+  void take(std::string& into) {
+    std::lock_guard<std::mutex> g(free_mu);
+    if (free_bufs.empty()) return;
+    into = std::move(free_bufs.back());
+    free_bufs.pop_back();
+    into.clear();
+  }
+  void give_back(std::string&& s) {
+    if (s.capacity() > (1ull << 30)) return;
+    std::lock_guard<std::mutex> g(free_mu);
+    if (free_bufs.size() < 64) free_bufs.push_back(std::move(s));
+  }
   char tmp[64];
   std::vector<kmcpg_match> scratch;  // the records of the query being formatted (kmcpg_expand_pairs)
   std::unordered_map<uint64_t, std::string> fpr_cache;  // the FPR of a match depends on (qKmers, mKmers) only
@@ -698,6 +795,7 @@ int main(int argc, char** argv) {
   }
   const bool verbose = !o.quiet;
   const auto t_start = std::chrono::steady_clock::now();
+  keep_to_one_numa_node();
   if (o.parse_only) {  // reader check, no database and no GPU: one summary line per input file
     // checksum = sum over records i (0-based, in file order) of fnv1a("id\tseq\n") * (2 i + 1) mod 2^64: order-sensitive, yet
     // every batch can be summed on its own thread
@@ -858,6 +956,104 @@ int main(int argc, char** argv) {
     if (stat(f.c_str(), &st) == 0) default_map = read_kvs(f);
   }
 
+  // ---- the reader starts NOW, before the database is opened: parsing the input needs neither the GPU nor the index, and the HIP
+  //      runtime alone takes 0.2 s to come up (tools/ubench_init.cpp) — by the time the index is resident the first batches (up to
+  //      q_in's capacity) are waiting.  Batch limits are the defaults until the open has finished; should the index turn out to be
+  //      paged (larger than the GPU's memory: a batch then costs passes - 1 uploads), the early batches are joined into large ones
+  //      before they are searched (Batch::append below).
+  Queue<std::unique_ptr<Batch>> q_in(24), q_out(3);
+  std::atomic<size_t> max_bases{(size_t)64 << 20}, batch_reads{(size_t)o.batch};
+  std::atomic<int> db_k{0};
+  std::atomic<bool> db_ready{false};
+  std::mutex ready_mu;
+  std::condition_variable ready_cv;
+  auto wait_db = [&] {
+    std::unique_lock<std::mutex> l(ready_mu);
+    ready_cv.wait(l, [&] { return db_ready.load(); });
+  };
+  double t_reader_blocked = 0, t_reader_total = 0;  // the reader thread: waiting for a free queue slot / its whole life
+  std::thread reader([&] {
+    if (o.gpu_passes >= 0) wait_db();
+    const auto tr0 = std::chrono::steady_clock::now();
+    uint64_t id = 0, seq = 0;
+    std::unique_ptr<Batch> b(new Batch());
+    b->paired = paired;
+    auto flush = [&] {
+      if (b->size() == 0) return;
+      b->seq = seq++;
+      const auto tp = std::chrono::steady_clock::now();
+      q_in.push(std::move(b));
+      t_reader_blocked += std::chrono::duration<double>(std::chrono::steady_clock::now() - tp).count();
+      b.reset(new Batch());
+      b->paired = paired;
+      b->first_idx = id;
+    };
+    auto add = [&](std::string_view qid, std::string_view s1, const std::string* s2) {
+      b->id_buf.insert(b->id_buf.end(), qid.begin(), qid.end());
+      b->id_offs.push_back(b->id_buf.size());
+      b->seqs.insert(b->seqs.end(), s1.begin(), s1.end());
+      b->offs.push_back(b->seqs.size());
+      if (s2) {
+        b->seqs2.insert(b->seqs2.end(), s2->begin(), s2->end());
+        b->offs2.push_back(b->seqs2.size());
+      }
+      id++;
+      if (b->size() >= batch_reads.load() || b->seqs.size() + b->seqs2.size() >= max_bases.load()) flush();
+    };
+    std::string id1, s1, id2, s2;
+    if (paired) {
+      if (verbose) info("reading from paired-end files: %s, %s", o.read1.c_str(), o.read2.c_str());
+      flush();
+      read_paired(o.read1, o.read2, batch_reads.load(), max_bases.load(), [&](std::unique_ptr<Batch> nb) {
+        nb->first_idx = id;
+        id += nb->size();
+        b = std::move(nb);
+        flush();
+      });
+      if (id == 0) warn("no valid sequences in files: %s, %s", o.read1.c_str(), o.read2.c_str());
+    } else {
+      std::string nnn;
+      if (o.whole_file) {  // the gap between records is k - 1 N's: the database's k is needed first
+        wait_db();
+        nnn.assign((size_t)std::max(0, db_k.load() - 1), 'N');
+      }
+      for (const auto& file : files) {
+        if (verbose) info("reading sequence file: %s", file.c_str());
+        if (o.whole_file) {  // search.go:885-935
+          FastxReader r(file);
+          std::string qid, whole;
+          bool first = true;
+          while (r.next(&id1, &s1)) {
+            if (first) {
+              qid = o.use_filename ? trim_ext(file) : (!o.query_id.empty() ? o.query_id : id1);
+              whole = s1;
+              first = false;
+            } else {
+              whole += s1;
+              whole += nnn;
+            }
+          }
+          if (first) { warn("no valid sequences in file: %s", file.c_str()); continue; }
+          add(qid, whole, nullptr);
+          continue;
+        }
+        flush();  // batches do not span input files on this path
+        const uint64_t got = read_single_end(file, batch_reads.load(), max_bases.load(), [&](std::unique_ptr<Batch> nb) {
+          nb->paired = false;
+          nb->first_idx = id;
+          id += nb->size();
+          b = std::move(nb);
+          flush();
+        });
+        if (got == 0) warn("no valid sequences in file: %s", file.c_str());
+      }
+    }
+    flush();
+    q_in.close();
+    t_reader_total = std::chrono::duration<double>(std::chrono::steady_clock::now() - tr0).count();
+  });
+
+
   if (verbose) info("loading database into GPU memory ...");
   kmcpg_db* db = nullptr;
   int32_t paged_passes = 0;
@@ -956,98 +1152,31 @@ int main(int argc, char** argv) {
   Out out(o.out_file);
   if (!o.no_header) out.write("#query\tqLen\tqKmers\tFPR\thits\ttarget\tchunkIdx\tchunks\ttLen\tkSize\tmKmers\tqCov\ttCov\tjacc\tqueryIdx\n");
 
-  Queue<std::unique_ptr<Batch>> q_in(3), q_out(3);
   uint64_t total = 0, matched = 0;
   // a batch also closes at 64 Mbases (long queries); paged indexes want the largest batches the host can hold
   // (a batch's device workspace is up to 24 B per base: the library says how many bases fit beside the resident index)
-  size_t max_bases = paged_passes > 1 ? std::min<size_t>((size_t)o.batch * 512, (size_t)2 << 30) : (size_t)64 << 20;
   {
+    size_t mb = paged_passes > 1 ? std::min<size_t>((size_t)o.batch * 512, (size_t)2 << 30) : (size_t)64 << 20;
     uint64_t hint = 0;
-    if (kmcpg_batch_hint(db, &hint) == 0 && hint > 0) max_bases = std::max<size_t>((size_t)1 << 20, std::min<size_t>(max_bases, (size_t)hint));
+    if (kmcpg_batch_hint(db, &hint) == 0 && hint > 0) mb = std::max<size_t>((size_t)1 << 20, std::min<size_t>(mb, (size_t)hint));
+    max_bases.store(mb);
+    batch_reads.store((size_t)o.batch);
+    db_k.store(dbi.k);
+    db_ready.store(true);
+    { std::lock_guard<std::mutex> g(ready_mu); }
+    ready_cv.notify_all();
   }
 
-  double t_reader_blocked = 0, t_reader_total = 0;  // the reader thread: waiting for a free queue slot / its whole life
-  std::thread reader([&] {
-    const auto tr0 = std::chrono::steady_clock::now();
-    uint64_t id = 0, seq = 0;
-    std::unique_ptr<Batch> b(new Batch());
-    b->paired = paired;
-    auto flush = [&] {
-      if (b->size() == 0) return;
-      b->seq = seq++;
-      const auto tp = std::chrono::steady_clock::now();
-      q_in.push(std::move(b));
-      t_reader_blocked += std::chrono::duration<double>(std::chrono::steady_clock::now() - tp).count();
-      b.reset(new Batch());
-      b->paired = paired;
-      b->first_idx = id;
-    };
-    auto add = [&](std::string_view qid, std::string_view s1, const std::string* s2) {
-      b->id_buf.insert(b->id_buf.end(), qid.begin(), qid.end());
-      b->id_offs.push_back(b->id_buf.size());
-      b->seqs.insert(b->seqs.end(), s1.begin(), s1.end());
-      b->offs.push_back(b->seqs.size());
-      if (s2) {
-        b->seqs2.insert(b->seqs2.end(), s2->begin(), s2->end());
-        b->offs2.push_back(b->seqs2.size());
-      }
-      id++;
-      if (b->size() >= (size_t)o.batch || b->seqs.size() + b->seqs2.size() >= max_bases) flush();
-    };
-    std::string id1, s1, id2, s2;
-    if (paired) {
-      if (verbose) info("reading from paired-end files: %s, %s", o.read1.c_str(), o.read2.c_str());
-      flush();
-      read_paired(o.read1, o.read2, (size_t)o.batch, max_bases, [&](std::unique_ptr<Batch> nb) {
-        nb->first_idx = id;
-        id += nb->size();
-        b = std::move(nb);
-        flush();
-      });
-      if (id == 0) warn("no valid sequences in files: %s, %s", o.read1.c_str(), o.read2.c_str());
-    } else {
-      const std::string nnn((size_t)std::max(0, dbi.k - 1), 'N');
-      for (const auto& file : files) {
-        if (verbose) info("reading sequence file: %s", file.c_str());
-        if (o.whole_file) {  // search.go:885-935
-          FastxReader r(file);
-          std::string qid, whole;
-          bool first = true;
-          while (r.next(&id1, &s1)) {
-            if (first) {
-              qid = o.use_filename ? trim_ext(file) : (!o.query_id.empty() ? o.query_id : id1);
-              whole = s1;
-              first = false;
-            } else {
-              whole += s1;
-              whole += nnn;
-            }
-          }
-          if (first) { warn("no valid sequences in file: %s", file.c_str()); continue; }
-          add(qid, whole, nullptr);
-          continue;
-        }
-        flush();  // batches do not span input files on this path
-        const uint64_t got = read_single_end(file, (size_t)o.batch, max_bases, [&](std::unique_ptr<Batch> nb) {
-          nb->paired = false;
-          nb->first_idx = id;
-          id += nb->size();
-          b = std::move(nb);
-          flush();
-        });
-        if (got == 0) warn("no valid sequences in file: %s", file.c_str());
-      }
-    }
-    flush();
-    q_in.close();
-    t_reader_total = std::chrono::duration<double>(std::chrono::steady_clock::now() - tr0).count();
-  });
-
+  int fmt_threads = 0;
+  double t_fmt_busy = 0;  // summed over the formatter threads: time inside the parts
+  double t_fmt_pool = 0, t_fmt_push = 0, t_fmt_wait = 0;  // of the writer loop: rows being formatted / waiting for the flusher / waiting for a searched batch
   double t_gpu = 0, t_fmt = 0, t_read_wait = 0;  // seconds spent inside libkmcpgpu / formatting+writing / waiting for input
   uint64_t sum_matches = 0, sum_check = 0;       // matches of the run and their order-independent checksum (log line below)
   // two searchers: libkmcpgpu serialises their GPU halves and runs the host half (thresholds, FPR, sorting) outside that lock,
   // so one batch is finalized while the next one's kernels run
-  const int n_search = 2;
+  // (a paged index searches one batch at a time inside the library and wants the largest batches: one searcher, which joins the
+  // batches the reader cut before the database was open — consecutive ones, so the order of the output is untouched)
+  const int n_search = paged_passes > 1 ? 1 : 2;
   std::mutex t_mu;
   std::atomic<int> live{n_search};
   std::vector<std::thread> searchers;
@@ -1056,23 +1185,66 @@ int main(int argc, char** argv) {
       std::unique_ptr<Batch> b;
       double my_gpu = 0, my_wait = 0;
       uint64_t my_sum = 0, my_matches = 0;
-      for (;;) {
-        const auto tw = std::chrono::steady_clock::now();
-        if (!q_in.pop(&b)) break;
-        const auto t0 = std::chrono::steady_clock::now();
-        my_wait += std::chrono::duration<double>(t0 - tw).count();
-        int rc = kmcpg_search_batch_pairs(db, b->seqs.data(), b->offs.data(), b->paired ? b->seqs2.data() : nullptr, b->paired ? b->offs2.data() : nullptr,
-                                          (uint32_t)b->size(), &params, &b->res);
-        if (rc != 0) die("%s", kmcpg_last_error());
-        my_gpu += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+      // Each searcher keeps `depth` batches in flight through kmcpg_submit / kmcpg_wait_pairs (round 6; one synchronous
+      // kmcpg_search_batch_pairs call per batch before): a submit returns once the batch is staged, so the upload and the kernels of
+      // the next batch queue up behind this one's instead of waiting for this thread to come back from the host half.
+      const size_t depth = paged_passes > 1 ? 1 : 2;
+      std::deque<std::pair<kmcpg_ticket*, std::unique_ptr<Batch>>> fl;
+      auto search_sync = [&](Batch& bb) {  // the one-call form: it also halves a batch whose workspace does not fit (kmcp_gpu.h kmcpg_batch_hint)
+        if (kmcpg_search_batch_pairs(db, bb.seqs.data(), bb.offs.data(), bb.paired ? bb.seqs2.data() : nullptr, bb.paired ? bb.offs2.data() : nullptr,
+                                     (uint32_t)bb.size(), &params, &bb.res) != 0)
+          die("%s", kmcpg_last_error());
+      };
+      auto publish = [&](std::unique_ptr<Batch> bb) {
         if (verbose) {  // order-independent checksum of the (query, column, mKmers) tuples: the same on 1, 2, 4, 8 GPUs
-          const kmcpg_result_pairs& r = b->res;
+          const kmcpg_result_pairs& r = bb->res;
           for (uint32_t i = 0; i < r.n_reads; i++)
             for (uint64_t j = r.match_offs[i]; j < r.match_offs[i + 1]; j++)
-              my_sum += tuple_mix(b->first_idx + i, r.pairs[j].col, r.pairs[j].count);
+              my_sum += tuple_mix(bb->first_idx + i, r.pairs[j].col, r.pairs[j].count);
           if (r.n_reads) my_matches += r.match_offs[r.n_reads];
         }
-        q_out.push(std::move(b));
+        q_out.push(std::move(bb));
+      };
+      auto finish_oldest = [&] {
+        kmcpg_ticket* t = fl.front().first;
+        std::unique_ptr<Batch> bb = std::move(fl.front().second);
+        fl.pop_front();
+        const auto t0 = std::chrono::steady_clock::now();
+        const int rc = kmcpg_wait_pairs(t, &bb->res);
+        if (rc == KMCPG_ENOMEM) search_sync(*bb);  // (kmcpg_wait consumed the ticket; the batch's buffers are still ours)
+        else if (rc != 0) die("%s", kmcpg_last_error());
+        my_gpu += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        publish(std::move(bb));
+      };
+      for (;;) {
+        const auto tw = std::chrono::steady_clock::now();
+        // (with batches of its own in flight a searcher does not sleep on an empty input queue: it brings its oldest batch home first)
+        if (!fl.empty() ? !q_in.try_pop(&b) : !q_in.pop(&b)) {
+          if (fl.empty()) break;
+          finish_oldest();
+          continue;
+        }
+        if (paged_passes > 1) {
+          std::unique_ptr<Batch> nb;
+          while (b->size() < batch_reads.load() && b->seqs.size() + b->seqs2.size() < max_bases.load() && q_in.try_pop(&nb)) b->append(*nb);
+        }
+        const auto t0 = std::chrono::steady_clock::now();
+        my_wait += std::chrono::duration<double>(t0 - tw).count();
+        kmcpg_ticket* t = nullptr;
+        int rc;
+        while ((rc = kmcpg_submit(db, b->seqs.data(), b->offs.data(), b->paired ? b->seqs2.data() : nullptr, b->paired ? b->offs2.data() : nullptr,
+                                  (uint32_t)b->size(), &params, &t)) == KMCPG_EBUSY && !fl.empty())
+          finish_oldest();  // every lane of the handle is taken: one of this thread's own comes back first
+        if (rc == KMCPG_EBUSY || rc == KMCPG_ENOMEM) {  // the lanes are all the other searcher's / a batch that must be halved: the one-call form
+          search_sync(*b);
+          my_gpu += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+          publish(std::move(b));
+          continue;
+        }
+        if (rc != 0) die("%s", kmcpg_last_error());
+        my_gpu += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        fl.emplace_back(t, std::move(b));
+        if (fl.size() >= depth) finish_oldest();
       }
       {
         std::lock_guard<std::mutex> g(t_mu);
@@ -1088,24 +1260,28 @@ int main(int argc, char** argv) {
   // queries, concatenated in order); with -o *.gz each range becomes its own gzip member, compressed in the same thread
   // (a multi-member .gz is what pgzip/gzip readers, `kmcp profile` included, accept).
   {
-    const int nfmt = std::max(1, std::min(o.threads > 0 ? o.threads : 8, 16));
+    // -j formatter threads; by default three quarters of the cores this process may use (the rest: two searchers, the reader's
+    // parsers, the library's workers, the flusher) — on the 16-core grant of a GPU box 12 threads were the knee, profiles/r06_cli_e2e.txt
+    const int nfmt = o.threads > 0 ? std::max(1, std::min(o.threads, 64)) : (int)std::max(4u, std::min(32u, usable_cpus() * 3 / 4));
+    fmt_threads = nfmt;
     FormatPool pool(nfmt);
     // the formatted text of a batch goes to the file on a thread of its own, while the next batch is being formatted
-    Queue<std::unique_ptr<std::vector<std::string>>> q_flush(4);
-    // text buffers go round: a match-heavy batch is hundreds of megabytes of rows, and fresh strings would be page-faulted in
-    // (and grown by doubling) again for every batch
-    std::mutex free_mu;
-    std::vector<std::string> free_bufs;
+    // One batch's text: the parts in order, each with the formatter that wrote it.  Text buffers go round — a match-heavy batch is hundreds
+    // of megabytes of rows, fresh strings would be page-faulted in (and grown by doubling) for every batch — and they go back to the
+    // THREAD that wrote them: a buffer another core filled last costs a cache-line transfer per line written (measured: formatting
+    // took 2-4x the thread-seconds of the same loop on thread-owned buffers, profiles/r06_cli_e2e.txt).
+    struct Text {
+      std::vector<std::string> part;
+      std::vector<RowFormatter*> owner;
+    };
+    Queue<std::unique_ptr<Text>> q_flush(4);
     std::thread flusher([&] {
-      std::unique_ptr<std::vector<std::string>> parts;
-      while (q_flush.pop(&parts)) {
-        for (const auto& p : *parts) out.write_raw(p);
-        std::lock_guard<std::mutex> g(free_mu);
-        for (auto& p : *parts)
-          if (free_bufs.size() < 64 && p.capacity() <= (1ull << 30)) {
-            p.clear();
-            free_bufs.push_back(std::move(p));
-          }
+      std::unique_ptr<Text> t;
+      while (q_flush.pop(&t)) {
+        for (size_t i = 0; i < t->part.size(); i++) {
+          out.write_raw(t->part[i]);
+          if (RowFormatter* F = t->owner[i]) F->give_back(std::move(t->part[i]));
+        }
       }
     });
     std::unique_ptr<Batch> b, got;
@@ -1117,20 +1293,24 @@ int main(int argc, char** argv) {
         b = std::move(it->second);
         pending.erase(it);
       } else {
-        if (!q_out.pop(&got)) break;
+        const auto tp0 = std::chrono::steady_clock::now();
+        const bool more = q_out.pop(&got);
+        t_fmt_wait += std::chrono::duration<double>(std::chrono::steady_clock::now() - tp0).count();
+        if (!more) break;
         if (got->seq != next_seq) {
           pending.emplace(got->seq, std::move(got));
           continue;
         }
         b = std::move(got);
       }
-      next_seq++;
+      next_seq += b->n_seq;
       const auto tf0 = std::chrono::steady_clock::now();
       const kmcpg_result_pairs& r = b->res;
       const uint32_t n = r.n_reads;
       // parts of about equal work: a query costs one unit, a row one more (reads of a family database carry hundreds of rows)
       const uint64_t rows = n ? r.match_offs[n] : 0;
-      const int parts = (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)nfmt, std::max<uint64_t>((n + 4095) / 4096, rows / 32768)));
+      // (up to four parts per thread, taken in turn: a thread that is descheduled for a while holds up a small part, not an eighth of the batch)
+      const int parts = (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)nfmt * 4, std::max<uint64_t>((n + 2047) / 2048, rows / 16384)));
       std::vector<uint32_t> cut((size_t)parts + 1, n);
       cut[0] = 0;
       for (int pi = 1; pi < parts; pi++) {
@@ -1142,18 +1322,18 @@ int main(int argc, char** argv) {
         }
         cut[(size_t)pi] = a;
       }
-      std::unique_ptr<std::vector<std::string>> chunk_p(new std::vector<std::string>((size_t)parts));
-      std::vector<std::string>& chunk = *chunk_p;
-      {
-        std::lock_guard<std::mutex> g(free_mu);
-        for (int pi = 0; pi < parts && !free_bufs.empty(); pi++) {
-          chunk[(size_t)pi] = std::move(free_bufs.back());
-          free_bufs.pop_back();
-        }
-      }
+      std::unique_ptr<Text> chunk_p(new Text());
+      chunk_p->part.resize((size_t)parts);
+      chunk_p->owner.assign((size_t)parts, nullptr);
+      std::vector<std::string>& chunk = chunk_p->part;
+      std::vector<RowFormatter*>& chunk_owner = chunk_p->owner;
       std::vector<uint64_t> part_matched((size_t)parts, 0);
+      std::vector<double> part_busy((size_t)parts, 0);
       const std::function<void(int, RowFormatter&)> work = [&](int pi, RowFormatter& F) {
+        const auto tb0 = std::chrono::steady_clock::now();
         std::string& buf = chunk[(size_t)pi];
+        F.take(buf);  // one of this thread's own buffers, if one has come back from the flusher
+        chunk_owner[(size_t)pi] = &F;
         const uint32_t lo = cut[(size_t)pi], hi = cut[(size_t)pi + 1];
         buf.reserve((size_t)(r.match_offs[hi] - r.match_offs[lo]) * 112 + (size_t)(hi - lo) * (o.keep_unmatched ? 64 : 8) + 256);
         for (uint32_t i = lo; i < hi; i++) {
@@ -1171,12 +1351,27 @@ int main(int argc, char** argv) {
           F.rows(buf, b->id(i), r.qlen[i], r.qkmers[i], F.scratch.data(), m1 - m0, target, r.ksize[i], qidx);
         }
         if (out.gz()) buf = gzip_member(buf);
+        part_busy[(size_t)pi] = std::chrono::duration<double>(std::chrono::steady_clock::now() - tb0).count();
       };
+      const auto tq0 = std::chrono::steady_clock::now();
       pool.run(parts, work);
-      for (int pi = 0; pi < parts; pi++) matched += part_matched[(size_t)pi];
+      const auto tq1 = std::chrono::steady_clock::now();
+      for (int pi = 0; pi < parts; pi++) {
+        matched += part_matched[(size_t)pi];
+        t_fmt_busy += part_busy[(size_t)pi];
+      }
       q_flush.push(std::move(chunk_p));
+      t_fmt_pool += std::chrono::duration<double>(tq1 - tq0).count();
+      t_fmt_push += std::chrono::duration<double>(std::chrono::steady_clock::now() - tq1).count();
       total += n;
       kmcpg_result_pairs_free(&b->res);
+      // the batch's vectors go back to the reader (fastx_reader.hpp ChunkPool)
+      ChunkPool::get().give(b->id_buf, b->id_offs, b->seqs, b->offs);
+      if (b->paired) {
+        std::vector<char> no_ids;
+        std::vector<uint64_t> no_offs{0};
+        ChunkPool::get().give(no_ids, no_offs, b->seqs2, b->offs2);
+      }
       t_fmt += std::chrono::duration<double>(std::chrono::steady_clock::now() - tf0).count();
       if (verbose && !o.quiet) {
         double min = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_search).count() / 60.0;
@@ -1198,6 +1393,8 @@ int main(int argc, char** argv) {
     info("done searching (pipeline: %.3f s in the GPU library, %.3f s formatting/writing, %.3f s waiting for the reader; reader: %.3f s parsing, %.3f s "
          "blocked; %.3f s before the search started)",
          t_gpu, t_fmt, t_read_wait, t_reader_total - t_reader_blocked, t_reader_blocked, std::chrono::duration<double>(t_search - t_start).count());
+    info("writer loop: %.3f s formatting rows on %d threads (%.3f thread-seconds inside the parts), %.3f s waiting for the flusher, %.3f s waiting for searched batches",
+         t_fmt_pool, fmt_threads, t_fmt_busy, t_fmt_push, t_fmt_wait);
     info("matches: %llu, checksum %016llx (order-independent over (queryIdx, column, mKmers): the same on any number of GPUs)", (unsigned long long)sum_matches,
          (unsigned long long)sum_check);
     if (o.out_file != "-") info("search results saved to: %s", o.out_file.c_str());
@@ -1211,12 +1408,20 @@ int main(int argc, char** argv) {
   trailer.append(tr, (size_t)n);
   out.write(trailer);
   out.close();
-  if (kmcpg_close(db) != 0) die("%s", kmcpg_last_error());
+  // Everything the user asked for is on disk.  Giving back pinned staging buffers, streams and a resident index one by one takes
+  // ~0.1 s and the runtime's own exit handlers as long again (profiles/r06_cli_e2e.txt) — a short-lived process leaves that to the
+  // kernel driver, which reclaims a dead process's GPU memory anyway (the Go reference exits the same way: search.go:1027).
+  // KMCP_SEARCH_FULL_TEARDOWN=1 closes the handle and returns through the runtime's handlers (leak checks, sanitizers).
+  const bool full_teardown = getenv("KMCP_SEARCH_FULL_TEARDOWN") != nullptr;
+  if (full_teardown && kmcpg_close(db) != 0) die("%s", kmcpg_last_error());
   if (verbose) {
     info("");
     info("elapsed time: %.3fs", std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count());
     info("");
   }
   if (g_log) fclose(g_log);
+  fflush(stdout);
+  fflush(stderr);
+  if (!full_teardown) _exit(0);
   return 0;
 }

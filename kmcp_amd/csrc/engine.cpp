@@ -14,6 +14,7 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <chrono>
 #include <atomic>
 #include <memory>
 #include <mutex>
@@ -295,7 +296,13 @@ struct UploadChunk {
 };
 
 int upload_blocks(kmcpg_db* db) {
-  const uint64_t kChunkBytes = 64ull << 20;
+  // 64-MB chunks for indexes of many GB; a small index (configs[1]: 1.4 GB) is cut finer — every loader thread pins a staging buffer of
+  // one chunk before it can start (0.17 ms per MB, serialised inside the runtime: 8 x 64 MB were 100 ms of a 200-ms upload,
+  // profiles/r06_cli_e2e.txt)
+  uint64_t local_bytes = 0;
+  for (auto& b : db->blocks)
+    if (b.local) local_bytes += b.h.num_sigs * (uint64_t)b.h.row_bytes;
+  const uint64_t kChunkBytes = local_bytes < (8ull << 30) ? (16ull << 20) : (64ull << 20);
   std::vector<UploadChunk> chunks;
   uint64_t cap = 1;
   for (auto& b : db->blocks) {
@@ -496,7 +503,18 @@ extern "C" int kmcpg_open(const char* db_dir, const kmcpg_opts* opts, kmcpg_db**
   int rc = check_opts(opts, &db->opts);
   if (rc) return rc;
   const bool meta_only = db->opts.device < 0;
+  // KMCPG_OPEN_TIMING=1: where the time of an open goes (stderr; profiles/r06_cli_e2e.txt)
+  const bool timing = getenv("KMCPG_OPEN_TIMING") != nullptr;
+  auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  double t_prev = now();
+  auto lap = [&](const char* what) {
+    if (!timing) return;
+    const double t = now();
+    fprintf(stderr, "kmcpg_open: %-28s %8.2f ms\n", what, t - t_prev);
+    t_prev = t;
+  };
   if (!meta_only) HIPCHK(hipSetDevice(db->opts.device));
+  lap("hipSetDevice (runtime init)");
   const std::string dir(db_dir);
   db->db_dir = dir;
   DbYml y;
@@ -536,16 +554,20 @@ extern "C" int kmcpg_open(const char* db_dir, const kmcpg_opts* opts, kmcpg_db**
   I.n_blocks = (int32_t)db->blocks.size();
   I.n_cols = base;
   if (I.num_hashes < 1 || I.num_hashes > 4) return kmcpg_fail(KMCPG_EUNSUPPORTED, "hashes=%d (kmcp index allows 1..4)", I.num_hashes);
+  lap("__db.yml + .uniki headers");
   assign_shards(db.get());
   form_groups(db.get());
   if (!meta_only) {
     rc = alloc_groups(db.get());
     if (rc) return rc;
+    lap("alloc_groups (hipMalloc)");
     rc = upload_blocks(db.get());
     if (rc) return rc;
+    lap("upload_blocks");
   }
   rc = finish_open(db.get());
   if (rc) return rc;
+  lap("finish_open (tables)");
   *out = db.release();
   return 0;
 }
