@@ -313,6 +313,27 @@ struct Batch {
   std::vector<uint64_t> offs{0}, offs2{0};
   kmcpg_result_pairs res{};  // compact result: (column, mKmers) pairs; the formatter threads expand a query's pairs right before its rows
   bool paired = false;
+  // -g queries (whole files) are packed where the reader first touches their bases: 2-bit codes + the runs of other bytes
+  // (kmcp_gpu.h kmcpg_pack2 / kmcpg_submit_packed); `seqs` stays empty, `offs` counts bases as ever
+  bool packed = false;
+  std::vector<uint8_t> codes;
+  std::vector<kmcpg_exc_run> exc;  // size = capacity; n_exc of them are in use
+  uint64_t n_exc = 0, n_bases = 0;
+  void pack_append(const char* s, size_t n) {
+    const size_t need = (size_t)((n_bases + n + 3) / 4 + 8);
+    if (codes.size() < need) codes.resize(std::max(need, codes.size() + codes.size() / 2 + (1u << 20)));
+    if (exc.size() < n_exc + 64) exc.resize(std::max<size_t>(1024, 2 * exc.size()));
+    for (;;) {
+      const uint64_t before = n_exc;
+      const int rc = kmcpg_pack2((const uint8_t*)s, n, n_bases, codes.data(), exc.data(), exc.size(), &n_exc);
+      if (rc == 0) break;
+      if (rc != KMCPG_ENOMEM) die("%s", kmcpg_last_error());
+      exc.resize(std::max<size_t>(2 * exc.size(), (size_t)n_exc + 1024));  // n_exc = how many runs there are in all
+      n_exc = before;
+    }
+    n_bases += n;
+  }
+  uint64_t bases() const { return packed ? n_bases : (uint64_t)(seqs.size() + seqs2.size()); }
   size_t size() const { return id_offs.size() - 1; }
   std::string_view id(size_t i) const { return std::string_view(id_buf.data() + id_offs[i], (size_t)(id_offs[i + 1] - id_offs[i])); }
   // the queries of `o` (the reader's next batch) behind this one's
@@ -988,18 +1009,6 @@ int main(int argc, char** argv) {
       b->paired = paired;
       b->first_idx = id;
     };
-    auto add = [&](std::string_view qid, std::string_view s1, const std::string* s2) {
-      b->id_buf.insert(b->id_buf.end(), qid.begin(), qid.end());
-      b->id_offs.push_back(b->id_buf.size());
-      b->seqs.insert(b->seqs.end(), s1.begin(), s1.end());
-      b->offs.push_back(b->seqs.size());
-      if (s2) {
-        b->seqs2.insert(b->seqs2.end(), s2->begin(), s2->end());
-        b->offs2.push_back(b->seqs2.size());
-      }
-      id++;
-      if (b->size() >= batch_reads.load() || b->seqs.size() + b->seqs2.size() >= max_bases.load()) flush();
-    };
     std::string id1, s1, id2, s2;
     if (paired) {
       if (verbose) info("reading from paired-end files: %s, %s", o.read1.c_str(), o.read2.c_str());
@@ -1020,21 +1029,28 @@ int main(int argc, char** argv) {
       for (const auto& file : files) {
         if (verbose) info("reading sequence file: %s", file.c_str());
         if (o.whole_file) {  // search.go:885-935
+          // the records of the file back to back, records 2..m each followed by k - 1 N's (search.go:899-914) — packed as they are
+          // read: the file's bases are touched once, the batch is a quarter of the text and the library copies it as it is
           FastxReader r(file);
-          std::string qid, whole;
+          std::string qid;
           bool first = true;
+          b->packed = true;
           while (r.next(&id1, &s1)) {
             if (first) {
               qid = o.use_filename ? trim_ext(file) : (!o.query_id.empty() ? o.query_id : id1);
-              whole = s1;
               first = false;
+              b->pack_append(s1.data(), s1.size());
             } else {
-              whole += s1;
-              whole += nnn;
+              b->pack_append(s1.data(), s1.size());
+              b->pack_append(nnn.data(), nnn.size());
             }
           }
           if (first) { warn("no valid sequences in file: %s", file.c_str()); continue; }
-          add(qid, whole, nullptr);
+          b->id_buf.insert(b->id_buf.end(), qid.begin(), qid.end());
+          b->id_offs.push_back(b->id_buf.size());
+          b->offs.push_back(b->n_bases);
+          id++;
+          if (b->size() >= batch_reads.load() || b->bases() >= max_bases.load()) flush();
           continue;
         }
         flush();  // batches do not span input files on this path
@@ -1156,7 +1172,9 @@ int main(int argc, char** argv) {
   // a batch also closes at 64 Mbases (long queries); paged indexes want the largest batches the host can hold
   // (a batch's device workspace is up to 24 B per base: the library says how many bases fit beside the resident index)
   {
-    size_t mb = paged_passes > 1 ? std::min<size_t>((size_t)o.batch * 512, (size_t)2 << 30) : (size_t)64 << 20;
+    // (-g: whole genomes as queries, packed 4 bases to a byte on the host — up to a gigabase per batch, 256 assemblies of 4 Mbp, if the
+    // device workspace allows: batches of fewer than ~190 genomes leave the chip to the slower chunked form of the kernel)
+    size_t mb = paged_passes > 1 ? std::min<size_t>((size_t)o.batch * 512, (size_t)2 << 30) : (o.whole_file ? (size_t)1 << 30 : (size_t)64 << 20);
     uint64_t hint = 0;
     if (kmcpg_batch_hint(db, &hint) == 0 && hint > 0) mb = std::max<size_t>((size_t)1 << 20, std::min<size_t>(mb, (size_t)hint));
     max_bases.store(mb);
@@ -1191,6 +1209,10 @@ int main(int argc, char** argv) {
       const size_t depth = paged_passes > 1 ? 1 : 2;
       std::deque<std::pair<kmcpg_ticket*, std::unique_ptr<Batch>>> fl;
       auto search_sync = [&](Batch& bb) {  // the one-call form: it also halves a batch whose workspace does not fit (kmcp_gpu.h kmcpg_batch_hint)
+        if (bb.packed) {  // (a rare path: the text again, the one-call form reads text)
+          bb.seqs.resize((size_t)bb.n_bases + 16);
+          if (kmcpg_unpack2(bb.codes.data(), bb.n_bases, bb.exc.data(), bb.n_exc, bb.seqs.data()) != 0) die("%s", kmcpg_last_error());
+        }
         if (kmcpg_search_batch_pairs(db, bb.seqs.data(), bb.offs.data(), bb.paired ? bb.seqs2.data() : nullptr, bb.paired ? bb.offs2.data() : nullptr,
                                      (uint32_t)bb.size(), &params, &bb.res) != 0)
           die("%s", kmcpg_last_error());
@@ -1224,7 +1246,7 @@ int main(int argc, char** argv) {
           finish_oldest();
           continue;
         }
-        if (paged_passes > 1) {
+        if (paged_passes > 1 && !b->packed) {
           std::unique_ptr<Batch> nb;
           while (b->size() < batch_reads.load() && b->seqs.size() + b->seqs2.size() < max_bases.load() && q_in.try_pop(&nb)) b->append(*nb);
         }
@@ -1232,8 +1254,9 @@ int main(int argc, char** argv) {
         my_wait += std::chrono::duration<double>(t0 - tw).count();
         kmcpg_ticket* t = nullptr;
         int rc;
-        while ((rc = kmcpg_submit(db, b->seqs.data(), b->offs.data(), b->paired ? b->seqs2.data() : nullptr, b->paired ? b->offs2.data() : nullptr,
-                                  (uint32_t)b->size(), &params, &t)) == KMCPG_EBUSY && !fl.empty())
+        while ((rc = b->packed ? kmcpg_submit_packed(db, b->codes.data(), b->offs.data(), b->exc.data(), b->n_exc, (uint32_t)b->size(), &params, &t)
+                               : kmcpg_submit(db, b->seqs.data(), b->offs.data(), b->paired ? b->seqs2.data() : nullptr, b->paired ? b->offs2.data() : nullptr,
+                                              (uint32_t)b->size(), &params, &t)) == KMCPG_EBUSY && !fl.empty())
           finish_oldest();  // every lane of the handle is taken: one of this thread's own comes back first
         if (rc == KMCPG_EBUSY || rc == KMCPG_ENOMEM) {  // the lanes are all the other searcher's / a batch that must be halved: the one-call form
           search_sync(*b);

@@ -246,6 +246,36 @@ typedef struct {
   kmcpg_pair* pairs;     /* [match_offs[n_reads]] */
   void* owner;           /* internal */
 } kmcpg_result_pairs;
+/* -- packed queries (round 6): long queries (genomes, contigs, HiFi reads) as 2-bit codes.  A batch of 256 assemblies is 1 GB of ASCII;
+ *    kmcpg_submit reads it once more to pack it into pinned staging (at 29 k genomes/s the host reads 117 GB/s of text for that).  A reader
+ *    that packs where it first touches the bases (kmcp-search -g does: cli/kmcp_search.cpp) hands the library a quarter of the bytes and no
+ *    second pass.  Reference counterpart of the input: the sequence a Query carries (util-db-search.go:50-57, search.go:885-915 for -g).
+ *    Layout: base j of the batch (all queries back to back, offs in BASES as for kmcpg_submit) sits in bits 2*(j % 4) of codes[j / 4];
+ *    code = (ascii >> 1) & 3, i.e. A/a 0, C/c 1, T/t/U/u 2, G/g 3.  Every other byte (N, IUPAC codes, gaps ...) is listed as a run
+ *    {first base, length, the byte}: it reaches the k-mer kernels verbatim (its code bits are ignored).  Runs must lie inside the batch and
+ *    must not overlap.  Exactness: the k-mer kernels see a base only through the ntHash seed tables, where all spellings of a base share an
+ *    entry (kmcp_amd/csrc/pack2.hpp) — results are those of kmcpg_submit on the text, bit for bit (tests/test_gpu_pack.py).
+ *    Single-end only.  Handles that must re-read the text (several k-mer sizes, paged indexes) unpack it on the host first: correct, slower.
+ *    kmcpg_pack2 appends n bases of text at base position `pos` of a codes array (any alignment; codes needs (pos + n + 3) / 4 + 8 bytes)
+ *    and writes the runs it met to exc[*n_exc ...] (positions absolute); when exc_cap is too small it returns KMCPG_ENOMEM with *n_exc =
+ *    the number needed in total (call again with room: packing the same bases twice is harmless).  kmcpg_unpack2 is its inverse
+ *    (canonical spelling A C G T for the coded bases). */
+typedef struct {
+  uint64_t pos;  /* first base of the run (position in the batch) */
+  uint32_t len;
+  uint32_t byte; /* the ASCII byte of every base of the run */
+} kmcpg_exc_run;
+int kmcpg_pack2(const uint8_t* seq, uint64_t n, uint64_t pos, uint8_t* codes, kmcpg_exc_run* exc, uint64_t exc_cap, uint64_t* n_exc);
+/* Page-locked host memory for a reader's batches.  Codes that live in memory from kmcpg_host_alloc are uploaded from where they are —
+ * kmcpg_submit_packed makes no staging copy of them (a quarter of a gigabyte per batch of 256 assemblies: the copy took longer than the GPU
+ * needs for the batch) — and must then stay untouched until kmcpg_wait / kmcpg_wait_pairs has returned for the ticket.  Codes in any other
+ * memory are copied inside the call as every other input is.  (offs and exc are small and always copied.) */
+int kmcpg_host_alloc(uint64_t bytes, void** out);
+int kmcpg_host_free(void* p);
+int kmcpg_unpack2(const uint8_t* codes, uint64_t n_bases, const kmcpg_exc_run* exc, uint64_t n_exc, uint8_t* out);
+int kmcpg_submit_packed(kmcpg_db* db, const uint8_t* codes, const uint64_t* offs, const kmcpg_exc_run* exc, uint64_t n_exc, uint32_t n_reads,
+                        const kmcpg_params* params, kmcpg_ticket** out);
+
 int kmcpg_search_batch_pairs(kmcpg_db* db, const uint8_t* seqs, const uint64_t* offs, const uint8_t* seqs2, const uint64_t* offs2,
                              uint32_t n_reads, const kmcpg_params* params, kmcpg_result_pairs* out);
 int kmcpg_wait_pairs(kmcpg_ticket* ticket, kmcpg_result_pairs* out);

@@ -6,6 +6,7 @@
 #include <stdint.h>
 
 #include <condition_variable>
+#include <functional>
 #include <memory>
 #include <mutex>
 #include <string>
@@ -264,6 +265,10 @@ inline bool fpr_bound_enabled() {
 }
 constexpr int kFprBoundAlways = 512;  // queries of up to this many k-mers are covered by the bound table whatever the batch holds
 void result_publish(ResultOwner* o, uint32_t n_reads, int k_used, kmcpg_result* out);
+// query.cpp: kmcpg_query_device with a prologue run under the handle's enqueue lock, in front of the batch's first kernel
+int query_device_after(kmcpg_db* db, const uint8_t* d_seqs, const uint64_t* d_offs, const uint8_t* d_seqs2, const uint64_t* d_offs2, uint32_t n_reads,
+                       uint64_t total_bases, uint32_t max_read_len, const kmcpg_params* params, kmcpg_hit* d_hits, uint64_t hit_cap, uint64_t* d_counters,
+                       int32_t* d_qkmers, int32_t* d_qlen, void* stream, const std::function<int()>* prologue);
 void result_records_to_pairs(ResultOwner* o);  // finalize.cpp: a result that holds records -> the pairs of a compact result
 
 }  // namespace kmcpg

@@ -86,6 +86,7 @@ struct Lane {
   DevBuf<ExcRun> d_exc;
   bool packed = false;
   uint32_t n_exc = 0;
+  const uint8_t* ext_pack = nullptr;  // codes that live in the CALLER's pinned memory (kmcpg_host_alloc): uploaded from there, no staging copy
   int32_t bound_n = 0;   // the -f bound of the LAST kmcpg_query_device call for this batch covered queries of up to this many k-mers
   bool grouped = false;  // this batch went through K3: h_pairs / h_roffs hold its result, h_hits is not filled
   hipEvent_t k3_ev = nullptr, eager_ev = nullptr;  // K3 done on the kernel stream -> the eager copy of the pairs on the copy stream
@@ -329,10 +330,64 @@ int stage(Lane* L, const uint8_t* seqs, const uint64_t* offs, const uint8_t* seq
   return 0;
 }
 
-int enqueue_query(kmcpg_db* db, AsyncState* A, Lane* L, const kmcpg_params& p) {
+// A batch that arrives as 2-bit codes + exception runs (kmcpg_submit_packed): the staging copy is a quarter of the text's; from the
+// upload on the lane looks exactly like one whose text stage() packed itself.
+struct PackedIn {
+  const uint8_t* codes;
+  const kmcpg_exc_run* exc;
+  uint64_t n_exc;
+};
+
+int stage_packed(Lane* L, const PackedIn& in, const uint64_t* offs, uint32_t n) {
+  static_assert(sizeof(kmcpg_exc_run) == sizeof(ExcRun), "one layout");
+  L->n = n;
+  L->packed = false;
+  L->n_exc = 0;
+  L->ext_pack = nullptr;
+  L->paired = false;
+  L->tb1 = L->tb2 = 0;
+  L->maxlen = 0;
+  L->copied = 0;
+  if (n == 0) return 0;
+  if (offs[0] != 0) return kmcpg_fail(KMCPG_EINVAL, "offs[0] must be 0");
+  uint64_t maxlen = 0;
+  for (uint32_t i = 0; i < n; i++) {
+    if (offs[i + 1] < offs[i]) return kmcpg_fail(KMCPG_EINVAL, "offsets must not decrease (read %u)", i);
+    maxlen = std::max(maxlen, offs[i + 1] - offs[i]);
+  }
+  if (maxlen > 0x7fffffffULL) return kmcpg_fail(KMCPG_EUNSUPPORTED, "query longer than 2^31-1 bases");
+  const uint64_t tb = offs[n];
+  if (in.n_exc > 0xffffffffULL) return kmcpg_fail(KMCPG_EINVAL, "too many exception runs");
+  for (uint64_t i = 0; i < in.n_exc; i++) {  // the device writes these runs into the batch's text: they must lie inside it
+    const kmcpg_exc_run& e = in.exc[i];
+    if (e.pos > tb || e.len > tb - e.pos || e.byte > 255) return kmcpg_fail(KMCPG_EINVAL, "exception run %llu lies outside the batch", (unsigned long long)i);
+  }
+  L->maxlen = (uint32_t)maxlen;
+  L->tb1 = tb;
+  // Codes in memory from kmcpg_host_alloc are page-locked already: the DMA engine reads them where they are (the caller keeps them untouched
+  // until kmcpg_wait has returned).  Staging 256 MB — a batch of 256 assemblies — took the submitting thread 15-25 ms, longer than the GPU
+  // needs for the batch (profiles/r06_h2h.txt); anything else is copied to the lane's pinned buffer as before.
+  bool pinned = false;
+  {
+    hipPointerAttribute_t at;
+    memset(&at, 0, sizeof at);
+    if (hipPointerGetAttributes(&at, in.codes) == hipSuccess) pinned = at.type == hipMemoryTypeHost;
+    else (void)hipGetLastError();  // ordinary memory: not an error
+  }
+  if (L->h_offs.ensure((size_t)n + 1) || (!pinned && L->h_pack.ensure(tb / 4 + 16)) || L->h_exc.ensure(in.n_exc + 1)) return kmcpg_fail(KMCPG_ENOMEM, "hipHostMalloc failed");
+  if (pinned) L->ext_pack = in.codes;
+  else par_memcpy(L->h_pack.p, in.codes, (tb + 3) / 4);
+  if (in.n_exc) memcpy(L->h_exc.p, in.exc, in.n_exc * sizeof(ExcRun));
+  par_memcpy(L->h_offs.p, offs, ((size_t)n + 1) * sizeof(uint64_t));
+  L->n_exc = (uint32_t)in.n_exc;
+  L->packed = true;
+  return 0;
+}
+
+int enqueue_query(kmcpg_db* db, AsyncState* A, Lane* L, const kmcpg_params& p, const std::function<int()>* prologue = nullptr) {
   hipStream_t st = L->st;
-  int rc = kmcpg_query_device(db, L->d_seqs.p, L->d_offs.p, L->paired ? L->d_seqs2.p : nullptr, L->paired ? L->d_offs2.p : nullptr, L->n, L->tb1 + L->tb2,
-                              L->maxlen, &p, L->d_hits.p, L->d_hits.cap, L->d_cnt.p, L->d_qk.p, L->d_ql.p, st);
+  int rc = query_device_after(db, L->d_seqs.p, L->d_offs.p, L->paired ? L->d_seqs2.p : nullptr, L->paired ? L->d_offs2.p : nullptr, L->n, L->tb1 + L->tb2,
+                              L->maxlen, &p, L->d_hits.p, L->d_hits.cap, L->d_cnt.p, L->d_qk.p, L->d_ql.p, st, prologue);
   if (rc) return rc;
   L->bound_n = tl_query_bound_n;
   HIPCHK(hipMemcpyAsync(L->h_cnt.p, L->d_cnt.p, 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
@@ -396,7 +451,7 @@ int enqueue(kmcpg_db* db, AsyncState* A, Lane* L, const kmcpg_params& p, bool ge
   hipStream_t up = A->up_stream;
   if (L->packed) {
     if (L->d_pack.ensure(L->tb1 / 4 + 16) || (L->n_exc && L->d_exc.ensure(L->n_exc))) return kmcpg_fail(KMCPG_ENOMEM, "hipMalloc failed");
-    HIPCHK(hipMemcpyAsync(L->d_pack.p, L->h_pack.p, (L->tb1 + 3) / 4, hipMemcpyHostToDevice, up));
+    HIPCHK(hipMemcpyAsync(L->d_pack.p, L->ext_pack ? L->ext_pack : L->h_pack.p, (L->tb1 + 3) / 4, hipMemcpyHostToDevice, up));
     if (L->n_exc) HIPCHK(hipMemcpyAsync(L->d_exc.p, L->h_exc.p, (size_t)L->n_exc * sizeof(ExcRun), hipMemcpyHostToDevice, up));
   } else if (L->tb1) {
     HIPCHK(hipMemcpyAsync(L->d_seqs.p, L->h_seqs.p, L->tb1, hipMemcpyHostToDevice, up));
@@ -407,9 +462,14 @@ int enqueue(kmcpg_db* db, AsyncState* A, Lane* L, const kmcpg_params& p, bool ge
     HIPCHK(hipMemcpyAsync(L->d_offs2.p, L->h_offs2.p, ((size_t)n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, up));
   }
   HIPCHK(hipEventRecord(L->uploaded, up));
-  HIPCHK(hipStreamWaitEvent(st, L->uploaded, 0));
-  if (L->packed) launch_unpack2(L->d_pack.p, L->d_seqs.p, L->tb1, L->n_exc ? L->d_exc.p : nullptr, L->n_exc, st);  // codes -> the ASCII K1 reads
-  int rc = enqueue_query(db, A, L, p);
+  // the kernel stream waits for the upload (and expands packed input) in front of THIS batch's first kernel, under the handle's enqueue
+  // lock: see query.cpp query_device_after
+  const std::function<int()> after_upload = [&]() -> int {
+    HIPCHK(hipStreamWaitEvent(st, L->uploaded, 0));
+    if (L->packed) launch_unpack2(L->d_pack.p, L->d_seqs.p, L->tb1, L->n_exc ? L->d_exc.p : nullptr, L->n_exc, st);  // codes -> the ASCII K1 reads
+    return 0;
+  };
+  int rc = enqueue_query(db, A, L, p, &after_upload);
   if (rc == KMCPG_ENOMEM) {
     // the shared workspace (hashes, dedup scratch, long-query counters) did not fit: hit buffers above the plain size are the
     // one thing on this handle that can give memory back — those of the idle lanes and this lane's own — then once more
@@ -600,7 +660,7 @@ int search_paged(kmcpg_db* front, const uint8_t* seqs, const uint64_t* offs, con
 }
 
 int submit_impl(kmcpg_db* db, const uint8_t* seqs, const uint64_t* offs, const uint8_t* seqs2, const uint64_t* offs2, uint32_t n, const kmcpg_params& p, bool retry,
-                bool block, kmcpg_ticket** out) {
+                bool block, kmcpg_ticket** out, const PackedIn* packed = nullptr) {
   std::unique_ptr<kmcpg_ticket> t(new kmcpg_ticket());
   t->db = db;
   t->n = n;
@@ -634,7 +694,7 @@ int submit_impl(kmcpg_db* db, const uint8_t* seqs, const uint64_t* offs, const u
   const bool can_pack = !seqs2 && !retry && (p.k > 0 || db->ks_desc.size() < 2);
   auto one = [&](size_t i) {
     auto& pt = t->parts[i];
-    rcs[i] = stage(pt.lane, seqs, offs, seqs2, offs2, n, can_pack);
+    rcs[i] = packed ? stage_packed(pt.lane, *packed, offs, n) : stage(pt.lane, seqs, offs, seqs2, offs2, n, can_pack);
     if (rcs[i] == 0) rcs[i] = enqueue(pt.shard, pt.shard->async, pt.lane, p);
     if (rcs[i]) errs[i] = kmcpg_err_ref();
   };
@@ -966,6 +1026,86 @@ static int submit_checked(kmcpg_db* db, const uint8_t* seqs, const uint64_t* off
 extern "C" int kmcpg_submit(kmcpg_db* db, const uint8_t* seqs, const uint64_t* offs, const uint8_t* seqs2, const uint64_t* offs2, uint32_t n_reads,
                             const kmcpg_params* params, kmcpg_ticket** out) {
   return submit_checked(db, seqs, offs, seqs2, offs2, n_reads, params, false, out);
+}
+
+// ---- packed queries (kmcp_gpu.h): the packer and its inverse for hosts, and the entry that takes codes
+extern "C" int kmcpg_pack2(const uint8_t* seq, uint64_t n, uint64_t pos, uint8_t* codes, kmcpg_exc_run* exc, uint64_t exc_cap, uint64_t* n_exc) {
+  if ((n && (!seq || !codes)) || !n_exc || (exc_cap && !exc)) return kmcpg_fail(KMCPG_EINVAL, "null argument");
+  static_assert(sizeof(kmcpg_exc_run) == sizeof(PackRun), "one layout");
+  static thread_local std::vector<PackRun> runs;
+  runs.clear();
+  pack2_append(seq, (size_t)n, codes, pos, runs);
+  const uint64_t have = *n_exc, total = have + runs.size();
+  // a run that continues the caller's last one (a gap of N's across two calls) is joined with it
+  size_t first = 0;
+  bool join = false;
+  if (have && have <= exc_cap && !runs.empty()) {
+    const kmcpg_exc_run& l = exc[have - 1];
+    join = l.byte == runs[0].byte && l.pos + l.len == runs[0].pos && (uint64_t)l.len + runs[0].len <= 0xffffffffu;
+  }
+  if (join) first = 1;
+  const uint64_t need = have + (runs.size() - first);
+  if (need > exc_cap) {  // nothing of the caller's list has been touched: the call can be repeated with more room
+    *n_exc = total;
+    return kmcpg_fail(KMCPG_ENOMEM, "kmcpg_pack2: room for %llu exception runs, %llu needed", (unsigned long long)exc_cap, (unsigned long long)total);
+  }
+  if (join) exc[have - 1].len += runs[0].len;
+  for (size_t i = first; i < runs.size(); i++) exc[have + (i - first)] = kmcpg_exc_run{runs[i].pos, runs[i].len, runs[i].byte};
+  *n_exc = need;
+  return 0;
+}
+
+extern "C" int kmcpg_host_alloc(uint64_t bytes, void** out) {
+  if (!out) return kmcpg_fail(KMCPG_EINVAL, "null argument");
+  *out = nullptr;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return kmcpg_fail(KMCPG_EDEVICE, "no HIP device available: libkmcpgpu has no CPU fallback");
+  if (hipHostMalloc(out, (size_t)std::max<uint64_t>(bytes, 64), hipHostMallocPortable) != hipSuccess) {
+    (void)hipGetLastError();
+    *out = nullptr;
+    return kmcpg_fail(KMCPG_ENOMEM, "hipHostMalloc of %llu bytes failed", (unsigned long long)bytes);
+  }
+  return 0;
+}
+
+extern "C" int kmcpg_host_free(void* p) {
+  if (p && hipHostFree(p) != hipSuccess) {
+    (void)hipGetLastError();
+    return kmcpg_fail(KMCPG_EINVAL, "not a pointer from kmcpg_host_alloc");
+  }
+  return 0;
+}
+
+extern "C" int kmcpg_unpack2(const uint8_t* codes, uint64_t n_bases, const kmcpg_exc_run* exc, uint64_t n_exc, uint8_t* out) {
+  if ((n_bases && (!codes || !out)) || (n_exc && !exc)) return kmcpg_fail(KMCPG_EINVAL, "null argument");
+  static const char lut[4] = {'A', 'C', 'T', 'G'};
+  for (uint64_t j = 0; j < n_bases; j++) out[j] = (uint8_t)lut[(codes[j >> 2] >> (2 * (j & 3))) & 3];
+  for (uint64_t i = 0; i < n_exc; i++) {
+    const kmcpg_exc_run& e = exc[i];
+    if (e.pos > n_bases || e.len > n_bases - e.pos || e.byte > 255) return kmcpg_fail(KMCPG_EINVAL, "exception run %llu lies outside the batch", (unsigned long long)i);
+    memset(out + e.pos, (int)e.byte, e.len);
+  }
+  return 0;
+}
+
+extern "C" int kmcpg_submit_packed(kmcpg_db* db, const uint8_t* codes, const uint64_t* offs, const kmcpg_exc_run* exc, uint64_t n_exc, uint32_t n_reads,
+                                   const kmcpg_params* params, kmcpg_ticket** out) {
+  if (!db || !out || (n_reads && (!codes || !offs)) || (n_exc && !exc)) return kmcpg_fail(KMCPG_EINVAL, "null argument");
+  *out = nullptr;
+  if (db->opts.shard_count != 1)
+    return kmcpg_fail(KMCPG_EINVAL, "kmcpg_submit/kmcpg_search_batch need the whole database: open it on one GPU or with kmcpg_open_devices; use kmcpg_query_device + kmcpg_finalize per shard");
+  if (db->shards.empty() && db->opts.device < 0 && db->paged_passes == 0) return kmcpg_fail(KMCPG_EDEVICE, "metadata-only handle (device -1): no GPU work possible");
+  const kmcpg_params p = params ? *params : default_params();
+  if (p.min_matched < 1) return kmcpg_fail(KMCPG_EINVAL, "min_matched must be >= 1");
+  // handles that read the batch's text again — the smaller k of a multi-k database (retry_unmatched), the passes of a paged index — get text
+  if (db->paged_passes > 0 || (p.k <= 0 && db->ks_desc.size() > 1)) {
+    const uint64_t tb = n_reads ? offs[n_reads] : 0;
+    std::vector<uint8_t, NoInitAlloc<uint8_t>> text((size_t)tb + 16);
+    if (int rc = kmcpg_unpack2(codes, tb, exc, n_exc, text.data())) return rc;
+    return submit_impl(db, text.data(), offs, nullptr, nullptr, n_reads, p, false, false, out);
+  }
+  const PackedIn in{codes, exc, n_exc};
+  return submit_impl(db, nullptr, offs, nullptr, nullptr, n_reads, p, false, false, out, &in);
 }
 
 extern "C" int kmcpg_wait(kmcpg_ticket* t, kmcpg_result* out) {

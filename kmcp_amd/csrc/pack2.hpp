@@ -147,6 +147,24 @@ inline bool pack2_parallel(const uint8_t* s, size_t n, uint8_t* d, std::vector<P
   return true;
 }
 
+// Appends n bases of s at base position `pos` of the codes array d (any alignment: a reader packs record after record into one batch).
+// The byte that holds base `pos` may already carry up to three codes of the previous record: it is completed, not overwritten;
+// bytes from the first whole one on are written.  Exceptions get their absolute positions.  d must have room for (pos + n + 3) / 4 + 8 bytes
+// (the vector path stores eight bytes at a time).
+inline void pack2_append(const uint8_t* s, size_t n, uint8_t* d, uint64_t pos, std::vector<PackRun>& exc) {
+  size_t j = 0;
+  if (pos & 3) {  // finish the byte the previous record left open
+    uint32_t v = d[pos >> 2] & ((1u << (2 * (pos & 3))) - 1u);
+    for (; j < n && ((pos + j) & 3); j++) {
+      const uint8_t c = s[j];
+      if (pack2_is_base(c)) v |= (uint32_t)((c >> 1) & 3) << (2 * ((pos + j) & 3));
+      else pack2_note(exc, pos + j, c);
+    }
+    d[pos >> 2] = (uint8_t)v;
+  }
+  if (j < n) pack2_range(s + j, 0, n - j, d + ((pos + j) >> 2), pos + j, exc);  // from a whole byte on: source index 0 <-> that byte
+}
+
 // what the device does (support.hip k_unpack2 + k_apply_exc), for the host test
 inline void unpack2_host(const uint8_t* d, size_t n, const std::vector<PackRun>& exc, uint8_t* out) {
   static const char lut[4] = {'A', 'C', 'T', 'G'};

@@ -280,10 +280,24 @@ extern "C" int kmcpg_kmers_device(kmcpg_db* db, const uint8_t* d_seqs, const uin
 extern "C" int kmcpg_query_device(kmcpg_db* db, const uint8_t* d_seqs, const uint64_t* d_offs, const uint8_t* d_seqs2, const uint64_t* d_offs2,
                                   uint32_t n_reads, uint64_t total_bases, uint32_t max_read_len, const kmcpg_params* params, kmcpg_hit* d_hits,
                                   uint64_t hit_cap, uint64_t* d_counters, int32_t* d_qkmers, int32_t* d_qlen, void* stream) {
+  return kmcpg::query_device_after(db, d_seqs, d_offs, d_seqs2, d_offs2, n_reads, total_bases, max_read_len, params, d_hits, hit_cap, d_counters, d_qkmers, d_qlen,
+                                   stream, nullptr);
+}
+
+// kmcpg_query_device with a prologue that runs once the handle's enqueue lock is held, i.e. right in front of this batch's first kernel.
+// host.cpp puts "wait for this batch's upload" (+ the expansion of packed input) there: enqueued BEFORE taking the lock, that wait could
+// land in the kernel stream between the k-mer kernels and the COBS kernel of the batch before — a call that reads a word back in the middle
+// (whole-genome queries) releases nothing until it returns — and the earlier batch's COBS kernel then sat behind the later batch's 4.5-ms
+// upload (profiles/r06_h2h.txt: 2.4 ms of idle GPU per batch of 256 assemblies).
+int kmcpg::query_device_after(kmcpg_db* db, const uint8_t* d_seqs, const uint64_t* d_offs, const uint8_t* d_seqs2, const uint64_t* d_offs2, uint32_t n_reads,
+                              uint64_t total_bases, uint32_t max_read_len, const kmcpg_params* params, kmcpg_hit* d_hits, uint64_t hit_cap, uint64_t* d_counters,
+                              int32_t* d_qkmers, int32_t* d_qlen, void* stream, const std::function<int()>* prologue) {
   if (!db || !d_seqs || !d_offs || !d_counters || !d_qkmers || !d_qlen || (!d_hits && hit_cap)) return kmcpg_fail(KMCPG_EINVAL, "null argument");
   if ((d_seqs2 == nullptr) != (d_offs2 == nullptr)) return kmcpg_fail(KMCPG_EINVAL, "seqs2 and offs2 must be given together");
   std::lock_guard<std::mutex> g(db->mu);
   KMCPG_USE_DEVICE(db);
+  if (prologue)
+    if (int rcp = (*prologue)()) return rcp;
   const kmcpg_params p = params ? *params : default_params();
   if (p.min_matched < 1) return kmcpg_fail(KMCPG_EINVAL, "min_matched must be >= 1");  // getFlagPositiveInt (search.go:165)
   if (p.k > 0 && std::find(db->ks_desc.begin(), db->ks_desc.end(), p.k) == db->ks_desc.end())

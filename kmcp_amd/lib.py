@@ -18,7 +18,65 @@ EXPORTS = [
     "kmcpg_last_timing", "kmcpg_open_devices", "kmcpg_build_db", "kmcpg_submit", "kmcpg_wait", "kmcpg_read_row_range", "kmcpg_timing_at", "kmcpg_last_gathered_bytes", "kmcpg_last_hash_bytes",
     "kmcpg_db_ks", "kmcpg_open_paged", "kmcpg_paged_info", "kmcpg_exchange_info", "kmcpg_batch_hint", "kmcpg_group_device", "kmcpg_finalize_grouped",
     "kmcpg_search_batch_pairs", "kmcpg_wait_pairs", "kmcpg_result_pairs_free", "kmcpg_expand_pairs", "kmcpg_save_db",
+    "kmcpg_pack2", "kmcpg_unpack2", "kmcpg_submit_packed", "kmcpg_host_alloc", "kmcpg_host_free",
 ]
+
+
+def pack2(pieces, codes=None, exc=None, pos=0):
+    """kmcpg_pack2 over a list of byte strings / uint8 arrays appended one after the other from base position `pos`:
+    returns (codes uint8[(total + 3) // 4 + 8], exc EXC_DTYPE[n_exc], total bases)."""
+    arrs = [np.frombuffer(x, dtype=np.uint8) if isinstance(x, (bytes, bytearray)) else np.ascontiguousarray(x, dtype=np.uint8) for x in pieces]
+    total = pos + sum(len(a) for a in arrs)
+    if codes is None:
+        codes = np.zeros((total + 3) // 4 + 8, dtype=np.uint8)
+    cap = 1024 if exc is None else max(1024, 2 * len(exc))
+    runs = np.zeros(cap, dtype=EXC_DTYPE)
+    n_exc = C.c_uint64(0)
+    if exc is not None and len(exc):
+        runs[:len(exc)] = exc
+        n_exc.value = len(exc)
+    at = pos
+    for a in arrs:
+        while True:
+            before = n_exc.value
+            rc = load().kmcpg_pack2(a.ctypes.data, len(a), at, codes.ctypes.data, runs.ctypes.data, len(runs), C.byref(n_exc))
+            if rc == 0:
+                break
+            if rc != -5:
+                _check(rc)
+            grown = np.zeros(max(2 * len(runs), int(n_exc.value) + 1024), dtype=EXC_DTYPE)
+            grown[:before] = runs[:before]
+            runs = grown
+            n_exc.value = before
+        at += len(a)
+    return codes, runs[:n_exc.value].copy(), total
+
+
+class PinnedBytes:
+    """uint8 array in page-locked memory from kmcpg_host_alloc (`.a`); freed by close() / the context manager."""
+
+    def __init__(self, n):
+        self._p = C.c_void_p()
+        _check(load().kmcpg_host_alloc(n, C.byref(self._p)))
+        self.a = np.ctypeslib.as_array(C.cast(self._p, C.POINTER(C.c_uint8)), shape=(max(int(n), 64),))
+
+    def close(self):
+        if self._p:
+            self.a = None
+            _check(load().kmcpg_host_free(self._p))
+            self._p = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+
+def unpack2(codes, n_bases, exc):
+    out = np.empty(n_bases, dtype=np.uint8)
+    _check(load().kmcpg_unpack2(codes.ctypes.data, n_bases, exc.ctypes.data if len(exc) else None, len(exc), out.ctypes.data))
+    return out
 
 
 class KmcpGpuError(RuntimeError):
@@ -81,6 +139,7 @@ class BuildCol(C.Structure):
 
 HIT_DTYPE = np.dtype([("read", np.uint32), ("col", np.uint32), ("count", np.uint32)])
 PAIR_DTYPE = np.dtype([("col", np.uint32), ("count", np.uint32)])
+EXC_DTYPE = np.dtype([("pos", np.uint64), ("len", np.uint32), ("byte", np.uint32)])  # kmcpg_exc_run
 MATCH_DTYPE = np.dtype([("col", np.uint32), ("target_idx", np.uint32), ("gsize", np.uint64), ("mkmers", np.int32),
                         ("reserved", np.int32), ("fpr", np.float64), ("qcov", np.float64), ("tcov", np.float64),
                         ("jacc", np.float64)])
@@ -161,6 +220,11 @@ def load():
     L.kmcpg_timing_at.argtypes = [vp, C.c_uint32, C.POINTER(C.c_float), C.POINTER(C.c_float)]
     L.kmcpg_build_db.argtypes = [C.c_char_p, C.POINTER(BuildCfg), C.POINTER(BuildCol), C.c_uint32, C.c_int32]
     L.kmcpg_save_db.argtypes = [vp, C.c_char_p]
+    L.kmcpg_pack2.argtypes = [vp, C.c_uint64, C.c_uint64, vp, vp, C.c_uint64, u64p]
+    L.kmcpg_unpack2.argtypes = [vp, C.c_uint64, vp, C.c_uint64, vp]
+    L.kmcpg_host_alloc.argtypes = [C.c_uint64, C.POINTER(vp)]
+    L.kmcpg_host_free.argtypes = [vp]
+    L.kmcpg_submit_packed.argtypes = [vp, vp, vp, vp, C.c_uint64, C.c_uint32, C.POINTER(Params), C.POINTER(vp)]
     _lib = L
     return L
 
@@ -372,6 +436,14 @@ class Database:
         n = len(offs) - 1
         _check(load().kmcpg_submit(self._h, seqs.ctypes.data, offs.ctypes.data, seqs2.ctypes.data if seqs2 is not None else None,
                                    offs2.ctypes.data if offs2 is not None else None, n, C.byref(p), C.byref(t)))
+        return t
+
+    def submit_packed(self, codes, offs, exc, params=None):
+        """kmcpg_submit_packed: a batch as 2-bit codes (pack2) + exception runs; offs in bases."""
+        p = params or default_params()
+        t = C.c_void_p()
+        n = len(offs) - 1
+        _check(load().kmcpg_submit_packed(self._h, codes.ctypes.data, offs.ctypes.data, exc.ctypes.data if len(exc) else None, len(exc), n, C.byref(p), C.byref(t)))
         return t
 
     def wait(self, ticket, count_only=False):

@@ -19,7 +19,7 @@ def L():
 
 def test_header_symbols_exported(L):
     hdr = open(os.path.join(ROOT, "include", "kmcp_gpu.h")).read()
-    declared = set(re.findall(r"\b(kmcpg_[a-z_]+)\s*\(", hdr))
+    declared = set(re.findall(r"\b(kmcpg_[a-z0-9_]+)\s*\(", hdr))
     assert declared == set(L.EXPORTS), declared ^ set(L.EXPORTS)
     lib = L.load()
     for s in declared:

@@ -190,6 +190,36 @@ def test_cli_paired_end_and_whole_file(oracle_lib, tmp_path):
     compare(run_cli(["-d", db_root, "-g", "-t", "0.35", fa], str(tmp_path / "g.tsv")), want, trailer)
     want, trailer = oracle_tsv(O, odb, ["asm"], [whole], params=p)
     compare(run_cli(["-d", db_root, "-g", "-G", "-t", "0.35", fa], str(tmp_path / "g2.tsv")), want, trailer)
+    # several files = several queries in one batch, packed 4 bases to a byte as they are read (kmcpg_pack2 / kmcpg_submit_packed): records
+    # of every length modulo 4, soft-masked stretches, N runs, IUPAC codes, U — and an assembly that matches nothing
+    rng = np.random.default_rng(5)
+    files, wholes, qids = [], [], []
+    for fi in range(7):
+        recs = []
+        for ri in range(1 + fi % 4):
+            g = genomes[(fi + ri) % len(genomes)]
+            a = int(rng.integers(0, len(g) - 6000))
+            s = bytearray(g[a:a + 1500 + int(rng.integers(0, 3000)) + ri])
+            if ri % 2:
+                s[100:400] = bytes(s[100:400]).lower()
+            if fi % 3 == 1:
+                s[700:700 + 37 + ri] = b"N" * (37 + ri)
+                for pp in rng.integers(0, len(s), size=6):
+                    s[int(pp)] = int(rng.choice(list(b"RYKMSWn")))
+            if fi == 5:
+                s = bytearray(bytes(s).replace(b"T", b"U"))
+            if fi == 6:
+                s = bytearray(rng.choice(list(b"ACGT"), len(s)).astype(np.uint8).tobytes())
+            recs.append((f"f{fi}c{ri}", bytes(s)))
+        fa_i = str(tmp_path / f"asm{fi}.fasta")
+        write_fasta(fa_i, recs)
+        files.append(fa_i)
+        qids.append(recs[0][0])
+        wholes.append(recs[0][1] + b"".join(r[1] + b"N" * 20 for r in recs[1:]))
+    want, trailer = oracle_tsv(O, odb, qids, wholes, params=p)
+    assert len(want) >= 6
+    compare(run_cli(["-d", db_root, "-g", "-t", "0.35"] + files, str(tmp_path / "g3.tsv")), want, trailer)
+    compare(run_cli(["-d", db_root, "-g", "-t", "0.35", "--gpu-batch", "3"] + files, str(tmp_path / "g4.tsv")), want, trailer)
     odb.close()
 
 

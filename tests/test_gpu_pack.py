@@ -103,3 +103,63 @@ def test_a_large_batch_of_long_reads_packs_by_itself(world):
     os.environ.pop("KMCPG_PACK", None)
     a, _ = _run(tmp, db_dir, reads[:300] + reads, "big", env)
     assert len(a) > 56 * 1000
+
+
+def test_submit_packed_equals_submit_on_the_text(world, oracle_lib):
+    """kmcpg_submit_packed (round 6): the caller packs (kmcpg_pack2, record after record at any base position) and the library takes the
+    codes as they are.  Same Match records, bit for bit, as kmcpg_submit on the text and as the oracle — N runs, IUPAC, lower case, U,
+    bytes >= 128, empty and 4-base queries included; several tickets in flight; a multi-k database takes the unpack-on-host path."""
+    import re
+    from kmcp_amd import Database, default_params, lib
+    tmp, genomes, db_dir = world
+    O = oracle_lib
+    reads = _weird_reads(genomes, 6)
+    seqs, offs = lib.pack_reads(reads)
+    codes, exc, total = lib.pack2(reads)                       # one kmcpg_pack2 call per query: every alignment 0..3 occurs
+    assert total == int(offs[-1]) and len(exc) > 50
+    fold = np.arange(256, dtype=np.uint8)
+    for c, f in zip(b"acgtuU", b"ACGTTT"):
+        fold[c] = f
+    assert np.array_equal(lib.unpack2(codes, total, exc), fold[seqs])  # lower case and U are re-spelled, every other byte is verbatim
+    odb = O.OracleDB(db_dir)
+    try:
+        with Database.open(db_dir) as db:
+            want = db.wait(db.submit(seqs, offs, params=default_params()))
+            t1 = db.submit_packed(codes, offs, exc, params=default_params())
+            t2 = db.submit_packed(codes, offs, exc, params=default_params(sort_by=2, min_qcov=0.4))
+            codes_copy = codes.copy()
+            codes[:] = 0xFF                                     # the caller's buffers are the caller's again at once
+            r2, r1 = db.wait(t2), db.wait(t1)
+            assert r1.matches.tobytes() == want.matches.tobytes() and np.array_equal(r1.qkmers, want.qkmers) and np.array_equal(r1.qlen, want.qlen)
+            assert synth.assert_parity(odb, r1, reads) > 30
+            assert synth.assert_parity(odb, r2, reads, oparams=O.default_params(sort_by=2, min_qcov=0.4)) > 30
+            # codes in page-locked memory from kmcpg_host_alloc are uploaded from where they are (no staging copy): same records
+            with lib.PinnedBytes(len(codes_copy)) as pin:
+                pin.a[:len(codes_copy)] = codes_copy
+                tk = [db.submit_packed(pin.a, offs, exc, params=default_params()) for _ in range(3)]
+                for t_ in tk:
+                    assert db.wait(t_).matches.tobytes() == want.matches.tobytes()
+            pr = db.wait_pairs(db.submit_packed(codes_copy, offs, exc, params=default_params()))
+            assert np.array_equal(pr.offs, want.offs) and np.array_equal(pr.pairs[:, 0], want.matches["col"])
+            # runs that lie outside the batch are refused
+            bad = np.array([(total - 2, 5, ord("N"))], dtype=lib.EXC_DTYPE)
+            with pytest.raises(lib.KmcpGpuError):
+                db.submit_packed(codes_copy, offs, bad)
+            e = db.wait(db.submit_packed(codes_copy[:8], np.zeros(1, np.uint64), exc[:0]))
+            assert len(e) == 0
+    finally:
+        odb.close()
+    # a database with two k-mer sizes re-reads the text of unmatched queries: the packed entry unpacks on the host for it
+    cols = []
+    for gi, g in enumerate(genomes[:8]):
+        h = np.concatenate([O.generate_kmers(g, O.sketch_cfg(k=k)) for k in (21, 31)])
+        cols.append((f"g{gi}", len(g), 0, 1, O.sort_unique(h)))
+    db2 = O.build_db(str(tmp / "db2k"), O.sketch_cfg(k=31), cols, num_hashes=1, fpr=0.1, threads=4, block_size=8)
+    yml = open(db2 + "/__db.yml").read()
+    open(db2 + "/__db.yml", "w").write(re.sub(r"ks:\n- 31\n", "ks:\n- 21\n- 31\n", yml))
+    with Database.open(db2) as db:
+        assert db.ks == [31, 21]
+        p = default_params(min_qcov=0.2)
+        a = db.wait(db.submit(seqs, offs, params=p))
+        b = db.wait(db.submit_packed(codes_copy, offs, exc, params=p))
+        assert a.matches.tobytes() == b.matches.tobytes() and np.array_equal(a.ksize, b.ksize) and len(a.matches) > 10
