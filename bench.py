@@ -117,6 +117,12 @@ WORKLOADS = {
                          batch_reads=1048576, kernel="k2_cobs<64,8,false,false,4>",
                          metric="reads/sec searched (150bp, k=21) vs a 200k-chunk index of 782-byte rows",
                          name="200k-chunk synthetic: 32 blocks x 6250 cols x ~1.12 M sigs (28 GB), 150bp k=21"),
+    # ... a 150 000-chunk one: 32 blocks x 4 688 columns = 586-byte rows (640-byte pitch): the 64-lane form with 40 of 64 lanes busy, or — with
+    # KMCPG_SPLIT_TILES=2 — a 512-byte tile on the 32-lane form + a 128-byte tile on the 8-lane form (profiles/r06_lpr_640.txt)
+    "mid_rows_586": dict(k=21, num_hashes=1, fpr=0.3, n_blocks=32, cols_per_block=4688, num_sigs=1121470, sigs_step=64, kmers_per_col=400000,
+                         batch_reads=1048576, kernel="k2_cobs<64,8,false,false,4>",
+                         metric="reads/sec searched (150bp, k=21) vs a 150k-chunk index of 586-byte rows",
+                         name="150k-chunk synthetic: 32 blocks x 4688 cols x ~1.12 M sigs (23 GB), 150bp k=21"),
     # EXPERIMENT (VERDICT r4 #3 gate, profiles/r05_rowsort_gate.txt): ONE narrow block of the HiFi index and enough reads to fill the
     # chip with (read, block) units; KMCPG_DEBUG_ROWSORT=1|2 re-orders every read's k-mers by the row they address
     "config4_oneblock": dict(k=21, num_hashes=1, fpr=0.3, n_blocks=1, cols_per_block=312, num_sigs=300000, sigs_step=0, kmers_per_col=100000, syncmer_s=11,

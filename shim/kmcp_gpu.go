@@ -9,8 +9,9 @@
 //
 // NOTE: there is no Go toolchain in the build container of this repository, so this file is delivered as source
 // and has not been compiled there.  The exact sequence of C calls it makes — malloc'd CSR buffers, kmcpg_submit,
-// kmcpg_wait from other threads, kmcpg_result_free, the error fetch on the failing thread — is replayed from several
-// threads by tests/shim_replay.c (tests/test_gpu_shim_replay.py), which is compiled and run with every GPU test run.
+// kmcpg_wait_pairs from other threads, kmcpg_expand_pairs per matched query into a malloc'd scratch array,
+// kmcpg_result_pairs_free, the error fetch on the failing thread — is replayed from several threads by tests/shim_replay.c
+// (tests/test_gpu_shim_replay.py), which is compiled and run with every GPU test run.
 package cmd
 
 // Tree layout the #cgo lines assume (shim/build.sh puts the files there): this file and kmcp_gpu_test.go in
@@ -206,15 +207,19 @@ func (db *GPUDB) Submit(queries []*Query, opt SearchOptions) (*gpuBatch, error) 
 	return b, nil
 }
 
-// Wait blocks until the batch's GPU work is done, lets the library run the host half (float64 thresholds, FPR, sort,
-// --try-se / smaller-k retries) on this thread, and converts the CSR result into the engine's own QueryResult/Match
-// structs (util-db-search.go:60-93).  Everything C returns is copied before kmcpg_result_free.
+// Wait blocks until the batch's GPU work is done and takes the batch's FINAL matches as compact (column, mKmers) pairs
+// (kmcpg_wait_pairs, round 5: every threshold, -f and --keep-top-scores applied, in print order; the --try-se / smaller-k
+// retries run inside the call on this thread).  The float64 values of a Match — qCov, tCov, jacc (util-db-search.go:7487-7489)
+// and the FPR column (util-fpr.go:32-50) — are derived one query at a time by kmcpg_expand_pairs into a small scratch array and
+// copied into the engine's own QueryResult/Match structs (util-db-search.go:60-93): the 56-byte records of a batch (1.5 GB per
+// 131 072 reads on a database full of close relatives) never exist as a whole.  Everything C returns is copied before
+// kmcpg_result_pairs_free.  The call sequence is replayed by tests/shim_replay.c (three threads, ASan) with every GPU test run.
 func (db *GPUDB) Wait(b *gpuBatch, dbID int) ([]*QueryResult, error) {
-	var res C.kmcpg_result
-	if err := gpuCall(func() C.int { return C.kmcpg_wait(b.ticket, &res) }); err != nil { // the ticket is consumed either way
+	var res C.kmcpg_result_pairs
+	if err := gpuCall(func() C.int { return C.kmcpg_wait_pairs(b.ticket, &res) }); err != nil { // the ticket is consumed either way
 		return nil, err
 	}
-	defer C.kmcpg_result_free(&res)
+	defer C.kmcpg_result_pairs_free(&res)
 	n := len(b.queries)
 	out := make([]*QueryResult, n)
 	if n == 0 {
@@ -224,24 +229,37 @@ func (db *GPUDB) Wait(b *gpuBatch, dbID int) ([]*QueryResult, error) {
 	qk := unsafe.Slice((*int32)(unsafe.Pointer(res.qkmers)), n)
 	ks := unsafe.Slice((*int32)(unsafe.Pointer(res.ksize)), n)
 	offs := unsafe.Slice((*uint64)(unsafe.Pointer(res.match_offs)), n+1)
-	var ms []C.kmcpg_match
+	var pairs []C.kmcpg_pair
 	if offs[n] > 0 {
-		ms = unsafe.Slice(res.matches, int(offs[n]))
+		pairs = unsafe.Slice(res.pairs, int(offs[n]))
 	}
+	// one query's records at a time, in C memory (no Go pointer crosses the boundary; grown to the largest query of the batch)
+	scratchCap := 256
+	scratch := (*C.kmcpg_match)(C.malloc(C.size_t(scratchCap) * C.size_t(unsafe.Sizeof(C.kmcpg_match{}))))
+	defer func() { C.free(unsafe.Pointer(scratch)) }()
 	for i, q := range b.queries {
 		r := poolQueryResult.Get().(*QueryResult)
 		r.QueryIdx, r.QueryID, r.QueryLen = q.Idx, q.ID, int(qlen[i])
 		r.DBId, r.K, r.NumKmers, r.Matches = dbID, int(ks[i]), int(qk[i]), nil
-		if offs[i+1] > offs[i] {
+		if m := int(offs[i+1] - offs[i]); m > 0 {
+			if m > scratchCap {
+				C.free(unsafe.Pointer(scratch))
+				scratchCap = m + m/2
+				scratch = (*C.kmcpg_match)(C.malloc(C.size_t(scratchCap) * C.size_t(unsafe.Sizeof(C.kmcpg_match{}))))
+			}
+			first := &pairs[offs[i]]
+			if err := gpuCall(func() C.int { return C.kmcpg_expand_pairs(db.h, C.int32_t(qk[i]), first, C.uint64_t(m), scratch) }); err != nil {
+				return nil, err
+			}
 			matches := poolMatches.Get().(*[]*Match)
 			// a pooled slice keeps whatever length its last user left it with unless every consumer resets it before Put (the
 			// reference does, search.go:582-583): reset here as well, so that the shim does not depend on it
 			*matches = (*matches)[:0]
-			for _, m := range ms[offs[i]:offs[i+1]] {
+			for _, mm := range unsafe.Slice(scratch, m) {
 				*matches = append(*matches, &Match{
-					Target: []string{db.names[int(m.col)]}, TargetIdx: []uint32{uint32(m.target_idx)},
-					GenomeSize: []uint64{uint64(m.gsize)}, NumKmers: int(m.mkmers), FPR: float64(m.fpr),
-					QCov: float64(m.qcov), TCov: float64(m.tcov), JaccardIndex: float64(m.jacc),
+					Target: []string{db.names[int(mm.col)]}, TargetIdx: []uint32{uint32(mm.target_idx)},
+					GenomeSize: []uint64{uint64(mm.gsize)}, NumKmers: int(mm.mkmers), FPR: float64(mm.fpr),
+					QCov: float64(mm.qcov), TCov: float64(mm.tcov), JaccardIndex: float64(mm.jacc),
 				})
 			}
 			r.Matches = matches

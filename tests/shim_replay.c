@@ -2,7 +2,9 @@
  *
  * What the cgo shim does per batch, from several OS threads at once:
  *   Submit: malloc two CSR buffers, fill them, kmcpg_submit, free them at once (the library has copied them);
- *   Wait (on ANOTHER thread than the submitter's): kmcpg_wait, read qlen/qkmers/ksize/match_offs/matches, kmcpg_result_free;
+ *   Wait (on ANOTHER thread than the submitter's; round 6: the compact form): kmcpg_wait_pairs, read qlen/qkmers/ksize/match_offs,
+ *         per matched query kmcpg_expand_pairs(db, qkmers[i], pairs + offs[i], m, scratch) into a malloc'd scratch array that grows to
+ *         the largest query of the batch, read the records, kmcpg_result_pairs_free — exactly (*GPUDB).Wait of shim/kmcp_gpu.go;
  *   open: kmcpg_db_info + one kmcpg_col_info per column (names cached on the caller's side);
  *   errors: the failing call and kmcpg_last_error() on the same thread.
  * One submitter thread and two waiter threads share a handle, with at most IN_FLIGHT tickets between them — RunGPUEngine's
@@ -97,20 +99,31 @@ static void* waiter(void* arg) {
     }
     job_t j = g_q[--g_qn]; /* LIFO on purpose: tickets are waited for out of order */
     pthread_mutex_unlock(&g_mu);
-    kmcpg_result r;
-    if (kmcpg_wait(j.ticket, &r) != 0) die("kmcpg_wait");
+    kmcpg_result_pairs r;
+    if (kmcpg_wait_pairs(j.ticket, &r) != 0) die("kmcpg_wait_pairs");
     uint64_t sum = 0, nm = r.match_offs[j.n];
+    size_t scratch_cap = 4; /* (the shim starts at 256; small here so that the growth path runs) */
+    kmcpg_match* scratch = (kmcpg_match*)malloc(scratch_cap * sizeof(kmcpg_match));
     for (uint32_t i = 0; i < j.n; i++) {
       sum = sum * 1099511628211ULL + (uint64_t)(uint32_t)r.qlen[i] * 31 + (uint64_t)(uint32_t)r.qkmers[i] * 7 + (uint64_t)(uint32_t)r.ksize[i];
-      for (uint64_t m = r.match_offs[i]; m < r.match_offs[i + 1]; m++) {
-        const kmcpg_match* M = &r.matches[m];
+      const uint64_t cnt = r.match_offs[i + 1] - r.match_offs[i];
+      if (cnt == 0) continue;
+      if (cnt > scratch_cap) {
+        free(scratch);
+        scratch_cap = (size_t)(cnt + cnt / 2);
+        scratch = (kmcpg_match*)malloc(scratch_cap * sizeof(kmcpg_match));
+      }
+      if (kmcpg_expand_pairs(g_db, r.qkmers[i], r.pairs + r.match_offs[i], cnt, scratch) != 0) die("kmcpg_expand_pairs");
+      for (uint64_t m = 0; m < cnt; m++) {
+        const kmcpg_match* M = &scratch[m];
         if (M->col >= g_ncols) die("column out of range");
         uint64_t qc;
         memcpy(&qc, &M->qcov, 8);
         sum = sum * 1099511628211ULL + ((uint64_t)M->col << 20) + (uint64_t)(uint32_t)M->mkmers + qc + (uint64_t)strlen(g_names[M->col]);
       }
     }
-    kmcpg_result_free(&r);
+    free(scratch);
+    kmcpg_result_pairs_free(&r);
     snprintf(g_lines[j.idx], sizeof g_lines[0], "batch %d reads %u matches %llu sum %016llx", j.idx, j.n, (unsigned long long)nm, (unsigned long long)sum);
     pthread_mutex_lock(&g_mu);
     g_tokens--;
