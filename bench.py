@@ -123,6 +123,12 @@ WORKLOADS = {
                          batch_reads=1048576, kernel="k2_cobs<64,8,false,false,4>",
                          metric="reads/sec searched (150bp, k=21) vs a 150k-chunk index of 586-byte rows",
                          name="150k-chunk synthetic: 32 blocks x 4688 cols x ~1.12 M sigs (23 GB), 150bp k=21"),
+    "mid_rows_575": dict(k=21, num_hashes=1, fpr=0.3, n_blocks=32, cols_per_block=4600, num_sigs=1121470, sigs_step=64, kmers_per_col=400000,
+                         batch_reads=1048576, kernel="k2_cobs<64,8,false,false,4>", metric="reads/sec searched (150bp, k=21) vs an index of 575-byte rows",
+                         name="synthetic: 32 blocks x 4600 cols x ~1.12 M sigs (23 GB), 575-byte rows (576-byte pitch), 150bp k=21"),
+    "mid_rows_750": dict(k=21, num_hashes=1, fpr=0.3, n_blocks=32, cols_per_block=6000, num_sigs=1121470, sigs_step=64, kmers_per_col=400000,
+                         batch_reads=1048576, kernel="k2_cobs<64,8,false,false,4>", metric="reads/sec searched (150bp, k=21) vs an index of 750-byte rows",
+                         name="synthetic: 32 blocks x 6000 cols x ~1.12 M sigs (27 GB), 750-byte rows (768-byte pitch), 150bp k=21"),
     # EXPERIMENT (VERDICT r4 #3 gate, profiles/r05_rowsort_gate.txt): ONE narrow block of the HiFi index and enough reads to fill the
     # chip with (read, block) units; KMCPG_DEBUG_ROWSORT=1|2 re-orders every read's k-mers by the row they address
     "config4_oneblock": dict(k=21, num_hashes=1, fpr=0.3, n_blocks=1, cols_per_block=312, num_sigs=300000, sigs_step=0, kmers_per_col=100000, syncmer_s=11,

@@ -243,8 +243,12 @@ int finish_open(kmcpg_db* db) {
     // units per wave) + 256 (16 lanes) + 64 (4 lanes), each aligned to its own tile size — the genome search's K2 took 9.35 ms instead
     // of 4.9 ms (same bytes moved): three launches read the hashes and compute the row indices three times, and the narrow parts run
     // on the fabric's request rate.  The idle lanes were never the cost (profiles/r05_split_tiles.txt).
-    const int split_tiles = getenv("KMCPG_SPLIT_TILES") ? atoi(getenv("KMCPG_SPLIT_TILES")) : 0;  // (read at every open: tests flip it)
-    const bool split = rem > 256 && rem <= 896 && __builtin_popcount(rem / 64u) <= 3 && (split_tiles == 2 || (split_tiles == 1 && db->info.num_hashes > 1));
+    // Round 6 (profiles/r06_lpr_640.txt, single-hash index, short reads, 23-27 GB): a remainder of 640 bytes as 512 (32-lane form) + 128
+    // (8-lane form) is 11-17 % faster than one 64-lane tile with 40 lanes busy (385 -> 329-347 ms per 1 M reads) and is now what a
+    // single-hash database gets; 576 = 512 + 64 gains 4.6 % and 768 = 512 + 256 gains 6.8 %: below the 10 % bar, left as one tile.
+    const int split_tiles = getenv("KMCPG_SPLIT_TILES") ? atoi(getenv("KMCPG_SPLIT_TILES")) : -1;  // (read at every open: tests flip it; -1 = the rule above)
+    const bool split = rem > 256 && rem <= 896 && __builtin_popcount(rem / 64u) <= 3 &&
+                       (split_tiles == 2 || (split_tiles == 1 && db->info.num_hashes > 1) || (split_tiles < 0 && rem == 640 && db->info.num_hashes == 1));
     if (rem && split) {
       uint32_t at = full * 1024u, left = rem;
       for (uint32_t part = 512; part >= 64 && left; part >>= 1)

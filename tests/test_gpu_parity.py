@@ -813,15 +813,20 @@ def test_threshold_at_the_top_of_a_plane_class(G, oracle_lib, tmp_path):
         assert int(cnt[0].item()) == 0
 
 
-@pytest.mark.parametrize("ncols,nh,split", [(6500, 3, "1"), (6500, 1, "2"), (3000, 1, "0"), (3900, 2, "0")])
+@pytest.mark.parametrize("ncols,nh,split", [(6500, 3, "1"), (6500, 1, "2"), (3000, 1, "0"), (3900, 2, "0"), (5000, 1, None)])
 def test_row_remainders_cut_into_power_of_two_tiles(G, oracle_lib, tmp_path, monkeypatch, ncols, nh, split):
     """Round 5: what is left of a row beyond its whole KiB tiles, 257..896 bytes, is cut into 512 / 256 / 128 / 64-byte tiles (32, 16, 8,
     4 lanes per unit) under KMCPG_SPLIT_TILES=1 (multi-hash databases) instead of one 64-lane tile with idle lanes: 6 500 columns = 813-byte
     rows -> 512 + 256 + 64 (an experiment that lost, profiles/r05_split_tiles.txt: the knob is off by default).  KMCPG_SPLIT_TILES=2 does the same
     to single-hash databases, 0 (the default) switches it off - and then 3 000 / 3 900 columns (375- / 488-byte rows) sit on ONE 32-lane
-    tile, the default for 257..512-byte remainders since round 5: same results everywhere.  Short reads (8 planes) and long queries (16 planes)."""
+    tile, the default for 257..512-byte remainders since round 5: same results everywhere.  Short reads (8 planes) and long queries (16 planes).
+    Round 6: with the knob unset a single-hash database whose remainder is exactly 640 bytes (5 000 columns = 625-byte rows) gets 512 + 128
+    by itself (+11-17 %, profiles/r06_lpr_640.txt)."""
     O = oracle_lib
-    monkeypatch.setenv("KMCPG_SPLIT_TILES", split)
+    if split is None:
+        monkeypatch.delenv("KMCPG_SPLIT_TILES", raising=False)
+    else:
+        monkeypatch.setenv("KMCPG_SPLIT_TILES", split)
     genomes = synth.random_genomes(ncols + 21, 420, seed=900 + ncols + nh)
     db_dir = synth.make_db(tmp_path, genomes, k=21, num_hashes=nh, fpr=0.05 if nh > 1 else 0.3, block_size=ncols, threads=4)
     reads = synth.sample_reads(genomes, 500, 150, sub_rate=0.01, seed=7, frac_random=0.1)
@@ -831,3 +836,20 @@ def test_row_remainders_cut_into_power_of_two_tiles(G, oracle_lib, tmp_path, mon
     kw = dict(min_qcov=0.2, min_matched=5)
     n, res = _run(G, O, db_dir, reads + longq, oracle_kw=kw, gpu_kw=kw)
     assert n > 400 and int(res.qkmers.max()) > 1024
+    if split is None:  # the default rule really cut the row: two slot classes (32-lane + 8-lane), visible as two tiles of hash traffic
+        import torch
+        with G["Database"].open(db_dir, device=0) as db:
+            assert db.block_info(0)["stride"] == 640
+            db.set_profiling(2)
+            seqs, offs = G["lib"].pack_reads(reads[:64])
+            dev = torch.device("cuda:0")
+            t_seqs, t_offs = torch.from_numpy(seqs).to(dev), torch.from_numpy(offs.view(np.int64)).to(dev)
+            hits = torch.zeros((4096, 3), dtype=torch.int32, device=dev)
+            cnt = torch.zeros(2, dtype=torch.int64, device=dev)
+            qk = torch.zeros(64, dtype=torch.int32, device=dev)
+            ql = torch.zeros(64, dtype=torch.int32, device=dev)
+            monkeypatch.setenv("KMCPG_PRUNE", "0")
+            db.query_device(t_seqs.data_ptr(), t_offs.data_ptr(), 64, len(seqs), 150, hits.data_ptr(), 4096, cnt.data_ptr(), qk.data_ptr(), ql.data_ptr(),
+                            params=G["default_params"]())
+            torch.cuda.synchronize()
+            assert db.last_hash_bytes() == 8 * int(qk.sum().item()) * 2  # every read's hashes fetched once per slot: 2 slots

@@ -1,10 +1,11 @@
 #!/bin/bash
 # rows of 513-640 bytes — one 640-byte tile on the 64-lane form (40 lanes busy) vs 512 (32-lane form) + 128 (8-lane form)
 set -u
-OUT=gpurun_out/r06_lpr640.txt
+OUT=gpurun_out/r06_lpr640_${1:-mid_rows_586}.txt
 : > $OUT
-B="python bench.py --workload mid_rows_586 --no-cpu-baseline --no-secondary --steps 6 --warmup 2"
-for rep in 1 2; do
+W=${1:-mid_rows_586}
+B="python bench.py --workload $W --no-cpu-baseline --no-secondary --steps 6 --warmup 2"
+for rep in 1; do
 for v in 0 2; do
   KMCPG_SPLIT_TILES=$v $B > /dev/null 2>> gpurun_out/r06_lpr640.err
   python - <<PY >> $OUT
