@@ -1016,7 +1016,10 @@ __global__ void __launch_bounds__(K1W_THREADS) k1_windows_wave(const K1Args a) {
   __syncthreads();
   K1WRing& ring = rings[tid >> 6];
   const int raw_bound = a.dedup_threshold > K1_WAVE_SORT_CAP ? a.dedup_threshold : K1_WAVE_SORT_CAP;
-  for (uint32_t r = blockIdx.x; r < a.n_reads; r += gridDim.x) {
+  // (behind k1_windows_roll: only the reads that kernel put on its list)
+  const uint32_t n_todo = a.seg_only_flagged ? *a.seg_nflag : a.n_reads;
+  for (uint32_t it = blockIdx.x; it < n_todo; it += gridDim.x) {
+    const uint32_t r = a.seg_only_flagged ? a.seg_list[it] : it;
     const uint64_t o1 = a.offs[r];
     const int len1 = (int)(a.offs[r + 1] - o1);
     uint64_t o2 = 0;
@@ -1054,6 +1057,270 @@ __global__ void __launch_bounds__(K1W_THREADS) k1_windows_wave(const K1Args a) {
       a.nk1[r] = raw1;
       a.qlen[r] = len1 + len2;
     }
+  }
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// Closed-syncmer sketches of long reads by ROLLING (round 6; docs/ROUND_NOTES.md has the costing).  k1_windows_wave gives a lane one
+// position and pays ~4.2 wave instructions per window (two 64-bit XOR scans, two closed-form hashes, a two-level arg-min); here a lane
+// owns a RUN of consecutive windows of one read (one wave per read, run = windows / 64 rounded up to 16) and walks it on 2-bit codes:
+//   * two rolling ntHash states (s-mers and k-mers; nthash.hpp: fh' = rol1(fh) ^ F2[out][in], rh' = ror1(rh ^ R2[out][in]), the pair
+//     tables as ONE 16-byte LDS look-up per roll); the codes of the four bases a step needs come from four 16-code shift registers that
+//     are refilled every 16 steps (runs start at multiples of 16, so the refill is uniform over the wave);
+//   * the leftmost minimum of the window's WSZ = 2 (k - s) s-mer hashes without a data-dependent branch: the s-mer hashes are cut into
+//     blocks of WSZ; a block's suffix minima (ties to the left) are scanned in place, in registers, once the block is complete, its
+//     prefix minima grow as the next block's hashes arrive, and window i = min(suffix[i], prefix[i + WSZ - 1]) with ties to the suffix
+//     (a per-lane monotonic queue would make SOME lane rescan at almost every step);
+//   * the k-mer hash of the emission position (within k - s of the window start) from a per-lane ring in LDS ([slot][lane]: every lane
+//     keeps to its own two banks whatever slot it reads);
+//   * emissions without adjacent repeats go to the lane's own stretch of hashes[] and are moved together in order afterwards, the runs
+//     stitched on their first / last values (what k1_windows_wave does across waves).
+// Same outputs as k1_windows_wave's fused path: scratch[offs[r] ...] + nk_adj[r], nk_raw / nk1 / qlen.  A read this kernel cannot take
+// — any byte other than A/C/G/T in either case, fewer windows than WR_MIN_WINDOWS, longer than the LDS holds, or an emission count
+// outside (raw_bound, HUGE_MIN] (the fused path does not apply) — is put on a list for k1_windows_wave, launched right behind.
+// Reference: sketches.NewSyncmerSketch / NextSyncmer behind generateKmers (util-db-search.go:1053,1068).
+// ------------------------------------------------------------------------------------------------
+constexpr int WR_MIN_WINDOWS = 1024;
+constexpr int WR_PAD_BASES = 1024 + 256;  // what the last lanes' (predicated-off) steps and the refills may still read: zeros
+
+__host__ __device__ __forceinline__ int wr_words_for(int max_read_len) { return (max_read_len + WR_PAD_BASES + 15) / 16 + 4; }
+__host__ __device__ __forceinline__ int wr_ring(int wsz) { return wsz <= 30 ? 16 : 32; }  // >= k - s + 1 = wsz / 2 + 1 slots
+__host__ __device__ __forceinline__ size_t wr_lds_bytes(int wsz, int words, int waves) { return 1024 + (size_t)waves * ((size_t)wr_ring(wsz) * 64 * 8 + (size_t)words * 4); }
+
+template <int WSZ, int WR_WAVES>
+__global__ void __launch_bounds__(64 * WR_WAVES) k1_windows_roll(const K1Args a, int words) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t wr_lds[];
+  constexpr int KR = WSZ <= 30 ? 16 : 32;
+  constexpr int D = WSZ / 2;  // k - s
+  uint4* const TK = reinterpret_cast<uint4*>(wr_lds);         // [16] {F2, R2} of the k-mer roll
+  uint4* const TS = TK + 16;                                   // [16] ... of the s-mer roll
+  uint64_t* const SD = reinterpret_cast<uint64_t*>(TS + 16);   // [4] seeds by code, [4] seeds of the complements
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  uint8_t* const mine_lds = wr_lds + 1024 + (size_t)w * ((size_t)KR * 64 * 8 + (size_t)words * 4);
+  uint64_t* const ring = reinterpret_cast<uint64_t*>(mine_lds);                    // [KR][64]
+  uint32_t* const Wd = reinterpret_cast<uint32_t*>(mine_lds + (size_t)KR * 64 * 8);  // [words]: 16 codes each
+  const int k = a.k, sm = (int)a.w_or_s;
+  if (tid < 16) {
+    const uint64_t fk = nt2_f2(tid >> 2, tid & 3, k), rk = nt2_r2(tid >> 2, tid & 3, k);
+    const uint64_t fs = nt2_f2(tid >> 2, tid & 3, sm), rs = nt2_r2(tid >> 2, tid & 3, sm);
+    TK[tid] = make_uint4((uint32_t)fk, (uint32_t)(fk >> 32), (uint32_t)rk, (uint32_t)(rk >> 32));
+    TS[tid] = make_uint4((uint32_t)fs, (uint32_t)(fs >> 32), (uint32_t)rs, (uint32_t)(rs >> 32));
+    if (tid < 4) {
+      SD[tid] = seed_of(nt2_letter(tid));
+      SD[4 + tid] = seed_of(nt2_letter(tid) & 7);
+    }
+  }
+  __syncthreads();
+  const uint32_t r = blockIdx.x * WR_WAVES + (uint32_t)w;
+  if (r >= a.n_reads) return;  // (no barrier below: the waves of a workgroup are independent from here on)
+  const uint64_t o1 = a.offs[r];
+  const int len = (int)(a.offs[r + 1] - o1);
+  const int Lw = 2 * k - sm - 1;
+  const int nw = len - Lw + 1;  // windows (WSZ > 0)
+  const int raw_bound = a.dedup_threshold > K1_WAVE_SORT_CAP ? a.dedup_threshold : K1_WAVE_SORT_CAP;
+  auto leave_to_wave_kernel = [&]() {
+    if (lane == 0) a.seg_list[atomicAdd(a.seg_nflag, 1u)] = r;
+  };
+  if (len < a.min_qlen || len <= raw_bound || nw < WR_MIN_WINDOWS || len + WR_PAD_BASES > (words - 4) * 16) {
+    leave_to_wave_kernel();
+    return;
+  }
+  // ---- the read as 2-bit codes (zeros behind its end)
+  {
+    const uint8_t* __restrict__ s = a.seqs + o1;
+    typedef uint32_t u32x4_any __attribute__((ext_vector_type(4), aligned(1)));
+    bool bad = false;
+    for (int gi = lane; gi < words; gi += 64) {
+      const int b0 = gi * 16;
+      uint32_t word = 0;
+      if (b0 + 16 <= len) {
+        const u32x4_any v = *reinterpret_cast<const u32x4_any*>(s + b0);
+        const uint32_t in[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int d = 0; d < 4; d++) {
+          const uint32_t c = nt2_codes4(in[d]);
+          bad |= !nt2_valid4(in[d], c);
+          word |= nt2_fold4(c) << (8 * d);
+        }
+      } else if (b0 < len) {
+        for (int j = 0; b0 + j < len; j++) {
+          const uint32_t ch = s[b0 + j], c = (ch >> 1) & 3u;
+          bad |= (ch & 0xDFu) != (uint32_t)nt2_letter((int)c);
+          word |= c << (2 * j);
+        }
+      }
+      Wd[gi] = word;
+    }
+    if (__ballot(bad) != 0) {
+      leave_to_wave_kernel();
+      return;
+    }
+  }
+  wave_lds_fence();
+  const int L = (((nw + 63) / 64) + 15) & ~15;  // windows per lane, a multiple of 16
+  const int q0 = lane * L, q1 = min(nw, q0 + L);
+  const bool scaled = a.scaled != 0;
+  const uint64_t max_hash = a.max_hash;
+  auto code_at = [&](int q) -> uint32_t { return (Wd[q >> 4] >> (2 * (q & 15))) & 3u; };
+  auto start_up = [&](int q, int kk, uint64_t& fh, uint64_t& rh) {  // fh = XOR_j rol(F[j], kk-1-j), rh = XOR_j rol(R[j], j) of the kk-mer at q
+    fh = 0;
+    rh = 0;
+    for (int j = 0; j < kk; j++) {
+      const uint32_t c = code_at(q + j);
+      fh = nt2_rol1(fh) ^ SD[c];
+      rh ^= rolv(SD[4 + c], j);
+    }
+  };
+  auto roll = [&](uint64_t& fh, uint64_t& rh, uint32_t oc, uint32_t ic, const uint4* T) __attribute__((always_inline)) {
+    const uint4 t = T[(oc << 2) | ic];
+    fh = nt2_rol1(fh) ^ (((uint64_t)t.y << 32) | t.x);
+    rh = nt2_ror1(rh ^ (((uint64_t)t.w << 32) | t.z));
+  };
+  // ---- warm-up: the first block of s-mer hashes, the first D k-mer hashes
+  uint64_t x[WSZ];
+  int pidx[WSZ];
+  uint64_t sfh, srh, kfh, krh;
+  start_up(q0, sm, sfh, srh);
+  x[0] = sfh < srh ? sfh : srh;
+#pragma unroll
+  for (int j = 1; j < WSZ; j++) {
+    roll(sfh, srh, code_at(q0 + j - 1), code_at(q0 + j - 1 + sm), TS);
+    x[j] = sfh < srh ? sfh : srh;
+  }
+  start_up(q0, k, kfh, krh);
+  ring[(q0 & (KR - 1)) * 64 + lane] = kfh < krh ? kfh : krh;
+  for (int t = 1; t <= D; t++) {  // k-mer hashes of q0 .. q0 + D: the roll stays ONE position ahead of what the next window may ask for
+    roll(kfh, krh, code_at(q0 + t - 1), code_at(q0 + t - 1 + k), TK);
+    ring[((q0 + t) & (KR - 1)) * 64 + lane] = kfh < krh ? kfh : krh;
+  }
+  auto suffix_scan = [&]() __attribute__((always_inline)) {  // x[j] <- min(x[j .. WSZ-1]), pidx[j] <- its leftmost position in the block
+    pidx[WSZ - 1] = WSZ - 1;
+#pragma unroll
+    for (int j = WSZ - 2; j >= 0; j--) {
+      const bool left = x[j] <= x[j + 1];
+      pidx[j] = left ? j : pidx[j + 1];
+      x[j] = left ? x[j] : x[j + 1];
+    }
+  };
+  suffix_scan();
+  // the codes a step needs, relative to its window i: s-mer roll out / in (to position i + WSZ), k-mer roll out / in (to i + D + 1)
+  const int d_so = WSZ - 1, d_si = WSZ - 1 + sm, d_ko = D, d_ki = D + k;
+  uint32_t c_so = 0, c_si = 0, c_ko = 0, c_ki = 0;
+  auto refill = [&](int i, int d) -> uint32_t {  // 16 codes from base i + d on (i is a multiple of 16)
+    const int b = i + d;
+    return nt2_funnel(Wd[(b >> 4) + 1], Wd[b >> 4], (uint32_t)(2 * (b & 15)));
+  };
+  uint64_t* __restrict__ temp = a.hashes + o1 + q0;
+  int cnt = 0, raw = 0;
+  uint64_t first = 0, last = 0, pv = ~0ULL;
+  int pp = 0;
+  auto emit = [&](uint64_t h, bool on) __attribute__((always_inline)) {
+    const bool keep = on && h != 0 && (!scaled || h <= max_hash);
+    if (keep) {
+      if (raw == 0) first = h;
+      if (raw == 0 || h != last) temp[cnt++] = h;
+      last = h;
+      raw++;
+    }
+  };
+  // The step is software-pipelined by hand: the k-mer hash of window i is ASKED for at the top of step i and USED at the top of step
+  // i + 1, and the pair-table entries of step i + 1's rolls are asked for at the end of step i — an LDS round trip is ~100 cycles and
+  // the first version (three of them waited for in every step, two waves per SIMD) ran at a fifth of the issue rate.
+  c_so = refill(q0, d_so);
+  c_si = refill(q0, d_si);
+  c_ko = refill(q0, d_ko);
+  c_ki = refill(q0, d_ki);
+  uint4 ts = TS[((c_so & 3u) << 2) | (c_si & 3u)], tk = TK[((c_ko & 3u) << 2) | (c_ki & 3u)];
+  uint64_t hq = 0;   // the k-mer hash window i - 1 emits (arriving)
+  bool on_q = false;  // ... and whether that window exists
+  const int nblk = (L + WSZ - 1) / WSZ;
+  int n = 0;  // windows done by every lane (uniform)
+  for (int b = 0; b < nblk; b++) {
+    const int base = q0 + b * WSZ;
+#pragma unroll
+    for (int j = 0; j < WSZ; j++, n++) {
+      const int i = base + j;
+      // window i: the suffix of this block from j on, the first j hashes of the next block
+      const bool right = pv < x[j];
+      const int m = right ? pp : base + pidx[j];
+      const int pos = (m - i < D) ? m : m + sm - k;
+      const uint64_t hcur = ring[(pos & (KR - 1)) * 64 + lane];
+      emit(hq, on_q);
+      // the s-mer hash at i + WSZ joins the next block's prefix; the k-mer hash at i + D + 1 enters the ring
+      sfh = nt2_rol1(sfh) ^ (((uint64_t)ts.y << 32) | ts.x);
+      srh = nt2_ror1(srh ^ (((uint64_t)ts.w << 32) | ts.z));
+      kfh = nt2_rol1(kfh) ^ (((uint64_t)tk.y << 32) | tk.x);
+      krh = nt2_ror1(krh ^ (((uint64_t)tk.w << 32) | tk.z));
+      const uint64_t hs = sfh < srh ? sfh : srh;
+      if (hs < pv) {
+        pv = hs;
+        pp = i + WSZ;
+      }
+      x[j] = hs;
+      ring[((i + D + 1) & (KR - 1)) * 64 + lane] = kfh < krh ? kfh : krh;
+      c_so >>= 2;
+      c_si >>= 2;
+      c_ko >>= 2;
+      c_ki >>= 2;
+      if (((n + 1) & 15) == 0) {  // uniform: the next 16 steps' codes
+        c_so = refill(q0 + n + 1, d_so);
+        c_si = refill(q0 + n + 1, d_si);
+        c_ko = refill(q0 + n + 1, d_ko);
+        c_ki = refill(q0 + n + 1, d_ki);
+      }
+      ts = TS[((c_so & 3u) << 2) | (c_si & 3u)];
+      tk = TK[((c_ko & 3u) << 2) | (c_ki & 3u)];
+      hq = hcur;
+      on_q = i < q1;
+    }
+    suffix_scan();
+    pv = ~0ULL;
+  }
+  emit(hq, on_q);
+  // ---- the runs' pieces move together, in order; a run whose first kept value repeats the previous run's last one drops it
+  const uint64_t has = __ballot(raw > 0);
+  const uint64_t lower = has & ((1ULL << lane) - 1ULL);
+  const int src = lower ? 63 - __clzll((unsigned long long)lower) : lane;
+  const uint64_t prev_last = __shfl(last, src);
+  const int drop = (raw > 0 && lower != 0 && first == prev_last) ? 1 : 0;
+  const int mine = cnt - drop;
+  int incl = mine, raw_all = raw;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const int t1 = __shfl_up(incl, off), t2 = __shfl_up(raw_all, off);
+    if (lane >= off) {
+      incl += t1;
+      raw_all += t2;
+    }
+  }
+  const int total = __builtin_amdgcn_readlane(incl, 63), raw_total = __builtin_amdgcn_readlane(raw_all, 63);
+  if (raw_total <= raw_bound || raw_total > (int)HUGE_MIN) {  // the fused path does not apply (k1_windows_wave decides the same way)
+    leave_to_wave_kernel();
+    return;
+  }
+  // every lane moves its own piece (its stretch of hashes[] -> its place in scratch[]), eight values in flight: a loop over the 64
+  // pieces with the whole wave copying one piece at a time was 64 dependent global round trips, ~100 us per read
+  {
+    uint64_t* __restrict__ fin = a.scratch + o1 + (incl - mine);
+    const uint64_t* __restrict__ src = temp + drop;
+    int most = mine;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) most = max(most, __shfl_xor(most, off));
+    for (int t = 0; t < most; t += 8) {
+      uint64_t v[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) v[u] = t + u < mine ? src[t + u] : 0;
+#pragma unroll
+      for (int u = 0; u < 8; u++)
+        if (t + u < mine) fin[t + u] = v[u];
+    }
+  }
+  if (lane == 0) {
+    a.nk_adj[r] = total;
+    a.nk_raw[r] = raw_total;
+    a.nk1[r] = raw_total;
+    a.qlen[r] = len;
   }
 }
 
@@ -1435,6 +1702,41 @@ bool launch_k1(const K1Args& a, uint32_t max_read_len, hipStream_t st) {
   if (max_read_len > 2048) {  // long queries: a whole workgroup per read
     unsigned blocks = a.n_reads > 65536 ? 65536 : a.n_reads;
     if (a.mode != 0 && a.scratch && wave_windows_usable(a) && !(a.flags & 4)) {  // window sketches: the barrier-free form
+      // closed syncmers with a window of 20 (k 21 / s 11) or 32 (k 31 / s 15) s-mers, single-end, the fused adjacent-repeat path wanted:
+      // the rolling kernel first, k1_windows_wave behind it for the reads it leaves on its list (flags bit 5 = 32: the old kernel alone)
+      const int wsz = a.mode == 2 ? 2 * (a.k - (int)a.w_or_s) : 0;
+      const int words = wr_words_for((int)max_read_len);
+      // reads (= waves) per workgroup: LDS per wave (k-mer ring 8 KB + 2-bit codes of the longest read) decides how many waves a CU holds —
+      // two per SIMD for 20-kb reads whatever the grouping (tools/ubench_lds_occ.cpp); 2 measured 0.7 % ahead of 4 and 1
+      int waves = getenv("KMCPG_WR_WAVES") ? atoi(getenv("KMCPG_WR_WAVES")) : 2;
+      if (waves != 1 && waves != 4) waves = 2;
+      while (waves > 1 && wr_lds_bytes(wsz, words, waves) > 65536) waves >>= 1;
+      if (a.mode == 2 && (wsz == 20 || wsz == 32) && a.k <= 64 && !a.offs2 && a.nk_adj && a.seg_list && !(a.flags & 32) && wr_lds_bytes(wsz, words, waves) <= 65536) {
+        K1Args b = a;
+        (void)hipMemsetAsync(b.seg_nflag, 0, sizeof(uint32_t), st);
+        const unsigned wg = (a.n_reads + waves - 1) / waves;
+        const size_t lds = wr_lds_bytes(wsz, words, waves);
+#define KMCPG_WR_LAUNCH(WSZ_, WV_) hipLaunchKernelGGL((k1_windows_roll<WSZ_, WV_>), dim3(wg), dim3(64 * WV_), lds, st, b, words)
+        if (wsz == 20) {
+          if (waves == 4) KMCPG_WR_LAUNCH(20, 4);
+          else if (waves == 2) KMCPG_WR_LAUNCH(20, 2);
+          else KMCPG_WR_LAUNCH(20, 1);
+        } else {
+          if (waves == 4) KMCPG_WR_LAUNCH(32, 4);
+          else if (waves == 2) KMCPG_WR_LAUNCH(32, 2);
+          else KMCPG_WR_LAUNCH(32, 1);
+        }
+#undef KMCPG_WR_LAUNCH
+        b.seg_only_flagged = 1;
+        hipLaunchKernelGGL(k1_windows_wave<2>, dim3(std::min(blocks, 1024u)), dim3(K1W_THREADS), 0, st, b);
+        if (getenv("KMCPG_K1_DEBUG")) {  // how many reads the rolling kernel left to k1_windows_wave
+          uint32_t nf = 0;
+          (void)hipStreamSynchronize(st);
+          (void)hipMemcpy(&nf, b.seg_nflag, sizeof nf, hipMemcpyDeviceToHost);
+          fprintf(stderr, "k1_windows_roll<%d>: %u of %u reads left to k1_windows_wave (max_read_len %u, %d words)\n", wsz, nf, a.n_reads, max_read_len, words);
+        }
+        return true;
+      }
       if (a.mode == 2) hipLaunchKernelGGL(k1_windows_wave<2>, dim3(blocks), dim3(K1W_THREADS), 0, st, a);
       else hipLaunchKernelGGL(k1_windows_wave<1>, dim3(blocks), dim3(K1W_THREADS), 0, st, a);
       return a.nk_adj != nullptr;

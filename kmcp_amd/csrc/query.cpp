@@ -80,6 +80,11 @@ int run_kmers(kmcpg_db* db, kmcpg_db::Workspace& W, const uint8_t* d_seqs, const
     a.seg_cnt = W.w_seg_cnt.p;
     a.segs_max = segs;
   }
+  if (a.mode != 0 && !d_seqs2 && d_scratch) {  // the list the rolling window-sketch kernel leaves to k1_windows_wave (launch_k1): count + read indices
+    if (W.w_seg_cnt.ensure((size_t)n_reads + 2)) return kmcpg_fail(KMCPG_ENOMEM, "hipMalloc failed");
+    a.seg_nflag = (uint32_t*)W.w_seg_cnt.p;
+    a.seg_list = a.seg_nflag + 1;
+  }
   a.nk_adj = d_nk_search;
   a.dedup_threshold = p.dedup_threshold;
   a.flags = getenv("KMCPG_K1_FLAGS") ? atoi(getenv("KMCPG_K1_FLAGS")) : 3;

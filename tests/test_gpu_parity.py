@@ -516,8 +516,12 @@ def test_window_sketch_kernel_forms_on_long_reads(G, oracle_lib, tmp_path, monke
     genomes = synth.random_genomes(6, 40000, seed=300)
     rng = np.random.default_rng(301)
     lens = [2049, 2100, 2500, 3000, 4097, 6000, 9000, 12000, 20000, 300, 512 + 30, 150]
-    for name, kw in (("syn", dict(syncmer_s=11)), ("min", dict(minimizer_w=7)), ("minwide", dict(minimizer_w=100)), ("synscaled", dict(syncmer_s=13, scale=3))):
-        db_dir = synth.make_db(tmp_path / name, genomes, k=21, n_chunks=2, overlap=150, threads=2, **kw)
+    # (round 6: closed syncmers with a window of 20 or 32 s-mers - k 21 / s 11, k 31 / s 15 - go through the rolling kernel k1_windows_roll
+    # under flags 3 and 7, with k1_windows_wave behind it for what it leaves: reads with an N, short ones, the -u boundary cases)
+    for name, kw in (("syn", dict(syncmer_s=11)), ("min", dict(minimizer_w=7)), ("minwide", dict(minimizer_w=100)), ("synscaled", dict(syncmer_s=13, scale=3)),
+                     ("syn31", dict(k=31, syncmer_s=15)), ("syn31scaled", dict(k=31, syncmer_s=15, scale=4))):
+        kk = kw.pop("k", 21)
+        db_dir = synth.make_db(tmp_path / name, genomes, k=kk, n_chunks=2, overlap=150, threads=2, **kw)
         r1 = [synth.sample_reads(genomes, 1, L, sub_rate=0.005, seed=int(rng.integers(1 << 30)), frac_random=0.0)[0] for L in lens]
         r1 += [b"ACGTTGCAAT" * 400, b"A" * 2600 + genomes[0][:2000], genomes[1][:5000] + b"N" * 300 + genomes[1][5000:9000]]
         n, res = _run(G, O, db_dir, r1)
