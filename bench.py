@@ -1331,8 +1331,10 @@ def main():
             "value": [18.9e3, 21.3e3], "unit": "reads/s", "threads": 40,
             "source": "reference benchmarks/searching/README.md:186-229 (1.14-1.41 M reads in 53.4-72.8 s, kmcp v0.9.0, hot page cache)"}
         # BASELINE.json configs[2] and configs[4] with queries that MATCH (families of relatives / reads sampled from planted chunks)
-        for nm, st_ in (("config2_genome_search", 6), ("config4_hifi", 10), ("config4_hifi_uniform_sigs", 6)):
-            r_ = run_workload(nm, ctx, min(max(args.steps, 3), st_), 2, cpu_baseline=not args.no_cpu_baseline and nm != "config4_hifi_uniform_sigs",
+        # (steps of 4-10 ms: 40 of them, so that the first step after an idle period — sometimes published late, profiles/r05_restart_stall.txt —
+        # is 1/40th of the average and not 1/6th)
+        for nm, st_ in (("config2_genome_search", 40), ("config4_hifi", 40), ("config4_hifi_uniform_sigs", 40)):
+            r_ = run_workload(nm, ctx, max(args.steps, st_), 5, cpu_baseline=not args.no_cpu_baseline and nm != "config4_hifi_uniform_sigs",
                               cpu_target_s=3.0)
             out["secondary"][nm] = {k: r_[k] for k in keys + ("metric",) if k in r_}
         if os.environ.get("KMCP_BENCH_CLI", "1") != "0":
