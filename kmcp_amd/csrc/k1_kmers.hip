@@ -1711,7 +1711,10 @@ bool launch_k1(const K1Args& a, uint32_t max_read_len, hipStream_t st) {
       int waves = getenv("KMCPG_WR_WAVES") ? atoi(getenv("KMCPG_WR_WAVES")) : 2;
       if (waves != 1 && waves != 4) waves = 2;
       while (waves > 1 && wr_lds_bytes(wsz, words, waves) > 65536) waves >>= 1;
-      if (a.mode == 2 && (wsz == 20 || wsz == 32) && a.k <= 64 && !a.offs2 && a.nk_adj && a.seg_list && !(a.flags & 32) && wr_lds_bytes(wsz, words, waves) <= 65536) {
+      // (no read of the batch can exceed the -u / wave-sort bound — planting, a huge -u —: the fused path is nobody's, the old kernel alone)
+      const bool any_fused = (long long)max_read_len > (long long)std::max(a.dedup_threshold, K1_WAVE_SORT_CAP);
+      if (a.mode == 2 && (wsz == 20 || wsz == 32) && a.k <= 64 && !a.offs2 && a.nk_adj && a.seg_list && !(a.flags & 32) && any_fused &&
+          wr_lds_bytes(wsz, words, waves) <= 65536) {
         K1Args b = a;
         (void)hipMemsetAsync(b.seg_nflag, 0, sizeof(uint32_t), st);
         const unsigned wg = (a.n_reads + waves - 1) / waves;
