@@ -216,6 +216,53 @@ def test_sketch_kernels_match_oracle_in_order(G, oracle_lib, tmp_path):
             assert np.array_equal(got, want), (kw, i)
 
 
+@pytest.mark.parametrize("k,s,scale", [(21, 11, 1), (31, 15, 1), (31, 15, 3), (25, 15, 1)])
+def test_rolling_window_sketch_kernel_at_its_boundaries(G, oracle_lib, monkeypatch, k, s, scale):
+    """k1_windows_roll (round 6: closed syncmers of long reads by per-lane rolling on 2-bit codes, windows of 20 or 32 s-mers) against the oracle
+    and against k1_windows_wave (KMCPG_K1_FLAGS=35) at the edges of what it takes: reads of exactly WR_MIN_WINDOWS windows and one fewer, window
+    counts around multiples of 64 x 16 (the lanes' runs are multiples of 16: the last lanes idle or hold one window), soft-masked reads, one N at
+    the very end / start (left to the wave kernel), a low-complexity read whose emissions repeat for hundreds of windows (the adjacent-repeat
+    stitching across lanes), a homopolymer (hash 0 never: all kept), the longest read the LDS takes; -u above and below the emission count."""
+    import torch
+    O = oracle_lib
+    lib = G["lib"]
+    dev = torch.device("cuda:0")
+    Lw = 2 * k - s - 1
+    g = synth.random_genomes(2, 40000, seed=500 + k + s)
+    lens = [Lw + 1022, Lw + 1023, Lw + 1024, Lw - 1 + 64 * 16, Lw - 1 + 64 * 16 + 1, Lw - 1 + 64 * 32 - 1, Lw - 1 + 64 * 32, 5000, 9999, 16384, 20011, 29000]
+    reads = [g[0][7:7 + n] for n in lens]
+    reads += [g[1][:6000].lower(), g[1][100:7000] + b"N", b"N" + g[1][200:7000], (b"ACGTTGCAAT" * 700)[:6500] + g[1][:3000], b"A" * 5000, b"AC" * 4000,
+              g[1][:3000] + g[1][:3000] + g[1][:3000]]
+    spec = lib.SynthSpec(k=k, num_hashes=1, fpr=0.3, n_blocks=1, cols_per_block=8, num_sigs=1000, kmers_per_col=10, seed=1, syncmer_s=s, scale=scale)
+    cfg = O.sketch_cfg(k=k, syncmer_s=s, scale=scale)
+    seqs, offs = lib.pack_reads(reads)
+    t_seqs = torch.from_numpy(seqs).to(dev)
+    t_offs = torch.from_numpy(offs.view(np.int64)).to(dev)
+    out = {}
+    with G["Database"].open_synthetic(spec) as db:
+        for flags in ("3", "35"):
+            monkeypatch.setenv("KMCPG_K1_FLAGS", flags)
+            for thr in (256, 3000):
+                t_h = torch.zeros(len(seqs) + 8, dtype=torch.int64, device=dev)
+                t_nk = torch.zeros(len(reads), dtype=torch.int32, device=dev)
+                p = G["default_params"](min_qlen=0, min_matched=1, dedup_threshold=thr)
+                db.kmers_device(t_seqs.data_ptr(), t_offs.data_ptr(), len(reads), len(seqs), max(len(r) for r in reads), t_h.data_ptr(), t_h.numel(), None,
+                                t_nk.data_ptr(), params=p)
+                torch.cuda.synchronize()
+                out[(flags, thr)] = (t_h.cpu().numpy().view(np.uint64), t_nk.cpu().numpy())
+    for thr in (256, 3000):
+        h3, n3 = out[("3", thr)]
+        h35, n35 = out[("35", thr)]
+        assert np.array_equal(n3, n35), (thr, n3, n35)
+        for i, r in enumerate(reads):
+            raw = O.generate_kmers(r, cfg)
+            want = O.sort_unique(raw) if len(raw) > thr else raw
+            got = h3[int(offs[i]):int(offs[i]) + int(n3[i])]
+            assert len(want) == n3[i], (k, s, thr, i, len(r), len(want), int(n3[i]))
+            assert np.array_equal(got, want), (k, s, thr, i, len(r))
+            assert np.array_equal(h35[int(offs[i]):int(offs[i]) + int(n35[i])], want), (k, s, thr, i)
+
+
 def test_mixed_block_widths_and_hash_counts(G, oracle_lib, tmp_path):
     """A database whose blocks fall into all three kernel classes (1125-, 38- and 3-byte rows), with 2 and 4 hash
     functions, k = 31 / 64 / 65 (rotations wrap past 64 bits)."""
@@ -833,13 +880,13 @@ def test_row_remainders_cut_into_power_of_two_tiles(G, oracle_lib, tmp_path, mon
         monkeypatch.setenv("KMCPG_SPLIT_TILES", split)
     genomes = synth.random_genomes(ncols + 21, 420, seed=900 + ncols + nh)
     db_dir = synth.make_db(tmp_path, genomes, k=21, num_hashes=nh, fpr=0.05 if nh > 1 else 0.3, block_size=ncols, threads=4)
-    reads = synth.sample_reads(genomes, 500, 150, sub_rate=0.01, seed=7, frac_random=0.1)
+    reads = synth.sample_reads(genomes, 500 if split is not None else 200, 150, sub_rate=0.01, seed=7, frac_random=0.1)
     # long queries: several genomes back to back (~1 600 distinct k-mers: the sort + unique path and 16 counter planes)
     rng = np.random.default_rng(11)
-    longq = [b"".join(genomes[int(j)] for j in rng.integers(0, len(genomes), size=4)) for _ in range(40)]
+    longq = [b"".join(genomes[int(j)] for j in rng.integers(0, len(genomes), size=4)) for _ in range(40 if split is not None else 12)]
     kw = dict(min_qcov=0.2, min_matched=5)
     n, res = _run(G, O, db_dir, reads + longq, oracle_kw=kw, gpu_kw=kw)
-    assert n > 400 and int(res.qkmers.max()) > 1024
+    assert n > (400 if split is not None else 150) and int(res.qkmers.max()) > 1024
     if split is None:  # the default rule really cut the row: two slot classes (32-lane + 8-lane), visible as two tiles of hash traffic
         import torch
         with G["Database"].open(db_dir, device=0) as db:
