@@ -1118,6 +1118,111 @@ def run_cli_end_to_end(ctx, n_reads=10_000_000, check_reads=100_000, check_budge
             shutil.rmtree(work, ignore_errors=True)
     return out
 
+
+def run_cli_genome_search(ctx, n_genomes=256, check_genomes=3):
+    """BASELINE configs[2] through the kmcp-search binary: the genome-search index on disk (kmcpg_save_db), `n_genomes` assemblies of 4 Mbp as
+    FASTA FILES (80 bases per line), `kmcp-search -g -t 0.4 -s jacc` over all of them (reference: search.go:885-915, benchmarks/searching/
+    README.md:382-432), wall clock exec to exit; the rows of the first `check_genomes` files are compared with the oracle's."""
+    import ctypes as C
+    import re
+    import shutil
+    import subprocess
+    from kmcp_amd import Database, lib
+    cli = os.path.join(ROOT, "kmcp_amd", "kmcp-search")
+    if not os.path.exists(cli):
+        return {"skipped": "kmcp_amd/kmcp-search is not built"}
+    wl = dict(WORKLOADS["config2_genome_search"])
+    L = int(wl["read_len"])
+    work = _pick_workdir(n_genomes * (L + L // 80 + 64) + 4.0e9)
+    if work is None:
+        return {"skipped": "no directory with enough free space"}
+    out = {"workdir": os.path.dirname(work), "genomes": n_genomes}
+    try:
+        t0 = time.time()
+        spec = lib.SynthSpec(k=wl["k"], num_hashes=wl["num_hashes"], fpr=wl["fpr"], n_blocks=wl["n_blocks"], cols_per_block=wl["cols_per_block"],
+                             num_sigs=wl["num_sigs"], kmers_per_col=wl["kmers_per_col"], seed=42, sigs_step=wl.get("sigs_step", 0), scale=wl.get("scale", 0))
+        db = Database.open_synthetic(spec, device=ctx.dev_index)
+        n_cols = int(db.info.n_cols)
+
+        def plant(frag, offs, n, total, maxlen, cols):
+            db.plant_reads_device(frag.data_ptr(), offs.data_ptr(), n, total, maxlen, cols.data_ptr())
+
+        bt = make_batch(ctx.dev, wl, n_genomes, n_cols, 9000, plant)
+        g = bt.reads.cpu().numpy().reshape(n_genomes, L)
+        del bt
+        files = []
+        nl = np.full((L // 80, 1), ord("\n"), dtype=np.uint8)
+        for i in range(n_genomes):
+            fn = os.path.join(work, f"asm{i:05d}.fasta")
+            with open(fn, "wb") as fh:
+                fh.write(b">asm%05d synthetic assembly\n" % i)
+                fh.write(np.concatenate([g[i].reshape(L // 80, 80), nl], axis=1).tobytes())
+            files.append(fn)
+        torch.cuda.synchronize()
+        db_root = os.path.join(work, "db")
+        db_dir = db.save(db_root)
+        db.close()
+        torch.cuda.empty_cache()
+        out["setup_s"] = time.time() - t0
+        tsv = os.path.join(work, "out.tsv")
+        env = dict(os.environ)
+        for k_ in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+            env.pop(k_, None)
+        lst = os.path.join(work, "files.txt")
+        with open(lst, "w") as fh:
+            fh.write("\n".join(files) + "\n")
+
+        def one():
+            if os.path.exists(tsv):
+                os.unlink(tsv)
+            t1 = time.perf_counter()
+            r = subprocess.run([cli, "-d", db_root, "-g", "-t", str(wl["min_qcov"]), "-s", "jacc", "--infile-list", lst, "-o", tsv], capture_output=True, text=True,
+                               env=env, timeout=900)
+            wall = time.perf_counter() - t1
+            if r.returncode != 0:
+                raise RuntimeError("kmcp-search -g failed: " + r.stderr[-2000:])
+            m = re.search(r"([\d.]+) s before the search started", r.stderr)
+            me = re.search(r"elapsed time: ([\d.]+)s", r.stderr)
+            return wall, (float(me.group(1)) - float(m.group(1))) if (m and me) else None
+
+        one()
+        runs = [one() for _ in range(3)]
+        best = min(runs, key=lambda x: x[0])
+        rows = sum(1 for ln in open(tsv, "rb") if not ln.startswith(b"#"))
+        out.update({"value": n_genomes / best[0], "unit": "queries/s", "wall_s": best[0], "wall_s_all": [r_[0] for r_ in runs], "rows": rows,
+                    "value_search_phase": (n_genomes / best[1]) if best[1] else None,
+                    "definition": "wall clock of `kmcp-search -g` (exec to exit, best of 3) over FASTA files of 4 Mbp each in /dev/shm: parallel file "
+                                  "readers pack every assembly to 2-bit codes as they join its lines, kmcpg_submit_packed, rows formatted from pairs"})
+        from oracle import oracle as O
+        odb = O.OracleDB(db_dir)
+        OL = O.lib()
+        p = O.default_params(min_qcov=wl["min_qcov"], sort_by=2)
+        want = []
+        buf = C.create_string_buffer(4096)
+        t2 = time.perf_counter()
+        for i in range(min(check_genomes, n_genomes)):
+            res = O.Result()
+            whole = g[i].tobytes()
+            OL.ko_search(odb.h, whole, len(whole), None, 0, C.byref(p), C.byref(res))
+            for j in range(max(0, res.nmatches)):
+                OL.ko_format_match(buf, 4096, b"asm%05d" % i, C.byref(res), C.byref(res.matches[j]), i)
+                want.append(buf.value)
+            OL.ko_result_free(C.byref(res))
+        odb.close()
+        got = []
+        with open(tsv, "rb") as fh:
+            for ln in fh:
+                if not ln.startswith(b"#") and int(ln.rsplit(b"\t", 1)[1]) < min(check_genomes, n_genomes):
+                    got.append(ln)
+        out["parity_on_sample"] = bool(want and got == want)
+        out["sample"] = f"rows of the first {min(check_genomes, n_genomes)} assemblies ({len(want)}) byte-compared with the oracle's ({time.perf_counter()-t2:.1f} s)"
+        out["sample_reads"] = min(check_genomes, n_genomes)
+        if not out["parity_on_sample"]:
+            out["parity_failure"] = {"gpu_only": len(set(got) - set(want)), "oracle_only": len(set(want) - set(got)), "qkmers_differ": 0}
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
+    return out
+
 # ---------------------------------------------------------------------------------------------------------------------------------
 # The ONE JSON line.  Numbers only, < 6 KB (the driver keeps an 8 KB tail of stdout and parses the line out of it): every sentence
 # (definitions, sources, sample descriptions) and every sub-measurement lives in the sidecar `bench_detail.json`.
@@ -1167,7 +1272,7 @@ def _secondary_numbers(o):
          "cpu_reference_shaped": (cb.get("reference_shaped") or {}).get("value"), "parity_on_sample": cb.get("parity_on_sample"),
          "planted_recall": o.get("planted_recall"),
          # (the kmcp-search end-to-end leg)
-         "value_dev_null": o.get("value_dev_null"), "value_search_phase": o.get("value_search_phase"), "wall_s": o.get("wall_s"), "rows_per_s": o.get("rows_per_s"), "reads": o.get("reads"),
+         "value_dev_null": o.get("value_dev_null"), "value_search_phase": o.get("value_search_phase"), "wall_s": o.get("wall_s"), "rows_per_s": o.get("rows_per_s"), "reads": o.get("reads"), "genomes": o.get("genomes"),
          "sample_reads": o.get("sample_reads")}
     if "parity_on_sample" in o:
         d["parity_on_sample"] = o["parity_on_sample"]
@@ -1264,7 +1369,7 @@ def main():
     ap.add_argument("--cpu-sample-reads", type=int, default=0, help="0 = size the CPU sample to several seconds of CPU work")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the configs[1] numbers that ride along at N=1")
-    ap.add_argument("--cli-only", type=int, default=0, metavar="READS", help="run only the kmcp-search end-to-end leg on this many reads and print its record")
+    ap.add_argument("--cli-only", type=int, default=0, metavar="READS", help="run only the kmcp-search end-to-end leg on this many reads and print its record (negative: the -g leg on that many genomes)")
     ap.add_argument("--no-extras", action="store_true", help="timed steps only (profiling runs: no pruning-off / host-boundary launches in the trace)")
     args = ap.parse_args()
 
@@ -1306,7 +1411,7 @@ def main():
             dist.init_process_group("nccl", device_id=ctx.dev)
 
     if args.cli_only:
-        rec = run_cli_end_to_end(ctx, n_reads=args.cli_only, check_reads=min(100_000, args.cli_only))
+        rec = run_cli_genome_search(ctx, n_genomes=-args.cli_only) if args.cli_only < 0 else run_cli_end_to_end(ctx, n_reads=args.cli_only, check_reads=min(100_000, args.cli_only))
         os.dup2(real_stdout, 1)
         os.write(1, (json.dumps(_finite(rec)) + "\n").encode())
         sys.exit(3 if rec.get("parity_failure") or rec.get("error") else 0)
@@ -1342,6 +1447,10 @@ def main():
                 out["secondary"]["cli_end_to_end"] = run_cli_end_to_end(ctx)
             except Exception as e:  # the leg must not take the headline line with it
                 out["secondary"]["cli_end_to_end"] = {"error": repr(e)[:300]}
+            try:
+                out["secondary"]["cli_genome_search"] = run_cli_genome_search(ctx)
+            except Exception as e:
+                out["secondary"]["cli_genome_search"] = {"error": repr(e)[:300]}
         out["secondary"]["config2_genome_search"]["published"] = {
             "value": [1.6, 1.9], "unit": "queries/s", "threads": 8,
             "source": "reference benchmarks/searching/README.md:382-432 (genome search against GTDB, FracMinHash scale 1000: 0.53-0.62 s per query, 8 threads)"}

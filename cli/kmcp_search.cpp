@@ -333,6 +333,30 @@ struct Batch {
     }
     n_bases += n;
   }
+  // a whole query that was packed on its own (from base 0 of `src`): its codes are moved behind this batch's — a plain copy when the batch
+  // ends on a byte, two shifts per byte otherwise — and its runs shifted to their place
+  void append_packed(const uint8_t* src, uint64_t nb, const kmcpg_exc_run* runs, uint64_t n_runs) {
+    const size_t need = (size_t)((n_bases + nb + 3) / 4 + 8);
+    if (codes.size() < need) codes.resize(std::max(need, codes.size() + codes.size() / 2 + (1u << 20)));
+    const size_t nbytes = (size_t)((nb + 3) / 4);
+    const unsigned sh = 2u * (unsigned)(n_bases & 3);
+    uint8_t* d = codes.data() + (n_bases >> 2);
+    if (sh == 0) {
+      memcpy(d, src, nbytes);
+    } else {
+      unsigned carry = d[0] & ((1u << sh) - 1u);
+      for (size_t i = 0; i < nbytes; i++) {
+        const unsigned v = src[i];
+        d[i] = (uint8_t)(carry | (v << sh));
+        carry = v >> (8 - sh);
+      }
+      d[nbytes] = (uint8_t)carry;
+    }
+    if (exc.size() < n_exc + n_runs) exc.resize(std::max<size_t>((size_t)(n_exc + n_runs), 2 * exc.size()));
+    for (uint64_t i = 0; i < n_runs; i++) exc[n_exc + i] = kmcpg_exc_run{runs[i].pos + n_bases, runs[i].len, runs[i].byte};
+    n_exc += n_runs;
+    n_bases += nb;
+  }
   uint64_t bases() const { return packed ? n_bases : (uint64_t)(seqs.size() + seqs2.size()); }
   size_t size() const { return id_offs.size() - 1; }
   std::string_view id(size_t i) const { return std::string_view(id_buf.data() + id_offs[i], (size_t)(id_offs[i + 1] - id_offs[i])); }
@@ -1026,33 +1050,77 @@ int main(int argc, char** argv) {
         wait_db();
         nnn.assign((size_t)std::max(0, db_k.load() - 1), 'N');
       }
-      for (const auto& file : files) {
-        if (verbose) info("reading sequence file: %s", file.c_str());
-        if (o.whole_file) {  // search.go:885-935
-          // the records of the file back to back, records 2..m each followed by k - 1 N's (search.go:899-914) — packed as they are
-          // read: the file's bases are touched once, the batch is a quarter of the text and the library copies it as it is
-          FastxReader r(file);
+      if (o.whole_file) {  // search.go:885-935
+        // One query per file: the records of the file back to back, records 2..m each followed by k - 1 N's (search.go:899-914) — packed to
+        // 2-bit codes as they are read (the file's bases are touched once, the batch is a quarter of the text and the library takes it as
+        // it is).  The files are parsed by several threads, a file each (a 4-Mbp assembly is ~4 ms of line joining and packing: one reader
+        // thread fed 250 genomes/s to a GPU that searches 40 000), and joined into batches in the order of the command line.
+        struct FileQuery {
+          Batch q;  // the file's one query, packed from base 0
           std::string qid;
-          bool first = true;
-          b->packed = true;
-          while (r.next(&id1, &s1)) {
-            if (first) {
-              qid = o.use_filename ? trim_ext(file) : (!o.query_id.empty() ? o.query_id : id1);
-              first = false;
-              b->pack_append(s1.data(), s1.size());
-            } else {
-              b->pack_append(s1.data(), s1.size());
-              b->pack_append(nnn.data(), nnn.size());
+          bool empty = true, done = false;
+        };
+        const size_t nf = files.size();
+        std::vector<std::unique_ptr<FileQuery>> slots(nf);
+        std::mutex fm;
+        std::condition_variable fcv;
+        std::atomic<size_t> next_file{0};
+        size_t consumed = 0;  // under fm: files the joiner has taken (workers stay at most `ahead` files in front of it)
+        const size_t n_workers = std::max<size_t>(1, std::min<size_t>({(size_t)8, (size_t)usable_cpus() / 2, nf}));
+        const size_t ahead = 4 * n_workers;
+        std::vector<std::thread> workers;
+        for (size_t wi = 0; wi < n_workers; wi++)
+          workers.emplace_back([&] {
+            std::string wid, ws;
+            for (;;) {
+              const size_t fi = next_file.fetch_add(1);
+              if (fi >= nf) return;
+              {
+                std::unique_lock<std::mutex> l(fm);
+                fcv.wait(l, [&] { return fi < consumed + ahead; });
+              }
+              std::unique_ptr<FileQuery> fq(new FileQuery());
+              fq->q.packed = true;
+              FastxReader r(files[fi]);
+              while (r.next(&wid, &ws)) {
+                if (fq->empty) {
+                  fq->qid = o.use_filename ? trim_ext(files[fi]) : (!o.query_id.empty() ? o.query_id : wid);
+                  fq->empty = false;
+                  fq->q.pack_append(ws.data(), ws.size());
+                } else {
+                  fq->q.pack_append(ws.data(), ws.size());
+                  fq->q.pack_append(nnn.data(), nnn.size());
+                }
+              }
+              fq->done = true;
+              std::lock_guard<std::mutex> l(fm);
+              slots[fi] = std::move(fq);
+              fcv.notify_all();
             }
+          });
+        for (size_t fi = 0; fi < nf; fi++) {
+          if (verbose) info("reading sequence file: %s", files[fi].c_str());
+          std::unique_ptr<FileQuery> fq;
+          {
+            std::unique_lock<std::mutex> l(fm);
+            fcv.wait(l, [&] { return slots[fi] != nullptr; });
+            fq = std::move(slots[fi]);
+            consumed = fi + 1;
+            fcv.notify_all();
           }
-          if (first) { warn("no valid sequences in file: %s", file.c_str()); continue; }
-          b->id_buf.insert(b->id_buf.end(), qid.begin(), qid.end());
+          if (fq->empty) { warn("no valid sequences in file: %s", files[fi].c_str()); continue; }
+          b->packed = true;
+          b->append_packed(fq->q.codes.data(), fq->q.n_bases, fq->q.exc.data(), fq->q.n_exc);
+          b->id_buf.insert(b->id_buf.end(), fq->qid.begin(), fq->qid.end());
           b->id_offs.push_back(b->id_buf.size());
           b->offs.push_back(b->n_bases);
           id++;
           if (b->size() >= batch_reads.load() || b->bases() >= max_bases.load()) flush();
-          continue;
         }
+        for (auto& t : workers) t.join();
+      }
+      for (const auto& file : o.whole_file ? std::vector<std::string>() : files) {
+        if (verbose) info("reading sequence file: %s", file.c_str());
         flush();  // batches do not span input files on this path
         const uint64_t got = read_single_end(file, batch_reads.load(), max_bases.load(), [&](std::unique_ptr<Batch> nb) {
           nb->paired = false;

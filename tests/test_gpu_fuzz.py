@@ -31,8 +31,28 @@ def _draw(rng):
     return k, kw, nh, fpr, n_genomes, glen, n_chunks, threads
 
 
+def _check_packed(db, res, reads, reads2, params):
+    """KMCP_FUZZ_PACKED=1 (round 6): the same single-end batch through kmcpg_pack2 + kmcpg_submit_packed — once from ordinary memory, once from
+    kmcpg_host_alloc memory (uploaded in place) — must give the records of the text entry bit for bit"""
+    if not os.environ.get("KMCP_FUZZ_PACKED") or reads2 is not None:
+        return
+    from kmcp_amd import lib
+    codes, exc, total = lib.pack2(reads)
+    _, offs = lib.pack_reads(reads)
+    assert total == int(offs[-1])
+    a = db.wait(db.submit_packed(codes, offs, exc, params=params))
+    with lib.PinnedBytes(len(codes)) as pin:
+        pin.a[:len(codes)] = codes
+        b = db.wait(db.submit_packed(pin.a, offs, exc, params=params))
+    for r in (a, b):
+        for f in ("qlen", "qkmers", "ksize", "offs"):
+            assert np.array_equal(getattr(res, f), getattr(r, f)), f
+        assert r.matches.tobytes() == res.matches.tobytes()
+
+
 def _check_pairs(db, res, reads, reads2, params):
     """KMCP_FUZZ_PAIRS=1: the compact result of the same search, expanded query by query, must be the records bit for bit"""
+    _check_packed(db, res, reads, reads2, params)
     if not os.environ.get("KMCP_FUZZ_PAIRS"):
         return
     pr = db.search_pairs(reads, reads2, params=params)
@@ -164,5 +184,51 @@ def test_random_mid_width_rows(oracle_lib, tmp_path, seed):
             res = db.search(reads + longq, params=default_params(**flags))
             _check_pairs(db, res, reads + longq, None, default_params(**flags))
         synth.assert_parity(odb, res, reads + longq, None, O.default_params(**flags))
+    finally:
+        odb.close()
+
+
+@pytest.mark.parametrize("seed", list(range(int(os.environ.get("KMCP_FUZZ_ROLL_SEEDS", "4")))))
+def test_random_long_syncmer_reads(oracle_lib, tmp_path, seed):
+    """Closed-Syncmer databases whose window is 20 or 32 s-mers (k - s = 10 or 16: what k1_windows_roll, round 6, takes) searched with long reads
+    of random lengths from just above its smallest window count to 30 kb: the lanes' run length, the number of idle lanes, the position of the
+    block boundaries and of the read's end relative to them all vary; a fraction of the reads is soft-masked, carries an N (those go to
+    k1_windows_wave), repeats itself (runs of equal emissions across lanes) or is shorter than the kernel takes; FracMinHash on top in half
+    of the draws; -u at its default, tiny or off.  Everything against the oracle."""
+    from kmcp_amd import Database, default_params
+    O = oracle_lib
+    rng = np.random.default_rng(12000 + seed)
+    d = int(rng.choice([10, 16]))
+    k = int(rng.choice([21, 25, 31, 32, 40]))
+    if k - d < 1:
+        k = d + 11
+    kw = dict(syncmer_s=k - d)
+    if rng.random() < 0.5:
+        kw["scale"] = int(rng.choice([2, 7]))
+    genomes = synth.random_genomes(6, 32000, seed=13000 + seed)
+    db_dir = synth.make_db(tmp_path, genomes, k=k, n_chunks=int(rng.choice([1, 3])), overlap=150, threads=2, **kw)
+    reads = []
+    Lw = 2 * k - (k - d) - 1
+    for _ in range(int(rng.integers(6, 20))):
+        L = int(rng.choice([Lw + 1023, Lw + 1024, int(rng.integers(1100, 4000)), int(rng.integers(4000, 12000)), int(rng.integers(12000, 30000))]))
+        r = bytearray(synth.sample_reads(genomes, 1, min(L, 31999), sub_rate=float(rng.choice([0, 0.001, 0.02])), seed=int(rng.integers(1 << 30)), frac_random=0.1)[0])
+        what = rng.random()
+        if what < 0.15:
+            r = bytearray(bytes(r).lower())
+        elif what < 0.3:
+            r[int(rng.integers(0, len(r)))] = ord("N")
+        elif what < 0.4:
+            unit = bytes(r[:int(rng.integers(40, 900))])
+            r = bytearray((unit * (len(r) // len(unit) + 1))[:len(r)])
+        reads.append(bytes(r))
+    reads += synth.sample_reads(genomes, 10, 150, seed=int(rng.integers(1 << 30)))
+    flags = dict(min_qcov=float(rng.choice([0.55, 0.35])), min_matched=int(rng.choice([1, 10])), dedup_threshold=int(rng.choice([256, 256, 0, 1 << 30])),
+                 sort_by=int(rng.integers(0, 3)))
+    odb = O.OracleDB(db_dir)
+    try:
+        with Database.open(db_dir, device=0) as db:
+            res = db.search(reads, params=default_params(**flags))
+            _check_pairs(db, res, reads, None, default_params(**flags))
+        synth.assert_parity(odb, res, reads, None, O.default_params(**flags))
     finally:
         odb.close()
