@@ -1220,7 +1220,12 @@ def run_cli_genome_search(ctx, n_genomes=256, check_genomes=3):
         if not out["parity_on_sample"]:
             out["parity_failure"] = {"gpu_only": len(set(got) - set(want)), "oracle_only": len(set(want) - set(got)), "qkmers_differ": 0}
     finally:
-        shutil.rmtree(work, ignore_errors=True)
+        keep = os.environ.get("KMCP_BENCH_KEEP")
+        if keep:
+            shutil.rmtree(keep, ignore_errors=True)
+            shutil.move(work, keep)
+        else:
+            shutil.rmtree(work, ignore_errors=True)
     return out
 
 # ---------------------------------------------------------------------------------------------------------------------------------

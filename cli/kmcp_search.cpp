@@ -1017,6 +1017,17 @@ int main(int argc, char** argv) {
     ready_cv.wait(l, [&] { return db_ready.load(); });
   };
   double t_reader_blocked = 0, t_reader_total = 0;  // the reader thread: waiting for a free queue slot / its whole life
+  if (o.whole_file && o.gpu_passes < 0) {
+    // -g needs the database's k before the first file can be joined (k - 1 N's between records): a metadata-only handle reads it from
+    // __db.yml and the block headers in a millisecond, without the GPU runtime, so that the files are parsed while the index is loaded
+    kmcpg_db* meta = nullptr;
+    kmcpg_opts mo{-1, 0, 1, 0};
+    if (kmcpg_open(db_dirs[0].c_str(), &mo, &meta) == 0) {
+      kmcpg_info mi;
+      if (kmcpg_db_info(meta, &mi) == 0) db_k.store(mi.k);
+      kmcpg_close(meta);
+    }
+  }
   std::thread reader([&] {
     if (o.gpu_passes >= 0) wait_db();
     const auto tr0 = std::chrono::steady_clock::now();
@@ -1047,7 +1058,7 @@ int main(int argc, char** argv) {
     } else {
       std::string nnn;
       if (o.whole_file) {  // the gap between records is k - 1 N's: the database's k is needed first
-        wait_db();
+        if (db_k.load() <= 0) wait_db();  // (normally known already: read from the headers before the GPU was touched, below)
         nnn.assign((size_t)std::max(0, db_k.load() - 1), 'N');
       }
       if (o.whole_file) {  // search.go:885-935
@@ -1240,9 +1251,10 @@ int main(int argc, char** argv) {
   // a batch also closes at 64 Mbases (long queries); paged indexes want the largest batches the host can hold
   // (a batch's device workspace is up to 24 B per base: the library says how many bases fit beside the resident index)
   {
-    // (-g: whole genomes as queries, packed 4 bases to a byte on the host — up to a gigabase per batch, 256 assemblies of 4 Mbp, if the
-    // device workspace allows: batches of fewer than ~190 genomes leave the chip to the slower chunked form of the kernel)
-    size_t mb = paged_passes > 1 ? std::min<size_t>((size_t)o.batch * 512, (size_t)2 << 30) : (o.whole_file ? (size_t)1 << 30 : (size_t)64 << 20);
+    // (-g: whole genomes as queries, packed 4 bases to a byte on the host — 256 Mbases per batch, 64 assemblies of 4 Mbp: the GPU needs
+    // ~2 ms for them while the readers need ~100, and the device workspace of a batch is 24 bytes per base — a gigabase batch made the
+    // process allocate, and the driver reclaim after it, 25 GB for nothing: profiles/r06_cli_e2e.txt)
+    size_t mb = paged_passes > 1 ? std::min<size_t>((size_t)o.batch * 512, (size_t)2 << 30) : (o.whole_file ? (size_t)256 << 20 : (size_t)64 << 20);
     uint64_t hint = 0;
     if (kmcpg_batch_hint(db, &hint) == 0 && hint > 0) mb = std::max<size_t>((size_t)1 << 20, std::min<size_t>(mb, (size_t)hint));
     max_bases.store(mb);
@@ -1503,8 +1515,10 @@ int main(int argc, char** argv) {
   // ~0.1 s and the runtime's own exit handlers as long again (profiles/r06_cli_e2e.txt) — a short-lived process leaves that to the
   // kernel driver, which reclaims a dead process's GPU memory anyway (the Go reference exits the same way: search.go:1027).
   // KMCP_SEARCH_FULL_TEARDOWN=1 closes the handle and returns through the runtime's handlers (leak checks, sanitizers).
+  // (The handle itself IS closed: device memory a process leaves behind is reclaimed by the driver while the NEXT process is starting —
+  // three back-to-back runs that each left 25 GB took 0.69, 0.90, 1.74 s.)
   const bool full_teardown = getenv("KMCP_SEARCH_FULL_TEARDOWN") != nullptr;
-  if (full_teardown && kmcpg_close(db) != 0) die("%s", kmcpg_last_error());
+  if (kmcpg_close(db) != 0) die("%s", kmcpg_last_error());
   if (verbose) {
     info("");
     info("elapsed time: %.3fs", std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count());
