@@ -46,6 +46,41 @@ int main() {
       if ((char)b[i] != c) { printf("FAIL spelling at %zu, case %d: %c vs %c\n", i, it, (char)b[i], c); return 1; }
     }
   }
+  // Batch::append (batches the reader cut before the database was open, joined for a paged index): ids, bases and both CSRs re-based
+  for (int pe = 0; pe < 2; pe++) {
+    Batch all, acc;
+    all.paired = acc.paired = pe != 0;
+    bool first = true;
+    for (int part = 0; part < 5; part++) {
+      Batch b;
+      b.paired = pe != 0;
+      const int n = part == 2 ? 0 : 1 + (int)(g() % 40);
+      for (int i = 0; i < n; i++) {
+        std::string id = "q" + std::to_string(g() % 100000), s1((size_t)(g() % 200), 'C'), s2((size_t)(g() % 200), 'G');
+        for (Batch* t : {&b, &all}) {
+          t->id_buf.insert(t->id_buf.end(), id.begin(), id.end());
+          t->id_offs.push_back(t->id_buf.size());
+          t->seqs.insert(t->seqs.end(), s1.begin(), s1.end());
+          t->offs.push_back(t->seqs.size());
+          if (pe) {
+            t->seqs2.insert(t->seqs2.end(), s2.begin(), s2.end());
+            t->offs2.push_back(t->seqs2.size());
+          }
+        }
+      }
+      if (first) {
+        acc.id_buf = b.id_buf; acc.id_offs = b.id_offs; acc.seqs = b.seqs; acc.offs = b.offs; acc.seqs2 = b.seqs2; acc.offs2 = b.offs2;
+        first = false;
+      } else {
+        acc.append(b);
+      }
+    }
+    if (acc.id_buf != all.id_buf || acc.id_offs != all.id_offs || acc.seqs != all.seqs || acc.offs != all.offs || acc.seqs2 != all.seqs2 ||
+        (pe && acc.offs2 != all.offs2) || acc.n_seq != 5) {
+      printf("FAIL Batch::append, paired %d\n", pe);
+      return 1;
+    }
+  }
   printf("ok\n");
   return 0;
 }

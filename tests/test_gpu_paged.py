@@ -107,6 +107,13 @@ def test_cli_falls_back_to_passes(oracle_lib, case):
     assert r.returncode == 0, r.stderr
     assert "does not fit in HBM" in r.stderr and "passes per batch" in r.stderr
     assert open(tmp / "auto.tsv").read().split("\n") == one
+    # round 6: the reader runs before the database is open, so a paged index meets batches that were cut for a resident one (here ~40 of
+    # ~60 reads each, through the multi-threaded parser): the searcher joins them into the large batches a paged index wants (Batch::append)
+    env2 = dict(env, KMCP_PARALLEL_MIN_BYTES="1", KMCP_READER_CHUNK="20000")
+    r = subprocess.run([CLI, "-d", db_root, fq, "-o", str(tmp / "auto2.tsv")], capture_output=True, text=True, timeout=300, env=env2)
+    assert r.returncode == 0, r.stderr
+    assert "passes per batch" in r.stderr
+    assert open(tmp / "auto2.tsv").read().split("\n") == one
     r = subprocess.run([CLI, "-d", db_root, fq, "-o", str(tmp / "p3.tsv"), "--gpu-passes", "3", "-q"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr
     assert open(tmp / "p3.tsv").read().split("\n") == one
