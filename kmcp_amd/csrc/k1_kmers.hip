@@ -1702,7 +1702,7 @@ bool launch_k1(const K1Args& a, uint32_t max_read_len, hipStream_t st) {
   if (max_read_len > 2048) {  // long queries: a whole workgroup per read
     unsigned blocks = a.n_reads > 65536 ? 65536 : a.n_reads;
     if (a.mode != 0 && a.scratch && wave_windows_usable(a) && !(a.flags & 4)) {  // window sketches: the barrier-free form
-      // closed syncmers with a window of 20 (k 21 / s 11) or 32 (k 31 / s 15) s-mers, single-end, the fused adjacent-repeat path wanted:
+      // closed syncmers with a window of 12 / 16 / 20 / 24 / 32 s-mers (k - s = 6 .. 16), single-end, the fused adjacent-repeat path wanted:
       // the rolling kernel first, k1_windows_wave behind it for the reads it leaves on its list (flags bit 5 = 32: the old kernel alone)
       const int wsz = a.mode == 2 ? 2 * (a.k - (int)a.w_or_s) : 0;
       const int words = wr_words_for((int)max_read_len);
@@ -1713,22 +1713,28 @@ bool launch_k1(const K1Args& a, uint32_t max_read_len, hipStream_t st) {
       while (waves > 1 && wr_lds_bytes(wsz, words, waves) > 65536) waves >>= 1;
       // (no read of the batch can exceed the -u / wave-sort bound — planting, a huge -u —: the fused path is nobody's, the old kernel alone)
       const bool any_fused = (long long)max_read_len > (long long)std::max(a.dedup_threshold, K1_WAVE_SORT_CAP);
-      if (a.mode == 2 && (wsz == 20 || wsz == 32) && a.k <= 64 && !a.offs2 && a.nk_adj && a.seg_list && !(a.flags & 32) && any_fused &&
+      const bool wsz_ok = wsz == 12 || wsz == 16 || wsz == 20 || wsz == 24 || wsz == 32;  // k - s = 6, 8, 10, 12, 16 (21/11, 31/15, 21/13, 31/19 ...)
+      if (a.mode == 2 && wsz_ok && a.k <= 64 && !a.offs2 && a.nk_adj && a.seg_list && !(a.flags & 32) && any_fused &&
           wr_lds_bytes(wsz, words, waves) <= 65536) {
         K1Args b = a;
         (void)hipMemsetAsync(b.seg_nflag, 0, sizeof(uint32_t), st);
         const unsigned wg = (a.n_reads + waves - 1) / waves;
         const size_t lds = wr_lds_bytes(wsz, words, waves);
 #define KMCPG_WR_LAUNCH(WSZ_, WV_) hipLaunchKernelGGL((k1_windows_roll<WSZ_, WV_>), dim3(wg), dim3(64 * WV_), lds, st, b, words)
-        if (wsz == 20) {
-          if (waves == 4) KMCPG_WR_LAUNCH(20, 4);
-          else if (waves == 2) KMCPG_WR_LAUNCH(20, 2);
-          else KMCPG_WR_LAUNCH(20, 1);
-        } else {
-          if (waves == 4) KMCPG_WR_LAUNCH(32, 4);
-          else if (waves == 2) KMCPG_WR_LAUNCH(32, 2);
-          else KMCPG_WR_LAUNCH(32, 1);
+#define KMCPG_WR_WAVES_OF(WSZ_)                \
+  do {                                         \
+    if (waves == 4) KMCPG_WR_LAUNCH(WSZ_, 4);  \
+    else if (waves == 2) KMCPG_WR_LAUNCH(WSZ_, 2); \
+    else KMCPG_WR_LAUNCH(WSZ_, 1);             \
+  } while (0)
+        switch (wsz) {
+          case 12: KMCPG_WR_WAVES_OF(12); break;
+          case 16: KMCPG_WR_WAVES_OF(16); break;
+          case 20: KMCPG_WR_WAVES_OF(20); break;
+          case 24: KMCPG_WR_WAVES_OF(24); break;
+          default: KMCPG_WR_WAVES_OF(32); break;
         }
+#undef KMCPG_WR_WAVES_OF
 #undef KMCPG_WR_LAUNCH
         b.seg_only_flagged = 1;
         hipLaunchKernelGGL(k1_windows_wave<2>, dim3(std::min(blocks, 1024u)), dim3(K1W_THREADS), 0, st, b);

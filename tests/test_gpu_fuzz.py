@@ -190,7 +190,7 @@ def test_random_mid_width_rows(oracle_lib, tmp_path, seed):
 
 @pytest.mark.parametrize("seed", list(range(int(os.environ.get("KMCP_FUZZ_ROLL_SEEDS", "4")))))
 def test_random_long_syncmer_reads(oracle_lib, tmp_path, seed):
-    """Closed-Syncmer databases whose window is 20 or 32 s-mers (k - s = 10 or 16: what k1_windows_roll, round 6, takes) searched with long reads
+    """Closed-Syncmer databases whose window is 12 / 16 / 20 / 24 / 32 s-mers (k - s = 6 .. 16: what k1_windows_roll, round 6, takes) searched with long reads
     of random lengths from just above its smallest window count to 30 kb: the lanes' run length, the number of idle lanes, the position of the
     block boundaries and of the read's end relative to them all vary; a fraction of the reads is soft-masked, carries an N (those go to
     k1_windows_wave), repeats itself (runs of equal emissions across lanes) or is shorter than the kernel takes; FracMinHash on top in half
@@ -198,7 +198,7 @@ def test_random_long_syncmer_reads(oracle_lib, tmp_path, seed):
     from kmcp_amd import Database, default_params
     O = oracle_lib
     rng = np.random.default_rng(12000 + seed)
-    d = int(rng.choice([10, 16]))
+    d = int(rng.choice([6, 8, 10, 12, 16, 10, 16]))
     k = int(rng.choice([21, 25, 31, 32, 40]))
     if k - d < 1:
         k = d + 11

@@ -216,9 +216,9 @@ def test_sketch_kernels_match_oracle_in_order(G, oracle_lib, tmp_path):
             assert np.array_equal(got, want), (kw, i)
 
 
-@pytest.mark.parametrize("k,s,scale", [(21, 11, 1), (31, 15, 1), (31, 15, 3), (25, 15, 1)])
+@pytest.mark.parametrize("k,s,scale", [(21, 11, 1), (31, 15, 1), (31, 15, 3), (25, 15, 1), (21, 15, 1), (21, 13, 2), (31, 19, 1)])
 def test_rolling_window_sketch_kernel_at_its_boundaries(G, oracle_lib, monkeypatch, k, s, scale):
-    """k1_windows_roll (round 6: closed syncmers of long reads by per-lane rolling on 2-bit codes, windows of 20 or 32 s-mers) against the oracle
+    """k1_windows_roll (round 6: closed syncmers of long reads by per-lane rolling on 2-bit codes, windows of 12 / 16 / 20 / 24 / 32 s-mers) against the oracle
     and against k1_windows_wave (KMCPG_K1_FLAGS=35) at the edges of what it takes: reads of exactly WR_MIN_WINDOWS windows and one fewer, window
     counts around multiples of 64 x 16 (the lanes' runs are multiples of 16: the last lanes idle or hold one window), soft-masked reads, one N at
     the very end / start (left to the wave kernel), a low-complexity read whose emissions repeat for hundreds of windows (the adjacent-repeat
