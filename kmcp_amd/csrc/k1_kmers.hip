@@ -1216,13 +1216,15 @@ __global__ void __launch_bounds__(64 * WR_WAVES) k1_windows_roll(const K1Args a,
   uint64_t first = 0, last = 0, pv = ~0ULL;
   int pp = 0;
   auto emit = [&](uint64_t h, bool on) __attribute__((always_inline)) {
+    // (almost every window keeps its value — a hash is 0 or above maxHash rarely — so what is kept is tracked with selects; the one
+    // branch is the store of a value that differs from the lane's previous one, a fifth of the steps per lane)
     const bool keep = on && h != 0 && (!scaled || h <= max_hash);
-    if (keep) {
-      if (raw == 0) first = h;
-      if (raw == 0 || h != last) temp[cnt++] = h;
-      last = h;
-      raw++;
+    if (keep && (raw == 0 || h != last)) {
+      if (cnt == 0) first = h;  // (the first kept value is always stored)
+      temp[cnt++] = h;
     }
+    last = keep ? h : last;
+    raw += keep ? 1 : 0;
   };
   // The step is software-pipelined by hand: the k-mer hash of window i is ASKED for at the top of step i and USED at the top of step
   // i + 1, and the pair-table entries of step i + 1's rolls are asked for at the end of step i — an LDS round trip is ~100 cycles and
