@@ -321,6 +321,9 @@ int kmcpg_last_gathered_bytes(kmcpg_db* db, uint64_t* bytes);
 /* ... and the bytes of k-mer hashes the same launches read (8 B per k-mer, once per (read, slot): 0.8 % of the row bytes for
  * 1-KB row tiles, 6 % for 128-byte rows).  Rows + hashes is what FETCH_SIZE sees.  Level 2 only. */
 int kmcpg_last_hash_bytes(kmcpg_db* db, uint64_t* bytes);
+/* ... and how many waves of those launches finished in tail mode (long queries on 1-KiB row tiles whose sectors had died down
+ * to at most four: the idle lanes take shares of the remaining rows, k2_cobs.hip; KMCPG_TAIL_SECTORS=0 switches it off).  Level 2 only. */
+int kmcpg_last_tail_waves(kmcpg_db* db, uint64_t* waves);
 int kmcpg_last_timing(kmcpg_db* db, float* kmers_ms, float* cobs_ms);
 /* The same for an earlier call: age 0 = the last one, 1 = the one before ... (the last 4 are kept), so that a caller with
  * several batches in flight can read the times of a finished one without waiting for the newest. */

@@ -114,6 +114,8 @@ struct K2Args {
   int32_t prune_every;   // the pruning test runs after every prune_every-th row group (1, 2, 4 or 8) and at the end of a chunk of 64 rows
   int32_t split_min;     // >0: queries with more k-mers are handled by the SPLIT launch
   int32_t slot_major;    // unit order: 1 = slot-major (unit u -> slot u / n_reads, read u % n_reads), 0 = read-major
+  int32_t tail_sectors;  // long queries on 1-KiB tiles: with at most this many live sectors (<= 4; 0 = never) and
+  int32_t tail_min;      // ... at least this many k-mers to go a wave finishes in tail mode (k2_cobs.hip)
   // long-query (SPLIT) form
   const uint32_t* long_list;  // indices of the long queries
   uint32_t n_long;

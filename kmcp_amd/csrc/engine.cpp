@@ -54,13 +54,29 @@ int kmcpg_fail(int code, const char* fmt, ...) {
 
 namespace {
 
-uint32_t device_stride(uint32_t row_bytes) {
+uint32_t device_stride(uint32_t row_bytes, uint32_t align = 64) {
   // rows are padded so a row never straddles more memory lines than it must: powers of two up to 64 B,
   // multiples of 64 B above (1872 -> 1920).  The disk format is untouched (serialization.go:288-300).
   if (row_bytes <= 16) return 16;
   if (row_bytes <= 32) return 32;
   if (row_bytes <= 64) return 64;
+  if (row_bytes > 128 && align == 128) return (row_bytes + 127) / 128 * 128;
   return (row_bytes + 63) / 64 * 64;
+}
+
+// Row pitch of a database's groups: multiples of 128 bytes for a database whose queries are long (sketches: FracMinHash, minimizer,
+// syncmer; several hash functions), of 64 bytes otherwise.  Rows of an odd number of 64-byte halves (782 -> 832 bytes) on a 64-byte pitch
+// start in the middle of a 128-byte memory line every other row: the same 7 lines per whole row either way, but a single live sector —
+// what long queries gather for the last 40 % of their k-mers, in tail mode (k2_cobs.hip) — is then two lines for half of the rows.
+// Genome search, same box: K2 4.69 -> 4.54 ms per 256 genomes.  Short reads on plain k-mer databases read whole rows almost to the
+// end and lose 1-6 % to the wider pitch (391-byte rows at 512 instead of 448: profiles/r06_tail_mode.txt), so they keep 64.
+// KMCPG_ROW_ALIGN=64 / 128 overrides (read at every open).
+uint32_t row_align_for(const kmcpg_info& info) {
+  if (const char* e = getenv("KMCPG_ROW_ALIGN")) {
+    const int v = atoi(e);
+    if (v == 64 || v == 128) return (uint32_t)v;
+  }
+  return (info.scaled || info.minimizer || info.syncmer || info.num_hashes > 1) ? 128u : 64u;
 }
 
 // lanes per row tile (16 B each): the narrowest form that covers the row, so that no lane of a wave idles (a 128-byte row on the
@@ -95,6 +111,7 @@ void assign_shards(kmcpg_db* db) {
 // long as the group's rows stay addressable in 16-byte units with 32 bits.  KMCPG_FUSE=0 keeps every block on its own.
 void form_groups(kmcpg_db* db) {
   const bool fuse = !(getenv("KMCPG_FUSE") && atoi(getenv("KMCPG_FUSE")) == 0);
+  const uint32_t align = row_align_for(db->info);
   db->groups.clear();
   for (size_t i = 0; i < db->blocks.size(); i++) {
     BlockMeta& b = db->blocks[i];
@@ -105,7 +122,7 @@ void form_groups(kmcpg_db* db) {
       for (size_t g = 0; g < db->groups.size(); g++) {
         const Group& G = db->groups[g];
         if (G.num_sigs != b.h.num_sigs) continue;
-        const uint64_t st = device_stride(G.row_bytes + b.h.row_bytes);
+        const uint64_t st = device_stride(G.row_bytes + b.h.row_bytes, align);
         if ((G.num_sigs + 1) * (st >> 4) <= 0xffffffffULL) gi = (int)g;
       }
     if (gi < 0) {
@@ -120,7 +137,7 @@ void form_groups(kmcpg_db* db) {
     G.members.push_back((int)i);
   }
   for (auto& G : db->groups) {
-    G.stride = device_stride(G.row_bytes);
+    G.stride = device_stride(G.row_bytes, align);
     for (int m : G.members) db->blocks[(size_t)m].stride = G.stride;
   }
 }

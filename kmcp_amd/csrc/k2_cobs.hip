@@ -125,9 +125,17 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((NPL =
       }
     }
   }
+  // (one unit per wave and a tail mode to make room for: what is the same in every lane is told to the compiler, which keeps it in
+  // scalar registers — the tail-mode forms have no vector register to spare)
+  constexpr bool UNI = LPR == 64 && NPL >= 16 && !SPLIT;
+  if constexpr (UNI) {
+    r = (uint32_t)__builtin_amdgcn_readfirstlane((int)r);
+    sidx = (uint32_t)__builtin_amdgcn_readfirstlane((int)sidx);
+  }
   const Slot slot = a.slots[sidx];
   const BlockDev* __restrict__ bd = a.blocks + slot.block;
   int n = valid ? a.nk[r] : 0;
+  if constexpr (UNI) n = __builtin_amdgcn_readfirstlane(n);
   if (SPLIT) n = max(0, min(n - k0, (int)a.split_chk));
   else if (a.split_min > 0 && n > a.split_min) n = 0;  // long queries are left to the SPLIT launch
   int nmax = n;
@@ -174,6 +182,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((NPL =
   }
   wave_lds_fence();
   constexpr int IT = G * CH / 64;  // (unit, k-mer) pairs of a chunk per lane
+  // Tail mode (round 6, below the chunk loop): a long query on a 1-KiB tile whose sectors have died down to a few.
+  constexpr bool TAIL = LPR == 64 && NPL >= 16 && !SPLIT;
+  [[maybe_unused]] int c_tail = -1;  // >= 0: the first k-mer the tail mode takes
 
   for (int c0 = 0; c0 < nmax; c0 += CH) {
     // ---- row indices of this chunk: loc = h % NumSigs (:6811), multi-hash h_i = uint32(a + b*i) (util-hash.go:125-142).
@@ -380,12 +391,150 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((NPL =
     }
     wave_lds_fence();
     if (!SPLIT && a.prune && __ballot(live) == 0) break;
+    if constexpr (TAIL) {
+      if (a.tail_sectors > 0 && nmax - (c0 + CH) >= a.tail_min) {  // wave-uniform
+        const uint64_t lv = __ballot(live);
+        int nsec = 0;
+#pragma unroll
+        for (int sc = 0; sc < 8; sc++) nsec += ((lv >> (8 * sc)) & 0xffull) ? 1 : 0;
+        if (nsec <= a.tail_sectors) {
+          c_tail = c0 + CH;
+          break;
+        }
+      }
+    }
+  }
+  // ---- Tail mode.  Once all but a few sectors of the tile are dead (unrelated references after ~60-70 % of a sketch; the sectors
+  //      that hold the query's relatives never die), the loop above keeps 8 rows x 8-32 lanes in flight per wave — every chunk of 64
+  //      k-mers is still eight dependent round trips to memory, for an eighth of the bytes: the genome search spent a fifth of its K2
+  //      time moving a twentieth of its traffic, with every wave of the launch in that state at once.  Here the idle lane octets help:
+  //      with nsec <= 4 live sectors every live octet gets ngr - 1 = 7 / 3 / 1 helpers, the 64 rows of a chunk are dealt out over the
+  //      ngr octets of a sector (8 / 16 / 32 rows each, all in flight together), helpers count into planes of their own, and at the
+  //      end the helpers' planes are added to the owner's (bit-sliced ripple add over __shfl).  No pruning test in here: what is
+  //      still alive this late holds a hit or a near-hit.  Counts, and so the hits, are the same (integer sums in another order).
+  if constexpr (TAIL) {
+    if (c_tail >= 0) {
+      const uint64_t lv = __ballot(live);
+      uint32_t secmask = 0;
+#pragma unroll
+      for (int sc = 0; sc < 8; sc++) secmask |= ((lv >> (8 * sc)) & 0xffull) ? (1u << sc) : 0u;
+      const int nsec = __popc(secmask);
+      const int ngr = nsec == 1 ? 8 : (nsec == 2 ? 4 : 2);  // octets per live sector
+      const int rpg = CH / ngr;                               // rows of a chunk per octet
+      // (what the chunk loop needs of a lane's new role is j0, t_live and t_base; the rest is worked out again for the reduction
+      // rather than kept in registers over the loop: the single-hash form has three registers to spare for its third wave)
+      int j0;
+      bool t_live, own;
+      const uint8_t* __restrict__ t_base;
+      {
+        const int oct = lane >> 3;
+        own = (secmask >> oct) & 1u;
+        const int below = __popc(secmask & ((1u << oct) - 1u));  // live octets below this one (own: the ordinal of its sector)
+        const int dead_rank = oct - below;                       // (helpers) dead octets below this one
+        const int ord = own ? below : dead_rank % nsec;          // the live sector this octet works for
+        const int grp = own ? 0 : 1 + dead_rank / nsec;          // ... as which of its octets
+        uint32_t m = secmask;
+#pragma unroll
+        for (int i = 0; i < 3; i++) m = i < ord ? (m & (m - 1u)) : m;
+        const int src_lane = (__ffs(m) - 1) * 8 + (lane & 7);    // the lane that owns these 16 bytes of the rows
+        t_live = grp < ngr && ((lv >> src_lane) & 1ull);
+        t_base = bd->rows + (int64_t)boff + (int64_t)(src_lane - lane) * 16;  // (boff = this lane's own 16 bytes)
+        j0 = grp * rpg;
+      }
+      if (!own) {
+#pragma unroll
+        for (int d = 0; d < 4; d++)
+#pragma unroll
+          for (int p = 0; p < NPL; p++) pl[d][p] = 0;
+      }
+      for (int c0 = c_tail; c0 < nmax; c0 += CH) {
+        {  // row indices of the chunk (one unit per wave: k-mer = lane), as above
+          const bool has = c0 + lane < s_unit[wave][0].n;
+          if (a.gathered) h_acc += (uint32_t)__popcll(__ballot(has));
+          const uint64_t h = has ? a.hashes[s_unit[wave][0].koff + (uint64_t)(c0 + lane)] : 0;
+          const uint64_t ns = s_unit[wave][0].ns, mh = s_unit[wave][0].mh;
+          const uint32_t s16 = s_unit[wave][0].s16;
+          if (has) {
+            if (!MULTI) {
+              s_rows[wave][0][lane] = (uint32_t)fastmod_u64(h, ns, mh) * s16;
+            } else {
+              const uint32_t ha = (uint32_t)(h >> 32), hb = (uint32_t)h;
+              for (int i = 0; i < nh; i++) s_rows[wave][i][lane] = (uint32_t)fastmod_u64((uint64_t)(uint32_t)(ha + hb * (uint32_t)i), ns, mh) * s16;
+            }
+          } else {
+            for (int i = 0; i < nh; i++) s_rows[wave][i][lane] = (uint32_t)ns * s16;
+          }
+        }
+        wave_lds_fence();
+        const int cnt = min(CH, nmax - c0);
+#pragma unroll 1
+        for (int gi = 0; 8 * gi < rpg; gi++) {  // (rolled: unrolled, the loads of several groups were hoisted together and cost the kernel a wave per SIMD)
+          {
+            const int j = j0 + 8 * gi;
+            const bool ld = t_live && j < cnt;
+            uint32_t ri[8];
+            uint4 x[8];
+#pragma unroll
+            for (int i = 0; i < 8; i++) ri[i] = s_rows[wave][0][(j + i) & (CH - 1)];
+#pragma unroll
+            for (int i = 0; i < 8; i++) x[i] = make_uint4(0, 0, 0, 0);
+            if (ld) {
+#pragma unroll
+              for (int i = 0; i < 8; i++) x[i] = load_row16_global(t_base + ((uint64_t)ri[i] << 4), a.nt_loads);
+            }
+            if (MULTI) {
+              for (int hh = 1; hh < nh; hh++) {
+                uint4 w[8];
+#pragma unroll
+                for (int i = 0; i < 8; i++) ri[i] = s_rows[wave][hh][(j + i) & (CH - 1)];
+#pragma unroll
+                for (int i = 0; i < 8; i++) w[i] = make_uint4(0, 0, 0, 0);
+                if (ld) {
+#pragma unroll
+                  for (int i = 0; i < 8; i++) w[i] = load_row16_global(t_base + ((uint64_t)ri[i] << 4), a.nt_loads);
+                }
+#pragma unroll
+                for (int i = 0; i < 8; i++) {
+                  x[i].x &= w[i].x; x[i].y &= w[i].y; x[i].z &= w[i].z; x[i].w &= w[i].w;
+                }
+              }
+            }
+            if (a.gathered) g_acc += (uint32_t)__popcll(__ballot(ld)) * 8u * (uint32_t)(MULTI ? nh : 1);
+            // (the weight-8 carry ripples at once: this loop waits for memory, the deferred carries of the loop above would buy nothing)
+            ripple<NPL, 3>(pl[0], csa8_low(pl[0], x[0].x, x[1].x, x[2].x, x[3].x, x[4].x, x[5].x, x[6].x, x[7].x));
+            ripple<NPL, 3>(pl[1], csa8_low(pl[1], x[0].y, x[1].y, x[2].y, x[3].y, x[4].y, x[5].y, x[6].y, x[7].y));
+            ripple<NPL, 3>(pl[2], csa8_low(pl[2], x[0].z, x[1].z, x[2].z, x[3].z, x[4].z, x[5].z, x[6].z, x[7].z));
+            ripple<NPL, 3>(pl[3], csa8_low(pl[3], x[0].w, x[1].w, x[2].w, x[3].w, x[4].w, x[5].w, x[6].w, x[7].w));
+          }
+        }
+        wave_lds_fence();
+      }
+      // the helpers' counts join the owner's: one helper octet per step, plane by plane with a rippling carry
+      const int below = __popc(secmask & ((1u << (lane >> 3)) - 1u));
+      for (int g2 = 1; g2 < ngr; g2++) {
+        const int rank = (g2 - 1) * nsec + below;  // (owners) the dead octet that was their helper g2
+        uint32_t dm = ~secmask & 0xffu;
+#pragma unroll
+        for (int i = 0; i < 6; i++) dm = i < rank ? (dm & (dm - 1u)) : dm;
+        const int from = own ? (__ffs(dm) - 1) * 8 + (lane & 7) : lane;
+        uint32_t cy[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int p = 0; p < NPL; p++)
+#pragma unroll
+          for (int d = 0; d < 4; d++) {
+            uint32_t v = (uint32_t)__shfl((int)pl[d][p], from);
+            v = own ? v : 0u;
+            CSA3(cy[d], pl[d][p], pl[d][p], v, cy[d]);
+          }
+      }
+    }
   }
   // what this wave asked the memory system for: one atomic per wave, spread over K2_GATHER_SLOTS counters a cache line apart
   // (one atomic per row group on a single counter made a GTDB-scale launch take 11 s instead of 0.49 s)
   if (a.gathered && lane == 0 && (g_acc | h_acc)) {
     atomicAdd(a.gathered + (size_t)(blockIdx.x % K2_GATHER_SLOTS) * 16, (unsigned long long)g_acc);
     atomicAdd(a.gathered + (size_t)(blockIdx.x % K2_GATHER_SLOTS) * 16 + 1, (unsigned long long)h_acc);  // same cache line
+    if (TAIL && c_tail >= 0) atomicAdd(a.gathered + (size_t)(blockIdx.x % K2_GATHER_SLOTS) * 16 + 2, 1ull);  // waves that finished in tail mode
   }
 
   if (SPLIT) {

@@ -432,6 +432,11 @@ int kmcpg::query_device_after(kmcpg_db* db, const uint8_t* d_seqs, const uint64_
   // slot-major unit order: the waves in flight share one (block, tile) slice of the index, so the address range they gather
   // from is ~1/64 of the index (GTDB scale: 575 -> 510 ms per 524 k reads; profiles/r02_order_exp.txt)
   a.slot_major = getenv("KMCPG_SLOT_MAJOR") ? atoi(getenv("KMCPG_SLOT_MAJOR")) : 1;
+  // tail mode of the 16/24-plane kernels on 1-KiB tiles (k2_cobs.hip): KMCPG_TAIL_SECTORS=0 switches it off
+  // (2, not 4: a wave that enters with 3-4 live sectors carries near misses that would have died a little later through the rest of the
+  // query, unpruned — same-box A/B on the genome search: 5.05 ms without, 4.74 with 2, 4.93 with 4; profiles/r06_tail_mode.txt)
+  a.tail_sectors = getenv("KMCPG_TAIL_SECTORS") ? std::max(0, std::min(atoi(getenv("KMCPG_TAIL_SECTORS")), 4)) : 2;
+  a.tail_min = getenv("KMCPG_TAIL_MIN") ? std::max(1, atoi(getenv("KMCPG_TAIL_MIN"))) : 64;
   if (db->profiling >= 2) {
     if (W.w_gathered.ensure((size_t)K2_GATHER_SLOTS * 16)) return kmcpg_fail(KMCPG_ENOMEM, "hipMalloc failed");
     HIPCHK(hipMemsetAsync(W.w_gathered.p, 0, (size_t)K2_GATHER_SLOTS * 16 * sizeof(uint64_t), st));
@@ -540,7 +545,7 @@ extern "C" int kmcpg_set_profiling(kmcpg_db* db, int enable) {
   return 0;
 }
 
-// word 0 of every counter slot: 16-byte row loads; word 1: 8-byte hash loads
+// word 0 of every counter slot: 16-byte row loads; word 1: 8-byte hash loads; word 2: waves that finished in tail mode
 static int read_gather_slots(kmcpg_db* db, int word, uint64_t unit, uint64_t* bytes) {
   if (!db || !bytes) return kmcpg_fail(KMCPG_EINVAL, "null argument");
   std::lock_guard<std::mutex> g(db->mu);
@@ -559,6 +564,7 @@ static int read_gather_slots(kmcpg_db* db, int word, uint64_t unit, uint64_t* by
 
 extern "C" int kmcpg_last_gathered_bytes(kmcpg_db* db, uint64_t* bytes) { return read_gather_slots(db, 0, 16, bytes); }
 extern "C" int kmcpg_last_hash_bytes(kmcpg_db* db, uint64_t* bytes) { return read_gather_slots(db, 1, 8, bytes); }
+extern "C" int kmcpg_last_tail_waves(kmcpg_db* db, uint64_t* waves) { return read_gather_slots(db, 2, 1, waves); }
 
 extern "C" int kmcpg_timing_at(kmcpg_db* db, uint32_t age, float* kmers_ms, float* cobs_ms) {
   if (!db) return kmcpg_fail(KMCPG_EINVAL, "null argument");

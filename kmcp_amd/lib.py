@@ -15,7 +15,7 @@ EXPORTS = [
     "kmcpg_open", "kmcpg_close", "kmcpg_last_error", "kmcpg_db_info", "kmcpg_col_info", "kmcpg_search_batch",
     "kmcpg_result_free", "kmcpg_query_device", "kmcpg_finalize", "kmcpg_open_synthetic", "kmcpg_plant",
     "kmcpg_read_rows", "kmcpg_block_info", "kmcpg_kmers_device", "kmcpg_plant_reads_device", "kmcpg_set_profiling",
-    "kmcpg_last_timing", "kmcpg_open_devices", "kmcpg_build_db", "kmcpg_submit", "kmcpg_wait", "kmcpg_read_row_range", "kmcpg_timing_at", "kmcpg_last_gathered_bytes", "kmcpg_last_hash_bytes",
+    "kmcpg_last_timing", "kmcpg_open_devices", "kmcpg_build_db", "kmcpg_submit", "kmcpg_wait", "kmcpg_read_row_range", "kmcpg_timing_at", "kmcpg_last_gathered_bytes", "kmcpg_last_hash_bytes", "kmcpg_last_tail_waves",
     "kmcpg_db_ks", "kmcpg_open_paged", "kmcpg_paged_info", "kmcpg_exchange_info", "kmcpg_batch_hint", "kmcpg_group_device", "kmcpg_finalize_grouped",
     "kmcpg_search_batch_pairs", "kmcpg_wait_pairs", "kmcpg_result_pairs_free", "kmcpg_expand_pairs", "kmcpg_save_db",
     "kmcpg_pack2", "kmcpg_unpack2", "kmcpg_submit_packed", "kmcpg_host_alloc", "kmcpg_host_free",
@@ -216,6 +216,7 @@ def load():
     L.kmcpg_set_profiling.argtypes = [vp, C.c_int]
     L.kmcpg_last_timing.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]
     L.kmcpg_last_gathered_bytes.argtypes = [vp, u64p]
+    L.kmcpg_last_tail_waves.argtypes = [vp, u64p]
     L.kmcpg_last_hash_bytes.argtypes = [vp, u64p]
     L.kmcpg_timing_at.argtypes = [vp, C.c_uint32, C.POINTER(C.c_float), C.POINTER(C.c_float)]
     L.kmcpg_build_db.argtypes = [C.c_char_p, C.POINTER(BuildCfg), C.POINTER(BuildCol), C.c_uint32, C.c_int32]
@@ -581,6 +582,12 @@ class Database:
     def last_gathered_bytes(self):
         n = C.c_uint64()
         _check(load().kmcpg_last_gathered_bytes(self._h, C.byref(n)))
+        return n.value
+
+    def last_tail_waves(self):
+        """Waves of the last query_device call's COBS kernels that finished in tail mode (profiling level 2)."""
+        n = C.c_uint64()
+        _check(load().kmcpg_last_tail_waves(self._h, C.byref(n)))
         return n.value
 
     def last_hash_bytes(self):

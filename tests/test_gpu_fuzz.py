@@ -188,6 +188,57 @@ def test_random_mid_width_rows(oracle_lib, tmp_path, seed):
         odb.close()
 
 
+@pytest.mark.parametrize("seed", list(range(int(os.environ.get("KMCP_FUZZ_TAIL_SEEDS", "3")))))
+def test_random_wide_rows_long_queries(oracle_lib, tmp_path, seed, monkeypatch):
+    """Rows of 513 .. 1 150 bytes (a 64-lane tile, with or without a remainder beside it) and queries of 1 000 .. 6 000 k-mers that are made
+    of a few whole references: most sectors of a tile die, the ones that hold the query's parts do not — the tail mode of the 16-plane
+    kernels (round 6), with 1 .. 4 (or more) live sectors, 1 .. 3 hash functions, default and forced settings — against the oracle."""
+    from kmcp_amd import Database, default_params
+    O = oracle_lib
+    rng = np.random.default_rng(12000 + seed)
+    ncols = int(rng.integers(4100, 9200))
+    extra = int(rng.choice([0, 40, 700]))
+    nh = int(rng.choice([1, 1, 3]))
+    k = int(rng.choice([21, 31]))
+    fpr = 0.3 if nh == 1 else float(rng.choice([0.05, 0.01]))
+    glen = int(rng.choice([420, 700]))
+    genomes = synth.random_genomes(ncols, glen, seed=12500 + seed) + synth.random_genomes(extra, glen + 160, seed=12700 + seed)
+    db_dir = synth.make_db(tmp_path, genomes, k=k, num_hashes=nh, fpr=fpr, block_size=ncols, threads=4)
+    longq = []
+    for _ in range(40):
+        m = int(rng.choice([2, 2, 3, 4, 6, 9]))
+        first = int(rng.integers(0, len(genomes)))
+        # parts from one neighbourhood of columns (one or two sectors) or from anywhere
+        near = rng.random() < 0.5
+        ids = [(first + int(rng.integers(0, 900))) % len(genomes) if near else int(rng.integers(0, len(genomes))) for _ in range(m)]
+        longq.append(b"".join(genomes[j] for j in ids))
+    reads = synth.sample_reads(genomes, 60, 150, sub_rate=0.01, seed=int(rng.integers(1 << 30)), frac_random=0.15)
+    # one hash function at fpr 0.3: a part of an m-part query reaches ~1/m + 0.3 (1 - 1/m) of the k-mers, an unrelated column ~0.3
+    t = float(rng.choice([0.34, 0.45])) if nh == 1 else float(rng.choice([0.08, 0.2, 0.3, 0.45]))
+    flags = dict(min_qcov=t, min_matched=int(rng.choice([1, 10])), sort_by=int(rng.integers(0, 3)))
+    if rng.random() < 0.5:
+        monkeypatch.setenv("KMCPG_SPLIT_MIN", "0")      # every query on the plain kernel, whatever its length
+    knob = rng.choice(["default", "4", "1"])
+    if knob != "default":
+        monkeypatch.setenv("KMCPG_TAIL_SECTORS", str(knob))
+        monkeypatch.setenv("KMCPG_TAIL_MIN", "1")
+    odb = O.OracleDB(db_dir)
+    try:
+        with Database.open(db_dir, device=0) as db:
+            assert any(db.block_info(b)["stride"] > 512 for b in range(db.info.n_blocks))
+            if os.environ.get("KMCP_FUZZ_TAIL_REPORT"):  # how many waves of this draw finished in tail mode (soak runs: the mode must not sit idle)
+                db.set_profiling(2)
+            res = db.search(longq + reads, params=default_params(**flags))
+            if os.environ.get("KMCP_FUZZ_TAIL_REPORT"):
+                with open(os.environ["KMCP_FUZZ_TAIL_REPORT"], "a") as f:
+                    f.write("%d %s nh=%d t=%.2f tail_waves=%d\n" % (seed, knob, nh, t, db.last_tail_waves()))
+                db.set_profiling(0)
+            _check_pairs(db, res, longq + reads, None, default_params(**flags))
+        synth.assert_parity(odb, res, longq + reads, None, O.default_params(**flags))
+    finally:
+        odb.close()
+
+
 @pytest.mark.parametrize("seed", list(range(int(os.environ.get("KMCP_FUZZ_ROLL_SEEDS", "4")))))
 def test_random_long_syncmer_reads(oracle_lib, tmp_path, seed):
     """Closed-Syncmer databases whose window is 12 / 16 / 20 / 24 / 32 s-mers (k - s = 6 .. 16: what k1_windows_roll, round 6, takes) searched with long reads
