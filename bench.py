@@ -77,6 +77,7 @@ WORKLOADS = {
     # fpr 0.3), 55.2 GB in total.
     "gtdb_unchunked_k31": dict(k=31, num_hashes=1, fpr=0.3, n_blocks=47, cols_per_block=1024, num_sigs=3000000, sigs_step=267000,
                                kmers_per_col=3200000, batch_reads=1048576, kernel="k2_cobs<8,8,false>", min_qcov=0.8,
+                               genome_query=dict(n=4, min_len=4600000, max_len=5600000, min_qcov=0.5),
                                metric="reads/sec searched (150bp, k=31, -t 0.8) vs the unchunked GTDB index of the reference's published benchmark",
                                name="gtdb r202 unchunked synthetic: 47 blocks x 1024 cols, 3.0-15.3 M sigs (55.2 GB), 150bp k=31, -t 0.8"),
     # BASELINE.json configs[2] — genome search (reference: benchmarks/searching/README.md:382-432): whole
@@ -815,6 +816,51 @@ def run_workload(name, ctx, steps, warmup, batch_reads=0, cpu_baseline=True, cpu
             for pin in pins:
                 pin.close()
         del hb
+        # ---- the reference's OTHER published case on this index (`kmcp search -g -t 0.5`, one 4.6-5.6-Mbp genome, ALL of its k-mers,
+        #      against the unchunked GTDB index: 12.7-13.7 s hot on 40 threads, benchmarks/searching/README.md:139-163): one query of ~5 M k-mers at a
+        #      time through kmcpg_search_batch — host text in, finalized matches out; sort + unique on the device, the chunked COBS kernel
+        if wl.get("genome_query"):
+            gq = wl["genome_query"]
+            gg = torch.Generator(device=dev)
+            gg.manual_seed(4242)
+            acgt = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=dev)
+            glens = [int(x) for x in np.linspace(gq["min_len"], gq["max_len"], gq["n"])]
+            goffs = torch.zeros(len(glens) + 1, dtype=torch.int64, device=dev)
+            goffs[1:] = torch.cumsum(torch.tensor(glens, dtype=torch.int64, device=dev), 0)
+            gseq = acgt[torch.randint(0, 4, (int(goffs[-1].item()),), generator=gg, device=dev)].contiguous()
+            gcols = torch.randint(0, n_cols, (len(glens),), generator=gg, device=dev).to(torch.int32).contiguous()
+            db.plant_reads_device(gseq.data_ptr(), goffs.contiguous().data_ptr(), len(glens), int(goffs[-1].item()), max(glens), gcols.data_ptr())
+            torch.cuda.synchronize()
+            gp = default_params()
+            gp.min_qcov = gq.get("min_qcov", 0.5)
+            gh, go = gseq.cpu().numpy(), goffs.cpu().numpy().astype(np.uint64)
+            per, found = [], 0
+            for i_ in range(len(glens)):
+                s_i = np.ascontiguousarray(gh[int(go[i_]):int(go[i_ + 1])])
+                o_i = np.array([0, len(s_i)], dtype=np.uint64)
+                best = 1e30
+                for _ in range(3):
+                    t1 = time.perf_counter()
+                    db.search_packed_count(s_i, o_i, params=gp)
+                    best = min(best, time.perf_counter() - t1)
+                per.append(best)
+                res = db.search_packed(s_i, o_i, params=gp)
+                mt = res.matches[int(res.offs[0]):int(res.offs[1])]
+                found += int(any(int(m_["col"]) == int(gcols[i_].item()) and int(m_["mkmers"]) == int(res.qkmers[0]) for m_ in mt))
+            db.search_packed_count(gh, go, params=gp)  # (untimed: the lanes' buffers grow to the batch)
+            tb = 1e30
+            for _ in range(2):
+                t1 = time.perf_counter()
+                db.search_packed_count(gh, go, params=gp)
+                tb = min(tb, time.perf_counter() - t1)
+            out["whole_genome_query"] = {"genomes": len(glens), "min_len": min(glens), "max_len": max(glens), "min_qcov": gp.min_qcov,
+                                         "ms_per_genome": float(np.mean(per)) * 1e3, "ms_per_genome_min_max": [min(per) * 1e3, max(per) * 1e3],
+                                         "ms_per_genome_in_one_batch": tb / len(glens) * 1e3, "planted_found_with_every_kmer": found,
+                                         "reference_published_s": [12.7, 13.7],
+                                         "note": "one kmcpg_search_batch call per genome (best of 3): host text in, finalized matches out; the reference: "
+                                                 "`kmcp search -g -t 0.5` of one 4.6-5.6-Mbp genome against this index layout, hot, 40 threads "
+                                                 "(benchmarks/searching/README.md:139-163)"}
+            del gseq, gh
 
     # ---- CPU oracle on a bounded sample.  N = 1: the cpu_baseline leg (timed, ALL blocks copied back from HBM when host memory
     #      allows) + parity of the GPU hits on that sample.  N > 1: the same parity check on rank 0 over rows fetched from every
@@ -1278,7 +1324,10 @@ def _secondary_numbers(o):
          "planted_recall": o.get("planted_recall"),
          # (the kmcp-search end-to-end leg)
          "value_dev_null": o.get("value_dev_null"), "value_search_phase": o.get("value_search_phase"), "wall_s": o.get("wall_s"), "rows_per_s": o.get("rows_per_s"), "reads": o.get("reads"), "genomes": o.get("genomes"),
-         "sample_reads": o.get("sample_reads")}
+         "sample_reads": o.get("sample_reads"),
+         # (the published whole-genome query on this index: ms per 5-Mbp genome, all k-mers; reference 12 700-13 700 ms)
+         "genome_query_ms": (o.get("whole_genome_query") or {}).get("ms_per_genome"),
+         "genome_query_found": (o.get("whole_genome_query") or {}).get("planted_found_with_every_kmer")}
     if "parity_on_sample" in o:
         d["parity_on_sample"] = o["parity_on_sample"]
     for k, v in (o.get("split") or {}).items():
@@ -1425,7 +1474,7 @@ def main():
     if ctx.world == 1 and args.workload == "gtdb" and not args.no_secondary and not args.batch_reads:
         sec = run_workload("config1", ctx, min(max(args.steps, 5), 20), 2, cpu_baseline=not args.no_cpu_baseline, cpu_target_s=3.0)
         keys = ("value", "value_host_to_host", "value_host_to_host_packed", "unit", "ms_per_step", "config", "roofline", "planted_recall", "sanity_batch", "device_only", "host_boundary",
-                "cpu_baseline", "hits_per_step", "matches_per_step", "setup_s", "parity_failure")
+                "cpu_baseline", "hits_per_step", "matches_per_step", "setup_s", "parity_failure", "whole_genome_query")
         out["secondary"] = {"config1": {k: sec[k] for k in keys if k in sec}}
         # the same index with every block on its own (what a database with a different NumSigs per block gets): KMCPG_FUSE=0
         os.environ["KMCPG_FUSE"] = "0"
