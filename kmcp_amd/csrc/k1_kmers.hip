@@ -4,6 +4,8 @@
 // NextHash / NextSyncmer / NextMinimizer behind generateKmers (kmcp/cmd/util-db-search.go:1037-1107).
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include <algorithm>
 
 #include "common.hpp"
@@ -1570,7 +1572,12 @@ __global__ void __launch_bounds__(64 * ROLL_WAVES) k1_seg_roll2(const K1Args a) 
   const int q0 = lane * ROLL_L;
   const int mine = max(0, min(wpos - q0, ROLL_L));  // k-mer positions of this lane
   const int kw = k >> 4, ksh = 2 * (k & 15);
-  auto walk = [&](auto&& emit) __attribute__((always_inline)) {
+  const uint32_t mh_hi = (uint32_t)(max_hash >> 32);
+  // SC = FracMinHash database (a constant inside the loops).  The filter `0 < h <= maxHash` (util-db-search.go:1072-1077) keeps one k-mer in
+  // ~500 at scale 1000, so the 64-bit minimum and the two 64-bit compares of every step are replaced by a 32-bit test that a kept hash
+  // must pass — the upper word of min(fh, rh) is min of the upper words — and only a step where some lane passes it computes h exactly.
+  auto walk = [&](auto sc_tag, auto&& emit) __attribute__((always_inline)) {
+    constexpr bool SC = decltype(sc_tag)::value;
     if (mine <= 0) return;
     uint64_t fh = 0, rh = 0;
     for (int j = 0; j < k; j++) {  // start-up: fh = XOR_j rol(F[j], k-1-j), rh = XOR_j rol(R[j], j)
@@ -1579,6 +1586,18 @@ __global__ void __launch_bounds__(64 * ROLL_WAVES) k1_seg_roll2(const K1Args a) 
       fh = nt2_rol1(fh) ^ S[c];
       rh ^= rolv(RC[c], j);
     }
+    auto test = [&](uint64_t f, uint64_t r_) __attribute__((always_inline)) {
+      if constexpr (SC) {
+        const uint32_t fhi = (uint32_t)(f >> 32), rhi = (uint32_t)(r_ >> 32);
+        if ((fhi < rhi ? fhi : rhi) <= mh_hi) {
+          const uint64_t h = f < r_ ? f : r_;
+          if (h != 0 && h <= max_hash) emit(h);
+        }
+      } else {
+        const uint64_t h = f < r_ ? f : r_;
+        if (h != 0) emit(h);
+      }
+    };
     const int w_out = 8 * lane;
     int t = 0;
     for (int g = 0; g < 8; g++) {
@@ -1589,8 +1608,7 @@ __global__ void __launch_bounds__(64 * ROLL_WAVES) k1_seg_roll2(const K1Args a) 
       if (mine - t >= 16) {
 #pragma unroll
         for (int j = 0; j < 16; j++) {
-          const uint64_t h = fh < rh ? fh : rh;
-          if (h != 0 && (!scaled || h <= max_hash)) emit(h);
+          test(fh, rh);
           const uint32_t idx = (m[j >> 3] >> (4 * (j & 7))) & 15u;
           fh = nt2_rol1(fh) ^ F2[idx];
           rh = nt2_ror1(rh ^ R2[idx]);
@@ -1599,8 +1617,7 @@ __global__ void __launch_bounds__(64 * ROLL_WAVES) k1_seg_roll2(const K1Args a) 
         if (t >= mine) return;
       } else {
         for (int j = 0; t < mine; j++, t++) {
-          const uint64_t h = fh < rh ? fh : rh;
-          if (h != 0 && (!scaled || h <= max_hash)) emit(h);
+          test(fh, rh);
           const uint32_t idx = (m[j >> 3] >> (4 * (j & 7))) & 15u;
           fh = nt2_rol1(fh) ^ F2[idx];
           rh = nt2_ror1(rh ^ R2[idx]);
@@ -1611,11 +1628,13 @@ __global__ void __launch_bounds__(64 * ROLL_WAVES) k1_seg_roll2(const K1Args a) 
   };
   int c = 0;
   uint64_t h0 = 0, h1 = 0;
-  walk([&](uint64_t h) __attribute__((always_inline)) {
+  auto count2 = [&](uint64_t h) __attribute__((always_inline)) {
     h0 = c == 0 ? h : h0;  // (selects, not branches into a two-element array on the stack)
     h1 = c == 1 ? h : h1;
     c++;
-  });
+  };
+  if (scaled) walk(std::true_type{}, count2);
+  else walk(std::false_type{}, count2);
   int incl = c;
 #pragma unroll
   for (int off = 1; off < 64; off <<= 1) {
@@ -1638,7 +1657,9 @@ __global__ void __launch_bounds__(64 * ROLL_WAVES) k1_seg_roll2(const K1Args a) 
       if (c == 2) out[1] = h1;
     } else {
       int i = 0;
-      walk([&](uint64_t h) __attribute__((always_inline)) { out[i++] = h; });
+      auto store = [&](uint64_t h) __attribute__((always_inline)) { out[i++] = h; };
+      if (scaled) walk(std::true_type{}, store);
+      else walk(std::false_type{}, store);
     }
   }
   if (tid == 0) a.seg_cnt[blockIdx.x] = total;
