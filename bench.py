@@ -816,52 +816,6 @@ def run_workload(name, ctx, steps, warmup, batch_reads=0, cpu_baseline=True, cpu
             for pin in pins:
                 pin.close()
         del hb
-        # ---- the reference's OTHER published case on this index (`kmcp search -g -t 0.5`, one 4.6-5.6-Mbp genome, ALL of its k-mers,
-        #      against the unchunked GTDB index: 12.7-13.7 s hot on 40 threads, benchmarks/searching/README.md:139-163): one query of ~5 M k-mers at a
-        #      time through kmcpg_search_batch — host text in, finalized matches out; sort + unique on the device, the chunked COBS kernel
-        if wl.get("genome_query"):
-            gq = wl["genome_query"]
-            gg = torch.Generator(device=dev)
-            gg.manual_seed(4242)
-            acgt = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=dev)
-            glens = [int(x) for x in np.linspace(gq["min_len"], gq["max_len"], gq["n"])]
-            goffs = torch.zeros(len(glens) + 1, dtype=torch.int64, device=dev)
-            goffs[1:] = torch.cumsum(torch.tensor(glens, dtype=torch.int64, device=dev), 0)
-            gseq = acgt[torch.randint(0, 4, (int(goffs[-1].item()),), generator=gg, device=dev)].contiguous()
-            gcols = torch.randint(0, n_cols, (len(glens),), generator=gg, device=dev).to(torch.int32).contiguous()
-            db.plant_reads_device(gseq.data_ptr(), goffs.contiguous().data_ptr(), len(glens), int(goffs[-1].item()), max(glens), gcols.data_ptr())
-            torch.cuda.synchronize()
-            gp = default_params()
-            gp.min_qcov = gq.get("min_qcov", 0.5)
-            gh, go = gseq.cpu().numpy(), goffs.cpu().numpy().astype(np.uint64)
-            per, found = [], 0
-            for i_ in range(len(glens)):
-                s_i = np.ascontiguousarray(gh[int(go[i_]):int(go[i_ + 1])])
-                o_i = np.array([0, len(s_i)], dtype=np.uint64)
-                best = 1e30
-                for _ in range(3):
-                    t1 = time.perf_counter()
-                    db.search_packed_count(s_i, o_i, params=gp)
-                    best = min(best, time.perf_counter() - t1)
-                per.append(best)
-                res = db.search_packed(s_i, o_i, params=gp)
-                mt = res.matches[int(res.offs[0]):int(res.offs[1])]
-                found += int(any(int(m_["col"]) == int(gcols[i_].item()) and int(m_["mkmers"]) == int(res.qkmers[0]) for m_ in mt))
-            db.search_packed_count(gh, go, params=gp)  # (untimed: the lanes' buffers grow to the batch)
-            tb = 1e30
-            for _ in range(2):
-                t1 = time.perf_counter()
-                db.search_packed_count(gh, go, params=gp)
-                tb = min(tb, time.perf_counter() - t1)
-            out["whole_genome_query"] = {"genomes": len(glens), "min_len": min(glens), "max_len": max(glens), "min_qcov": gp.min_qcov,
-                                         "ms_per_genome": float(np.mean(per)) * 1e3, "ms_per_genome_min_max": [min(per) * 1e3, max(per) * 1e3],
-                                         "ms_per_genome_in_one_batch": tb / len(glens) * 1e3, "planted_found_with_every_kmer": found,
-                                         "reference_published_s": [12.7, 13.7],
-                                         "note": "one kmcpg_search_batch call per genome (best of 3): host text in, finalized matches out; the reference: "
-                                                 "`kmcp search -g -t 0.5` of one 4.6-5.6-Mbp genome against this index layout, hot, 40 threads "
-                                                 "(benchmarks/searching/README.md:139-163)"}
-            del gseq, gh
-
     # ---- CPU oracle on a bounded sample.  N = 1: the cpu_baseline leg (timed, ALL blocks copied back from HBM when host memory
     #      allows) + parity of the GPU hits on that sample.  N > 1: the same parity check on rank 0 over rows fetched from every
     #      rank (each owner reads its blocks back, rank 0 receives them), untimed: the merged hit list of a multi-GPU run is
@@ -972,6 +926,53 @@ def run_workload(name, ctx, steps, warmup, batch_reads=0, cpu_baseline=True, cpu
             print(f"bench.py: PARITY FAILURE on the sample: {out['parity_failure']}", file=sys.stderr)
     if coll:
         dist.barrier()
+
+    # ---- (last: this leg plants whole genomes into the index, which the oracle comparison above must not see)
+    # ---- the reference's OTHER published case on this index (`kmcp search -g -t 0.5`, one 4.6-5.6-Mbp genome, ALL of its k-mers,
+    #      against the unchunked GTDB index: 12.7-13.7 s hot on 40 threads, benchmarks/searching/README.md:139-163): one query of ~5 M k-mers at a
+    #      time through kmcpg_search_batch — host text in, finalized matches out; sort + unique on the device, the chunked COBS kernel
+    if wl.get("genome_query") and rank == 0 and world == 1 and extras:
+        gq = wl["genome_query"]
+        gg = torch.Generator(device=dev)
+        gg.manual_seed(4242)
+        acgt = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=dev)
+        glens = [int(x) for x in np.linspace(gq["min_len"], gq["max_len"], gq["n"])]
+        goffs = torch.zeros(len(glens) + 1, dtype=torch.int64, device=dev)
+        goffs[1:] = torch.cumsum(torch.tensor(glens, dtype=torch.int64, device=dev), 0)
+        gseq = acgt[torch.randint(0, 4, (int(goffs[-1].item()),), generator=gg, device=dev)].contiguous()
+        gcols = torch.randint(0, n_cols, (len(glens),), generator=gg, device=dev).to(torch.int32).contiguous()
+        db.plant_reads_device(gseq.data_ptr(), goffs.contiguous().data_ptr(), len(glens), int(goffs[-1].item()), max(glens), gcols.data_ptr())
+        torch.cuda.synchronize()
+        gp = default_params()
+        gp.min_qcov = gq.get("min_qcov", 0.5)
+        gh, go = gseq.cpu().numpy(), goffs.cpu().numpy().astype(np.uint64)
+        per, found = [], 0
+        for i_ in range(len(glens)):
+            s_i = np.ascontiguousarray(gh[int(go[i_]):int(go[i_ + 1])])
+            o_i = np.array([0, len(s_i)], dtype=np.uint64)
+            best = 1e30
+            for _ in range(3):
+                t1 = time.perf_counter()
+                db.search_packed_count(s_i, o_i, params=gp)
+                best = min(best, time.perf_counter() - t1)
+            per.append(best)
+            res = db.search_packed(s_i, o_i, params=gp)
+            mt = res.matches[int(res.offs[0]):int(res.offs[1])]
+            found += int(any(int(m_["col"]) == int(gcols[i_].item()) and int(m_["mkmers"]) == int(res.qkmers[0]) for m_ in mt))
+        db.search_packed_count(gh, go, params=gp)  # (untimed: the lanes' buffers grow to the batch)
+        tb = 1e30
+        for _ in range(2):
+            t1 = time.perf_counter()
+            db.search_packed_count(gh, go, params=gp)
+            tb = min(tb, time.perf_counter() - t1)
+        out["whole_genome_query"] = {"genomes": len(glens), "min_len": min(glens), "max_len": max(glens), "min_qcov": gp.min_qcov,
+                                     "ms_per_genome": float(np.mean(per)) * 1e3, "ms_per_genome_min_max": [min(per) * 1e3, max(per) * 1e3],
+                                     "ms_per_genome_in_one_batch": tb / len(glens) * 1e3, "planted_found_with_every_kmer": found,
+                                     "reference_published_s": [12.7, 13.7],
+                                     "note": "one kmcpg_search_batch call per genome (best of 3): host text in, finalized matches out; the reference: "
+                                             "`kmcp search -g -t 0.5` of one 4.6-5.6-Mbp genome against this index layout, hot, 40 threads "
+                                             "(benchmarks/searching/README.md:139-163)"}
+        del gseq, gh
 
     db.close()
     del bufs, batches
