@@ -1,12 +1,10 @@
 #!/bin/bash
 set -u
-R=$PWD
-OUT=$R/gpurun_out
-cd /tmp && export TMPDIR=/tmp
-python $R/tools/ab/r06_gq_probe.py gtdb_unchunked_k31 4 > $OUT/r06_gq_probe.txt 2>&1
-rm -rf $OUT/_prof_gq
-timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/_prof_gq -o gq -- python $R/tools/ab/r06_gq_probe.py gtdb_unchunked_k31 4 > /dev/null 2> $OUT/r06_gq_prof.err
-python $R/profiles/extract_rocprof.py $OUT/_prof_gq/gq_results.db $OUT/r06_gq >> $OUT/r06_gq_prof.err 2>&1
-rm -rf $OUT/_prof_gq
-cat $OUT/r06_gq_probe.txt
-grep kmcpg $OUT/r06_gq_kernel_stats.txt | head -30
+timeout 1200 python bench.py --workload config2_genome_search --no-secondary --steps 10 --warmup 2 --cpu-sample-reads 64 > gpurun_out/r06_gq_line.json 2> gpurun_out/r06_gq.err
+tail -3 gpurun_out/r06_gq.err
+python - <<'PY'
+import json
+j = json.load(open("bench_detail.json"))
+print(json.dumps(j.get("whole_genome_query"), indent=1))
+print("value", j["value"], "k2", j["roofline"]["kernel_ms"])
+PY
