@@ -447,11 +447,14 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((NPL =
 #pragma unroll
           for (int p = 0; p < NPL; p++) pl[d][p] = 0;
       }
+      // (the hashes of the NEXT chunk are asked for before this chunk's rows: a chunk is three round trips to memory here, not four)
+      uint64_t h_next = c_tail + lane < s_unit[wave][0].n ? a.hashes[s_unit[wave][0].koff + (uint64_t)(c_tail + lane)] : 0;
       for (int c0 = c_tail; c0 < nmax; c0 += CH) {
         {  // row indices of the chunk (one unit per wave: k-mer = lane), as above
           const bool has = c0 + lane < s_unit[wave][0].n;
           if (a.gathered) h_acc += (uint32_t)__popcll(__ballot(has));
-          const uint64_t h = has ? a.hashes[s_unit[wave][0].koff + (uint64_t)(c0 + lane)] : 0;
+          const uint64_t h = h_next;
+          h_next = c0 + CH + lane < s_unit[wave][0].n ? a.hashes[s_unit[wave][0].koff + (uint64_t)(c0 + CH + lane)] : 0;
           const uint64_t ns = s_unit[wave][0].ns, mh = s_unit[wave][0].mh;
           const uint32_t s16 = s_unit[wave][0].s16;
           if (has) {
