@@ -688,9 +688,6 @@ extern "C" int kmcpg_close(kmcpg_db* db) {
   kmcpg::async_release(db);
   if (db->k1_stream) (void)hipStreamDestroy(db->k1_stream);
   if (db->cobs_ev) (void)hipEventDestroy(db->cobs_ev);
-  for (hipStream_t s2 : db->class_streams) (void)hipStreamDestroy(s2);
-  for (hipEvent_t e2 : db->class_events) (void)hipEventDestroy(e2);
-  if (db->class_fork) (void)hipEventDestroy(db->class_fork);
   if (db->fin_ev) (void)hipEventDestroy(db->fin_ev);
   for (auto& ev : db->ev)
     if (ev) (void)hipEventDestroy(ev);

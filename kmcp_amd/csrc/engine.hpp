@@ -158,9 +158,6 @@ struct kmcpg_db {
   int ws_last = 0;             // slot of the last kmcpg_query_device call (kmcpg_last_gathered_bytes reads its counters)
   hipStream_t k1_stream = nullptr;  // experiment (KMCPG_K1_STREAM=1): the k-mer kernels on a high-priority stream of the handle's own
   hipEvent_t cobs_ev = nullptr;  // end of the last call's COBS kernels: the next call's COBS kernels wait for it
-  std::vector<hipStream_t> class_streams;  // long queries: the COBS launches of the 2nd, 3rd ... lane form run beside the first (query.cpp)
-  std::vector<hipEvent_t> class_events;
-  hipEvent_t class_fork = nullptr;
   bool cobs_ev_valid = false;
   hipEvent_t fin_ev = nullptr;   // K3's scratch (w_fin_cnt, w_fin_sums) has one user at a time, whatever the k-mer slots do
   bool fin_ev_valid = false;

@@ -451,39 +451,10 @@ int kmcpg::query_device_after(kmcpg_db* db, const uint8_t* d_seqs, const uint64_
   // COBS kernels one batch at a time (the k-mer kernels above may have run beside the previous batch's)
   if (int rcc = chain_begin(&db->cobs_ev, db->cobs_ev_valid, st)) return rcc;
   if (db->profiling) HIPCHK(hipEventRecord(pev[1], st));
-  // Long queries, several lane forms (a 1-KiB tile + a narrower remainder of the same rows): the forms' launches go to streams of their own
-  // and run beside each other.  A batch of 16 384 HiFi reads is five rounds of the chip on the 64-lane form and a round and a third on the
-  // 16-lane one (4 units per wave): in a single stream the second launch waits for the last wave of the first, and both end on a
-  // part-filled round.  Side by side, the second launch's workgroups take the slots the first one frees (the dispatcher feeds the kernel
-  // that came first while it has workgroups left).  Short reads (8 / 10 planes) have launches of many rounds and keep the one stream.
-  // KMCPG_CLASS_STREAMS=0: one stream, as before round 6.
-  const bool side_by_side = db->classes.size() > 1 && npl >= 16 && !(getenv("KMCPG_CLASS_STREAMS") && atoi(getenv("KMCPG_CLASS_STREAMS")) == 0);
-  if (side_by_side) {
-    while (db->class_streams.size() + 1 < db->classes.size()) {
-      hipStream_t s2 = nullptr;
-      hipEvent_t e2 = nullptr;
-      HIPCHK(hipStreamCreateWithFlags(&s2, hipStreamNonBlocking));
-      db->class_streams.push_back(s2);
-      HIPCHK(hipEventCreateWithFlags(&e2, hipEventDisableTiming));
-      db->class_events.push_back(e2);
-    }
-    if (!db->class_fork) HIPCHK(hipEventCreateWithFlags(&db->class_fork, hipEventDisableTiming));
-    HIPCHK(hipEventRecord(db->class_fork, st));
-  }
-  for (size_t ci = 0; ci < db->classes.size(); ci++) {  // (which form goes first makes no difference: 3.05 ms either way)
-    const auto& c = db->classes[ci];
+  for (const auto& c : db->classes) {
     a.slots = c.d_slots;
     a.nslots = (uint32_t)c.slots.size();
-    hipStream_t sc = st;
-    if (side_by_side && ci > 0) {
-      sc = db->class_streams[ci - 1];
-      HIPCHK(hipStreamWaitEvent(sc, db->class_fork, 0));
-    }
-    if (launch_k2(a, c.lpr, npl, sc) != 0) return kmcpg_fail(KMCPG_EINVAL, "batch too large for one launch: split it");
-    if (sc != st) {
-      HIPCHK(hipEventRecord(db->class_events[ci - 1], sc));
-      HIPCHK(hipStreamWaitEvent(st, db->class_events[ci - 1], 0));
-    }
+    if (launch_k2(a, c.lpr, npl, st) != 0) return kmcpg_fail(KMCPG_EINVAL, "batch too large for one launch: split it");
   }
   if (n_long) {
     a.ncols_total = (uint32_t)db->info.n_cols;
