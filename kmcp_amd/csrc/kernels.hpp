@@ -12,6 +12,8 @@ void launch_nk_simple(const int32_t* nk_raw, int32_t* nk_search, uint32_t n, int
 void launch_dedup(DedupArgs a, uint64_t max_n, hipStream_t st);  // queries above HUGE_MIN are left to huge_dedup
 // lpr in {4,8,16,32,64}: lanes per row tile; npl in {8,10,16,24}: counter planes.  <0 on bad arguments.
 int launch_k2(const K2Args& a, int lpr, int npl, hipStream_t st);
+// two lane forms in one grid (long queries: the 64-lane tiles + the remainder's form); -1 when there is no such kernel: launch them one by one
+int launch_k2_pair(const K2Args& a64, const K2Args& b, int lprb, int npl, hipStream_t st);
 // long queries: chunked counting into a.long_counts, then one thresholding pass
 int launch_k2_split(const K2Args& a, int lpr, hipStream_t st);
 void launch_list_long(const int32_t* nk, uint32_t n_reads, int32_t split_min, uint32_t* list, uint32_t* meta, hipStream_t st);

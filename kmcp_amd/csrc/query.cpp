@@ -451,7 +451,19 @@ int kmcpg::query_device_after(kmcpg_db* db, const uint8_t* d_seqs, const uint64_
   // COBS kernels one batch at a time (the k-mer kernels above may have run beside the previous batch's)
   if (int rcc = chain_begin(&db->cobs_ev, db->cobs_ev_valid, st)) return rcc;
   if (db->profiling) HIPCHK(hipEventRecord(pev[1], st));
+  // Long queries on rows cut into a 64-lane tile form + one narrower form: both in one grid (k2_cobs_pair: the second form's workgroups
+  // take the slots the first one's last waves free; KMCPG_PAIR=0: two launches, as before round 6)
+  bool paired = false;
+  if (npl >= 16 && db->classes.size() == 2 && db->classes[0].lpr == 64 && db->classes[1].lpr < 64 && !(getenv("KMCPG_PAIR") && atoi(getenv("KMCPG_PAIR")) == 0)) {
+    K2Args a1 = a, b1 = a;
+    a1.slots = db->classes[0].d_slots;
+    a1.nslots = (uint32_t)db->classes[0].slots.size();
+    b1.slots = db->classes[1].d_slots;
+    b1.nslots = (uint32_t)db->classes[1].slots.size();
+    paired = launch_k2_pair(a1, b1, db->classes[1].lpr, npl, st) == 0;
+  }
   for (const auto& c : db->classes) {
+    if (paired) break;
     a.slots = c.d_slots;
     a.nslots = (uint32_t)c.slots.size();
     if (launch_k2(a, c.lpr, npl, st) != 0) return kmcpg_fail(KMCPG_EINVAL, "batch too large for one launch: split it");

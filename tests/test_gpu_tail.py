@@ -135,10 +135,12 @@ def _check(db, torch, reads, offs, lens, n, total, params, n_blocks, cols, nh, c
     with _Env(KMCPG_SPLIT_MIN=0, KMCPG_TAIL_SECTORS=4, KMCPG_TAIL_MIN=1):  # 3 and 4 live sectors: one helper octet each
         h_four, _, _ = _run(db, torch, reads, offs, n, total, max(lens), params, cap)
         assert db.last_tail_waves() >= tail_waves
+    with _Env(KMCPG_SPLIT_MIN=0, KMCPG_PAIR=0):  # the two lane forms of a database as two launches (default: one grid, k2_cobs_pair)
+        h_seq, _, _ = _run(db, torch, reads, offs, n, total, max(lens), params, cap)
     db.set_profiling(0)
     assert np.array_equal(qk, qk2) and np.array_equal(ql, ql2)
     assert h_on.shape == h_off.shape and np.array_equal(h_on, h_off)
-    assert np.array_equal(h_one, h_off) and np.array_equal(h_four, h_off)
+    assert np.array_equal(h_one, h_off) and np.array_equal(h_four, h_off) and np.array_equal(h_seq, h_off)
     assert tail_waves > 0
     # no pruning inside the tail: a little more traffic than the plain loop is the price, not a multiple
     assert bytes_on <= 1.35 * bytes_off, (bytes_on, bytes_off)
