@@ -339,6 +339,18 @@ int kmcpg_block_info(const kmcpg_db* db, uint32_t block, uint64_t* num_sigs, uin
 int kmcpg_kmers_device(kmcpg_db* db, const uint8_t* d_seqs, const uint64_t* d_offs, uint32_t n_reads,
                        uint64_t total_bases, uint32_t max_read_len, const kmcpg_params* params,
                        uint64_t* d_hashes, uint64_t hashes_cap, uint64_t* d_koff, int32_t* d_nk, void* stream);
+/* The same on a batch that is on the device as 2-bit codes (the layout of kmcpg_submit_packed: base j of the batch in bits 2 (j % 4)
+ * of d_codes[j / 4], 16 readable bytes behind the last one, 4-byte aligned; d_exc = its n_exc runs of foreign bytes on the device)
+ * and d_text = total_bases + 16 writable bytes for whatever has to be expanded: whole genomes (k <= 128, plain or FracMinHash k-mers)
+ * are hashed from the codes directly and only the 65 536-position segments a foreign byte reaches become text (k1_kmers.hip);
+ * every other shape of batch is expanded whole first.  Debug/tests. */
+int kmcpg_kmers_device_packed(kmcpg_db* db, const uint8_t* d_codes, const kmcpg_exc_run* d_exc, uint32_t n_exc, uint8_t* d_text,
+                              const uint64_t* d_offs, uint32_t n_reads, uint64_t total_bases, uint32_t max_read_len,
+                              const kmcpg_params* params, uint64_t* d_hashes, uint64_t hashes_cap, uint64_t* d_koff, int32_t* d_nk,
+                              void* stream);
+/* Batches of this handle so far whose k-mer kernels read 2-bit codes directly (packed whole-genome batches), and packed batches that
+ * were expanded to text first. */
+int kmcpg_k1_codes_batches(kmcpg_db* db, uint64_t* direct, uint64_t* expanded);
 
 /* -- index building on the GPU ("next" row of SURVEY.md §8f): the Bloom-column scatter of `kmcp index`
  *    (kmcp/cmd/index.go:657-682 block layout, :1023 signature size, :1107-1309 scatter, index/serialization.go:159-300 file,

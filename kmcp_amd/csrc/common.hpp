@@ -74,7 +74,26 @@ struct K1Args {
   uint32_t* seg_list;    // ... the segments k1_seg_roll2 left to the byte kernel, and how many (launch_k1 places both behind seg_cnt[])
   uint32_t* seg_nflag;
   int32_t seg_only_flagged;  // k1_seg_roll as the fallback of k1_seg_roll2: only the segments that kernel marked (seg_cnt == -1)
+  // whole genomes that arrived as 2-bit codes (kmcpg_submit_packed / a batch stage() packed): k1_seg_roll2 takes its codes from the packed
+  // stream as it is — base j of the batch in bits 2 (j % 4) of byte j / 4 — and only the segments a run of foreign bytes reaches are expanded
+  // to text (seqs_w = the buffer `seqs` points at) for the byte kernel.  nullptr: `seqs` holds the text already.
+  const uint8_t* codes;
+  const ExcRun* exc;
+  uint32_t n_exc;
+  uint8_t* seqs_w;
+  uint32_t* seg_exc;     // per (read, segment): != 0 when a foreign byte lies among the bases the segment's k-mers cover (k_mark_exc)
 };
+
+// the packed source of the batch the calling thread is about to enqueue (host.cpp -> run_kmers): codes + runs on the device, and the
+// text buffer the expansion goes to when the k-mer kernels of this batch read text
+struct PackedSrc {
+  const uint8_t* codes = nullptr;
+  const ExcRun* exc = nullptr;
+  uint32_t n_exc = 0;
+  uint8_t* text = nullptr;
+  uint64_t n_bases = 0;
+};
+extern thread_local PackedSrc tl_packed_src;
 
 struct DedupArgs {
   const uint64_t* offs;

@@ -155,6 +155,7 @@ struct kmcpg_db {
   };
   Workspace ws[2];
   uint64_t ws_calls = 0;       // kmcpg_query_device calls so far: slot = ws_calls & 1 (when the second slot may be used)
+  uint64_t k1_codes_direct = 0, k1_codes_expanded = 0;  // packed batches: k-mer kernels on the codes / on text expanded first (kmcpg_k1_codes_batches)
   int ws_last = 0;             // slot of the last kmcpg_query_device call (kmcpg_last_gathered_bytes reads its counters)
   hipStream_t k1_stream = nullptr;  // experiment (KMCPG_K1_STREAM=1): the k-mer kernels on a high-priority stream of the handle's own
   hipEvent_t cobs_ev = nullptr;  // end of the last call's COBS kernels: the next call's COBS kernels wait for it

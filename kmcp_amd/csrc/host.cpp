@@ -386,6 +386,21 @@ int stage_packed(Lane* L, const PackedIn& in, const uint64_t* offs, uint32_t n) 
 
 int enqueue_query(kmcpg_db* db, AsyncState* A, Lane* L, const kmcpg_params& p, const std::function<int()>* prologue = nullptr) {
   hipStream_t st = L->st;
+  // packed input: the k-mer stage of this call (query.cpp run_kmers, on this thread) reads the codes where it can — whole genomes — and
+  // expands them to the text in d_seqs where it cannot; a rerun of the batch (ENOMEM, hit-buffer overflow) does the same again
+  struct PackedScope {
+    explicit PackedScope(Lane* L) {
+      if (!L->packed) return;
+      PackedSrc s;
+      s.codes = L->d_pack.p;
+      s.exc = L->n_exc ? L->d_exc.p : nullptr;
+      s.n_exc = L->n_exc;
+      s.text = L->d_seqs.p;
+      s.n_bases = L->tb1;
+      tl_packed_src = s;
+    }
+    ~PackedScope() { tl_packed_src = PackedSrc{}; }
+  } packed_scope(L);
   int rc = query_device_after(db, L->d_seqs.p, L->d_offs.p, L->paired ? L->d_seqs2.p : nullptr, L->paired ? L->d_offs2.p : nullptr, L->n, L->tb1 + L->tb2,
                               L->maxlen, &p, L->d_hits.p, L->d_hits.cap, L->d_cnt.p, L->d_qk.p, L->d_ql.p, st, prologue);
   if (rc) return rc;
@@ -466,7 +481,6 @@ int enqueue(kmcpg_db* db, AsyncState* A, Lane* L, const kmcpg_params& p, bool ge
   // lock: see query.cpp query_device_after
   const std::function<int()> after_upload = [&]() -> int {
     HIPCHK(hipStreamWaitEvent(st, L->uploaded, 0));
-    if (L->packed) launch_unpack2(L->d_pack.p, L->d_seqs.p, L->tb1, L->n_exc ? L->d_exc.p : nullptr, L->n_exc, st);  // codes -> the ASCII K1 reads
     return 0;
   };
   int rc = enqueue_query(db, A, L, p, &after_upload);

@@ -1531,7 +1531,27 @@ __global__ void __launch_bounds__(64 * ROLL_WAVES) k1_seg_roll2(const K1Args a) 
   uint32_t* __restrict__ Wd = codes[w];
   auto slot = [&](int word) -> int { return (word >> 3) * R2_PITCH + (word & 7); };  // word = base / 16 within the wave's stretch
   __syncthreads();  // s_bad = 0 before anybody raises it
-  {
+  if (a.codes) {
+    // the batch came as 2-bit codes: 16 of them are the 32 bits at bit 2 G of the packed stream (G = the word's first base in the batch) —
+    // two dwords and a funnel shift; a foreign byte among the segment's bases has been noted per segment by k_mark_exc
+    const uint32_t* __restrict__ C32 = reinterpret_cast<const uint32_t*>(a.codes);
+    const uint64_t G0 = o1 + (uint64_t)P0;
+    const int nb = wpos > 0 ? wpos + k - 1 : 0;  // bases this wave needs
+    for (int gi = lane; gi < 8 * 66; gi += 64) {
+      const int b0 = gi * 16;
+      uint32_t word = 0;
+      if (b0 < nb) {
+        const uint64_t G = G0 + (uint64_t)b0;
+        const uint64_t d = G >> 4;
+        const uint32_t sh = 2u * (uint32_t)(G & 15u);
+        const uint32_t lo = C32[d], hi = C32[d + 1];  // (the device copy of the codes ends 16 bytes behind the last base)
+        word = nt2_funnel(hi, lo, sh);
+        if (b0 + 16 > nb) word &= (1u << (2 * (nb - b0))) - 1u;  // what follows belongs to the next query
+      }
+      Wd[slot(gi)] = word;
+    }
+    if (tid == 0 && a.seg_exc && a.seg_exc[blockIdx.x]) s_bad = 1;
+  } else {
     const uint8_t* __restrict__ s = a.seqs + o1 + P0;
     const int nb = wpos > 0 ? wpos + k - 1 : 0;  // bases this wave needs
     typedef uint32_t u32x4_any __attribute__((ext_vector_type(4), aligned(1)));
@@ -1665,6 +1685,61 @@ __global__ void __launch_bounds__(64 * ROLL_WAVES) k1_seg_roll2(const K1Args a) 
   if (tid == 0) a.seg_cnt[blockIdx.x] = total;
 }
 
+// Packed whole-genome batches (a.codes): which segments hold a foreign byte, and the text of exactly those for the byte kernel.
+// k_mark_exc: one thread per run of foreign bytes (positions count from the start of the batch; a run of equal bytes may continue from the
+// end of one query into the next) -> seg_exc[(read, segment)] = 1 for every segment whose k-mers cover one of its bytes: segment g of a
+// read owns the k-mer positions [g K1SEG, (g + 1) K1SEG), i.e. the bases [g K1SEG, (g + 1) K1SEG + k - 1).
+__global__ void __launch_bounds__(256) k_mark_exc(const K1Args a) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= a.n_exc) return;
+  uint64_t pos = a.exc[i].pos;
+  const uint64_t end = pos + a.exc[i].len;
+  uint32_t lo = 0, hi = a.n_reads;  // the read r with offs[r] <= pos < offs[r + 1]: the last r with offs[r] <= pos
+  while (hi - lo > 1) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if (a.offs[mid] <= pos) lo = mid;
+    else hi = mid;
+  }
+  uint32_t r = lo;
+  while (pos < end && r < a.n_reads) {
+    const uint64_t o1 = a.offs[r], o2 = a.offs[r + 1];
+    if (pos >= o2) {  // (empty queries in between)
+      r++;
+      continue;
+    }
+    const uint64_t s = pos - o1, e = (end < o2 ? end : o2) - o1;  // the run's bases [s, e) of read r
+    const uint64_t g_lo = s >= (uint64_t)(a.k - 1) ? (s - (uint64_t)(a.k - 1)) / K1SEG : 0, g_hi = (e - 1) / K1SEG;
+    for (uint64_t g = g_lo; g <= g_hi && g < a.segs_max; g++) a.seg_exc[(uint64_t)r * a.segs_max + g] = 1u;
+    pos = o2;
+    r++;
+  }
+}
+
+// the bases of the listed segments (k1_seg_roll2's list: the segments k_mark_exc marked) as text, four per packed byte and thread; a byte
+// that straddles the segment's ends is expanded whole (its neighbours' bases get the value they have anyway); k_apply_exc behind this
+// launch restores the foreign bytes, the byte kernel behind that reads the text
+__global__ void __launch_bounds__(256) k_unpack2_list(const K1Args a) {
+  constexpr uint32_t LUT = NT2_LETTERS;
+  const uint32_t n_todo = *a.seg_nflag;
+  for (uint32_t it = blockIdx.x; it < n_todo; it += gridDim.x) {
+    const uint32_t bid = a.seg_list[it];
+    const uint32_t r = bid / a.segs_max, seg = bid % a.segs_max;
+    const uint64_t o1 = a.offs[r], o2 = a.offs[r + 1];
+    const uint64_t g0 = o1 + (uint64_t)seg * K1SEG;
+    uint64_t g1 = g0 + K1SEG + (uint64_t)(a.k - 1);
+    if (g1 > o2) g1 = o2;
+    if (g0 >= g1) continue;
+    const uint64_t b0 = g0 >> 2, b1 = (g1 + 3) >> 2;  // packed bytes [b0, b1)
+    for (uint64_t b = b0 + threadIdx.x; b < b1; b += blockDim.x) {
+      const uint32_t byte = a.codes[b];
+      uint32_t v = 0;
+#pragma unroll
+      for (int j = 0; j < 4; j++) v |= ((LUT >> (8 * ((byte >> (2 * j)) & 3u))) & 0xffu) << (8 * j);
+      reinterpret_cast<uint32_t*>(a.seqs_w)[b] = v;
+    }
+  }
+}
+
 __global__ void __launch_bounds__(256) k1_seg_pack(const K1Args a) {
   const uint32_t r = blockIdx.x / a.segs_max, seg = blockIdx.x % a.segs_max;
   const uint64_t o1 = a.offs[r];
@@ -1712,6 +1787,23 @@ bool launch_k1(const K1Args& a, uint32_t max_read_len, hipStream_t st) {
       b.seg_nflag = (uint32_t*)(a.seg_cnt + blocks);
       b.seg_list = b.seg_nflag + 1;
       (void)hipMemsetAsync(b.seg_nflag, 0, sizeof(uint32_t), st);
+      if (a.codes) {  // packed batch (run_kmers sized seg_cnt[] for it: the marks live behind the list)
+        b.seg_exc = nullptr;
+        if (a.n_exc) {
+          b.seg_exc = b.seg_list + blocks;
+          (void)hipMemsetAsync(b.seg_exc, 0, (size_t)blocks * sizeof(uint32_t), st);
+          hipLaunchKernelGGL(k_mark_exc, dim3((a.n_exc + 255) / 256), dim3(256), 0, st, b);
+        }
+        hipLaunchKernelGGL(k1_seg_roll2, dim3(blocks), dim3(64 * ROLL_WAVES), 0, st, b);
+        if (a.n_exc) {  // (no foreign byte in the batch: nothing is on the list, nothing reads text)
+          hipLaunchKernelGGL(k_unpack2_list, dim3(std::min(blocks, 512u)), dim3(256), 0, st, b);
+          launch_apply_exc(a.exc, a.n_exc, a.seqs_w, st);
+          b.seg_only_flagged = 1;
+          hipLaunchKernelGGL(k1_seg_roll, dim3(std::min(blocks, 512u)), dim3(64 * ROLL_WAVES), 0, st, b);
+        }
+        hipLaunchKernelGGL(k1_seg_pack, dim3(blocks), dim3(256), 0, st, a);
+        return false;
+      }
       hipLaunchKernelGGL(k1_seg_roll2, dim3(blocks), dim3(64 * ROLL_WAVES), 0, st, b);  // 2-bit codes; lists the segments it cannot take
       b.seg_only_flagged = 1;
       // ... and the byte kernel does those: a grid that fills the chip once (2 workgroups of 8 waves per CU) walks the list — nothing

@@ -37,6 +37,7 @@ void launch_build_scatter(uint8_t* sigs, uint64_t num_sigs, uint64_t mh, uint32_
 // 2-bit packed bases (4 per byte, base j in bits 2*(j%4) of byte j/4; A=0 C=1 T=2 G=3 = (ascii >> 1) & 3) -> ASCII, then the
 // exception runs (every byte that is not A/C/G/T/U in either case) written over them
 void launch_unpack2(const uint8_t* packed, uint8_t* out, uint64_t n_bases, const ExcRun* runs, uint32_t n_runs, hipStream_t st);
+void launch_apply_exc(const ExcRun* runs, uint32_t n_runs, uint8_t* out, hipStream_t st);  // the runs alone, over text that is there
 
 // experiment only (KMCPG_DEBUG_ROWSORT): every query's hashes re-ordered by h % num_sigs of one block; mode 2 = rotated
 void launch_debug_rowsort(uint64_t* hashes, const uint64_t* offs, const int32_t* nk, uint32_t n_reads, uint64_t num_sigs, uint64_t mh, int mode, hipStream_t st);

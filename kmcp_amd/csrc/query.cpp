@@ -40,6 +40,8 @@ void release_fpr_bounds(kmcpg_db* db) {
 // ------------------------------------------------------------------------------------------------
 // GPU half
 // ------------------------------------------------------------------------------------------------
+thread_local kmcpg::PackedSrc kmcpg::tl_packed_src;
+
 namespace {
 
 uint64_t max_hash_for(uint32_t scale) {
@@ -73,12 +75,32 @@ int run_kmers(kmcpg_db* db, kmcpg_db::Workspace& W, const uint8_t* d_seqs, const
   a.nk_raw = d_nk_raw;
   a.nk1 = d_nk1;
   a.qlen = d_qlen;
+  a.flags = getenv("KMCPG_K1_FLAGS") ? atoi(getenv("KMCPG_K1_FLAGS")) : 3;
   // whole genomes (single-end, plain or FracMinHash k-mers): segments of a read on their own workgroups
   const uint32_t segs = (max_read_len + (uint32_t)k1_segment_len() - 1) / (uint32_t)k1_segment_len();
   if (a.mode == 0 && !d_seqs2 && segs > 1 && d_scratch && (uint64_t)n_reads * segs <= (1ull << 21)) {  // one workgroup of 1024 threads per segment, < 2^32 threads per launch
-    if (W.w_seg_cnt.ensure(2 * (size_t)n_reads * segs + 1)) return kmcpg_fail(KMCPG_ENOMEM, "hipMalloc failed");  // counts + launch_k1's fallback list
+    if (W.w_seg_cnt.ensure(3 * (size_t)n_reads * segs + 2)) return kmcpg_fail(KMCPG_ENOMEM, "hipMalloc failed");  // counts + launch_k1's fallback list + its marks
     a.seg_cnt = W.w_seg_cnt.p;
     a.segs_max = segs;
+  }
+  // A batch that came as 2-bit codes (host.cpp: kmcpg_submit_packed, or text stage() packed): the whole-genome kernel reads the codes as
+  // they are, and text exists only for the segments a foreign byte reaches (launch_k1); every other k-mer kernel reads text, expanded
+  // here.  (A batch with a run per 4 kb or more is not what the direct form is for: expanded whole.)  KMCPG_K1_CODES=0: always expand.
+  const PackedSrc src = tl_packed_src;
+  tl_packed_src = PackedSrc{};
+  if (src.codes) {
+    static const bool codes_off = getenv("KMCPG_K1_CODES") && atoi(getenv("KMCPG_K1_CODES")) == 0;
+    const bool direct = !codes_off && a.seg_cnt && a.segs_max > 1 && a.k <= 128 && !(a.flags & 24) && src.text == d_seqs &&
+                        (uint64_t)src.n_exc <= src.n_bases / 4096 + 64;
+    if (direct) {
+      a.codes = src.codes;
+      a.exc = src.exc;
+      a.n_exc = src.n_exc;
+      a.seqs_w = src.text;
+    } else {
+      launch_unpack2(src.codes, src.text, src.n_bases, src.n_exc ? src.exc : nullptr, src.n_exc, st);  // codes -> the text the kernels read
+    }
+    (direct ? db->k1_codes_direct : db->k1_codes_expanded)++;
   }
   if (a.mode != 0 && !d_seqs2 && d_scratch) {  // the list the rolling window-sketch kernel leaves to k1_windows_wave (launch_k1): count + read indices
     if (W.w_seg_cnt.ensure((size_t)n_reads + 2)) return kmcpg_fail(KMCPG_ENOMEM, "hipMalloc failed");
@@ -87,7 +109,6 @@ int run_kmers(kmcpg_db* db, kmcpg_db::Workspace& W, const uint8_t* d_seqs, const
   }
   a.nk_adj = d_nk_search;
   a.dedup_threshold = p.dedup_threshold;
-  a.flags = getenv("KMCPG_K1_FLAGS") ? atoi(getenv("KMCPG_K1_FLAGS")) : 3;
   const bool adj_done = launch_k1(a, max_read_len, st);
   uint64_t ub = max_read_len >= (uint32_t)a.k ? (uint64_t)(max_read_len - a.k + 1) : 0;
   if (d_seqs2) ub *= 2;
@@ -279,6 +300,33 @@ extern "C" int kmcpg_kmers_device(kmcpg_db* db, const uint8_t* d_seqs, const uin
   ql.release();
   if (rc) return rc;
   if (e != hipSuccess) return kmcpg_fail(KMCPG_EDEVICE, "k-mer kernel failed: %s", hipGetErrorString(e));
+  return 0;
+}
+
+extern "C" int kmcpg_kmers_device_packed(kmcpg_db* db, const uint8_t* d_codes, const kmcpg_exc_run* d_exc, uint32_t n_exc, uint8_t* d_text,
+                                         const uint64_t* d_offs, uint32_t n_reads, uint64_t total_bases, uint32_t max_read_len,
+                                         const kmcpg_params* params, uint64_t* d_hashes, uint64_t hashes_cap, uint64_t* d_koff, int32_t* d_nk,
+                                         void* stream) {
+  static_assert(sizeof(kmcpg_exc_run) == sizeof(ExcRun), "one layout");
+  if (!d_codes || !d_text || (n_exc && !d_exc)) return kmcpg_fail(KMCPG_EINVAL, "null argument");
+  if (((uintptr_t)d_codes & 3) || ((uintptr_t)d_text & 3)) return kmcpg_fail(KMCPG_EINVAL, "d_codes and d_text must be 4-byte aligned");
+  PackedSrc src;
+  src.codes = d_codes;
+  src.exc = reinterpret_cast<const ExcRun*>(d_exc);
+  src.n_exc = n_exc;
+  src.text = d_text;
+  src.n_bases = total_bases;
+  tl_packed_src = src;
+  const int rc = kmcpg_kmers_device(db, d_text, d_offs, n_reads, total_bases, max_read_len, params, d_hashes, hashes_cap, d_koff, d_nk, stream);
+  tl_packed_src = PackedSrc{};  // (a call that failed before the k-mer kernels has not taken it)
+  return rc;
+}
+
+extern "C" int kmcpg_k1_codes_batches(kmcpg_db* db, uint64_t* direct, uint64_t* expanded) {
+  if (!db) return kmcpg_fail(KMCPG_EINVAL, "null argument");
+  std::lock_guard<std::mutex> g(db->mu);
+  if (direct) *direct = db->k1_codes_direct;
+  if (expanded) *expanded = db->k1_codes_expanded;
   return 0;
 }
 

@@ -257,6 +257,10 @@ __global__ void __launch_bounds__(256) k_apply_exc(const ExcRun* __restrict__ ru
   }
 }
 
+void launch_apply_exc(const ExcRun* runs, uint32_t n_runs, uint8_t* out, hipStream_t st) {
+  if (n_runs) hipLaunchKernelGGL(k_apply_exc, dim3(std::min<unsigned>(n_runs, 65536u)), dim3(256), 0, st, runs, n_runs, out);
+}
+
 void launch_unpack2(const uint8_t* packed, uint8_t* out, uint64_t n_bases, const ExcRun* runs, uint32_t n_runs, hipStream_t st) {
   if (n_bases == 0) return;
   const uint64_t threads = n_bases / 16 + 1;

@@ -19,6 +19,7 @@ EXPORTS = [
     "kmcpg_db_ks", "kmcpg_open_paged", "kmcpg_paged_info", "kmcpg_exchange_info", "kmcpg_batch_hint", "kmcpg_group_device", "kmcpg_finalize_grouped",
     "kmcpg_search_batch_pairs", "kmcpg_wait_pairs", "kmcpg_result_pairs_free", "kmcpg_expand_pairs", "kmcpg_save_db",
     "kmcpg_pack2", "kmcpg_unpack2", "kmcpg_submit_packed", "kmcpg_host_alloc", "kmcpg_host_free",
+    "kmcpg_kmers_device_packed", "kmcpg_k1_codes_batches",
 ]
 
 
@@ -212,6 +213,9 @@ def load():
     L.kmcpg_read_row_range.argtypes = [vp, C.c_uint32, C.c_uint64, C.c_uint64, vp]
     L.kmcpg_kmers_device.argtypes = [vp, vp, vp, C.c_uint32, C.c_uint64, C.c_uint32, C.POINTER(Params), vp, C.c_uint64,
                                      vp, vp, vp]
+    L.kmcpg_kmers_device_packed.argtypes = [vp, vp, vp, C.c_uint32, vp, vp, C.c_uint32, C.c_uint64, C.c_uint32, C.POINTER(Params), vp, C.c_uint64,
+                                            vp, vp, vp]
+    L.kmcpg_k1_codes_batches.argtypes = [vp, u64p, u64p]
     L.kmcpg_plant_reads_device.argtypes = [vp, vp, vp, C.c_uint32, C.c_uint64, C.c_uint32, vp, vp]
     L.kmcpg_set_profiling.argtypes = [vp, C.c_int]
     L.kmcpg_last_timing.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]
@@ -515,6 +519,19 @@ class Database:
         p = params or default_params()
         _check(load().kmcpg_kmers_device(self._h, d_seqs, d_offs, n_reads, total_bases, max_read_len, C.byref(p),
                                          d_hashes, hashes_cap, d_koff, d_nk, stream))
+
+    def kmers_device_packed(self, d_codes, d_exc, n_exc, d_text, d_offs, n_reads, total_bases, max_read_len, d_hashes, hashes_cap, d_koff, d_nk,
+                            params=None, stream=None):
+        """kmers_device on a batch that is on the device as 2-bit codes + runs of foreign bytes (kmcpg_kmers_device_packed)"""
+        p = params or default_params()
+        _check(load().kmcpg_kmers_device_packed(self._h, d_codes, d_exc, n_exc, d_text, d_offs, n_reads, total_bases, max_read_len, C.byref(p),
+                                                d_hashes, hashes_cap, d_koff, d_nk, stream))
+
+    def k1_codes_batches(self):
+        """(packed batches whose k-mer kernels read the codes directly, packed batches expanded to text first)"""
+        a, b = C.c_uint64(0), C.c_uint64(0)
+        _check(load().kmcpg_k1_codes_batches(self._h, C.byref(a), C.byref(b)))
+        return int(a.value), int(b.value)
 
     def finalize(self, hits, qkmers, qlen, params=None):
         """hits: structured array HIT_DTYPE (any order, may be the concatenation of all shards)."""

@@ -163,3 +163,60 @@ def test_submit_packed_equals_submit_on_the_text(world, oracle_lib):
         a = db.wait(db.submit(seqs, offs, params=p))
         b = db.wait(db.submit_packed(codes_copy, offs, exc, params=p))
         assert a.matches.tobytes() == b.matches.tobytes() and np.array_equal(a.ksize, b.ksize) and len(a.matches) > 10
+
+
+def test_packed_whole_genomes_are_hashed_from_their_codes(world, oracle_lib):
+    """Round 6: queries above 65 536 bases that arrive as 2-bit codes (kmcpg_submit_packed, or text that kmcpg_submit packed itself) are
+    hashed by k1_seg_roll2 straight from the packed stream; text is made only for the segments that hold a foreign byte.  Same Match
+    records as the text upload and as the oracle: clean assemblies, N runs inside and across segments and queries, IUPAC codes, soft
+    masking, short and empty queries in the same batch; the handle counts the batches that took the direct form."""
+    from kmcp_amd import Database, default_params, lib
+    tmp, genomes, db_dir = world
+    O = oracle_lib
+    rng = np.random.default_rng(11)
+
+    def asm(ids, edit=None):
+        b = bytearray(b"".join(genomes[i] for i in ids))
+        if edit:
+            edit(b)
+        return bytes(b)
+
+    def gaps(b):
+        for _ in range(4):
+            p = int(rng.integers(0, len(b) - 3000))
+            ln = int(rng.integers(1, 2500))
+            b[p:p + ln] = b"N" * ln
+        b[65536 - 10:65536 + 40] = b"N" * 50
+        b[-500:] = b"N" * 500
+
+    def head_gap(b):
+        b[:200] = b"N" * 200
+        for p_ in rng.integers(0, len(b), size=25):
+            b[int(p_)] = int(rng.choice(list(b"RYKMSWBDHVn")))
+
+    reads = [asm([0, 1, 2]), asm([3, 4, 5, 6], gaps), asm([7, 8, 9], head_gap), asm([10, 11, 12]).lower(), b"", genomes[13][:5000], asm([14, 15, 0, 1, 2]),
+             genomes[3][100:120], asm([5, 6, 7])[:65536 + 20]]
+    seqs, offs = lib.pack_reads(reads)
+    codes, exc, total = lib.pack2(reads)
+    p = default_params(min_qcov=0.15)
+    odb = O.OracleDB(db_dir)
+    try:
+        with Database.open(db_dir) as db:
+            want = db.wait(db.submit(seqs, offs, params=p))         # 1.1 MB: below the size kmcpg_submit packs by itself
+            assert db.k1_codes_batches() == (0, 0)
+            got = db.wait(db.submit_packed(codes, offs, exc, params=p))
+            assert db.k1_codes_batches() == (1, 0)
+            assert got.matches.tobytes() == want.matches.tobytes() and np.array_equal(got.qkmers, want.qkmers) and np.array_equal(got.qlen, want.qlen)
+            assert synth.assert_parity(odb, got, reads, oparams=O.default_params(min_qcov=0.15)) >= 15
+            # several in flight, pairs; a batch of short queries alone is expanded whole (no segment path for it)
+            tk = [db.submit_packed(codes, offs, exc, params=p) for _ in range(3)]
+            for t_ in tk:
+                assert db.wait(t_).matches.tobytes() == want.matches.tobytes()
+            short = [r for r in reads if len(r) <= 5000]
+            c2, e2, _ = lib.pack2(short)
+            s2, o2 = lib.pack_reads(short)
+            a = db.wait(db.submit_packed(c2, o2, e2, params=p))
+            assert db.k1_codes_batches() == (4, 1)
+            assert a.matches.tobytes() == db.wait(db.submit(s2, o2, params=p)).matches.tobytes()
+    finally:
+        odb.close()

@@ -527,8 +527,19 @@ def test_genome_path_two_bit_kernel_and_its_fallback(G, oracle_lib, monkeypatch,
         for p in rng.integers(0, len(b), size=60):
             b[int(p)] = int(rng.choice(list(b"RYKMSWBDHV-*.") + [200]))
 
+    def n_tail(b):
+        b[-700:] = b"N" * 700  # ... and the next query starts with N: as packed input that is ONE run of foreign bytes across two queries
+
+    def n_head(b):
+        b[:300] = b"N" * 300
+        b[65536 + k - 2] = ord("N")  # the last base segment 0's k-mers cover
+
+    def n_edge(b):
+        b[65536 + k - 1] = ord("n")  # the first base they do not: segment 1 alone goes to the byte kernel
+
     huge = [g[0][:280000], edit(g[1][:250001], soft_mask), edit(g[2][:262144 + k - 1], one_n), edit(g[0][:299990], n_runs), edit(g[1][:70000], rna),
-            edit(g[2][:200017], iupac), g[0][:65536 + k], g[1][:65536 * 2 + k - 1], g[2][:131072 + 5], edit(g[0][100:66000], soft_mask)]
+            edit(g[2][:200017], iupac), g[0][:65536 + k], g[1][:65536 * 2 + k - 1], g[2][:131072 + 5], edit(g[0][100:66000], soft_mask),
+            edit(g[1][1000:91003], n_tail), b"", edit(g[2][5:140007], n_head), b"NNNN", g[0][7:k + 6], edit(g[1][3:150002], n_edge), g[2][11:3000]]
     for kw in (dict(), dict(scale=7)):
         spec = lib.SynthSpec(k=k, num_hashes=1, fpr=0.3, n_blocks=1, cols_per_block=8, num_sigs=1000, kmers_per_col=10, seed=1, scale=kw.get("scale", 1))
         cfg = O.sketch_cfg(k=k, **kw)
@@ -544,11 +555,38 @@ def test_genome_path_two_bit_kernel_and_its_fallback(G, oracle_lib, monkeypatch,
             torch.cuda.synchronize()
             h = t_h.cpu().numpy().view(np.uint64)
             nk = t_nk.cpu().numpy()
+            wants = [O.generate_kmers(r, cfg) for r in huge]
             for i, r in enumerate(huge):
-                want = O.generate_kmers(r, cfg)
                 got = h[int(offs[i]):int(offs[i]) + int(nk[i])]
-                assert len(want) == nk[i], (kw, i, len(r), len(want), nk[i])
-                assert np.array_equal(got, want), (kw, i, len(r))
+                assert len(wants[i]) == nk[i], (kw, i, len(r), len(wants[i]), nk[i])
+                assert np.array_equal(got, wants[i]), (kw, i, len(r))
+            # Round 6: the same batch as 2-bit codes + runs of foreign bytes (what kmcpg_submit_packed uploads).  k1_seg_roll2 takes the codes
+            # from the packed stream itself, the segments a run reaches are listed by k_mark_exc and expanded for the byte kernel — a run
+            # across two queries, one that ends on the last base a segment's k-mers cover, one that starts right behind it.  Same hashes.
+            codes, exc, total = lib.pack2(huge)
+            assert total == len(seqs) and len(exc) > 60
+            assert any(int(e["pos"]) < int(o) < int(e["pos"]) + int(e["len"]) for e in exc for o in offs[1:-1]), "no run crosses a query boundary"
+            pad = np.zeros((total + 3) // 4 + 16, dtype=np.uint8)
+            pad[:(total + 3) // 4] = codes[:(total + 3) // 4]
+            pad[(total + 3) // 4:] = 0xA5  # (what lies behind the last base must not matter)
+            t_codes = torch.from_numpy(pad).to(dev)
+            t_exc = torch.from_numpy(exc.view(np.uint8).copy()).to(dev)
+            t_text = torch.full((total + 16,), ord("G"), dtype=torch.uint8, device=dev)
+            t_h2 = torch.zeros(len(seqs) + 8, dtype=torch.int64, device=dev)
+            t_nk2 = torch.zeros(len(huge), dtype=torch.int32, device=dev)
+            before = db.k1_codes_batches()
+            db.kmers_device_packed(t_codes.data_ptr(), t_exc.data_ptr(), len(exc), t_text.data_ptr(), t_offs.data_ptr(), len(huge), total,
+                                   max(len(r) for r in huge), t_h2.data_ptr(), t_h2.numel(), None, t_nk2.data_ptr(), params=p)
+            torch.cuda.synchronize()
+            after = db.k1_codes_batches()
+            assert (after[0] - before[0], after[1] - before[1]) == ((1, 0) if flags == "3" else (0, 1)), (before, after)
+            h2 = t_h2.cpu().numpy().view(np.uint64)
+            nk2 = t_nk2.cpu().numpy()
+            for i, r in enumerate(huge):
+                assert len(wants[i]) == nk2[i], ("packed", kw, i, len(r), len(wants[i]), nk2[i])
+                assert np.array_equal(h2[int(offs[i]):int(offs[i]) + int(nk2[i])], wants[i]), ("packed", kw, i, len(r))
+            if flags == "3":  # text exists only where the byte kernel needed it: the first query (clean) was never expanded
+                assert bytes(t_text[:1000].cpu().numpy()) == b"G" * 1000
 
 
 @pytest.mark.parametrize("flags", ["3", "7", "4"])
