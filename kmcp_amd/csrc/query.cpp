@@ -89,9 +89,9 @@ int run_kmers(kmcpg_db* db, kmcpg_db::Workspace& W, const uint8_t* d_seqs, const
   const PackedSrc src = tl_packed_src;
   tl_packed_src = PackedSrc{};
   if (src.codes) {
-    static const bool codes_off = getenv("KMCPG_K1_CODES") && atoi(getenv("KMCPG_K1_CODES")) == 0;
-    const bool direct = !codes_off && a.seg_cnt && a.segs_max > 1 && a.k <= 128 && !(a.flags & 24) && src.text == d_seqs &&
-                        (uint64_t)src.n_exc <= src.n_bases / 4096 + 64;
+    static const int codes_mode = getenv("KMCPG_K1_CODES") ? atoi(getenv("KMCPG_K1_CODES")) : 1;  // 2 (tests): however many runs there are
+    const bool direct = codes_mode != 0 && a.seg_cnt && a.segs_max > 1 && a.k <= 128 && !(a.flags & 24) && src.text == d_seqs &&
+                        (codes_mode == 2 || (uint64_t)src.n_exc <= src.n_bases / 4096 + 64);
     if (direct) {
       a.codes = src.codes;
       a.exc = src.exc;
