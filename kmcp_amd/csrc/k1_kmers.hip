@@ -1505,10 +1505,22 @@ constexpr int R2_PITCH = 9;                    // dwords per lane run (8 of code
 constexpr int R2_WORDS = 66 * R2_PITCH;        // 64 runs + what k - 1 <= 127 further bases and the funnel's upper word reach into
 
 __global__ void __launch_bounds__(64 * ROLL_WAVES) k1_seg_roll2(const K1Args a) {
-  __shared__ uint64_t S[4], RC[4], F2[16], R2[16];  // seeds by code (A 0, C 1, T 2, G 3 = (ascii >> 1) & 3), complements, the two pair tables
-  __shared__ uint32_t codes[ROLL_WAVES][R2_WORDS];
-  __shared__ int s_cnt[ROLL_WAVES];
-  __shared__ int s_bad;
+  // one block of LDS with the pair tables in front: their addresses — table index x 8 — then fit the offset fields of one ds_read2_b64
+  // and the walk's inner loop needs no base address (an add per roll)
+  struct Sh {
+    uint64_t F2[16], R2[16];  // the two pair tables
+    uint64_t S[4], RC[4];     // seeds by code (A 0, C 1, T 2, G 3 = (ascii >> 1) & 3), complements
+    uint32_t codes[ROLL_WAVES][R2_WORDS];
+    int s_cnt[ROLL_WAVES];
+    int s_bad;
+  };
+  __shared__ __attribute__((aligned(16))) Sh sh;
+  uint64_t* const F2 = sh.F2;
+  uint64_t* const R2 = sh.R2;
+  uint64_t* const S = sh.S;
+  uint64_t* const RC = sh.RC;
+  int* const s_cnt = sh.s_cnt;
+  int& s_bad = sh.s_bad;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int k = a.k;
   if (tid < 16) {
@@ -1528,7 +1540,7 @@ __global__ void __launch_bounds__(64 * ROLL_WAVES) k1_seg_roll2(const K1Args a) 
   const bool on = len >= a.min_qlen && p_lo < npos;  // (:778-786 gate; ErrShortSeq => no k-mers) — uniform over the workgroup
   const int P0 = p_lo + w * 64 * ROLL_L;             // first position of this wave
   const int wpos = on ? max(0, min(npos - P0, 64 * ROLL_L)) : 0;  // positions of this wave
-  uint32_t* __restrict__ Wd = codes[w];
+  uint32_t* __restrict__ Wd = sh.codes[w];
   auto slot = [&](int word) -> int { return (word >> 3) * R2_PITCH + (word & 7); };  // word = base / 16 within the wave's stretch
   __syncthreads();  // s_bad = 0 before anybody raises it
   if (a.codes) {
@@ -1609,7 +1621,9 @@ __global__ void __launch_bounds__(64 * ROLL_WAVES) k1_seg_roll2(const K1Args a) 
     auto test = [&](uint64_t f, uint64_t r_) __attribute__((always_inline)) {
       if constexpr (SC) {
         const uint32_t fhi = (uint32_t)(f >> 32), rhi = (uint32_t)(r_ >> 32);
-        if ((fhi < rhi ? fhi : rhi) <= mh_hi) {
+        uint32_t mn;  // (written out: the compiler folds the plain expression into the 64-bit compares below — six instructions for these two)
+        asm("v_min_u32 %0, %1, %2" : "=v"(mn) : "v"(fhi), "v"(rhi));
+        if (mn <= mh_hi) {
           const uint64_t h = f < r_ ? f : r_;
           if (h != 0 && h <= max_hash) emit(h);
         }
