@@ -1501,17 +1501,26 @@ __global__ void __launch_bounds__(64 * ROLL_WAVES) k1_seg_roll(const K1Args a) {
 // arithmetic: ~22 operations per base.  A segment that holds ANY other byte (N, IUPAC codes, U: their hashes depend on the exact byte)
 // is left to k1_seg_roll: this kernel marks it (seg_cnt = -1) and the launcher runs the byte kernel behind it for the marked segments only.
 // Same outputs as k1_seg_roll / k1_seg_hash (out[], seg_cnt): tests/test_gpu_parity.py::test_k1_all_forms_across_k and the fuzz sweeps.
-constexpr int R2_PITCH = 9;                    // dwords per lane run (8 of codes + 1: runs 9 apart put the lanes' j-th words on 64 different banks)
-constexpr int R2_WORDS = 66 * R2_PITCH;        // 64 runs + what k - 1 <= 127 further bases and the funnel's upper word reach into
+// A lane walks R2_L = 256 consecutive positions (round 6; 128 before): what a lane pays once per run — the k start-up steps, its share of
+// the scans and of the copy-out — is paid half as often, and a workgroup is 4 waves for the same segment and the same LDS.
+#ifndef KMCPG_R2_L
+#define KMCPG_R2_L 256
+#endif
+constexpr int R2_L = KMCPG_R2_L, R2_WAVES = K1SEG / (64 * R2_L), R2_G = R2_L / 16;  // positions per lane, waves per workgroup, code words per lane run
+constexpr int R2_KEEP = R2_L > 128 ? 4 : 2;  // kept hashes a lane holds in registers (a FracMinHash lane keeps R2_L / scale of them: more is a second walk)
+static_assert(64 * R2_L * R2_WAVES == K1SEG, "a workgroup covers one segment");
+constexpr int R2_PITCH = R2_G + 1;             // dwords per lane run (+ 1: an odd pitch puts the lanes' j-th words on different banks)
+constexpr int R2_RUNS = 64 + (9 + R2_G - 1) / R2_G;  // 64 runs + the 9 words that k - 1 <= 127 further bases and the funnel's upper word reach into
+constexpr int R2_WORDS = R2_RUNS * R2_PITCH;
 
-__global__ void __launch_bounds__(64 * ROLL_WAVES) k1_seg_roll2(const K1Args a) {
+__global__ void __launch_bounds__(64 * R2_WAVES) k1_seg_roll2(const K1Args a) {
   // one block of LDS with the pair tables in front: their addresses — table index x 8 — then fit the offset fields of one ds_read2_b64
   // and the walk's inner loop needs no base address (an add per roll)
   struct Sh {
     uint64_t F2[16], R2[16];  // the two pair tables
     uint64_t S[4], RC[4];     // seeds by code (A 0, C 1, T 2, G 3 = (ascii >> 1) & 3), complements
-    uint32_t codes[ROLL_WAVES][R2_WORDS];
-    int s_cnt[ROLL_WAVES];
+    uint32_t codes[R2_WAVES][R2_WORDS];
+    int s_cnt[R2_WAVES];
     int s_bad;
   };
   __shared__ __attribute__((aligned(16))) Sh sh;
@@ -1538,10 +1547,10 @@ __global__ void __launch_bounds__(64 * ROLL_WAVES) k1_seg_roll2(const K1Args a) 
   const int npos = len - k + 1;
   const int p_lo = (int)seg * K1SEG;
   const bool on = len >= a.min_qlen && p_lo < npos;  // (:778-786 gate; ErrShortSeq => no k-mers) — uniform over the workgroup
-  const int P0 = p_lo + w * 64 * ROLL_L;             // first position of this wave
-  const int wpos = on ? max(0, min(npos - P0, 64 * ROLL_L)) : 0;  // positions of this wave
+  const int P0 = p_lo + w * 64 * R2_L;               // first position of this wave
+  const int wpos = on ? max(0, min(npos - P0, 64 * R2_L)) : 0;  // positions of this wave
   uint32_t* __restrict__ Wd = sh.codes[w];
-  auto slot = [&](int word) -> int { return (word >> 3) * R2_PITCH + (word & 7); };  // word = base / 16 within the wave's stretch
+  auto slot = [&](int word) -> int { return (word / R2_G) * R2_PITCH + (word % R2_G); };  // word = base / 16 within the wave's stretch
   __syncthreads();  // s_bad = 0 before anybody raises it
   if (a.codes) {
     // the batch came as 2-bit codes: 16 of them are the 32 bits at bit 2 G of the packed stream (G = the word's first base in the batch) —
@@ -1549,7 +1558,7 @@ __global__ void __launch_bounds__(64 * ROLL_WAVES) k1_seg_roll2(const K1Args a) 
     const uint32_t* __restrict__ C32 = reinterpret_cast<const uint32_t*>(a.codes);
     const uint64_t G0 = o1 + (uint64_t)P0;
     const int nb = wpos > 0 ? wpos + k - 1 : 0;  // bases this wave needs
-    for (int gi = lane; gi < 8 * 66; gi += 64) {
+    for (int gi = lane; gi < R2_G * R2_RUNS; gi += 64) {
       const int b0 = gi * 16;
       uint32_t word = 0;
       if (b0 < nb) {
@@ -1568,7 +1577,7 @@ __global__ void __launch_bounds__(64 * ROLL_WAVES) k1_seg_roll2(const K1Args a) 
     const int nb = wpos > 0 ? wpos + k - 1 : 0;  // bases this wave needs
     typedef uint32_t u32x4_any __attribute__((ext_vector_type(4), aligned(1)));
     bool bad = false;
-    for (int gi = lane; gi < 8 * 66; gi += 64) {  // every word the walks may touch gets a value (zero past the stretch)
+    for (int gi = lane; gi < R2_G * R2_RUNS; gi += 64) {  // every word the walks may touch gets a value (zero past the stretch)
       const int b0 = gi * 16;
       uint32_t word = 0;
       if (b0 + 16 <= nb) {
@@ -1601,8 +1610,8 @@ __global__ void __launch_bounds__(64 * ROLL_WAVES) k1_seg_roll2(const K1Args a) 
   }
   const bool scaled = a.scaled != 0;
   const uint64_t max_hash = a.max_hash;
-  const int q0 = lane * ROLL_L;
-  const int mine = max(0, min(wpos - q0, ROLL_L));  // k-mer positions of this lane
+  const int q0 = lane * R2_L;
+  const int mine = max(0, min(wpos - q0, R2_L));  // k-mer positions of this lane
   const int kw = k >> 4, ksh = 2 * (k & 15);
   const uint32_t mh_hi = (uint32_t)(max_hash >> 32);
   // SC = FracMinHash database (a constant inside the loops).  The filter `0 < h <= maxHash` (util-db-search.go:1072-1077) keeps one k-mer in
@@ -1611,13 +1620,20 @@ __global__ void __launch_bounds__(64 * ROLL_WAVES) k1_seg_roll2(const K1Args a) 
   auto walk = [&](auto sc_tag, auto&& emit) __attribute__((always_inline)) {
     constexpr bool SC = decltype(sc_tag)::value;
     if (mine <= 0) return;
+    // start-up: fh = XOR_j rol(F[j], k-1-j), rh = XOR_j rol(R[j], j) over the run's first k bases, a code word at a time; the reverse strand
+    // is gathered as XOR_j ror(R[j], k-1-j) — one fixed rotate per base like the forward strand — and turned by k - 1 at the end
     uint64_t fh = 0, rh = 0;
-    for (int j = 0; j < k; j++) {  // start-up: fh = XOR_j rol(F[j], k-1-j), rh = XOR_j rol(R[j], j)
-      const int q = q0 + j;
-      const uint32_t c = (Wd[slot(q >> 4)] >> (2 * (q & 15))) & 3u;
-      fh = nt2_rol1(fh) ^ S[c];
-      rh ^= rolv(RC[c], j);
+    const int w_out = R2_G * lane;
+    for (int j0 = 0; j0 < k; j0 += 16) {
+      const uint32_t wd = Wd[slot(w_out + (j0 >> 4))];
+      const int jn = min(16, k - j0);
+      for (int j = 0; j < jn; j++) {
+        const uint32_t c = (wd >> (2 * j)) & 3u;
+        fh = nt2_rol1(fh) ^ S[c];
+        rh = nt2_ror1(rh) ^ RC[c];
+      }
     }
+    rh = rolv(rh, k - 1);
     auto test = [&](uint64_t f, uint64_t r_) __attribute__((always_inline)) {
       if constexpr (SC) {
         const uint32_t fhi = (uint32_t)(f >> 32), rhi = (uint32_t)(r_ >> 32);
@@ -1632,9 +1648,8 @@ __global__ void __launch_bounds__(64 * ROLL_WAVES) k1_seg_roll2(const K1Args a) 
         if (h != 0) emit(h);
       }
     };
-    const int w_out = 8 * lane;
     int t = 0;
-    for (int g = 0; g < 8; g++) {
+    for (int g = 0; g < R2_G; g++) {
       const uint32_t outw = Wd[slot(w_out + g)];
       const uint32_t inw = nt2_funnel(Wd[slot(w_out + g + kw + 1)], Wd[slot(w_out + g + kw)], (uint32_t)ksh);
       // the table index of every roll of the group, a nibble each: (code going out << 2) | code coming in
@@ -1661,10 +1676,10 @@ __global__ void __launch_bounds__(64 * ROLL_WAVES) k1_seg_roll2(const K1Args a) 
     }
   };
   int c = 0;
-  uint64_t h0 = 0, h1 = 0;
+  uint64_t hk[R2_KEEP] = {};
   auto count2 = [&](uint64_t h) __attribute__((always_inline)) {
-    h0 = c == 0 ? h : h0;  // (selects, not branches into a two-element array on the stack)
-    h1 = c == 1 ? h : h1;
+#pragma unroll
+    for (int i = 0; i < R2_KEEP; i++) hk[i] = c == i ? h : hk[i];  // (selects, not branches into an array on the stack)
     c++;
   };
   if (scaled) walk(std::true_type{}, count2);
@@ -1679,16 +1694,17 @@ __global__ void __launch_bounds__(64 * ROLL_WAVES) k1_seg_roll2(const K1Args a) 
   __syncthreads();
   int before = 0, total = 0;
 #pragma unroll
-  for (int i = 0; i < ROLL_WAVES; i++) {
+  for (int i = 0; i < R2_WAVES; i++) {
     const int ci = s_cnt[i];
     if (i < w) before += ci;
     total += ci;
   }
   if (c > 0) {
     uint64_t* __restrict__ out = a.scratch + o1 + p_lo + before + (incl - c);
-    if (c <= 2) {
-      out[0] = h0;
-      if (c == 2) out[1] = h1;
+    if (c <= R2_KEEP) {
+#pragma unroll
+      for (int i = 0; i < R2_KEEP; i++)
+        if (i < c) out[i] = hk[i];
     } else {
       int i = 0;
       auto store = [&](uint64_t h) __attribute__((always_inline)) { out[i++] = h; };
@@ -1808,7 +1824,7 @@ bool launch_k1(const K1Args& a, uint32_t max_read_len, hipStream_t st) {
           (void)hipMemsetAsync(b.seg_exc, 0, (size_t)blocks * sizeof(uint32_t), st);
           hipLaunchKernelGGL(k_mark_exc, dim3((a.n_exc + 255) / 256), dim3(256), 0, st, b);
         }
-        hipLaunchKernelGGL(k1_seg_roll2, dim3(blocks), dim3(64 * ROLL_WAVES), 0, st, b);
+        hipLaunchKernelGGL(k1_seg_roll2, dim3(blocks), dim3(64 * R2_WAVES), 0, st, b);
         if (a.n_exc) {  // (no foreign byte in the batch: nothing is on the list, nothing reads text)
           hipLaunchKernelGGL(k_unpack2_list, dim3(std::min(blocks, 512u)), dim3(256), 0, st, b);
           launch_apply_exc(a.exc, a.n_exc, a.seqs_w, st);
@@ -1818,7 +1834,7 @@ bool launch_k1(const K1Args& a, uint32_t max_read_len, hipStream_t st) {
         hipLaunchKernelGGL(k1_seg_pack, dim3(blocks), dim3(256), 0, st, a);
         return false;
       }
-      hipLaunchKernelGGL(k1_seg_roll2, dim3(blocks), dim3(64 * ROLL_WAVES), 0, st, b);  // 2-bit codes; lists the segments it cannot take
+      hipLaunchKernelGGL(k1_seg_roll2, dim3(blocks), dim3(64 * R2_WAVES), 0, st, b);  // 2-bit codes; lists the segments it cannot take
       b.seg_only_flagged = 1;
       // ... and the byte kernel does those: a grid that fills the chip once (2 workgroups of 8 waves per CU) walks the list — nothing
       // but the read of one counter for a clean batch, where a launch over all segments was up to 2^21 workgroups exiting at once
