@@ -1502,12 +1502,14 @@ __global__ void __launch_bounds__(64 * ROLL_WAVES) k1_seg_roll(const K1Args a) {
 // is left to k1_seg_roll: this kernel marks it (seg_cnt = -1) and the launcher runs the byte kernel behind it for the marked segments only.
 // Same outputs as k1_seg_roll / k1_seg_hash (out[], seg_cnt): tests/test_gpu_parity.py::test_k1_all_forms_across_k and the fuzz sweeps.
 // A lane walks R2_L = 256 consecutive positions (round 6; 128 before): what a lane pays once per run — the k start-up steps, its share of
-// the scans and of the copy-out — is paid half as often, and a workgroup is 4 waves for the same segment and the same LDS.
+// the scans and of the copy-out — is paid half as often, and a workgroup is 4 waves for the same segment and the same LDS.  512 (2 waves
+// per workgroup: half the waves per SIMD) executes the same number of instructions 15 % slower; table indices from two bit-field shifts
+// per roll instead of the nibble words: +5 % instructions (profiles/r06_roll2_min.txt).
 #ifndef KMCPG_R2_L
 #define KMCPG_R2_L 256
 #endif
 constexpr int R2_L = KMCPG_R2_L, R2_WAVES = K1SEG / (64 * R2_L), R2_G = R2_L / 16;  // positions per lane, waves per workgroup, code words per lane run
-constexpr int R2_KEEP = R2_L > 128 ? 4 : 2;  // kept hashes a lane holds in registers (a FracMinHash lane keeps R2_L / scale of them: more is a second walk)
+constexpr int R2_KEEP = R2_L > 256 ? 6 : R2_L > 128 ? 4 : 2;  // kept hashes a lane holds in registers (a FracMinHash lane keeps R2_L / scale of them: more is a second walk)
 static_assert(64 * R2_L * R2_WAVES == K1SEG, "a workgroup covers one segment");
 constexpr int R2_PITCH = R2_G + 1;             // dwords per lane run (+ 1: an odd pitch puts the lanes' j-th words on different banks)
 constexpr int R2_RUNS = 64 + (9 + R2_G - 1) / R2_G;  // 64 runs + the 9 words that k - 1 <= 127 further bases and the funnel's upper word reach into
