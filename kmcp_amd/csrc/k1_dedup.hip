@@ -251,12 +251,13 @@ __global__ void __launch_bounds__(NT) k_dedup(const DedupArgs a) {
 // databases whose hashes all lie below maxHash), a scan of the bucket sizes, a scatter, and an insertion sort of every bucket
 // (2 elements on average) — ten barriers in all, same output as the sort (ascending, then unique).  A query whose values are
 // not spread out (some bucket above 24 elements: low-complexity sequence) takes the bitonic network instead, in this kernel.
-constexpr int DB_NT = 256, DB_MAXB = 24;
-template <int CAP, int NB>
+constexpr int DB_MAXB = 24;
+template <int CAP, int NB, int DB_NT = 256>
 __global__ void __launch_bounds__(DB_NT) k_dedup_bucket(const DedupArgs a) {
   constexpr int BPT = NB / DB_NT;  // buckets per thread
   constexpr int SHIFT = 64 - (NB == 1024 ? 10 : 11);
   static_assert(NB == 1024 || NB == 2048, "bucket bits");
+  static_assert(NB % DB_NT == 0 && BPT >= 1, "whole buckets per thread");
   __shared__ uint64_t o[CAP];
   __shared__ int cnt[NB];
   __shared__ int st[NB + 1];
@@ -350,13 +351,22 @@ void launch_dedup(DedupArgs a, uint64_t max_n, hipStream_t st) {
   // classes by the number m of elements to sort; the grids stride over the reads, sized for what the chip holds at once
   a.lo = 0;
   a.hi = 2048;
-  hipLaunchKernelGGL((k_dedup_bucket<2048, 1024>), dim3(std::min(grid, 256u * 12)), dim3(DB_NT), 0, st, a);
+  hipLaunchKernelGGL((k_dedup_bucket<2048, 1024>), dim3(std::min(grid, 256u * 12)), dim3(256), 0, st, a);
   if (max_n <= 2048) return;
   a.lo = 2048;  // (a query the class before finished shows its NumKmers <= lo here)
   a.hi = 4096;
-  hipLaunchKernelGGL((k_dedup_bucket<4096, 2048>), dim3(std::min(grid, 256u * 6)), dim3(DB_NT), 0, st, a);
+  hipLaunchKernelGGL((k_dedup_bucket<4096, 2048>), dim3(std::min(grid, 256u * 6)), dim3(256), 0, st, a);
   if (max_n > 4096) {
+    // FracMinHash sketches of whole genomes (4 000 - 16 000 hashes, uniform below maxHash): the distribution pass again, 1024 threads and
+    // 144 KB of LDS per query (one workgroup per CU) instead of the bitonic network's 105 barrier-separated stages
+    static const bool big_bucket = !(getenv("KMCPG_DEDUP_BIG_BUCKET") && atoi(getenv("KMCPG_DEDUP_BIG_BUCKET")) == 0);
     a.lo = 4096;
+    if (big_bucket) {
+      a.hi = 16384;
+      hipLaunchKernelGGL((k_dedup_bucket<16384, 2048, 1024>), dim3(std::min(grid, 256u)), dim3(1024), 0, st, a);
+      if (max_n <= 16384) return;
+      a.lo = 16384;
+    }
     a.hi = 0x7fffffff;
     hipLaunchKernelGGL((k_dedup<1024, 16384>), dim3(std::min(grid, 1024u)), dim3(1024), 0, st, a);
   }

@@ -636,9 +636,10 @@ def test_dedup_classes_at_their_boundaries(G, oracle_lib):
         return bytes(s)
 
     sizes = [1, 9, 64, 255, 256, 257, 300, 511, 512, 513, 1000, 4095, 4096, 4097, 9000, 16384, 16385, 20000]
-    reads = [repetitive(n) for n in sizes] + [synth.random_genomes(1, n + k - 1, seed=79 + n)[0] for n in (260, 512, 513, 4096, 4097)]
+    reads = [repetitive(n) for n in sizes] + [synth.random_genomes(1, n + k - 1, seed=79 + n)[0] for n in (260, 512, 513, 4096, 4097, 9000, 16384, 16385)]
     # no spread at all: every k-mer of a homopolymer / short tandem repeat falls into one or two buckets of the distribution sort
-    reads += [b"A" * 3000, b"AC" * 1500, b"ACG" * 700, b"ACGTTGCA" * 500 + synth.random_genomes(1, 1500, seed=99)[0]]
+    reads += [b"A" * 3000, b"AC" * 1500, b"ACG" * 700, b"ACGTTGCA" * 500 + synth.random_genomes(1, 1500, seed=99)[0], b"AC" * 5000,
+              b"ACGTTGCA" * 900 + synth.random_genomes(1, 6000, seed=98)[0]]
     for sk in (0, 11):  # plain k-mers, and Closed Syncmers (runs of equal emissions: the fused adjacent-repeat filter of long reads)
         spec = lib.SynthSpec(k=k, num_hashes=1, fpr=0.3, n_blocks=1, cols_per_block=8, num_sigs=1000, kmers_per_col=10, seed=1, syncmer_s=sk)
         cfg = O.sketch_cfg(k=k, syncmer_s=sk)
@@ -662,6 +663,33 @@ def test_dedup_classes_at_their_boundaries(G, oracle_lib):
                         got = h[int(offs[i]):int(offs[i]) + int(nk[i])]
                         assert nk[i] == len(want), (sk, thr, i, len(raw), nk[i], len(want))
                         assert np.array_equal(got, want), (sk, thr, i, len(raw))
+    # FracMinHash sketches of whole genomes (what the genome search sorts: 4 096 < m <= 16 384 hashes, all below maxHash — the distribution
+    # pass of the 1024-thread class shifts the largest possible hash up to bit 63 first), around that class's bounds, with duplicated stretches
+    g = synth.random_genomes(3, 300000, seed=801)
+    whole = [g[0][:70000] + g[0][:40000], g[1][:200000], g[2][:262000] + g[2][:30000], g[0][:66000], g[1][:131072] + g[1][1000:131072]]
+    raws = []
+    for scale in (48, 30):
+        spec = lib.SynthSpec(k=k, num_hashes=1, fpr=0.3, n_blocks=1, cols_per_block=8, num_sigs=1000, kmers_per_col=10, seed=1, scale=scale)
+        cfg = O.sketch_cfg(k=k, scale=scale)
+        with G["Database"].open_synthetic(spec) as db:
+            seqs, offs = lib.pack_reads(whole)
+            t_seqs = torch.from_numpy(seqs).to(dev)
+            t_offs = torch.from_numpy(offs.view(np.int64)).to(dev)
+            t_h = torch.zeros(len(seqs) + 8, dtype=torch.int64, device=dev)
+            t_nk = torch.zeros(len(whole), dtype=torch.int32, device=dev)
+            db.kmers_device(t_seqs.data_ptr(), t_offs.data_ptr(), len(whole), len(seqs), max(len(r) for r in whole), t_h.data_ptr(), t_h.numel(), None,
+                            t_nk.data_ptr(), params=G["default_params"](min_qlen=0, min_matched=1, dedup_threshold=256))
+            torch.cuda.synchronize()
+            h = t_h.cpu().numpy().view(np.uint64)
+            nk = t_nk.cpu().numpy()
+            for i, r in enumerate(whole):
+                raw = O.generate_kmers(r, cfg)
+                want = O.sort_unique(raw)
+                raws.append(len(raw))
+                assert len(want) < len(raw) or i in (1, 3)  # (the others hold a stretch twice)
+                assert nk[i] == len(want), (scale, i, nk[i], len(want))
+                assert np.array_equal(h[int(offs[i]):int(offs[i]) + int(nk[i])], want), (scale, i)
+    assert sum(1 for m in raws if 4096 < m <= 16384) >= 4 and max(raws) > 16384 and min(raws) <= 4096, raws
 
 
 def test_batch_larger_than_one_launch(G):
