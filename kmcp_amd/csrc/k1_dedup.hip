@@ -275,11 +275,21 @@ __global__ void __launch_bounds__(DB_NT) k_dedup_bucket(const DedupArgs a) {
     if (tid == 0) s_bad = 0;
     for (int i = tid; i < NB; i += DB_NT) cnt[i] = 0;
     __syncthreads();
-    // the elements stay in global memory (L2) for the two passes that read them: LDS holds the sorted copy only.
+    // a thread's elements (<= CAP / DB_NT of them) are fetched once, all loads in flight together, and both passes work from registers
+    // (round 6: one exposed memory round trip per query instead of one per element and pass); LDS holds the sorted copy only.
     // lz: the hashes are uniform over [0, maxHash] (FracMinHash) or the whole 64-bit range; the host passes the shift that
     // brings the top of that range to bit 63
     const int lz = a.key_shift;
-    for (int i = tid; i < m; i += DB_NT) atomicAdd(&cnt[(int)((in[i] << lz) >> SHIFT)], 1);
+    constexpr int EPT = CAP / DB_NT;
+    uint64_t v[EPT];
+#pragma unroll
+    for (int e = 0; e < EPT; e++) {
+      const int i = tid + e * DB_NT;
+      v[e] = i < m ? in[i] : 0;
+    }
+#pragma unroll
+    for (int e = 0; e < EPT; e++)
+      if (tid + e * DB_NT < m) atomicAdd(&cnt[(int)((v[e] << lz) >> SHIFT)], 1);
     __syncthreads();
     // exclusive scan of the bucket sizes (BPT buckets per thread)
     int c4[BPT], sum = 0, big = 0;
@@ -308,10 +318,9 @@ __global__ void __launch_bounds__(DB_NT) k_dedup_bucket(const DedupArgs a) {
     const bool bad = s_bad != 0;
     __syncthreads();
     if (!bad) {
-      for (int i = tid; i < m; i += DB_NT) {
-        const uint64_t x = in[i];
-        o[atomicAdd(&cnt[(int)((x << lz) >> SHIFT)], 1)] = x;
-      }
+#pragma unroll
+      for (int e = 0; e < EPT; e++)
+        if (tid + e * DB_NT < m) o[atomicAdd(&cnt[(int)((v[e] << lz) >> SHIFT)], 1)] = v[e];
       __syncthreads();
 #pragma unroll
       for (int j = 0; j < BPT; j++) {  // insertion sort of this thread's buckets
@@ -328,7 +337,9 @@ __global__ void __launch_bounds__(DB_NT) k_dedup_bucket(const DedupArgs a) {
       }
       __syncthreads();
     } else {
-      for (int i = tid; i < m; i += DB_NT) o[i] = in[i];
+#pragma unroll
+      for (int e = 0; e < EPT; e++)
+        if (tid + e * DB_NT < m) o[tid + e * DB_NT] = v[e];
       __syncthreads();
       bitonic_sort(o, m, tid, DB_NT);
     }
