@@ -1814,7 +1814,7 @@ bool launch_k1(const K1Args& a, uint32_t max_read_len, hipStream_t st) {
     // rolling hashes for every k the staging halo holds (flags bit 3 = 8: the prefix-XOR form, for A/B runs)
     // (flags bit 4 = 16: the byte kernel alone, for A/B runs)
     if (a.k <= 128 && !(a.flags & 8) && !(a.flags & 16)) {
-      // the list of segments the 2-bit kernel leaves to the byte kernel lives behind seg_cnt[] (run_kmers sizes it: 2 * blocks + 1 words)
+      // the list of segments the 2-bit kernel leaves to the byte kernel lives behind seg_cnt[] (run_kmers sizes it: counts, the counter, the list and — packed batches — a mark per segment: 3 * blocks + 2 words)
       K1Args b = a;
       b.seg_nflag = (uint32_t*)(a.seg_cnt + blocks);
       b.seg_list = b.seg_nflag + 1;
