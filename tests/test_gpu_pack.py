@@ -212,11 +212,23 @@ def test_packed_whole_genomes_are_hashed_from_their_codes(world, oracle_lib):
             tk = [db.submit_packed(codes, offs, exc, params=p) for _ in range(3)]
             for t_ in tk:
                 assert db.wait(t_).matches.tobytes() == want.matches.tobytes()
+            # >= 8 MB of text with queries of >= 1 kb on average: kmcpg_submit packs it while staging, and the whole genomes among it take the
+            # direct form too (16 copies of the batch: every copy's records are the first one's)
+            big = reads * 16
+            sb, ob = lib.pack_reads(big)
+            assert len(sb) >= (8 << 20)
+            d0 = db.k1_codes_batches()[0]
+            rb = db.wait(db.submit(sb, ob, params=p))
+            assert db.k1_codes_batches()[0] > d0, "the staged text was not packed / not hashed from its codes"
+            per = len(want.matches)
+            assert len(rb.matches) == 16 * per and np.array_equal(rb.qkmers, np.tile(want.qkmers, 16))
+            for c in range(16):
+                assert rb.matches[c * per:(c + 1) * per].tobytes() == want.matches.tobytes(), c
             short = [r for r in reads if len(r) <= 5000]
             c2, e2, _ = lib.pack2(short)
             s2, o2 = lib.pack_reads(short)
             a = db.wait(db.submit_packed(c2, o2, e2, params=p))
-            assert db.k1_codes_batches() == (4, 1)
+            assert db.k1_codes_batches()[1] == 1 and db.k1_codes_batches()[0] >= 5
             assert a.matches.tobytes() == db.wait(db.submit(s2, o2, params=p)).matches.tobytes()
     finally:
         odb.close()
