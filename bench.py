@@ -343,10 +343,14 @@ def run_workload(name, ctx, steps, warmup, batch_reads=0, cpu_baseline=True, cpu
     # D2H (and, N > 1, the exchange) of a finished step while the next step's kernels run on `main`: a high-priority stream, so
     # that its small copies / collectives are not queued behind a 60-500 ms kernel that fills the chip
     side = torch.cuda.Stream(dev, priority=-1)
-    # KMCP_BENCH_STREAMS=2 (experiment, with KMCPG_WS_SLOTS=2): two kernel streams taken in turn by consecutive steps, so that K1 of
-    # step i + 1 (VALU-bound) may run beside K2 of step i (memory-bound); the K2s themselves follow each other (query.cpp cobs_ev).
-    # Default: everything on one stream - the two-stream form lost on four of five workloads (profiles/r05_k1_beside_k2.txt)
-    kstreams = [main, torch.cuda.Stream(dev)] if os.environ.get("KMCP_BENCH_STREAMS", "1") == "2" else [main, main]
+    # Two kernel streams taken in turn by consecutive steps, so that K1 of step i + 1 (VALU-bound) runs beside K2 of step i (memory-bound); the
+    # K2s themselves follow each other (query.cpp cobs_ev).  Default: for batches of WHOLE GENOMES only — what the library does for its own
+    # lanes and workspace slots (engine.hpp whole_genome_batch: plain / FracMinHash k-mers, single-end, a query above 65 536 bases): their K1 is
+    # one fat kernel that fits beside the COBS kernel (genome search +9 %, profiles/r06_cobs_overlap.txt); every other shape loses 3-11 % to the
+    # cross-stream waits (profiles/r05_k1_beside_k2.txt).  KMCP_BENCH_STREAMS=1 / 2 forces one / two (with KMCPG_WS_SLOTS to match).
+    whole_genomes = not wl.get("syncmer_s") and not wl.get("minimizer_w") and max(b.maxlen for b in batches) > 65536
+    two_streams = os.environ.get("KMCP_BENCH_STREAMS", "2" if whole_genomes else "1") == "2"
+    kstreams = [main, torch.cuda.Stream(dev)] if two_streams else [main, main]
     poll = os.environ.get("KMCP_BENCH_POLL") == "1"  # experiment: busy-poll hipEventQuery instead of hipEventSynchronize
     # experiment (profiles/r05_restart_stall.txt): wait for a step by polling a word of PINNED memory that the step's last copy writes (its
     # sequence number), i.e. without asking the runtime whether an event has completed
@@ -580,7 +584,7 @@ def run_workload(name, ctx, steps, warmup, batch_reads=0, cpu_baseline=True, cpu
         "config": {"workload": wl["name"], "batch_reads": B, "read_len": wl.get("read_len", READ_LEN), "bases_per_batch": int(bases_per_launch),
                    "mean_kmers_per_query": kmers_per_launch / B, "k": wl["k"], "num_hashes": wl["num_hashes"],
                    "index_bytes": int(info.matrix_bytes), "index_bytes_this_rank": int(info.matrix_bytes_local),
-                   "blocks": int(info.n_blocks), "columns": n_cols, "parallelism": f"block-shard x{world}",
+                   "blocks": int(info.n_blocks), "columns": n_cols, "parallelism": f"block-shard x{world}", "kernel_streams": 2 if two_streams else 1,
                    "search_flags": f"-t {params.min_qcov:g} -c 10 -m 30 -f 0.01 -u 256 -s {('qcov', 'tcov', 'jacc')[params.sort_by]}"},
         "roofline": {"bound": "hbm", "kernel": wl["kernel"], "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
                      "traffic_source": None,
@@ -1418,6 +1422,10 @@ def main():
     # to the real stdout at the very end.
     real_stdout = os.dup(1)
     os.dup2(2, 1)
+    # HIP streams are multiplexed onto GPU_MAX_HW_QUEUES hardware queues (default 4).  This process holds up to three torch streams of its own
+    # beside the library handle's four (kernels x 2, upload, copy-back): with four queues the uploads of the host-to-host legs end up behind
+    # kernels (genome search, packed entry: 43.6 k -> 48.1 k genomes/s with eight; `value` itself does not move: profiles/r06_cobs_overlap.txt)
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)

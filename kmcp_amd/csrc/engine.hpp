@@ -259,6 +259,9 @@ int finalize_grouped_trusted(const kmcpg_db* db, const kmcpg_pair* pairs, const 
 // call in tl_query_bound_n on the calling thread; host.cpp keeps it with the batch (Lane::bound_n) and hands it to the finalizer, which
 // takes a compact segment as final only for n <= bound_n — it does not look at the environment again.
 extern thread_local int32_t tl_query_bound_n;
+// batches of whole genomes (segment path of the k-mer stage): the ones whose k-mer kernels run beside the previous batch's COBS kernel by
+// default — second workspace slot (query.cpp pick_slot) and second kernel stream (host.cpp enqueue; bench.py does the same with its streams)
+bool whole_genome_batch(const kmcpg_db* db, uint32_t max_read_len, bool paired);
 // KMCPG_FPR_BOUND (default on): K2 leaves out counts that cannot pass -f for queries of up to 512 (1024) k-mers (query.cpp fpr_bound)
 inline bool fpr_bound_enabled() {
   const char* e = getenv("KMCPG_FPR_BOUND");

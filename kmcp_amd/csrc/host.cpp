@@ -122,6 +122,7 @@ struct AsyncState {
   // kernels of the one before it (with KMCPG_WS_SLOTS=2 the handle keeps two k-mer workspaces, engine.hpp).  Off unless KMCPG_KSTREAMS=2: measured a loss on
   // four of five workloads (profiles/r05_k1_beside_k2.txt)
   hipStream_t stream2 = nullptr;
+  int kstreams = 0;  // KMCPG_KSTREAMS: 2 = consecutive batches alternate between the two kernel streams, 1 = never, 0 (unset) = batches of whole genomes only
   uint64_t enqueued = 0;
   std::atomic<uint64_t> hits_hint{0};  // hits per 1024 reads seen lately: sizes the hit buffers and the eager D2H of the next batches
   uint64_t lane_hit_budget = 0;        // entries a lane's device hit buffer may grow to beyond the plain size (from free HBM at first use)
@@ -201,7 +202,8 @@ int async_state(kmcpg_db* db, AsyncState** out) {
     if (hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi) != hipSuccess) prio_lo = prio_hi = 0;
     HIPCHK(hipStreamCreateWithPriority(&a->copy_stream, hipStreamNonBlocking, prio_hi));
     HIPCHK(hipStreamCreateWithFlags(&a->up_stream, hipStreamNonBlocking));
-    if (getenv("KMCPG_KSTREAMS") && atoi(getenv("KMCPG_KSTREAMS")) >= 2) HIPCHK(hipStreamCreateWithFlags(&a->stream2, hipStreamNonBlocking));
+    if (getenv("KMCPG_KSTREAMS")) a->kstreams = atoi(getenv("KMCPG_KSTREAMS")) >= 2 ? 2 : 1;  // 2: every batch, 1: never; unset: batches of whole genomes
+    if (a->kstreams == 2) HIPCHK(hipStreamCreateWithFlags(&a->stream2, hipStreamNonBlocking));
     if (const char* e = getenv("KMCPG_INFLIGHT")) a->max_lanes = (size_t)std::max(1, std::min(atoi(e), 16));
     if (const char* e = getenv("KMCPG_DEVICE_FINALIZE")) a->device_finalize = atoi(e) != 0;
     // Hit buffers follow the data (a database full of close relatives returns hundreds of hits per read) but must never crowd
@@ -425,8 +427,12 @@ int enqueue(kmcpg_db* db, AsyncState* A, Lane* L, const kmcpg_params& p, bool ge
   const uint32_t n = L->n;
   if (n == 0) return 0;
   {
+    // two kernel streams taken in turn: for every batch (KMCPG_KSTREAMS=2) or, by default, for batches of whole genomes — their k-mer kernel runs
+    // beside the COBS kernel of the batch before (query.cpp pick_slot gives such a batch the second workspace); the stream is made when first needed
     std::lock_guard<std::mutex> g(A->mu);
-    L->st = (A->stream2 && (A->enqueued++ & 1)) ? A->stream2 : A->stream;
+    const bool two = A->kstreams == 2 || (A->kstreams == 0 && whole_genome_batch(db, L->maxlen, L->paired));
+    if (two && !A->stream2) HIPCHK(hipStreamCreateWithFlags(&A->stream2, hipStreamNonBlocking));
+    L->st = (two && (A->enqueued++ & 1)) ? A->stream2 : A->stream;
   }
   hipStream_t st = L->st;
   // ~1 hit per read is typical for distinct references, dozens to hundreds for a database full of close relatives: the

@@ -42,6 +42,11 @@ void release_fpr_bounds(kmcpg_db* db) {
 // ------------------------------------------------------------------------------------------------
 thread_local kmcpg::PackedSrc kmcpg::tl_packed_src;
 
+// a batch the k-mer stage hashes segment by segment (run_kmers: plain or FracMinHash k-mers, single-end, some query above one segment)
+bool kmcpg::whole_genome_batch(const kmcpg_db* db, uint32_t max_read_len, bool paired) {
+  return !paired && !db->info.syncmer && !db->info.minimizer && max_read_len > (uint32_t)k1_segment_len();
+}
+
 namespace {
 
 uint64_t max_hash_for(uint32_t scale) {
@@ -164,9 +169,13 @@ int run_kmers(kmcpg_db* db, kmcpg_db::Workspace& W, const uint8_t* d_seqs, const
 // for the last kernel of the previous user of ITS slot, so the k-mer kernels of a batch may run beside the COBS kernels of the
 // batch before it when the two calls are on different streams.  The second slot costs a second workspace (24 bytes per base of a
 // batch): it is used only while that fits into a quarter of the free HBM (or is there already).
-int pick_slot(kmcpg_db* db, uint64_t total_bases) {
-  static const int env = getenv("KMCPG_WS_SLOTS") ? atoi(getenv("KMCPG_WS_SLOTS")) : 1;  // (default 1: see profiles/r05_k1_beside_k2.txt)
-  if (env < 2) return 0;
+// Which batches: by default those of WHOLE GENOMES only (kmcpg::whole_genome_batch) — their k-mer stage is one fat VALU-bound kernel that fits
+// beside the memory-bound COBS kernel of the batch before (genome search 47.2 -> 51.5 k genomes/s, profiles/r06_cobs_overlap.txt); on every other
+// shape the second stream costs more in cross-stream waits than it hides (-3 ... -11 %, profiles/r05_k1_beside_k2.txt and the same file).
+// KMCPG_WS_SLOTS=1: never, 2: every batch.
+int pick_slot(kmcpg_db* db, uint64_t total_bases, bool whole_genomes) {
+  static const int env = getenv("KMCPG_WS_SLOTS") ? atoi(getenv("KMCPG_WS_SLOTS")) : -1;
+  if (env >= 0 ? env < 2 : !whole_genomes) return 0;
   const int slot = (int)(db->ws_calls & 1);
   if (slot == 0) return 0;
   kmcpg_db::Workspace& W = db->ws[1];
@@ -364,7 +373,7 @@ int kmcpg::query_device_after(kmcpg_db* db, const uint8_t* d_seqs, const uint64_
   if (test_hooks)
     if (const char* e = getenv("KMCPG_TEST_MAX_BASES"))
       if (total_bases > (uint64_t)atoll(e)) return kmcpg_fail(KMCPG_ENOMEM, "hipMalloc failed (KMCPG_TEST_MAX_BASES)");
-  const int slot = pick_slot(db, total_bases);
+  const int slot = pick_slot(db, total_bases, whole_genome_batch(db, max_read_len, d_seqs2 != nullptr));
   db->ws_calls++;
   db->ws_last = slot;
   kmcpg_db::Workspace& W = db->ws[slot];
@@ -497,7 +506,10 @@ int kmcpg::query_device_after(kmcpg_db* db, const uint8_t* d_seqs, const uint64_
   a.hit_cap = hit_cap;
   a.counter = (unsigned long long*)d_counters;
   // COBS kernels one batch at a time (the k-mer kernels above may have run beside the previous batch's)
-  if (int rcc = chain_begin(&db->cobs_ev, db->cobs_ev_valid, st)) return rcc;
+  // (KMCPG_COBS_CHAIN=0, experiment with two kernel streams + two workspace slots: the next batch's COBS kernel may start in the previous
+  // one's ragged end — nothing is shared between them but the read-only index; their HIP-event durations then overlap)
+  static const bool cobs_chain = !(getenv("KMCPG_COBS_CHAIN") && atoi(getenv("KMCPG_COBS_CHAIN")) == 0);
+  if (int rcc = chain_begin(&db->cobs_ev, cobs_chain && db->cobs_ev_valid, st)) return rcc;
   if (db->profiling) HIPCHK(hipEventRecord(pev[1], st));
   // Long queries on rows cut into a 64-lane tile form + one narrower form: both in one grid (k2_cobs_pair: the second form's workgroups
   // take the slots the first one's last waves free; KMCPG_PAIR=0: two launches, as before round 6)
