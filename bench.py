@@ -342,7 +342,12 @@ def run_workload(name, ctx, steps, warmup, batch_reads=0, cpu_baseline=True, cpu
     main = torch.cuda.current_stream(dev)
     # D2H (and, N > 1, the exchange) of a finished step while the next step's kernels run on `main`: a high-priority stream, so
     # that its small copies / collectives are not queued behind a 60-500 ms kernel that fills the chip
-    side = torch.cuda.Stream(dev, priority=-1)
+    # (one side stream and one second kernel stream per process, not per workload: torch never gives a stream back, HIP multiplexes all
+    # live streams onto GPU_MAX_HW_QUEUES hardware queues, and a kernel stream that shares its queue with another one serialises behind it —
+    # the genome search as the fifth workload of a run lost its whole two-stream gain that way, profiles/r06_cobs_overlap.txt)
+    if getattr(ctx, "side_stream", None) is None:
+        ctx.side_stream = torch.cuda.Stream(dev, priority=-1)
+    side = ctx.side_stream
     # Two kernel streams taken in turn by consecutive steps, so that K1 of step i + 1 (VALU-bound) runs beside K2 of step i (memory-bound); the
     # K2s themselves follow each other (query.cpp cobs_ev).  Default: for batches of WHOLE GENOMES only — what the library does for its own
     # lanes and workspace slots (engine.hpp whole_genome_batch: plain / FracMinHash k-mers, single-end, a query above 65 536 bases): their K1 is
@@ -350,7 +355,9 @@ def run_workload(name, ctx, steps, warmup, batch_reads=0, cpu_baseline=True, cpu
     # cross-stream waits (profiles/r05_k1_beside_k2.txt).  KMCP_BENCH_STREAMS=1 / 2 forces one / two (with KMCPG_WS_SLOTS to match).
     whole_genomes = not wl.get("syncmer_s") and not wl.get("minimizer_w") and max(b.maxlen for b in batches) > 65536
     two_streams = os.environ.get("KMCP_BENCH_STREAMS", "2" if whole_genomes else "1") == "2"
-    kstreams = [main, torch.cuda.Stream(dev)] if two_streams else [main, main]
+    if two_streams and getattr(ctx, "kernel_stream2", None) is None:
+        ctx.kernel_stream2 = torch.cuda.Stream(dev)
+    kstreams = [main, ctx.kernel_stream2] if two_streams else [main, main]
     poll = os.environ.get("KMCP_BENCH_POLL") == "1"  # experiment: busy-poll hipEventQuery instead of hipEventSynchronize
     # experiment (profiles/r05_restart_stall.txt): wait for a step by polling a word of PINNED memory that the step's last copy writes (its
     # sequence number), i.e. without asking the runtime whether an event has completed

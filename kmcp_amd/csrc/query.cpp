@@ -176,7 +176,11 @@ int run_kmers(kmcpg_db* db, kmcpg_db::Workspace& W, const uint8_t* d_seqs, const
 int pick_slot(kmcpg_db* db, uint64_t total_bases, bool whole_genomes) {
   static const int env = getenv("KMCPG_WS_SLOTS") ? atoi(getenv("KMCPG_WS_SLOTS")) : -1;
   if (env >= 0 ? env < 2 : !whole_genomes) return 0;
-  const int slot = (int)(db->ws_calls & 1);
+  // (by default not before the handle's fifth batch: the second workspace of a 256-Mbase batch is 6 GB to allocate and map, more than a run of
+  // `kmcp-search -g` over a few hundred assemblies — four batches — can win back: 0.38 -> 0.49 s exec to exit when it was taken at once)
+  // (... and then at once, with the fifth: a caller that warms up with five batches has the allocation behind it)
+  if (env < 0 && db->ws_calls < 4) return 0;
+  const int slot = (int)((db->ws_calls + (env < 0 ? 1 : 0)) & 1);
   if (slot == 0) return 0;
   kmcpg_db::Workspace& W = db->ws[1];
   if (W.w_hashes.cap >= total_bases + 1 && W.w_scratch.cap >= 2 * total_bases + 2) return 1;

@@ -224,11 +224,19 @@ def test_packed_whole_genomes_are_hashed_from_their_codes(world, oracle_lib):
             assert len(rb.matches) == 16 * per and np.array_equal(rb.qkmers, np.tile(want.qkmers, 16))
             for c in range(16):
                 assert rb.matches[c * per:(c + 1) * per].tobytes() == want.matches.tobytes(), c
+            # from its fifth batch of whole genomes on a handle alternates between two k-mer workspaces and two kernel streams (the k-mer kernel of
+            # one batch beside the COBS kernel of the one before): six more, four in flight, same records
+            tk = [db.submit_packed(codes, offs, exc, params=p) for _ in range(4)]
+            for _ in range(2):
+                assert db.wait(tk.pop(0)).matches.tobytes() == want.matches.tobytes()
+                tk.append(db.submit(seqs, offs, params=p))
+            for t_ in tk:
+                assert db.wait(t_).matches.tobytes() == want.matches.tobytes()
             short = [r for r in reads if len(r) <= 5000]
             c2, e2, _ = lib.pack2(short)
             s2, o2 = lib.pack_reads(short)
             a = db.wait(db.submit_packed(c2, o2, e2, params=p))
-            assert db.k1_codes_batches()[1] == 1 and db.k1_codes_batches()[0] >= 5
+            assert db.k1_codes_batches()[1] == 1 and db.k1_codes_batches()[0] >= 9
             assert a.matches.tobytes() == db.wait(db.submit(s2, o2, params=p)).matches.tobytes()
     finally:
         odb.close()

@@ -1,26 +1,18 @@
 #!/bin/bash
+# kmcp-search -g (256 assemblies, four batches) and the bench's genome search with the second workspace taken from the fifth batch on
 set -u
 OUT=gpurun_out/r06_cli_g.txt
 : > $OUT
-KMCP_BENCH_KEEP=/dev/shm/kmcp_cli_keep python bench.py --cli-only -256 > /dev/null 2>> $OUT
-D=/dev/shm/kmcp_cli_keep
-CLI=kmcp_amd/kmcp-search
 for i in 1 2; do
-  rm -f $D/out.tsv
-  s=$(date +%s%N)
-  sed "s#/dev/shm/[^/]*/#$D/#" $D/files.txt > $D/files2.txt; $CLI -d $D/db -g -t 0.4 -s jacc --infile-list $D/files2.txt -o $D/out.tsv 2> $D/log.txt
-  e=$(date +%s%N)
-  echo "== run $i: $(( (e - s) / 1000000 )) ms wall" >> $OUT
-  grep -E "pipeline|writer loop|elapsed" $D/log.txt | sed 's/^.*\] //' >> $OUT
+timeout 600 python bench.py --cli-only -256 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.read()); print('cli -g [default]:', d.get('value'), d.get('wall_s'), d.get('value_search_phase'), d.get('parity_on_sample'))" >> $OUT
+KMCPG_WS_SLOTS=1 KMCPG_KSTREAMS=1 timeout 600 python bench.py --cli-only -256 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.read()); print('cli -g [one stream, one slot]:', d.get('value'), d.get('wall_s'), d.get('value_search_phase'), d.get('parity_on_sample'))" >> $OUT
 done
-# the reader alone
-s=$(date +%s%N); $CLI --parse-only -g $(head -64 $D/files2.txt) > /dev/null 2> $D/log2.txt; e=$(date +%s%N)
-echo "== parse-only 64 files: $(( (e - s) / 1000000 )) ms" >> $OUT
-tail -2 $D/log2.txt >> $OUT
-# one file through the reader in a loop: how long does a 4-Mbp FASTA take?
-python - <<PY >> $OUT
-import time, subprocess
-t=time.time(); subprocess.run(["$CLI","--parse-only","$D/asm00000.fasta"],capture_output=True); print("parse-only one file (process incl.): %.1f ms" % ((time.time()-t)*1e3))
-PY
-rm -rf $D
+timeout 600 python bench.py --workload config2_genome_search --steps 40 --warmup 5 --no-cpu-baseline 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.read()); r=d['roofline']
+print('config2: value', d['value'], 'ms_per_step', d['ms_per_step'], 'k2', r.get('kernel_ms'), 'h2h', d.get('value_host_to_host'), d.get('value_host_to_host_packed'))" >> $OUT
 cat $OUT
