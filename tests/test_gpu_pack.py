@@ -232,11 +232,35 @@ def test_packed_whole_genomes_are_hashed_from_their_codes(world, oracle_lib):
                 tk.append(db.submit(seqs, offs, params=p))
             for t_ in tk:
                 assert db.wait(t_).matches.tobytes() == want.matches.tobytes()
+            # ... and from two host threads at once, each with two tickets in flight (the handle's four lanes), packed and text entries mixed
+            import threading
+            errs = []
+
+            def pump(tid):
+                try:
+                    mine = []
+                    for j in range(6):
+                        mine.append(db.submit_packed(codes, offs, exc, params=p) if (tid + j) & 1 else db.submit(seqs, offs, params=p))
+                        if len(mine) == 2:
+                            if db.wait(mine.pop(0)).matches.tobytes() != want.matches.tobytes():
+                                errs.append((tid, j))
+                    for t_ in mine:
+                        if db.wait(t_).matches.tobytes() != want.matches.tobytes():
+                            errs.append((tid, "tail"))
+                except Exception as e:  # noqa: BLE001
+                    errs.append((tid, repr(e)))
+
+            th = [threading.Thread(target=pump, args=(i,)) for i in range(2)]
+            for t_ in th:
+                t_.start()
+            for t_ in th:
+                t_.join()
+            assert not errs, errs
             short = [r for r in reads if len(r) <= 5000]
             c2, e2, _ = lib.pack2(short)
             s2, o2 = lib.pack_reads(short)
             a = db.wait(db.submit_packed(c2, o2, e2, params=p))
-            assert db.k1_codes_batches()[1] == 1 and db.k1_codes_batches()[0] >= 9
+            assert db.k1_codes_batches()[1] == 1 and db.k1_codes_batches()[0] >= 12
             assert a.matches.tobytes() == db.wait(db.submit(s2, o2, params=p)).matches.tobytes()
     finally:
         odb.close()
